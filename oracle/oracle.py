@@ -1,0 +1,272 @@
+"""ctypes binding of oracle/libsfq_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsfq_oracle.so")
+    src = os.path.join(_HERE, "sfq_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libsfq_oracle.so"])
+    return so
+
+
+def ref_binary():
+    """Path of the compiled reference (oracle/_ref/slimfastq_ref) or None."""
+    p = os.path.join(_HERE, "_ref", "slimfastq_ref")
+    return p if os.path.exists(p) else None
+
+
+class Opts(C.Structure):
+    _fields_ = [("level", C.c_int), ("quiet", C.c_int), ("gen_bits", C.c_int),
+                ("orig_filename", C.c_char_p), ("orig_size", C.c_longlong)]
+
+
+class GenSide(C.Structure):
+    _fields_ = [("ns", C.POINTER(C.c_uint64)), ("n_ns", C.c_size_t),
+                ("nn", C.POINTER(C.c_uint64)), ("n_nn", C.c_size_t), ("n_byte", C.c_int)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
+        L.sfqo_compress.restype = vp
+        L.sfqo_compress.argtypes = [C.c_char_p, sz, C.POINTER(Opts)]
+        L.sfqo_decompress.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz)]
+        L.sfqo_archive_from_image.restype = vp
+        L.sfqo_archive_from_image.argtypes = [C.c_char_p, sz]
+        L.sfqo_archive_image.restype = u8p
+        L.sfqo_archive_image.argtypes = [vp, C.POINTER(sz)]
+        L.sfqo_archive_free.argtypes = [vp]
+        L.sfqo_nstreams.argtypes = [vp]
+        L.sfqo_stream_name.restype = C.c_char_p
+        L.sfqo_stream_name.argtypes = [vp, C.c_int]
+        L.sfqo_stream_size.restype = sz
+        L.sfqo_stream_size.argtypes = [vp, C.c_int]
+        L.sfqo_stream_read.restype = C.c_longlong
+        L.sfqo_stream_read.argtypes = [vp, C.c_int, C.c_char_p, sz]
+        L.sfqo_info_get.restype = C.c_char_p
+        L.sfqo_info_get.argtypes = [vp, C.c_char_p]
+        L.sfqo_last_error.restype = C.c_char_p
+        L.sfqo_free.argtypes = [vp]
+        for f in ("sfqo_qlt_encode", "sfqo_qlt_decode", "sfqo_gen_encode", "sfqo_gen_decode_raw",
+                  "sfqo_rec_encode", "sfqo_xfile_encode_u", "sfqo_xfile_decode_u"):
+            getattr(L, f).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _err():
+    return OracleError(lib().sfqo_last_error().decode("latin1"))
+
+
+class Archive:
+    """An in-memory .sfq container: {stream name: bytes} + info dict, directory order kept."""
+
+    def __init__(self, handle):
+        L = lib()
+        self.streams = {}
+        self.order = []
+        n = L.sfqo_nstreams(handle)
+        for i in range(n):
+            name = "<info>" if i == 0 else L.sfqo_stream_name(handle, i).decode("latin1")
+            size = L.sfqo_stream_size(handle, i)
+            buf = C.create_string_buffer(max(size, 1))
+            got = L.sfqo_stream_read(handle, i, buf, size)
+            if got != size:
+                raise OracleError("bad stream chain for %s" % name)
+            self.streams[name] = buf.raw[:size]
+            self.order.append(name)
+        sz = C.c_size_t()
+        p = L.sfqo_archive_image(handle, C.byref(sz))
+        self.image = C.string_at(p, sz.value)
+        self.info = {}
+        for line in self.streams["<info>"].decode("latin1").split("\n"):
+            if "=" in line:
+                k, v = line.split("=", 1)
+                self.info.setdefault(k, v)
+
+    def payload_bytes(self):
+        """Sum of stream bytes (the ratio metric, SURVEY.md section 5 'Metrics')."""
+        return sum(len(v) for v in self.streams.values())
+
+
+def compress(fastq: bytes, level=3, quiet=True, gen_bits=0, orig_filename=None, orig_size=-1) -> Archive:
+    L = lib()
+    o = Opts(level, int(quiet), gen_bits, orig_filename, orig_size)
+    h = L.sfqo_compress(fastq, len(fastq), C.byref(o))
+    if not h:
+        raise _err()
+    try:
+        return Archive(h)
+    finally:
+        L.sfqo_archive_free(h)
+
+
+def parse(image: bytes) -> Archive:
+    L = lib()
+    h = L.sfqo_archive_from_image(image, len(image))
+    if not h:
+        raise _err()
+    try:
+        return Archive(h)
+    finally:
+        L.sfqo_archive_free(h)
+
+
+def decompress(image: bytes) -> bytes:
+    L = lib()
+    h = L.sfqo_archive_from_image(image, len(image))
+    if not h:
+        raise _err()
+    try:
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        if L.sfqo_decompress(h, C.byref(out), C.byref(n)) != 0:
+            raise _err()
+        data = C.string_at(out, n.value)
+        L.sfqo_free(out)
+        return data
+    finally:
+        L.sfqo_archive_free(h)
+
+
+def _take(ptr, n):
+    data = C.string_at(ptr, n.value) if n.value else b""
+    lib().sfqo_free(ptr)
+    return data
+
+
+def _arr(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def qlt_encode(buf: bytes, off, length, level=3):
+    """-> (stream bytes, extra_hi count).  qlts.cpp:74-136."""
+    L = lib()
+    off, po = _arr(off, np.uint64)
+    length, pl = _arr(length, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); hi = C.c_uint32()
+    L.sfqo_qlt_encode.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+    if L.sfqo_qlt_encode(buf, po, pl, len(off), level, C.byref(out), C.byref(n), C.byref(hi)) != 0:
+        raise _err()
+    return _take(out, n), hi.value
+
+
+def qlt_decode(stream: bytes, off, length, total, level=3) -> bytes:
+    L = lib()
+    off, po = _arr(off, np.uint64)
+    length, pl = _arr(length, np.uint32)
+    dst = C.create_string_buffer(total + 1)
+    L.sfqo_qlt_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if L.sfqo_qlt_decode(stream, len(stream), dst, po, pl, len(off), level) != 0:
+        raise _err()
+    return dst.raw[:total]
+
+
+def gen_encode(buf: bytes, goff, glen, qoff, qlen, gen_bits=24):
+    """-> (stream, Ns positions, Nn positions, N byte).  gens.cpp:91-159."""
+    L = lib()
+    goff, pgo = _arr(goff, np.uint64); glen, pgl = _arr(glen, np.uint32)
+    qoff, pqo = _arr(qoff, np.uint64); qlen, pql = _arr(qlen, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); side = GenSide()
+    L.sfqo_gen_encode.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(GenSide)]
+    if L.sfqo_gen_encode(buf, pgo, pgl, pqo, pql, len(goff), gen_bits, C.byref(out), C.byref(n), C.byref(side)) != 0:
+        raise _err()
+    ns = np.ctypeslib.as_array(side.ns, (side.n_ns,)).copy() if side.n_ns else np.zeros(0, np.uint64)
+    nn = np.ctypeslib.as_array(side.nn, (side.n_nn,)).copy() if side.n_nn else np.zeros(0, np.uint64)
+    L.sfqo_free(side.ns); L.sfqo_free(side.nn)
+    return _take(out, n), ns, nn, side.n_byte
+
+
+def gen_decode_raw(stream: bytes, goff, glen, total, gen_bits=24, solid=False) -> bytes:
+    L = lib()
+    goff, pgo = _arr(goff, np.uint64); glen, pgl = _arr(glen, np.uint32)
+    dst = C.create_string_buffer(total + 1)
+    L.sfqo_gen_decode_raw.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    if L.sfqo_gen_decode_raw(stream, len(stream), dst, pgo, pgl, len(goff), gen_bits, int(solid)) != 0:
+        raise _err()
+    return dst.raw[:total]
+
+
+def rec_encode(buf: bytes, off, length):
+    """-> (stream, 1-based record numbers that went to rec.x).  recs.cpp:277-372."""
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    xr = C.POINTER(C.c_uint64)(); nx = C.c_size_t()
+    L.sfqo_rec_encode.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                  C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]
+    if L.sfqo_rec_encode(buf, po, pl, len(off), C.byref(out), C.byref(n), C.byref(xr), C.byref(nx)) != 0:
+        raise _err()
+    x = np.ctypeslib.as_array(xr, (nx.value,)).copy() if nx.value else np.zeros(0, np.uint64)
+    L.sfqo_free(xr)
+    return _take(out, n), x
+
+
+def xfile_encode_u(vals) -> bytes:
+    L = lib()
+    vals, pv = _arr(vals, np.uint64)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    L.sfqo_xfile_encode_u.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    if L.sfqo_xfile_encode_u(pv, len(vals), C.byref(out), C.byref(n)) != 0:
+        raise _err()
+    return _take(out, n)
+
+
+def xfile_decode_u(stream: bytes, count: int):
+    L = lib()
+    vals = np.zeros(count, np.uint64)
+    L.sfqo_xfile_decode_u.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    if L.sfqo_xfile_decode_u(stream, len(stream), vals.ctypes.data_as(C.c_void_p), count) != 0:
+        raise _err()
+    return vals
+
+
+# ---- driving the compiled reference (container only; never on the GPU box) --------------------------
+def ref_compress(fastq: bytes, level=3, quiet=True) -> bytes:
+    """Run oracle/_ref/slimfastq_ref on stdin (path-independent info page) -> .sfq image."""
+    import tempfile
+    exe = ref_binary()
+    if exe is None:
+        raise OracleError("oracle/_ref/slimfastq_ref not built")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.sfq")
+        cmd = [exe, "-f", out, "-O", "-l", str(level)] + (["-q"] if quiet else [])
+        p = subprocess.run(cmd, input=fastq, capture_output=True)
+        if p.returncode != 0:
+            raise OracleError("reference failed: " + p.stderr.decode("latin1"))
+        return open(out, "rb").read()
+
+
+def ref_decompress(image: bytes) -> bytes:
+    import tempfile
+    exe = ref_binary()
+    if exe is None:
+        raise OracleError("oracle/_ref/slimfastq_ref not built")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "i.sfq")
+        open(src, "wb").write(image)
+        p = subprocess.run([exe, "-d", "-f", src], capture_output=True)
+        if p.returncode != 0:
+            raise OracleError("reference failed: " + p.stderr.decode("latin1"))
+        return p.stdout
