@@ -1,0 +1,174 @@
+/*
+ * slimfastq_amd.h -- C ABI of the MI355X-native slimfastq hot path.
+ *
+ * This is the drop-in boundary: everything the reference does between `UsrSave::encode()` /
+ * `UsrLoad::decode()` (usrs.cpp:392-407 / 539-574) and `FilerSave::put()` / `FilerLoad::get()`
+ * (filer.hpp:70-75, 94-97) -- i.e. the stream models qlts.cpp / gens.cpp / recs.cpp, the rangers
+ * (base2_ranger.hpp, log64_ranger.hpp, power_ranger.hpp), the range coder (coder.hpp) and the
+ * exception side streams (xfile.cpp) -- runs behind these entry points as hand-written gfx950 HIP
+ * kernels.  The reference has no FFI of its own; each entry point names the C++ call it replaces.
+ *
+ * Conventions: extern "C", plain pointers and sizes, int status (0 = ok, <0 = error, never exit(),
+ * no exceptions across the boundary).  The caller owns every buffer it passes; the context owns
+ * device tables, scratch and its HIP stream.  One context per host thread per GPU; calls on
+ * different contexts are concurrent-safe.  Pointers named d_* are DEVICE pointers, h_* are host
+ * pointers.  There is no CPU fallback: without a HIP device sfq_ctx_create fails.
+ */
+#ifndef SLIMFASTQ_AMD_H
+#define SLIMFASTQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFQ_ABI_VERSION 1
+
+/* status codes */
+#define SFQ_OK              0
+#define SFQ_E_ARG          -1   /* bad argument                                              */
+#define SFQ_E_HIP          -2   /* HIP runtime error / no device                             */
+#define SFQ_E_NOMEM        -3   /* device or host allocation failed                          */
+#define SFQ_E_FORMAT       -4   /* input is not 4-line FASTQ (reference: croak, usrs.cpp:162-172) */
+#define SFQ_E_OVERFLOW     -5   /* an output arena was too small                             */
+#define SFQ_E_CORRUPT      -6   /* compressed stream inconsistent                            */
+#define SFQ_E_UNSUPPORTED  -7   /* e.g. records over the reference's 65535-base model limit (usrs.hpp:34-36) */
+#define SFQ_E_GENCHAR      -8   /* unexpected genome char (gens.cpp:125-126) / switched N byte (gens.cpp:107-108) */
+
+/* Stream ids: the reference's stream names (FilerSave(name) call sites). */
+enum sfq_stream {
+    SFQ_S_REC = 0,      /* "rec"     recs.cpp:40      */
+    SFQ_S_GEN = 1,      /* "gen"     gens.cpp:63      */
+    SFQ_S_QLT = 2,      /* "qlt"     qlts.cpp:46      */
+    SFQ_S_GEN_NS = 3,   /* "gen.Ns"  gens.cpp:69      */
+    SFQ_S_GEN_NN = 4,   /* "gen.Nn"  gens.cpp:70      */
+    SFQ_S_REC_X = 5,    /* "rec.x"   recs.cpp:44      */
+    SFQ_S_USR_X = 6,    /* "usr.x"   usrs.cpp:48      */
+    SFQ_S_USR_XQ = 7,   /* "usr.x.q" usrs.cpp:49      */
+    SFQ_S_USR_PFG = 8,  /* "usr.pfg" usrs.cpp:50      */
+    SFQ_S_USR_PFQ = 9,  /* "usr.pfq" usrs.cpp:51      */
+    SFQ_NSTREAMS = 10
+};
+const char* sfq_stream_name(int stream);
+
+/* Which models to run (config C2 of BASELINE.json runs SFQ_M_QLT alone). */
+#define SFQ_M_REC 1u
+#define SFQ_M_GEN 2u
+#define SFQ_M_QLT 4u
+#define SFQ_M_USR 8u
+#define SFQ_M_ALL 15u
+
+typedef struct sfq_ctx sfq_ctx;
+
+typedef struct sfq_params {
+    int32_t  level;        /* 1..4 : conf.level (config.cpp:260-263, clamped like config.cpp:232-237) */
+    uint32_t block_reads;  /* records per independent block; 0 = a single block, i.e. streams that are
+                              byte-identical to the reference's own (format 6)                        */
+    int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
+    uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
+    uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks) */
+    uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
+                              Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
+    uint32_t reserved[2];
+} sfq_params;
+
+/* One entry per block: what a decoder needs besides the stream bytes (the "block index").
+ * The per-block stream bytes are the reference's streams for a FASTQ consisting of that block alone,
+ * with g_record_count / g_genofs_count (config.cpp:43-44) restarting at the block. */
+typedef struct sfq_block_info {
+    uint64_t first_record;                 /* 0-based index of the block's first record           */
+    uint32_t n_records;                    /* num_records (usrs.cpp:405)                          */
+    uint32_t llen;                         /* "llen"      (usrs.cpp:265)                          */
+    uint8_t  solid;                        /* "usr.solid" (usrs.cpp:262)                          */
+    uint8_t  two_id;                       /* "usr.2id"   (usrs.cpp:266)                          */
+    uint8_t  n_byte;                       /* "gen.N_byte" (gens.cpp:104), 0 = none seen          */
+    uint8_t  gen_bits;                     /* context bits used by the base model of this block   */
+    uint32_t extra_hi;                     /* "qlt.extra.hi" (qlts.cpp:57-61)                     */
+    uint32_t first_hdr_len;                /* "rec.first" length (recs.cpp:68-75)                 */
+    uint64_t first_hdr_off;                /* its offset in the first-header blob                 */
+    uint32_t size[SFQ_NSTREAMS];           /* bytes of each stream of this block (0 = absent)     */
+    uint32_t status;                       /* 0 or -SFQ_E_* for this block                        */
+    uint32_t hdr_bytes;                    /* sum of header-line lengths (sizes the decoder's staging; 0 = unknown) */
+} sfq_block_info;
+
+typedef struct sfq_result {
+    uint64_t n_records;
+    uint32_t n_blocks;
+    uint32_t abi_version;
+    uint64_t stream_bytes[SFQ_NSTREAMS];   /* per stream: sum over blocks                          */
+    uint64_t stream_offset[SFQ_NSTREAMS];  /* per stream: where its block-concatenation starts in d_out */
+    uint64_t total_bytes;                  /* bytes used in d_out                                  */
+    uint64_t first_hdr_bytes;              /* size of the first-header blob (see sfq_get_first_headers) */
+    double   kernel_ms[8];                 /* device time of the last call, by phase (see SFQ_T_*) */
+} sfq_result;
+
+#define SFQ_T_FRAME   0   /* line index + block descriptors                     */
+#define SFQ_T_QLT     1   /* quality model kernel(s)                            */
+#define SFQ_T_GEN     2   /* base model kernel(s)                               */
+#define SFQ_T_REC     3   /* header model kernel(s)                             */
+#define SFQ_T_USR     4   /* framing-exception kernel(s)                        */
+#define SFQ_T_PACK    5   /* size scan + compaction / FASTQ assembly            */
+#define SFQ_T_TOTAL   6   /* first launch -> last launch of the call            */
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* Replaces the reference's process-wide singletons (conf, onef, g_record_count, g_genofs_count:
+ * config.hpp:62-64) with an explicit, re-entrant object bound to one HIP device. */
+int  sfq_ctx_create(sfq_ctx** out, int hip_device);
+void sfq_ctx_destroy(sfq_ctx* ctx);
+const char* sfq_last_error(const sfq_ctx* ctx);         /* replaces croak() text (config.cpp:54-68) */
+/* Upper bound on device bytes the context may hold for model tables (default: 1/3 of the device). */
+int  sfq_ctx_set_table_budget(sfq_ctx* ctx, uint64_t bytes);
+/* The HIP stream the context launches on (a hipStream_t), for callers that order work against it. */
+void* sfq_ctx_stream(sfq_ctx* ctx);
+int  sfq_ctx_synchronize(sfq_ctx* ctx);
+
+/* ---- compress ------------------------------------------------------------------------------
+ * Replaces the body of UsrSave::encode()'s record loop (usrs.cpp:400-404: gen.save / rec.save /
+ * qlt.save per record) plus UsrSave::get_record()'s framing (usrs.cpp:303-390) for a whole buffer
+ * of FASTQ text resident on the device.  d_out receives, stream after stream, the concatenation of
+ * every block's bytes for that stream; sfq_get_block_index() tells the per-block sizes.
+ * Worst-case d_out size: sfq_encode_bound(nbytes). Asynchronous errors are reported at return
+ * (the call synchronizes the context's stream once, at the end). */
+uint64_t sfq_encode_bound(uint64_t fastq_bytes);
+int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
+                      uint8_t* d_out, uint64_t out_cap, sfq_result* result);
+/* BASELINE.json config C2: the quality model alone == QltSave::save over all records (qlts.hpp:82-90). */
+int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
+                          uint8_t* d_out, uint64_t out_cap, sfq_result* result);
+/* Same with host buffers (stages through the context's device memory; PCIe-inclusive). */
+int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
+                           uint8_t* h_out, uint64_t out_cap, sfq_result* result);
+
+/* Block index / first headers of the LAST encode call on this context (host copies). */
+int sfq_get_block_index(sfq_ctx* ctx, sfq_block_info* h_blocks, uint32_t cap);
+int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
+
+/* ---- decompress ----------------------------------------------------------------------------
+ * Replaces UsrLoad::decode()'s loop (usrs.cpp:555-571: rec.load / qlt.load / gen.load / save).
+ * d_streams holds the streams laid out as sfq_encode_blocks wrote them (stream_offset[] + running
+ * sum of sfq_block_info.size[]); a reference-written format-6 archive is the one-block case with
+ * gen_bits = the level's.  h_first_hdrs is the first-header blob (one "rec.first" per block).
+ * Writes the FASTQ text to d_fastq_out; *out_bytes = its length. */
+int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* params, const sfq_block_info* h_blocks, uint32_t n_blocks,
+                      const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                      const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
+                      uint8_t* d_fastq_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* result);
+int sfq_decode_blocks_host(sfq_ctx* ctx, const sfq_params* params, const sfq_block_info* h_blocks, uint32_t n_blocks,
+                           const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                           const uint8_t* h_streams, uint64_t streams_bytes, const uint64_t stream_offset[SFQ_NSTREAMS],
+                           uint8_t* h_fastq_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* result);
+
+/* ---- utilities (host only, no GPU) ----------------------------------------------------------- */
+/* Deterministic synthetic FASTQ. kind 0 = 150 bp-style Illumina reads of
+ * read_len bases; kind 1 = long reads, lengths log-uniform in [10000, 50000] (read_len ignored).
+ * Returns bytes written, or the required size when h_out == NULL, or <0. */
+int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed, int kind,
+                        uint8_t* h_out, uint64_t cap);
+int sfq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIMFASTQ_AMD_H */

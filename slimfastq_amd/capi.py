@@ -1,0 +1,199 @@
+"""ctypes binding of libslimfastq_amd.so (include/slimfastq_amd.h).  No fallback of any kind."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslimfastq_amd.so")
+
+NSTREAMS = 10
+STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"]
+M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
+T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
+
+EXPORTS = [
+    "sfq_stream_name", "sfq_ctx_create", "sfq_ctx_destroy", "sfq_last_error", "sfq_ctx_set_table_budget",
+    "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
+    "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
+    "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("level", C.c_int32), ("block_reads", C.c_uint32), ("gen_bits", C.c_int32), ("models", C.c_uint32),
+                ("kernel", C.c_uint32), ("version", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("first_record", C.c_uint64), ("n_records", C.c_uint32), ("llen", C.c_uint32),
+                ("solid", C.c_uint8), ("two_id", C.c_uint8), ("n_byte", C.c_uint8), ("gen_bits", C.c_uint8),
+                ("extra_hi", C.c_uint32), ("first_hdr_len", C.c_uint32), ("first_hdr_off", C.c_uint64),
+                ("size", C.c_uint32 * NSTREAMS), ("status", C.c_uint32), ("hdr_bytes", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_blocks", C.c_uint32), ("abi_version", C.c_uint32),
+                ("stream_bytes", C.c_uint64 * NSTREAMS), ("stream_offset", C.c_uint64 * NSTREAMS),
+                ("total_bytes", C.c_uint64), ("first_hdr_bytes", C.c_uint64), ("kernel_ms", C.c_double * 8)]
+
+
+class SfqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("slimfastq_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -m slimfastq_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u64, u8p = C.c_void_p, C.c_uint64, C.c_void_p
+        L.sfq_stream_name.restype = C.c_char_p
+        L.sfq_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.sfq_ctx_destroy.argtypes = [vp]
+        L.sfq_ctx_destroy.restype = None
+        L.sfq_last_error.argtypes = [vp]
+        L.sfq_last_error.restype = C.c_char_p
+        L.sfq_ctx_set_table_budget.argtypes = [vp, u64]
+        L.sfq_ctx_stream.argtypes = [vp]
+        L.sfq_ctx_stream.restype = vp
+        L.sfq_ctx_synchronize.argtypes = [vp]
+        L.sfq_encode_bound.argtypes = [u64]
+        L.sfq_encode_bound.restype = u64
+        for f in (L.sfq_encode_blocks, L.sfq_encode_qlt_blocks, L.sfq_encode_blocks_host):
+            f.argtypes = [vp, u8p, u64, C.POINTER(Params), u8p, u64, C.POINTER(Result)]
+        L.sfq_get_block_index.argtypes = [vp, C.POINTER(BlockInfo), C.c_uint32]
+        L.sfq_get_first_headers.argtypes = [vp, u8p, u64]
+        L.sfq_decode_blocks.argtypes = [vp, C.POINTER(Params), C.POINTER(BlockInfo), C.c_uint32, u8p, u64, u8p,
+                                        C.POINTER(u64), u8p, u64, C.POINTER(u64), C.POINTER(Result)]
+        L.sfq_decode_blocks_host.argtypes = [vp, C.POINTER(Params), C.POINTER(BlockInfo), C.c_uint32, u8p, u64, u8p, u64,
+                                             C.POINTER(u64), u8p, u64, C.POINTER(u64), C.POINTER(Result)]
+        L.sfq_synth_fastq.argtypes = [u64, u64, C.c_uint32, u64, C.c_int, u8p, u64]
+        L.sfq_synth_fastq.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def synth_fastq(n_reads, read_len=150, seed=1, kind=0, first_read=0) -> bytes:
+    """Deterministic synthetic FASTQ (host-side generator inside the library)."""
+    L = lib()
+    need = L.sfq_synth_fastq(first_read, n_reads, read_len, seed, kind, None, 0)
+    if need < 0:
+        raise SfqError(need, "synth")
+    buf = np.empty(need, np.uint8)
+    got = L.sfq_synth_fastq(first_read, n_reads, read_len, seed, kind, buf.ctypes.data_as(C.c_void_p), need)
+    if got != need:
+        raise SfqError(got, "synth")
+    return buf.tobytes()
+
+
+class Encoded:
+    """Host copy of one sfq_encode_blocks result."""
+
+    def __init__(self, res, blocks, first_hdrs, data):
+        self.res, self.blocks, self.first_hdrs, self.data = res, blocks, first_hdrs, data
+
+    def stream(self, s, block=None) -> bytes:
+        """Bytes of stream s (an id or a name): the whole concatenation, or one block's part."""
+        if isinstance(s, str):
+            s = STREAM_NAMES.index(s)
+        off = self.res.stream_offset[s]
+        if block is None:
+            return bytes(self.data[off:off + self.res.stream_bytes[s]])
+        for b in range(block):
+            off += self.blocks[b].size[s]
+        return bytes(self.data[off:off + self.blocks[block].size[s]])
+
+    @property
+    def payload_bytes(self):
+        return int(self.res.total_bytes)
+
+
+class Context:
+    def __init__(self, device=0, table_budget=None):
+        self._h = C.c_void_p()
+        rc = lib().sfq_ctx_create(C.byref(self._h), device)
+        if rc != 0:
+            raise SfqError(rc, "sfq_ctx_create failed (a HIP device is required; there is no CPU path)")
+        if table_budget:
+            lib().sfq_ctx_set_table_budget(self._h, int(table_budget))
+
+    def close(self):
+        if self._h:
+            lib().sfq_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SfqError(rc, lib().sfq_last_error(self._h).decode("latin1"))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def index(self, n_blocks):
+        blocks = (BlockInfo * n_blocks)()
+        got = lib().sfq_get_block_index(self._h, blocks, n_blocks)
+        if got < 0:
+            self._check(got)
+        return blocks
+
+    def first_headers(self, nbytes):
+        buf = C.create_string_buffer(max(int(nbytes), 1))
+        self._check(lib().sfq_get_first_headers(self._h, buf, nbytes))
+        return buf.raw[:nbytes]
+
+    def encode_host(self, fastq: bytes, level=3, block_reads=0, gen_bits=0, models=0, kernel=0) -> Encoded:
+        L = lib()
+        p = Params(level, block_reads, gen_bits, models, kernel, 0)
+        res = Result()
+        cap = L.sfq_encode_bound(len(fastq))
+        out = np.empty(cap, np.uint8)
+        src = np.frombuffer(fastq, np.uint8)
+        self._check(L.sfq_encode_blocks_host(self._h, src.ctypes.data_as(C.c_void_p), len(fastq), C.byref(p),
+                                             out.ctypes.data_as(C.c_void_p), cap, C.byref(res)))
+        blocks = self.index(res.n_blocks)
+        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy())
+
+    def encode_device(self, d_ptr, nbytes, d_out, out_cap, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, qlt_only=False):
+        """Device-pointer entry point (ints from torch .data_ptr()). Returns the Result struct."""
+        L = lib()
+        p = Params(level, block_reads, gen_bits, models, kernel, 0)
+        res = Result()
+        f = L.sfq_encode_qlt_blocks if qlt_only else L.sfq_encode_blocks
+        self._check(f(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p), C.c_void_p(d_out), out_cap, C.byref(res)))
+        return res
+
+    def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
+        """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
+        L = lib()
+        if isinstance(enc_or_parts, Encoded):
+            blocks, first, data = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data
+            soff = (C.c_uint64 * NSTREAMS)(*list(enc_or_parts.res.stream_offset))
+        else:
+            blocks, first, data, so = enc_or_parts
+            soff = (C.c_uint64 * NSTREAMS)(*so)
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
+        p = Params(level, 0, 0, 0, 0, version)
+        res = Result()
+        if out_cap is None:
+            out_cap = 64 * len(data) + (1 << 20)
+        out = np.empty(out_cap, np.uint8)
+        n = C.c_uint64()
+        fb = np.frombuffer(first if len(first) else b"\0", np.uint8)
+        self._check(L.sfq_decode_blocks_host(self._h, C.byref(p), blocks, len(blocks), fb.ctypes.data_as(C.c_void_p), len(first),
+                                             data.ctypes.data_as(C.c_void_p), len(data), soff,
+                                             out.ctypes.data_as(C.c_void_p), out_cap, C.byref(n), C.byref(res)))
+        return out[:n.value].tobytes()

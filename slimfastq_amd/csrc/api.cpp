@@ -1,0 +1,562 @@
+// api.cpp -- host side of the C ABI (include/slimfastq_amd.h): context, device memory, launch
+// sequencing.  No entropy-coding arithmetic lives here: every model / coder step runs in the HIP
+// kernels (models_*.hip, decode_l.hip); this file only frames, sizes, launches and packs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct Tables {
+    DevBuf q_slots, q_hdr, p_slots, p_hdr, g_tab;
+    u32 slots = 0;      // block slots the tables were sized for
+    u32 q_rows = 0;
+    u32 g_bits = 0;
+};
+
+}  // namespace
+
+struct sfq_ctx {
+    int dev = 0;
+    hipStream_t st = nullptr;
+    hipStream_t st_aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[16] = {};
+    std::string err;
+    u64 table_budget = 0;
+    u64 dev_total = 0;
+    u32 epoch_base = 0;
+    Tables tab;
+    // scratch (grow-only)
+    DevBuf chunk_counts, chunk_base, scan_tmp, line_off, status, blocks, arena, blk_stream_off, stream_total,
+           lens, blob_off, blob, in_stage, out_stage;
+    // decode scratch
+    DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
+    // last encode, host copies
+    std::vector<sfq_block_info> index;
+    std::vector<u8> first_hdrs;
+};
+
+namespace {
+
+int fail(sfq_ctx* c, int code, const char* fmt, ...) {
+    char b[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof b, fmt, ap); va_end(ap);
+    if (c) c->err = b;
+    return code;
+}
+#define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail(ctx, e_ == hipErrorOutOfMemory ? SFQ_E_NOMEM : SFQ_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+int reserve(sfq_ctx* ctx, DevBuf& b, size_t bytes, bool zero_new = false) {
+    if (bytes <= b.cap && b.p) return SFQ_OK;
+    if (b.p) { HIPC(hipStreamSynchronize(ctx->st)); HIPC(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIPC(hipMalloc(&b.p, want));
+    b.cap = want;
+    if (zero_new) HIPC(hipMemsetAsync(b.p, 0, want, ctx->st));
+    return SFQ_OK;
+}
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+int level_gen_bits(int level) {   // gens.hpp:43-53
+    switch (level) { case 1: return 18; case 2: return 22; case 3: return 24; default: return 26; }
+}
+int clamp_level(int level) { return level > 4 ? 4 : level < 1 ? 1 : level; }   // config.cpp:232-237
+
+// Size the model tables for `want` concurrent block slots (or fewer if the budget says so).
+int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u32* got) {
+    const u64 per_q = (models & SFQ_M_QLT) ? (u64)q_rows * (L64_NSYM * 4 + sizeof(RowHdr)) : 0;
+    const u64 per_p = (u64)PR_ROWS * (PW_NSYM * 4 + sizeof(RowHdr));
+    const u64 per_g = (models & SFQ_M_GEN) ? ((u64)4 << g_bits) : 0;
+    const u64 per = per_q + per_p + per_g;
+    u64 fit = ctx->table_budget / per;
+    if (fit == 0) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B too small for one block slot (%llu B)",
+                              (unsigned long long)ctx->table_budget, (unsigned long long)per);
+    u32 slots = (u32)std::min<u64>(want, fit);
+    Tables& t = ctx->tab;
+    // Row tables are epoch-tagged: they must be zero when first used and whenever their geometry changes.
+    const bool regeom = t.q_rows != q_rows;
+    int rc;
+    if (per_q) {
+        const size_t need_s = (size_t)slots * q_rows * L64_NSYM * 4, need_h = (size_t)slots * q_rows * sizeof(RowHdr);
+        if (regeom || need_s > t.q_slots.cap) {
+            if ((rc = reserve(ctx, t.q_slots, need_s))) return rc;
+            release(t.q_hdr);
+        }
+        if (!t.q_hdr.p) { if ((rc = reserve(ctx, t.q_hdr, need_h, true))) return rc; }
+        t.q_rows = q_rows;
+    }
+    {
+        const size_t need_s = (size_t)slots * PR_ROWS * PW_NSYM * 4, need_h = (size_t)slots * PR_ROWS * sizeof(RowHdr);
+        if (need_s > t.p_slots.cap) { if ((rc = reserve(ctx, t.p_slots, need_s))) return rc; release(t.p_hdr); }
+        if (!t.p_hdr.p) { if ((rc = reserve(ctx, t.p_hdr, need_h, true))) return rc; }
+    }
+    if (per_g) { if ((rc = reserve(ctx, t.g_tab, (size_t)slots * per_g))) return rc; t.g_bits = g_bits; }
+    t.slots = slots;
+    *got = slots;
+    return SFQ_OK;
+}
+
+void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_bits) {
+    memset(&a, 0, sizeof a);
+    Tables& t = ctx->tab;
+    a.line_off = (const u64*)ctx->line_off.p;
+    a.blocks = (BlockDesc*)ctx->blocks.p;
+    a.nblocks = nblocks;
+    a.arena = (u8*)ctx->arena.p;
+    a.level = level;
+    a.epoch_base = ctx->epoch_base;
+    a.q_slots = (u32*)t.q_slots.p; a.q_hdr = (RowHdr*)t.q_hdr.p; a.q_rows = t.q_rows;
+    a.p_slots = (u32*)t.p_slots.p; a.p_hdr = (RowHdr*)t.p_hdr.p;
+    a.g_tab = (u32*)t.g_tab.p; a.g_bits = g_bits;
+}
+
+// epochs are unique per (context lifetime, block); on wrap the row headers are cleared
+int advance_epoch(sfq_ctx* ctx, u32 nblocks) {
+    if ((u64)ctx->epoch_base + nblocks + 2 >= 0xFFFFFFFFull) {
+        Tables& t = ctx->tab;
+        if (t.q_hdr.p) HIPC(hipMemsetAsync(t.q_hdr.p, 0, t.q_hdr.cap, ctx->st));
+        if (t.p_hdr.p) HIPC(hipMemsetAsync(t.p_hdr.p, 0, t.p_hdr.cap, ctx->st));
+        ctx->epoch_base = 0;
+    }
+    return SFQ_OK;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+}  // namespace
+
+extern "C" {
+
+const char* sfq_stream_name(int s) {
+    static const char* names[SFQ_NSTREAMS] = { "rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq" };
+    return (s >= 0 && s < SFQ_NSTREAMS) ? names[s] : "";
+}
+int sfq_abi_version(void) { return SFQ_ABI_VERSION; }
+
+int sfq_ctx_create(sfq_ctx** out, int hip_device) {
+    if (!out) return SFQ_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SFQ_E_HIP;      // no CPU fallback, by design
+    if (hip_device < 0 || hip_device >= n) return SFQ_E_ARG;
+    if (hipSetDevice(hip_device) != hipSuccess) return SFQ_E_HIP;
+    sfq_ctx* ctx = new sfq_ctx();
+    ctx->dev = hip_device;
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    for (auto& s : ctx->st_aux) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    ctx->dev_total = tot;
+    ctx->table_budget = tot / 3;
+    *out = ctx;
+    return SFQ_OK;
+}
+
+void sfq_ctx_destroy(sfq_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipStreamSynchronize(ctx->st);
+    DevBuf* all[] = { &ctx->tab.q_slots, &ctx->tab.q_hdr, &ctx->tab.p_slots, &ctx->tab.p_hdr, &ctx->tab.g_tab,
+        &ctx->chunk_counts, &ctx->chunk_base, &ctx->scan_tmp, &ctx->line_off, &ctx->status, &ctx->blocks, &ctx->arena,
+        &ctx->blk_stream_off, &ctx->stream_total, &ctx->lens, &ctx->blob_off, &ctx->blob, &ctx->in_stage, &ctx->out_stage,
+        &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
+        &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first };
+    for (DevBuf* b : all) release(*b);
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
+    if (ctx->st) (void)hipStreamDestroy(ctx->st);
+    delete ctx;
+}
+
+const char* sfq_last_error(const sfq_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+int sfq_ctx_set_table_budget(sfq_ctx* ctx, uint64_t bytes) { if (!ctx) return SFQ_E_ARG; ctx->table_budget = bytes; return SFQ_OK; }
+void* sfq_ctx_stream(sfq_ctx* ctx) { return ctx ? (void*)ctx->st : nullptr; }
+int sfq_ctx_synchronize(sfq_ctx* ctx) {
+    if (!ctx) return SFQ_E_ARG;
+    HIPC(hipStreamSynchronize(ctx->st));
+    return SFQ_OK;
+}
+
+uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
+
+// -------------------------------------------------------------------------------------------------
+// compress
+// -------------------------------------------------------------------------------------------------
+static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+                       sfq_result* res, u32 force_models) {
+    if (!ctx || !d_fastq || !pp || !d_out || !res) return fail(ctx, SFQ_E_ARG, "null argument");
+    if (nbytes == 0) return fail(ctx, SFQ_E_FORMAT, "empty input");
+    HIPC(hipSetDevice(ctx->dev));
+    sfq_params p = *pp;
+    p.level = clamp_level(p.level);
+    u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
+    memset(res, 0, sizeof *res);
+    res->abi_version = SFQ_ABI_VERSION;
+    hipStream_t st = ctx->st;
+    int rc;
+
+    // ---- framing -------------------------------------------------------------------------------
+    HIPC(hipEventRecord(ctx->ev[0], st));
+    const u32 nchunks = (u32)((nbytes + FRAME_CHUNK - 1) / FRAME_CHUNK);
+    if ((rc = reserve(ctx, ctx->chunk_counts, (size_t)nchunks * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->chunk_base, ((size_t)nchunks + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nchunks / 1024 + 4) * 8 + 65536))) return rc;
+    if ((rc = reserve(ctx, ctx->status, 256))) return rc;
+    HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
+    launch_count_newlines(d_fastq, nbytes, (u32*)ctx->chunk_counts.p, nchunks, st);
+    launch_scan_u32((const u32*)ctx->chunk_counts.p, (u64*)ctx->chunk_base.p, nchunks, (u64*)ctx->scan_tmp.p, st);
+    u64 nlines = 0; u8 last_byte = 0;
+    HIPC(hipMemcpyAsync(&nlines, (u64*)ctx->chunk_base.p + nchunks, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(&last_byte, d_fastq + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (last_byte != '\n') return fail(ctx, SFQ_E_FORMAT, "fastq file: record seems truncated (no final newline)");   // usrs.cpp:169-172
+    if (nlines == 0 || (nlines & 3)) return fail(ctx, SFQ_E_FORMAT, "fastq file: %llu lines is not a multiple of 4", (unsigned long long)nlines);
+    const u64 nrec = nlines / 4;
+    if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
+    if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
+    launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
+    launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, (u32*)ctx->status.p, st);
+
+    const u32 block_reads = p.block_reads ? p.block_reads : (u32)std::min<u64>(nrec, 0xFFFFFFFFu);
+    const u64 nblocks64 = (nrec + block_reads - 1) / block_reads;
+    if (nblocks64 > (1u << 24)) return fail(ctx, SFQ_E_ARG, "too many blocks (%llu)", (unsigned long long)nblocks64);
+    const u32 nblocks = (u32)nblocks64;
+    // base-model context bits: the level's in single-block mode (reference parity); otherwise capped so a
+    // block's table is not much larger than the block (a block cannot fill more contexts than it has bases)
+    int g_bits = p.gen_bits ? p.gen_bits : level_gen_bits(p.level);
+    if (!p.gen_bits && p.block_reads) {
+        const double bases = (double)block_reads * ((double)nbytes / (double)nrec) * 0.5;
+        int cap = 12;
+        while (cap < 26 && (double)(1u << cap) < bases) cap += 2;
+        g_bits = std::min(g_bits, cap);
+    }
+    if (g_bits < 2 || g_bits > 26 ) return fail(ctx, SFQ_E_ARG, "gen_bits %d out of range", g_bits);
+    if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
+    launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
+    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 7 + (size_t)nblocks * 1024 + 4096))) return rc;
+    u32 h_status = 0;
+    HIPC(hipMemcpyAsync(&h_status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(ctx->ev[1], st));
+    HIPC(hipStreamSynchronize(st));
+    if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
+    if (h_status) return fail(ctx, -(int)h_status, "record over the model path's line limits (usrs.hpp:34-36): oversize side streams are not implemented");
+
+    // ---- models --------------------------------------------------------------------------------
+    const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);       // qlts.hpp:36-40
+    u32 slots = 0;
+    if ((rc = ensure_tables(ctx, nblocks, q_rows, (u32)g_bits, models, &slots))) return rc;
+    if ((rc = advance_epoch(ctx, nblocks))) return rc;
+    ModelArgs a;
+    fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
+    a.fq = d_fastq;
+    // one event pair per model (kernels of one model over all batches are contiguous on the stream)
+    const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
+    for (int m = 0; m < 4; m++) {
+        HIPC(hipEventRecord(ctx->ev[2 + m], st));
+        if (!(models & order[m])) continue;
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+            a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
+            switch (order[m]) {
+            case SFQ_M_QLT: launch_qlt_encode_l(a, st); break;
+            case SFQ_M_GEN:
+                launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, st);   // base2_ranger.hpp:68-71
+                launch_gen_encode_l(a, st); break;
+            case SFQ_M_REC: launch_rec_encode_l(a, st); break;
+            case SFQ_M_USR: launch_usr_encode_l(a, st); break;
+            }
+        }
+    }
+    HIPC(hipEventRecord(ctx->ev[6], st));
+    ctx->epoch_base += nblocks;
+
+    // ---- pack ----------------------------------------------------------------------------------
+    if ((rc = reserve(ctx, ctx->blk_stream_off, (size_t)nblocks * SFQ_NSTREAMS * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->stream_total, 2 * SFQ_NSTREAMS * 8))) return rc;
+    launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, st);
+    // first headers -> blob
+    if ((rc = reserve(ctx, ctx->lens, (size_t)nblocks * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->blob_off, ((size_t)nblocks + 1) * 8))) return rc;
+    const u64 blob_cap = std::min<u64>(nbytes, (u64)nblocks * SFQ_MAX_ID_LLEN);
+    if ((rc = reserve(ctx, ctx->blob, blob_cap))) return rc;
+    launch_first_hdr_lens((const BlockDesc*)ctx->blocks.p, nblocks, (u32*)ctx->lens.p, st);
+    launch_scan_u32((const u32*)ctx->lens.p, (u64*)ctx->blob_off.p, nblocks, (u64*)ctx->scan_tmp.p, st);
+    launch_gather_first_hdrs((const BlockDesc*)ctx->blocks.p, nblocks, d_fastq, (const u64*)ctx->blob_off.p, (u8*)ctx->blob.p, blob_cap, st);
+    u64 totals[SFQ_NSTREAMS];
+    HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, sizeof totals, hipMemcpyDeviceToHost, st));
+    std::vector<BlockDesc> hb(nblocks);
+    HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+    std::vector<u64> hboff((size_t)nblocks + 1);
+    HIPC(hipMemcpyAsync(hboff.data(), ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    u64 bases[SFQ_NSTREAMS], run = 0;
+    for (int s = 0; s < SFQ_NSTREAMS; s++) { bases[s] = run; run += totals[s]; res->stream_bytes[s] = totals[s]; res->stream_offset[s] = bases[s]; }
+    res->total_bytes = run;
+    // per-block status first: an overflowed block has a meaningless size
+    int worst = 0;
+    for (u32 b = 0; b < nblocks; b++) if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
+    if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
+                           -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" : "see status codes");
+    if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
+    HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
+    launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
+                   (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+    HIPC(hipEventRecord(ctx->ev[7], st));
+    ctx->first_hdrs.resize((size_t)hboff[nblocks]);
+    if (hboff[nblocks] > blob_cap) return fail(ctx, SFQ_E_OVERFLOW, "first-header blob overflow");
+    if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+
+    ctx->index.resize(nblocks);
+    for (u32 b = 0; b < nblocks; b++) {
+        sfq_block_info& bi = ctx->index[b];
+        const BlockDesc& d = hb[b];
+        memset(&bi, 0, sizeof bi);
+        bi.first_record = d.rec0; bi.n_records = d.nrec; bi.llen = d.llen;
+        bi.solid = d.solid; bi.two_id = d.two_id; bi.n_byte = (u8)d.n_byte; bi.gen_bits = d.gen_bits;
+        bi.extra_hi = d.extra_hi; bi.first_hdr_len = d.first_hdr_len; bi.first_hdr_off = hboff[b];
+        for (int s = 0; s < SFQ_NSTREAMS; s++) bi.size[s] = d.size[s];
+        bi.status = 0; bi.hdr_bytes = d.hdr_bytes;
+    }
+    res->n_records = nrec; res->n_blocks = nblocks; res->first_hdr_bytes = hboff[nblocks];
+    res->kernel_ms[SFQ_T_FRAME] = ev_ms(ctx->ev[0], ctx->ev[1]);
+    res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
+    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[3], ctx->ev[4]);
+    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[4], ctx->ev[5]);
+    res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[5], ctx->ev[6]);
+    res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[6], ctx->ev[7]);
+    res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[7]);
+    return SFQ_OK;
+}
+
+int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
+                      uint8_t* d_out, uint64_t out_cap, sfq_result* result) {
+    return encode_impl(ctx, d_fastq, nbytes, params, d_out, out_cap, result, 0);
+}
+int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
+                          uint8_t* d_out, uint64_t out_cap, sfq_result* result) {
+    return encode_impl(ctx, d_fastq, nbytes, params, d_out, out_cap, result, SFQ_M_QLT);
+}
+int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
+                           uint8_t* h_out, uint64_t out_cap, sfq_result* result) {
+    if (!ctx || !h_fastq || !h_out) return fail(ctx, SFQ_E_ARG, "null argument");
+    HIPC(hipSetDevice(ctx->dev));
+    int rc;
+    if ((rc = reserve(ctx, ctx->in_stage, (size_t)nbytes + 16))) return rc;
+    const u64 bound = sfq_encode_bound(nbytes);
+    if ((rc = reserve(ctx, ctx->out_stage, (size_t)bound))) return rc;
+    HIPC(hipMemcpyAsync(ctx->in_stage.p, h_fastq, (size_t)nbytes, hipMemcpyHostToDevice, ctx->st));
+    rc = encode_impl(ctx, (const u8*)ctx->in_stage.p, nbytes, params, (u8*)ctx->out_stage.p, bound, result, 0);
+    if (rc) return rc;
+    if (result->total_bytes > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes", (unsigned long long)result->total_bytes);
+    HIPC(hipMemcpyAsync(h_out, ctx->out_stage.p, (size_t)result->total_bytes, hipMemcpyDeviceToHost, ctx->st));
+    HIPC(hipStreamSynchronize(ctx->st));
+    return SFQ_OK;
+}
+
+int sfq_get_block_index(sfq_ctx* ctx, sfq_block_info* h_blocks, uint32_t cap) {
+    if (!ctx || !h_blocks) return SFQ_E_ARG;
+    if (cap < ctx->index.size()) return fail(ctx, SFQ_E_ARG, "index has %zu blocks", ctx->index.size());
+    if (!ctx->index.empty()) memcpy(h_blocks, ctx->index.data(), ctx->index.size() * sizeof(sfq_block_info));
+    return (int)ctx->index.size();
+}
+int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
+    if (!ctx || !h_blob) return SFQ_E_ARG;
+    if (cap < ctx->first_hdrs.size()) return fail(ctx, SFQ_E_ARG, "blob has %zu bytes", ctx->first_hdrs.size());
+    if (!ctx->first_hdrs.empty()) memcpy(h_blob, ctx->first_hdrs.data(), ctx->first_hdrs.size());
+    return SFQ_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// decompress
+// -------------------------------------------------------------------------------------------------
+int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* h_blocks, uint32_t nblocks,
+                      const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                      const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
+                      uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* res) {
+    if (!ctx || !pp || !h_blocks || !nblocks || !d_streams || !stream_offset || !d_out || !out_bytes)
+        return fail(ctx, SFQ_E_ARG, "null argument");
+    HIPC(hipSetDevice(ctx->dev));
+    sfq_params p = *pp;
+    p.level = clamp_level(p.level);
+    const u32 version = p.version ? p.version : 6;
+    if (version > 6) return fail(ctx, SFQ_E_UNSUPPORTED, "archive version %u is newer than 6 (config.cpp:373-377)", version);
+    hipStream_t st = ctx->st;
+    int rc;
+    sfq_result local; if (!res) res = &local;
+    memset(res, 0, sizeof *res);
+    res->abi_version = SFQ_ABI_VERSION;
+    HIPC(hipEventRecord(ctx->ev[0], st));
+
+    // device block descriptors + per-block stream offsets
+    std::vector<BlockDesc> hb(nblocks);
+    std::vector<u64> bso((size_t)nblocks * SFQ_NSTREAMS);
+    u64 run[SFQ_NSTREAMS];
+    for (int s = 0; s < SFQ_NSTREAMS; s++) run[s] = stream_offset[s];
+    u64 nrec = 0; u32 block_reads = h_blocks[0].n_records; int g_bits = 0;
+    for (u32 b = 0; b < nblocks; b++) {
+        const sfq_block_info& bi = h_blocks[b];
+        BlockDesc& d = hb[b];
+        memset(&d, 0, sizeof d);
+        if (bi.first_record != nrec) return fail(ctx, SFQ_E_ARG, "block %u: first_record %llu, expected %llu", b, (unsigned long long)bi.first_record, (unsigned long long)nrec);
+        if (b + 1 < nblocks && bi.n_records != block_reads) return fail(ctx, SFQ_E_ARG, "block %u: non-uniform block size", b);
+        if (bi.n_records == 0 || (b + 1 == nblocks && bi.n_records > block_reads)) return fail(ctx, SFQ_E_ARG, "block %u: bad record count", b);
+        if (bi.first_hdr_off + bi.first_hdr_len > first_hdr_bytes) return fail(ctx, SFQ_E_ARG, "block %u: first header outside the blob", b);
+        if (bi.gen_bits < 2 || bi.gen_bits > 26) return fail(ctx, SFQ_E_ARG, "block %u: gen_bits %u", b, bi.gen_bits);
+        d.rec0 = nrec; d.nrec = bi.n_records; d.llen = bi.llen; d.solid = bi.solid; d.two_id = bi.two_id;
+        d.gen_bits = bi.gen_bits; d.n_byte = bi.n_byte; d.first_hdr_off = bi.first_hdr_off; d.first_hdr_len = bi.first_hdr_len;
+        g_bits = std::max<int>(g_bits, bi.gen_bits);
+        for (int s = 0; s < SFQ_NSTREAMS; s++) { d.size[s] = bi.size[s]; bso[(size_t)b * SFQ_NSTREAMS + s] = run[s]; run[s] += bi.size[s]; }
+        nrec += bi.n_records;
+    }
+    if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
+    if ((rc = reserve(ctx, ctx->blk_stream_off, bso.size() * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->d_first, (size_t)first_hdr_bytes + 16))) return rc;
+    HIPC(hipMemcpyAsync(ctx->blocks.p, hb.data(), (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->blk_stream_off.p, bso.data(), bso.size() * 8, hipMemcpyHostToDevice, st));
+    if (first_hdr_bytes) HIPC(hipMemcpyAsync(ctx->d_first.p, h_first_hdrs, (size_t)first_hdr_bytes, hipMemcpyHostToDevice, st));
+
+    const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);
+    u32 slots = 0;
+    if ((rc = ensure_tables(ctx, nblocks, q_rows, (u32)g_bits, SFQ_M_ALL, &slots))) return rc;
+    if ((rc = advance_epoch(ctx, nblocks))) return rc;
+
+    if ((rc = reserve(ctx, ctx->slen, (size_t)nrec * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->qlen, (size_t)nrec * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->pfg, (size_t)nrec))) return rc;
+    if ((rc = reserve(ctx, ctx->pfq, (size_t)nrec))) return rc;
+    if ((rc = reserve(ctx, ctx->soff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->qoff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->hlen, (size_t)nrec * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->hoff, (size_t)nrec * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->rsize, (size_t)nrec * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->roff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
+
+    DecodeArgs da;
+    memset(&da, 0, sizeof da);
+    fill_model_args(ctx, da.m, nblocks, p.level, (u32)g_bits);
+    da.streams = d_streams;
+    da.blk_stream_off = (const u64*)ctx->blk_stream_off.p;
+    da.first_hdrs = (const u8*)ctx->d_first.p;
+    da.slen = (u32*)ctx->slen.p; da.qlen = (u32*)ctx->qlen.p; da.pfg = (u8*)ctx->pfg.p; da.pfq = (u8*)ctx->pfq.p;
+    da.soff = (const u64*)ctx->soff.p; da.qoff = (const u64*)ctx->qoff.p;
+    da.hlen = (u32*)ctx->hlen.p; da.hoff = (u64*)ctx->hoff.p;
+    da.block_reads = block_reads; da.version = version;
+
+    // 1. framing exceptions -> per-record line lengths
+    for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_usr_decode_l(da, st); }
+    launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+    launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+    u64 tot_s = 0, tot_q = 0;
+    HIPC(hipMemcpyAsync(&tot_s, (u64*)ctx->soff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(&tot_q, (u64*)ctx->qoff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(ctx->ev[1], st));
+    HIPC(hipStreamSynchronize(st));
+    if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 16))) return rc;
+    if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
+    da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
+
+    // 2. quality, then bases (the N rule reads the decoded qualities)
+    HIPC(hipEventRecord(ctx->ev[2], st));
+    for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
+    HIPC(hipEventRecord(ctx->ev[3], st));
+    for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+        da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
+        launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st);
+        launch_gen_decode_l(da, st);
+    }
+    HIPC(hipEventRecord(ctx->ev[4], st));
+
+    // 3. headers; the staging size comes from the index when known, else grows on overflow
+    std::vector<u64> hso((size_t)nblocks + 1);
+    std::vector<u32> hsc(nblocks);
+    if ((rc = reserve(ctx, ctx->hso, ((size_t)nblocks + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->hsc, (size_t)nblocks * 4))) return rc;
+    for (int attempt = 0; ; attempt++) {
+        u64 o = 0;
+        for (u32 b = 0; b < nblocks; b++) {
+            const sfq_block_info& bi = h_blocks[b];
+            u64 cap = bi.hdr_bytes ? (u64)bi.hdr_bytes + bi.n_records + SFQ_MAX_ID_LLEN + 64
+                                   : ((u64)bi.n_records * 96 << attempt) + 2 * SFQ_MAX_ID_LLEN + 64;
+            if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+            hso[b] = o; hsc[b] = (u32)cap; o += (cap + 15) & ~15ull;
+        }
+        hso[nblocks] = o;
+        if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
+        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nblocks + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st));
+        HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st));
+        da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
+        if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; ctx->epoch_base += nblocks; da.m.epoch_base = ctx->epoch_base; }
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st); }
+        HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        bool overflow = false; int worst = 0;
+        for (u32 b = 0; b < nblocks; b++) {
+            if (hb[b].status == (u32)(-SFQ_E_OVERFLOW) && !h_blocks[b].hdr_bytes) overflow = true;
+            else if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
+        }
+        if (worst) return fail(ctx, -worst, "decode: block kernel reported error %d (corrupt or truncated stream)", -worst);
+        if (!overflow) break;
+        if (attempt >= 8) return fail(ctx, SFQ_E_OVERFLOW, "decode: header staging overflow");
+        for (u32 b = 0; b < nblocks; b++) hb[b].status = 0;
+        HIPC(hipMemcpyAsync(ctx->blocks.p, hb.data(), (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
+    }
+    ctx->epoch_base += nblocks;
+    HIPC(hipEventRecord(ctx->ev[5], st));
+
+    // 4. lay the records out
+    launch_record_sizes(da, nrec, (u32*)ctx->rsize.p, st);
+    launch_scan_u32((const u32*)ctx->rsize.p, (u64*)ctx->roff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+    u64 total = 0;
+    HIPC(hipMemcpyAsync(&total, (u64*)ctx->roff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    *out_bytes = total;
+    if (total > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "decoded text needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)out_cap);
+    launch_assemble(da, nrec, (const u64*)ctx->roff.p, d_out, st);
+    HIPC(hipEventRecord(ctx->ev[6], st));
+    HIPC(hipStreamSynchronize(st));
+    res->n_records = nrec; res->n_blocks = nblocks; res->total_bytes = total;
+    res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[0], ctx->ev[1]);
+    res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
+    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[3], ctx->ev[4]);
+    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[4], ctx->ev[5]);
+    res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[5], ctx->ev[6]);
+    res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[6]);
+    return SFQ_OK;
+}
+
+int sfq_decode_blocks_host(sfq_ctx* ctx, const sfq_params* params, const sfq_block_info* h_blocks, uint32_t n_blocks,
+                           const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                           const uint8_t* h_streams, uint64_t streams_bytes, const uint64_t stream_offset[SFQ_NSTREAMS],
+                           uint8_t* h_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* result) {
+    if (!ctx || !h_streams || !h_out) return fail(ctx, SFQ_E_ARG, "null argument");
+    HIPC(hipSetDevice(ctx->dev));
+    int rc;
+    if ((rc = reserve(ctx, ctx->in_stage, (size_t)streams_bytes + 16))) return rc;
+    if ((rc = reserve(ctx, ctx->out_stage, (size_t)out_cap + 16))) return rc;
+    HIPC(hipMemcpyAsync(ctx->in_stage.p, h_streams, (size_t)streams_bytes, hipMemcpyHostToDevice, ctx->st));
+    rc = sfq_decode_blocks(ctx, params, h_blocks, n_blocks, h_first_hdrs, first_hdr_bytes, (const u8*)ctx->in_stage.p,
+                           stream_offset, (u8*)ctx->out_stage.p, out_cap, out_bytes, result);
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(h_out, ctx->out_stage.p, (size_t)*out_bytes, hipMemcpyDeviceToHost, ctx->st));
+    HIPC(hipStreamSynchronize(ctx->st));
+    return SFQ_OK;
+}
+
+}  // extern "C"

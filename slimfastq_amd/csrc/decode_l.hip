@@ -1,0 +1,362 @@
+// decode_l.hip -- lane-per-block decode kernels + FASTQ re-assembly.
+//
+// Decoding is serial per chain by nature (the next context needs the previous symbol), so one lane
+// owns one block's chain, as in models_l.hip.  The reference interleaves rec.load / qlt.load /
+// gen.load per record (usrs.cpp:555-571); here the chains are independent kernels that write staging
+// buffers, and a last streaming kernel lays the 4-line records out (UsrLoad::save, usrs.cpp:512-535).
+// Order on the stream: usr (line lengths) -> scans -> qlt -> gen (needs the qualities: gens.cpp:200-213)
+// and rec, -> record sizes -> scan -> assemble.
+#include "kernels.h"
+#include "dev_models.h"
+
+#define LAST_QLT 63u
+
+struct DSlot {
+    u32 b, epoch;
+    u32* q_slots; RowHdr* q_hdr;
+    PwTab pw;
+    u32* g_tab;
+};
+__device__ __forceinline__ bool dslot_init(const ModelArgs& a, DSlot& s) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nbatch) return false;
+    s.b = a.batch0 + t;
+    s.epoch = a.epoch_base + s.b + 1;
+    s.q_slots = a.q_slots ? a.q_slots + (size_t)t * a.q_rows * L64_NSYM : nullptr;
+    s.q_hdr   = a.q_hdr ? a.q_hdr + (size_t)t * a.q_rows : nullptr;
+    s.pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM;
+    s.pw.hdr   = a.p_hdr + (size_t)t * PR_ROWS;
+    s.pw.epoch = s.epoch;
+    s.g_tab = a.g_tab ? a.g_tab + ((size_t)t << a.g_bits) : nullptr;
+    return true;
+}
+__device__ __forceinline__ void dset_status(BlockDesc* d, int code) { atomicMax(&d->status, (u32)(-code)); }
+__device__ __forceinline__ ByteSrc stream_src(const DecodeArgs& a, const BlockDesc* d, u32 b, int s) {
+    ByteSrc r; r.p = a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + s]; r.pos = 0; r.n = d->size[s];
+    return r;
+}
+__device__ __forceinline__ u32 calc_last_delta_d(u32& delta, u32 q, u32 q1, u32 q2) {   // qlts.hpp:62-74
+    if (q1 > q) delta += q1 - q;
+    u32 d3 = delta >> 3;
+    return (q | ((q1 < q2 ? q2 : q1) << 6) | ((u32)(q1 == q2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+}
+
+// ---- UsrLoad::update (usrs.cpp:471-510): per-record line lengths and SOLiD prefixes ----------------
+__global__ __launch_bounds__(64) void k_usr_decode_l(DecodeArgs a) {
+    DSlot sl;
+    if (!dslot_init(a.m, sl)) return;
+    BlockDesc* d = &a.m.blocks[sl.b];
+    XfDec x_llen, x_qlen, x_sgen, x_sqlt;
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_USR_X);   x_llen.init(s.p, s.n, XF_USR_X); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_USR_XQ);  x_qlen.init(s.p, s.n, XF_USR_XQ); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_USR_PFG); x_sgen.init(s.p, s.n, XF_USR_PFG); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_USR_PFQ); x_sqlt.init(s.p, s.n, XF_USR_PFQ); }
+    u64 i_llen = x_llen.get(sl.pw), i_qlen = x_qlen.get(sl.pw), i_sgen = x_sgen.get(sl.pw), i_sqlt = x_sqlt.get(sl.pw);
+    const u32 solid = d->solid;
+    u32 llen = d->llen, qlen = llen, pfg = 0, pfq = 0, bad = 0;
+    for (u32 k = 0; k < d->nrec; k++) {
+        const u64 r = d->rec0 + k, rcnt = (u64)k + 1;
+        if (i_llen == rcnt) { llen = (u32)x_llen.get(sl.pw); qlen = llen; i_llen += x_llen.get(sl.pw); }
+        if (i_qlen == rcnt) { qlen = (u32)x_qlen.get(sl.pw); i_qlen += x_qlen.get(sl.pw); }
+        else if (qlen != llen) qlen = llen;
+        if (solid && i_sgen == rcnt) { pfg = x_sgen.get_chr(sl.pw); i_sgen += x_sgen.get(sl.pw); }
+        if (solid && i_sqlt == rcnt) { pfq = x_sqlt.get_chr(sl.pw); i_sqlt += x_sqlt.get(sl.pw); }
+        if (llen > 0xffff || qlen > 0xffff) { bad = 1; llen = qlen = 0; }
+        a.slen[r] = llen; a.qlen[r] = qlen; a.pfg[r] = (u8)pfg; a.pfq[r] = (u8)pfq;
+    }
+    if (bad | x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) dset_status(d, SFQ_E_CORRUPT);
+}
+void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_usr_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ---- QltLoad::load_1/2/3 (qlts.cpp:163-234) ------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
+    DSlot sl;
+    if (!dslot_init(a.m, sl)) return;
+    BlockDesc* d = &a.m.blocks[sl.b];
+    ByteSrc src = stream_src(a, d, sl.b, SFQ_S_QLT);
+    RcDec rc; rc.init(src);
+    const int level = a.m.level;
+    for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
+        const u32 n = a.qlen[r];
+        u8* p = a.qual_stage + a.qoff[r];
+        u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
+        for (u32 i = 0; i < n; i++) {
+            u32 b = Log64::get(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch, rc, src);
+            if (b == LAST_QLT) b = sl.pw.get(PR_EXQ_ROW, rc, src);                          // qlts.cpp:168-171
+            p[i] = (u8)('!' + b);
+            if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
+            else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
+            else if (++di & 1) { last = calc_last_delta_d(delta, b, q1, q2); q2 = b; }
+            else               { last = calc_last_delta_d(delta, b, q2, q1); q1 = b; }
+        }
+    }
+    if (rc.err) dset_status(d, SFQ_E_CORRUPT);
+}
+void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ---- GenLoad::load_x + normalize_gen (gens.cpp:200-249) ---------------------------------------------------
+__global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
+    DSlot sl;
+    if (!dslot_init(a.m, sl)) return;
+    BlockDesc* d = &a.m.blocks[sl.b];
+    ByteSrc src = stream_src(a, d, sl.b, SFQ_S_GEN);
+    RcDec rc; rc.init(src);
+    XfDec x_ns, x_nn;
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NS); x_ns.init(s.p, s.n, XF_GEN_NS); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NN); x_nn.init(s.p, s.n, XF_GEN_NN); }
+    u64 ns_index = x_ns.get(sl.pw), nn_index = x_nn.get(sl.pw);                             // gens.cpp:187-188
+    const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
+    const u32 code = d->solid ? 0x33323130u /* "0123" */ : 0x54474341u /* "ACGT" */;        // gens.cpp:173-178
+    const u32 mask = (1u << d->gen_bits) - 1u;
+    u64 genofs = 0;
+    for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
+        const u32 llen = a.slen[r], qlen = a.qlen[r];
+        u8* g = a.seq_stage + a.soff[r];
+        const u8* q = a.qual_stage + a.qoff[r];
+        u32 last = 0x007616c7u;
+        for (u32 i = 0; i < llen; i++) {
+            last &= mask;
+            u32 b;
+            sl.g_tab[last] = b2_get(sl.g_tab[last], rc, src, b);
+            u32 ch = (code >> (8 * b)) & 0xff;
+            last = (last << 2) + b;
+            const u32 qc = i < qlen ? q[i] : 40u;
+            genofs++;                                                                       // normalize_gen gens.cpp:200-213
+            if (nn_index == genofs) nn_index += x_nn.get(sl.pw);
+            else if (qc == '!') ch = n_byte;
+            else if (ns_index == genofs) { ch = n_byte; ns_index += x_ns.get(sl.pw); }
+            g[i] = (u8)ch;
+        }
+    }
+    if (rc.err | x_ns.rc.err | x_nn.rc.err) dset_status(d, SFQ_E_CORRUPT);
+}
+void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ---- RecLoad::load (recs.cpp:374-461) ----------------------------------------------------------------------
+enum {
+    ST_DGT = 0, ST_DLT = 1, ST_STR = 2, ST_HGT = 3, ST_HLT = 4, ST_HGT_Z = 5, ST_HLT_Z = 6,
+    ST_HGTC = 7, ST_HLTC = 8, ST_HGTC_Z = 9, ST_HLTC_Z = 10, ST_DGT_Z = 11, ST_DLT_Z = 12
+};
+struct DSpaceMap { u16 off[66]; u16 wln[66]; u8 str[66]; u32 len; };
+__device__ __forceinline__ bool d_isword(u32 c) { return (c - '0' < 10u) || ((c | 0x20) - 'a' < 26u); }
+__device__ bool d_map_space(const u8* p, u32 n, DSpaceMap& m) {       // recs.cpp:141-157
+    m.len = 0; m.off[0] = 0;
+    for (u32 i = 0; ; i++) {
+        u32 c = i < n ? p[i] : '\n';
+        if (!d_isword(c)) {
+            m.wln[m.len] = (u16)(i - m.off[m.len]);
+            m.str[m.len++] = (u8)c;
+            m.off[m.len] = (u16)(i + 1);
+            if (i >= n || c == 0) break;
+            if (m.len > 64) return false;
+        }
+    }
+    return m.len <= 64;
+}
+// sprintf("%lld" / "%llx" / "%llX") of a non-zero value (recs.cpp:453-456)
+__device__ u32 fmt_dec(u8* b, u64 val) {
+    u32 n = 0;
+    i64 sv = (i64)val;
+    u64 mag = sv < 0 ? (u64)0 - val : val;
+    if (sv < 0) b[n++] = '-';
+    u8 tmp[20]; u32 k = 0;
+    while (mag) { tmp[k++] = (u8)('0' + mag % 10); mag /= 10; }
+    while (k) b[n++] = tmp[--k];
+    return n;
+}
+__device__ u32 fmt_hex(u8* b, u64 val, bool upper) {
+    u32 n = 0; int sh = 60;
+    while (sh > 0 && ((val >> sh) & 0xf) == 0) sh -= 4;
+    for (; sh >= 0; sh -= 4) {
+        u32 d = (u32)(val >> sh) & 0xf;
+        b[n++] = (u8)(d < 10 ? '0' + d : (upper ? 'A' : 'a') + d - 10);
+    }
+    return n;
+}
+__device__ bool d_is_number(const u8* p, int len, i64& num) {          // recs.cpp:265-275
+    if (*p == '0') return false;
+    num = 0;
+    for (int i = 0; i < len; i++) {
+        if (p[i] - '0' < 10u) num = (num << 3) + (num << 1) + p[i] - '0';
+        else return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_rec_decode_l(DecodeArgs a) {
+    DSlot sl;
+    if (!dslot_init(a.m, sl)) return;
+    BlockDesc* d = &a.m.blocks[sl.b];
+    ByteSrc src = stream_src(a, d, sl.b, SFQ_S_REC);
+    RcDec rc; rc.init(src);
+    XfDec x_rec;
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_REC_X); x_rec.init(s.p, s.n, XF_REC_X); }
+    u64 index = x_rec.get(sl.pw);                                                           // recs.cpp:104
+    u8* const stage = a.hdr_stage + a.hdr_stage_off[sl.b];
+    const u64 cap = a.hdr_stage_cap[sl.b];
+    u64 pos = 0;            // write cursor in stage
+    DSpaceMap sm;
+    u8  ctype[2][66];
+    u64 cnumb[2][66];
+    u32 imap = 0;
+    int bad = 0;
+    const u8* prev = nullptr; u32 prev_n = 0;
+    for (u32 k = 0; k < d->nrec; k++) {
+        const u64 r = d->rec0 + k, rcnt = (u64)k + 1;
+        // worst case for one header: every field regenerated at its longest (MAX_ID_LLEN) -> bounded check
+        if (pos + SFQ_MAX_ID_LLEN + 2 > cap) { bad = SFQ_E_OVERFLOW; break; }
+        u8* buf = stage + pos;
+        u32 n = 0;
+        if (k == 0) {                                                                       // load_first_line recs.cpp:113-119
+            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+            imap = 0;
+            n = d->first_hdr_len;
+            const u8* f = a.first_hdrs + d->first_hdr_off;
+            for (u32 i = 0; i < n; i++) buf[i] = f[i];
+        } else {
+            const u32 pmap = imap;
+            imap ^= 1;
+            if (index == rcnt) {                                                            // recs.cpp:386-393
+                u64 len = x_rec.get(sl.pw);
+                if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
+                for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)x_rec.get_chr(sl.pw);
+                n = (u32)len;
+                index += x_rec.get(sl.pw);
+                for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            } else {
+                if (!d_map_space(prev, prev_n, sm)) { bad = SFQ_E_CORRUPT; break; }
+                const u64 map = sl.pw.get_u(0 * 16 + 2, rc, src);
+                u8* b = buf;
+                for (u32 i = 0; i < sm.len; i++) {
+                    if ((u64)(b - buf) + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
+                    const u32 rr = (i + 1) * 16;
+                    if (a.version >= 5) {                                                   // recs.cpp:403-459
+                        if (!(map & (1ULL << i))) {
+                            const u8* pp = prev + sm.off[i];
+                            for (u32 j = 0; j < sm.wln[i]; j++) b[j] = pp[j];
+                            b += sm.wln[i];
+                            *b++ = sm.str[i];
+                            ctype[imap][i] = ctype[pmap][i];
+                            cnumb[imap][i] = cnumb[pmap][i];
+                            continue;
+                        }
+                        const u32 type = sl.pw.get(rr + 0, rc, src);
+                        if (type == ST_STR) {
+                            u64 len = sl.pw.get_u(rr + 2, rc, src);
+                            if (len > SFQ_MAX_ID_LLEN || (u64)(b - buf) + len + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
+                            for (u32 j = 0; j < (u32)len; j++) b[j] = (u8)sl.pw.get(rr + 1, rc, src);
+                            b += len;
+                            ctype[imap][i] = 0;
+                            *b++ = sm.str[i];
+                            continue;
+                        }
+                        const u64 pval = ctype[pmap][i] == 0 ? 0 : cnumb[pmap][i];
+                        const u64 gap = sl.pw.get_u(rr + 2, rc, src);
+                        if (type > ST_DLT_Z) { bad = SFQ_E_CORRUPT; break; }
+                        const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC ||
+                                          type == ST_HLTC_Z || type == ST_DLT_Z;
+                        const u64 val = less ? pval - gap : pval + gap;
+                        const bool deci = type < ST_STR || type >= ST_DGT_Z;
+                        const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z ||
+                                          type == ST_DGT_Z || type == ST_DLT_Z;
+                        const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
+                        ctype[imap][i] = deci ? 1 : 2;
+                        cnumb[imap][i] = val;
+                        if (val == 0) *b++ = '0';                                            // recs.cpp:453-454
+                        else {
+                            if (lead) *b++ = '0';
+                            b += deci ? fmt_dec(b, val) : fmt_hex(b, val, upper);
+                        }
+                        *b++ = sm.str[i];
+                    } else {                                                                // load_pre5 recs.cpp:463-510
+                        if (map & (1ULL << i)) {
+                            const u32 type = sl.pw.get(rr + 0, rc, src);
+                            if (type == ST_DGT || type == ST_DLT) {
+                                i64 pval = 0;
+                                d_is_number(prev + sm.off[i], sm.wln[i], pval);
+                                const i64 gap = (i64)sl.pw.get_u(rr + 2, rc, src);
+                                const i64 val = type == ST_DGT ? pval + gap : pval - gap;
+                                if (val == 0) *b++ = '0'; else b += fmt_dec(b, (u64)val);
+                            } else if (type == ST_STR) {
+                                u64 len = sl.pw.get_u(rr + 2, rc, src);
+                                if (len > SFQ_MAX_ID_LLEN || (u64)(b - buf) + len + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
+                                for (u32 j = 0; j < (u32)len; j++) b[j] = (u8)sl.pw.get(rr + 1, rc, src);
+                                b += len;
+                            } else { bad = SFQ_E_CORRUPT; break; }
+                        } else {
+                            const u8* pp = prev + sm.off[i];
+                            for (u32 j = 0; j < sm.wln[i]; j++) b[j] = pp[j];
+                            b += sm.wln[i];
+                        }
+                        *b++ = sm.str[i];
+                    }
+                }
+                if (bad) break;
+                n = (u32)(b - buf) - 1;                                                     // recs.cpp:460
+            }
+        }
+        buf[n] = '\n';
+        a.hlen[r] = n; a.hoff[r] = a.hdr_stage_off[sl.b] + pos;
+        prev = buf; prev_n = n;
+        pos += (u64)n + 1;
+        if (rc.err | x_rec.rc.err) { bad = SFQ_E_CORRUPT; break; }
+    }
+    if (bad) {
+        dset_status(d, bad);
+        // leave the remaining records empty so the assembly stays in bounds
+        for (u32 k = 0; k < d->nrec; k++) { const u64 r = d->rec0 + k; if (a.hoff[r] == ~0ULL) { a.hlen[r] = 0; a.hoff[r] = a.hdr_stage_off[sl.b]; } }
+    }
+}
+void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+void launch_gen_fixup(const DecodeArgs&, u64, hipStream_t) {}
+
+// ---- UsrLoad::save (usrs.cpp:512-535): '@'hdr \n [pf]bases \n '+'[hdr] \n [pf]quals \n --------------------
+__global__ __launch_bounds__(256) void k_record_sizes(DecodeArgs a, u64 nrec, u32* rsize) {
+    u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const BlockDesc* d = &a.m.blocks[a.block_reads ? r / a.block_reads : 0];
+    const u32 h = a.hlen[r], s = d->solid;
+    rsize[r] = 1 + h + 1 + s + a.slen[r] + 1 + 1 + (d->two_id ? h : 0) + 1 + s + a.qlen[r] + 1;
+}
+void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st) {
+    hipLaunchKernelGGL(k_record_sizes, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, a, nrec, rsize);
+}
+__device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 n, u32 lane) {
+    for (u32 i = lane; i < n; i += 64) dst[i] = src[i];
+}
+// one wave per record; 4 records per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const u64* roff, u8* out) {
+    const u32 lane = threadIdx.x & 63;
+    u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrec) return;
+    const BlockDesc* d = &a.m.blocks[a.block_reads ? r / a.block_reads : 0];
+    const u32 h = a.hlen[r], s = d->solid, sl = a.slen[r], ql = a.qlen[r];
+    const u8* hp = a.hdr_stage + a.hoff[r];
+    u8* o = out + roff[r];
+    if (lane == 0) o[0] = '@';
+    wave_copy(o + 1, hp, h, lane);
+    o += 1 + h;
+    if (lane == 0) { o[0] = '\n'; if (s) o[1] = a.pfg[r]; }
+    o += 1 + s;
+    wave_copy(o, a.seq_stage + a.soff[r], sl, lane);
+    o += sl;
+    if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
+    o += 2;
+    if (d->two_id) { wave_copy(o, hp, h, lane); o += h; }
+    if (lane == 0) { o[0] = '\n'; if (s) o[1] = a.pfq[r]; }
+    o += 1 + s;
+    wave_copy(o, a.qual_stage + a.qoff[r], ql, lane);
+    o += ql;
+    if (lane == 0) o[0] = '\n';
+}
+void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_assemble, dim3((u32)((nrec + 3) / 4)), dim3(256), 0, st, a, nrec, roff, out);
+}

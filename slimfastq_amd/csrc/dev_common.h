@@ -1,0 +1,64 @@
+// dev_common.h -- types shared by the host side of the C ABI and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+#include "../../include/slimfastq_amd.h"
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t  i32;
+typedef int64_t  i64;
+
+// Limits of the reference's model path (usrs.hpp:34-36): longer lines go through its raw "oversize"
+// side streams, which the block kernels do not implement (SFQ_E_UNSUPPORTED).
+#define SFQ_MAX_ID_LLEN 0x2000
+#define SFQ_MAX_GN_LLEN 0x10000
+
+// ---- adaptive-table rows in HBM ---------------------------------------------------------------
+// A ranger row is kept as 64 (Log64Ranger) or 256 (PowerRanger) dword slots, slot = freq | sym<<16,
+// i.e. the reference's parallel arrays freq[]/syms[] (log64_ranger.hpp:45-49, power_ranger.hpp:43-48)
+// interleaved so one coalesced dword-per-lane load fetches a whole Log64 row.  The scalar members
+// (total, iend, count) live in a 16-byte header next to an epoch tag: a row whose epoch differs from
+// the running block's epoch is "fresh" (the all-zero state of a new reference process), so tables are
+// reused from block to block without clearing.
+struct RowHdr {
+    u32 total;
+    u16 iend;
+    u8  count;
+    u8  pad;
+    u32 epoch;
+    u32 pad2;
+};
+
+#define L64_NSYM 64
+#define PW_NSYM  256
+
+// PowerRanger rows of one block slot.  Header model: ranger_t ranger[66] = {type, str, num[14]}
+// (recs.hpp:42-48) -> row = field*16 + {0 type, 1 str, 2+k num.p[k]}.  Each XFile: 14 PowerRangerU
+// rows + 1 string row (xfile.hpp:44-46) -> 16 rows.  Plus the quality escape row (qlts.hpp:45).
+#define PR_REC_ROWS   (66 * 16)
+#define PR_XF_BASE    PR_REC_ROWS
+#define PR_XF_ROWS    16
+#define PR_XF_COUNT   8          // gen.Ns gen.Nn rec.x usr.x usr.x.q usr.pfg usr.pfq (+1 spare)
+#define PR_EXQ_ROW    (PR_XF_BASE + PR_XF_ROWS * PR_XF_COUNT)
+#define PR_ROWS       (PR_EXQ_ROW + 8)   // padded
+
+enum { XF_GEN_NS = 0, XF_GEN_NN = 1, XF_REC_X = 2, XF_USR_X = 3, XF_USR_XQ = 4, XF_USR_PFG = 5, XF_USR_PFQ = 6 };
+
+// ---- per-block descriptor (device) ---------------------------------------------------------------
+struct BlockDesc {
+    u64 rec0;           // first record (global index)
+    u32 nrec;
+    u32 llen;           // usrs.cpp:265 (after the solid adjustment)
+    u8  solid, two_id, gen_bits, pad;
+    u32 status;         // 0 or SFQ_E_* (positive)
+    u64 first_hdr_off;  // into the FASTQ buffer (text after '@')
+    u32 first_hdr_len;
+    u32 n_byte;         // gens.cpp:100-105
+    u32 extra_hi;       // qlts.cpp:57-61
+    u32 size[SFQ_NSTREAMS];
+    u64 out_off[SFQ_NSTREAMS];  // where the block's stream lives in the scratch arena
+    u32 out_cap[SFQ_NSTREAMS];
+    u32 hdr_bytes;      // sum of header lengths in the block
+};

@@ -1,0 +1,211 @@
+// dev_models.h -- the adaptive frequency tables ("rangers") as lane-serial device code:
+//   Base2Ranger  (base2_ranger.hpp)   4 symbols, 4 x u8 counts in one dword
+//   Log64Ranger  (log64_ranger.hpp)   64 symbols, STEP 6
+//   PowerRanger / PowerRangerU (power_ranger.hpp) 256 symbols, STEP 14, varint wrapper
+// Rows live in HBM as dword slots (freq | sym << 16) + a RowHdr; see dev_common.h.
+#pragma once
+#include "dev_coder.h"
+
+// ---------------------------------------------------------------------------------------------------
+// Base2Ranger.  Row = freq[0..3] in the four bytes of a dword, initial 0x03030303 (base2_ranger.hpp:68-71).
+// ---------------------------------------------------------------------------------------------------
+#define B2_INIT 0x03030303u
+
+__device__ __forceinline__ u32 b2_update(u32 v, u32 sym) {       // base2_ranger.hpp:60-66, normalize 48-53
+    u32 f = (v >> (8 * sym)) & 0xff;
+    if (f > 254) v = ((v & ~0x01010101u) >> 1) | (v & 0x01010101u);
+    return v + (1u << (8 * sym));
+}
+__device__ __forceinline__ u32 b2_put(u32 v, RcEnc& rc, ByteSink& s, u32 sym) {   // base2_ranger.hpp:74-84
+    u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+    u32 total = (f0 + f1) + (f2 + f3);
+    u32 cum = sym == 0 ? 0u : sym == 1 ? f0 : sym == 2 ? f0 + f1 : f0 + f1 + f2;
+    u32 f = (v >> (8 * sym)) & 0xff;
+    rc.encode(s, cum, f, total);
+    return b2_update(v, sym);
+}
+__device__ __forceinline__ u32 b2_get(u32 v, RcDec& rc, ByteSrc& s, u32& sym_out) {   // base2_ranger.hpp:86-104
+    u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+    u32 total = (f0 + f1) + (f2 + f3);
+    u32 prob = rc.get_freq(total);
+    u32 sym, cum, f;
+    if (f0 > prob)                { sym = 0; cum = 0;            f = f0; }
+    else if (f0 + f1 > prob)      { sym = 1; cum = f0;           f = f1; }
+    else if (f0 + f1 + f2 > prob) { sym = 2; cum = f0 + f1;      f = f2; }
+    else                          { sym = 3; cum = f0 + f1 + f2; f = f3; if (prob >= total) rc.err = 1; }  // reference: assert(i<4)
+    rc.decode(s, cum, f);
+    sym_out = sym;
+    return b2_update(v, sym);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Log64Ranger / PowerRanger share one scheme (log64_ranger.hpp:51-138, power_ranger.hpp:49-131);
+// they differ in NSYM / STEP / MAX_FREQ and in the saturation slack (20 vs 256).
+// ---------------------------------------------------------------------------------------------------
+template <int NSYM, int STEP, int MAXF, int SAT>
+struct Ranger {
+    // open a row: a stale epoch means the all-zero state of a fresh table
+    static __device__ __forceinline__ void open(const RowHdr* hp, u32 epoch, u32& total, u32& iend, u32& count) {
+        RowHdr h = *hp;
+        if (h.epoch == epoch) { total = h.total; iend = h.iend; count = h.count; }
+        else { total = 0; iend = 0; count = 0; }
+    }
+    static __device__ __forceinline__ void close(RowHdr* hp, u32 epoch, u32 total, u32 iend, u32 count) {
+        RowHdr h; h.total = total; h.iend = (u16)iend; h.count = (u8)count; h.pad = 0; h.epoch = epoch; h.pad2 = 0;
+        *hp = h;
+    }
+    // update_freq (log64_ranger.hpp:69-87 / power_ranger.hpp:66-84); s = slot i as loaded.
+    static __device__ __forceinline__ void update(u32* slots, u32 i, u32 s, u32& total, u32 iend, u32& count) {
+        u32 f = s & 0xffff;
+        if (f > (u32)(MAXF - STEP)) {
+            if (i == 0 && f + (u32)SAT > total) return;
+            u32 t = 0;                                       // normalize
+            for (u32 k = 0; k < iend; k++) {
+                u32 v = slots[k];
+                u32 nf = (v & 0xffff) >> 1;
+                slots[k] = (v & 0xffff0000u) | nf;
+                t += nf;
+            }
+            total = t;
+            f >>= 1;
+        }
+        f += STEP;
+        total += STEP;
+        u32 ns = (s & 0xffff0000u) | f;
+        if (i != 0) {
+            count = (count + 1) & 0xff;
+            if ((count & 0xf) == 0) {
+                u32 pv = slots[i - 1];
+                if (f > (pv & 0xffff)) {                     // down_level
+                    slots[i - 1] = ns;
+                    slots[i] = pv;
+                    return;
+                }
+            }
+        }
+        slots[i] = ns;
+    }
+    // put (log64_ranger.hpp:98-112 / power_ranger.hpp:91-104)
+    static __device__ __forceinline__ void put(u32* slots, RowHdr* hp, u32 epoch, RcEnc& rc, ByteSink& snk, u32 sym) {
+        u32 total, iend, count;
+        open(hp, epoch, total, iend, count);
+        if (iend <= sym) { for (u32 k = iend; k <= sym; k++) slots[k] = k << 16; iend = sym + 1; }
+        u32 i = 0, sumf = 0, s;
+        for (;;) {
+            s = slots[i];
+            if ((s >> 16) == sym) break;
+            sumf += s & 0xffff;
+            if (++i >= (u32)NSYM) { rc.err = 1; i = NSYM - 1; s = slots[i]; break; }   // unreachable on sane tables
+        }
+        rc.encode(snk, sumf + i, (s & 0xffff) + 1, total + NSYM);
+        update(slots, i, s, total, iend, count);
+        close(hp, epoch, total, iend, count);
+    }
+    // get (log64_ranger.hpp:114-138 / power_ranger.hpp:106-130)
+    static __device__ __forceinline__ u32 get(u32* slots, RowHdr* hp, u32 epoch, RcDec& rc, ByteSrc& src) {
+        u32 total, iend, count;
+        open(hp, epoch, total, iend, count);
+        u32 vtot = total + NSYM;
+        u32 prob = rc.get_freq(vtot);
+        u32 i, sumf = 0, s = 0;
+        for (i = 0; i < (u32)NSYM; i++) {
+            if (iend == i) { slots[i] = i << 16; iend++; }
+            s = slots[i];
+            u32 f1 = (s & 0xffff) + 1;
+            if (sumf + f1 <= prob) sumf += f1; else break;
+        }
+        if (i >= (u32)NSYM) { rc.err = 1; i = NSYM - 1; sumf -= (s & 0xffff) + 1; }
+        rc.decode(src, sumf, (s & 0xffff) + 1);
+        u32 sym = s >> 16;
+        update(slots, i, s, total, iend, count);
+        close(hp, epoch, total, iend, count);
+        return sym & 0xff;
+    }
+};
+
+typedef Ranger<64, 6, (1 << 16) - 64, 20>    Log64;   // log64_ranger.hpp:37-42, 72
+typedef Ranger<256, 14, (1 << 15) - 32, 256> Power;   // power_ranger.hpp:37-41, 70
+
+// A block slot's PowerRanger rows.
+struct PwTab {
+    u32*    slots;   // [PR_ROWS][256]
+    RowHdr* hdr;     // [PR_ROWS]
+    u32     epoch;
+    __device__ __forceinline__ void put(u32 row, RcEnc& rc, ByteSink& s, u32 sym) const {
+        Power::put(slots + (size_t)row * PW_NSYM, hdr + row, epoch, rc, s, sym);
+    }
+    __device__ __forceinline__ u32 get(u32 row, RcDec& rc, ByteSrc& s) const {
+        return Power::get(slots + (size_t)row * PW_NSYM, hdr + row, epoch, rc, s);
+    }
+    // PowerRangerU::put_u (power_ranger.hpp:138-163); rows row0 .. row0+13
+    __device__ void put_u(u32 row0, RcEnc& rc, ByteSink& s, u64 num) const {
+        if (num <= 0x7f) { put(row0, rc, s, (u32)num); return; }
+        if (num < 0x7ffe) {
+            put(row0, rc, s, 0xff & (0x80 | (u32)(num >> 8)));
+            put(row0 + 1, rc, s, 0xff & (u32)num);
+            return;
+        }
+        put(row0, rc, s, 0xff);
+        if (num < (1ULL << 32)) {
+            put(row0 + 1, rc, s, 0xfe);
+            for (int sh = 0, i = 2; sh < 32; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh));
+            return;
+        }
+        put(row0 + 1, rc, s, 0xff);
+        for (int sh = 0, i = 6; sh < 64; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh));
+    }
+    // PowerRangerU::get_u (power_ranger.hpp:165-190)
+    __device__ u64 get_u(u32 row0, RcDec& rc, ByteSrc& s) const {
+        u64 num = get(row0, rc, s);
+        if (num > 0x7f) {
+            num = (num << 8) | get(row0 + 1, rc, s);
+            if (num < 0xfffe) num &= 0x7fff;
+            else if (num == 0xfffe) {
+                num = 0;
+                for (int sh = 0, i = 2; sh < 32; sh += 8, i++) num |= (u64)get(row0 + i, rc, s) << sh;
+            } else {
+                num = 0;
+                for (int sh = 0, i = 6; sh < 64; sh += 8, i++) num |= (u64)get(row0 + i, rc, s) << sh;
+            }
+        }
+        return num;
+    }
+};
+
+// XFileSave (xfile.cpp:40-74): a lazily created side stream with its own coder; rows row0..row0+14.
+struct XfEnc {
+    RcEnc rc;
+    ByteSink sink;
+    u32 row0;
+    u32 opened;
+    __device__ __forceinline__ void init(u8* p, u32 cap, u32 xf) {
+        sink.p = p; sink.pos = 0; sink.cap = cap; row0 = PR_XF_BASE + xf * PR_XF_ROWS; opened = 0; rc.init();
+    }
+    __device__ __forceinline__ void put(const PwTab& t, u64 gap) { opened = 1; t.put_u(row0, rc, sink, gap); }        // xfile.cpp:66-69
+    __device__ __forceinline__ void put_chr(const PwTab& t, u32 c) { opened = 1; t.put(row0 + 14, rc, sink, c); }     // xfile.cpp:71-74
+    __device__ __forceinline__ void put_str(const PwTab& t, const u8* p, u32 len) {                                  // xfile.cpp:95-99
+        put(t, len);
+        for (u32 j = 0; j < len; j++) t.put(row0 + 14, rc, sink, p[j]);
+    }
+    // ~XFileSave: terminator + flush, only if the stream exists (xfile.cpp:40-47). Returns its size.
+    __device__ __forceinline__ u32 finish(const PwTab& t) {
+        if (!opened) return 0;
+        put(t, 0);
+        rc.done(sink);
+        return sink.pos;
+    }
+};
+
+// XFileLoad (xfile.cpp:76-106): an absent stream reads as 0 forever.
+struct XfDec {
+    RcDec rc;
+    ByteSrc src;
+    u32 row0;
+    u32 valid;
+    __device__ __forceinline__ void init(const u8* p, u32 n, u32 xf) {
+        src.p = p; src.pos = 0; src.n = n; row0 = PR_XF_BASE + xf * PR_XF_ROWS; valid = n > 0;
+        if (valid) rc.init(src); else { rc.low = rc.code = 0; rc.range = 0xFFFFFFFFu; rc.err = 0; }
+    }
+    __device__ __forceinline__ u64 get(const PwTab& t) { return valid ? t.get_u(row0, rc, src) : 0; }
+    __device__ __forceinline__ u32 get_chr(const PwTab& t) { return valid ? t.get(row0 + 14, rc, src) : 0; }
+};

@@ -1,0 +1,321 @@
+// frame.hip -- device-side FASTQ framing and packing.
+//
+// The reference frames records on one host core with a 1 MiB sliding buffer (UsrSave::get_record,
+// usrs.cpp:303-390).  Here the whole text is resident in HBM and framing is a newline index:
+//   count '\n' per 16 KiB chunk -> exclusive scan -> write line start offsets,
+// then per-record validation ('@' / '+' prefixes: usrs.cpp:311,346; line-length limits usrs.hpp:34-36)
+// and one descriptor per record block (the first-record analysis of UsrSave::determine_record,
+// usrs.cpp:186-267).  All of it is streaming, coalesced, HBM-bound work.
+#include "kernels.h"
+
+#define HIP_KCHECK() do { } while (0)
+
+__device__ __forceinline__ u32 nl_mask(u32 x) {          // 0x80 in every byte of x that equals '\n'
+    u32 y = x ^ 0x0a0a0a0au;
+    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+}
+
+// Block-wide exclusive scan of one u32 per thread (256 threads = 4 waves). Returns the exclusive
+// prefix; *total receives the block sum.
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* lds /* >= 8 u32 */, u32* total) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 o = __shfl_up(incl, d, 64);
+        if (lane >= (u32)d) incl += o;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < 4; w++) { u32 s = lds[w]; if (w < wave) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// One 16-byte piece of the text as 4 dwords; bytes at or past n read as 0.
+__device__ __forceinline__ void load16(const u8* fq, u64 pos, u64 n, bool aligned, u32 w[4]) {
+    if (aligned && pos + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(fq + pos);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+        for (int k = 0; k < 4; k++) {
+            u32 x = 0;
+            for (int j = 0; j < 4; j++) { u64 p = pos + 4 * k + j; if (p < n) x |= (u32)fq[p] << (8 * j); }
+            w[k] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_newlines(const u8* fq, u64 n, u32* chunk_counts, bool aligned) {
+    __shared__ u32 lds[8];
+    const u64 cbase = (u64)blockIdx.x * FRAME_CHUNK;
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u64 pos = cbase + (u64)j * 4096 + (u64)threadIdx.x * 16;
+        if (pos < n) {
+            u32 w[4]; load16(fq, pos, n, aligned, w);
+            cnt += __popc(nl_mask(w[0])) + __popc(nl_mask(w[1])) + __popc(nl_mask(w[2])) + __popc(nl_mask(w[3]));
+        }
+    }
+    u32 total;
+    block_excl_scan_256(cnt, lds, &total);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, bool aligned) {
+    __shared__ u32 lds[8];
+    const u64 cbase = (u64)blockIdx.x * FRAME_CHUNK;
+    u64 run = chunk_base[blockIdx.x];          // newlines before this chunk
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_off[0] = 0;
+    for (int j = 0; j < 4; j++) {
+        u64 pos = cbase + (u64)j * 4096 + (u64)threadIdx.x * 16;
+        u32 w[4] = {0, 0, 0, 0};
+        u32 cnt = 0;
+        if (pos < n) {
+            load16(fq, pos, n, aligned, w);
+            cnt = __popc(nl_mask(w[0])) + __popc(nl_mask(w[1])) + __popc(nl_mask(w[2])) + __popc(nl_mask(w[3]));
+        }
+        u32 total;
+        u32 ex = block_excl_scan_256(cnt, lds, &total);
+        u64 k = run + ex;
+        if (cnt) {
+            for (int q = 0; q < 4; q++) {
+                u32 m = nl_mask(w[q]);
+                while (m) {
+                    int bit = __ffs(m) - 1;           // 7, 15, 23, 31
+                    m &= m - 1;
+                    line_off[++k] = pos + 4 * q + (bit >> 3) + 1;
+                }
+            }
+        }
+        run += total;
+    }
+}
+
+void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st) {
+    bool aligned = ((uintptr_t)fq & 15) == 0;
+    hipLaunchKernelGGL(k_count_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_counts, aligned);
+}
+void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st) {
+    bool aligned = ((uintptr_t)fq & 15) == 0;
+    hipLaunchKernelGGL(k_write_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_base, line_off, aligned);
+}
+
+// ---- generic exclusive scan u32 -> u64 -------------------------------------------------------------
+#define SCAN_TILE 1024u
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* in, u64 n, u64* sums) {
+    __shared__ u32 lds[8];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * 4;
+    u32 s = 0;
+    for (int j = 0; j < 4; j++) if (base + j < n) s += in[base + j];
+    u32 total;
+    block_excl_scan_256(s, lds, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_scan_sums(u64* sums, u64 ntiles) {   // single workgroup, in place, exclusive
+    __shared__ u64 carry_s;
+    __shared__ u64 wsum[4];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u64 i0 = 0; i0 < ntiles; i0 += 256) {
+        u64 i = i0 + threadIdx.x;
+        u64 v = i < ntiles ? sums[i] : 0;
+        u64 incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            u64 o = __shfl_up(incl, d, 64);
+            if (lane >= (u32)d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u64 base = carry_s;
+        for (u32 w = 0; w < wave; w++) base += wsum[w];
+        if (i < ntiles) sums[i] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[ntiles] = carry_s;
+}
+__global__ __launch_bounds__(256) void k_scan_tiles(const u32* in, u64 n, const u64* sums, u64* out, u64 ntiles) {
+    __shared__ u32 lds[8];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * 4;
+    u32 v[4]; u32 s = 0;
+    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    u32 total;
+    u32 ex = block_excl_scan_256(s, lds, &total);
+    u64 run = sums[blockIdx.x] + ex;
+    for (int j = 0; j < 4; j++) { if (base + j < n) out[base + j] = run; run += v[j]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[ntiles];
+}
+void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
+    u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (ntiles == 0) ntiles = 1;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((u32)ntiles), dim3(256), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, tmp, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(256), 0, st, in, n, (const u64*)tmp, out, ntiles);
+}
+
+// ---- record validation ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status) {
+    u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
+    u32 bad = 0;
+    if (fq[l0] != '@' || fq[l2] != '+') bad = (u32)(-SFQ_E_FORMAT);           // usrs.cpp:311, 346
+    // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367)
+    else if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > 0xfffe)
+        bad = (u32)(-SFQ_E_UNSUPPORTED);
+    else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);               // empty base line: usrs.cpp:217-222 mis-frames it
+    if (bad) atomicMax(status, bad);
+}
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, status);
+}
+
+// ---- block descriptors: UsrSave::determine_record (usrs.cpp:186-267) on each block's first record ----
+__global__ __launch_bounds__(64) void k_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads,
+                                                      BlockDesc* blocks, u32 nblocks, i32 gen_bits) {
+    u32 b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nblocks) return;
+    BlockDesc d;
+    d.rec0 = (u64)b * block_reads;
+    u64 rend = d.rec0 + block_reads; if (rend > nrec) rend = nrec;
+    d.nrec = (u32)(rend - d.rec0);
+    const u64 r = d.rec0;
+    const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3];
+    d.first_hdr_off = l0 + 1;
+    d.first_hdr_len = (u32)(l1 - l0 - 2);
+    u32 llen = (u32)(l2 - l1 - 1);
+    u32 two_id = 0;
+    for (u64 p = l2 + 1; p + 1 < l3; p++) if (fq[p] != ' ') two_id = 1;      // usrs.cpp:233-236
+    u32 solid = 0;
+    for (u32 i = 1; i < llen; i++) {                                          // usrs.cpp:239-257
+        u32 c = fq[l1 + i] | 0x20;
+        if (c >= '0' && c <= '3') { solid = 1; break; }
+        if (c == 'a' || c == 'c' || c == 'g' || c == 't') break;
+    }
+    if (solid) llen--;
+    d.llen = llen; d.solid = (u8)solid; d.two_id = (u8)two_id; d.gen_bits = (u8)gen_bits; d.pad = 0;
+    d.status = 0; d.n_byte = 0; d.extra_hi = 0; d.hdr_bytes = 0;
+    // scratch-arena regions: sized from the block's text bytes (overflow is detected, never silent)
+    const u64 t0 = l0, t1 = line_off[4 * rend];
+    const u64 bb = t1 - t0;
+    u64 off = t0 * 7 + (u64)b * 1024;
+    const u32 caps[SFQ_NSTREAMS] = {
+        (u32)(bb + bb / 2 + 64),   // rec
+        (u32)(bb * 3 / 4 + 64),    // gen
+        (u32)(bb + 64),            // qlt
+        (u32)(bb / 2 + 64),        // gen.Ns
+        (u32)(bb / 2 + 64),        // gen.Nn
+        (u32)(bb + 64),            // rec.x
+        (u32)(bb / 2 + 64),        // usr.x
+        (u32)(bb / 2 + 64),        // usr.x.q
+        (u32)(bb / 4 + 64),        // usr.pfg
+        (u32)(bb / 4 + 64) };      // usr.pfq
+    for (int s = 0; s < SFQ_NSTREAMS; s++) {
+        d.size[s] = 0; d.out_off[s] = off; d.out_cap[s] = caps[s];
+        off += (caps[s] + 15u) & ~15u;
+    }
+    blocks[b] = d;
+}
+void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
+                          u64 nbytes, i32 level, i32 gen_bits, hipStream_t st) {
+    (void)nbytes; (void)level;
+    hipLaunchKernelGGL(k_block_prepare, dim3((nblocks + 63) / 64), dim3(64), 0, st, fq, line_off, nrec, block_reads, blocks, nblocks, gen_bits);
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(u32* p, u64 n, u32 v) {
+    u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    const u64 stride = (u64)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 4 <= n) *reinterpret_cast<uint4*>(p + i) = make_uint4(v, v, v, v);
+        else for (u64 j = i; j < n; j++) p[j] = v;
+    }
+}
+void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st) {
+    if (!n) return;
+    u64 nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192; if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_fill_u32, dim3((u32)nb), dim3(256), 0, st, p, n, v);
+}
+
+// ---- packing: per-block stream sizes -> offsets -> compact copy ---------------------------------------
+// One workgroup per stream walks the blocks in order (nblocks is in the thousands).
+__global__ __launch_bounds__(256) void k_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total) {
+    __shared__ u64 carry_s;
+    __shared__ u64 wsum[4];
+    const u32 s = blockIdx.x;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 i0 = 0; i0 < nblocks; i0 += 256) {
+        u32 i = i0 + threadIdx.x;
+        u64 v = i < nblocks ? blocks[i].size[s] : 0;
+        u64 incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            u64 o = __shfl_up(incl, d, 64);
+            if (lane >= (u32)d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u64 base = carry_s;
+        for (u32 w = 0; w < wave; w++) base += wsum[w];
+        if (i < nblocks) blk_stream_off[(u64)i * SFQ_NSTREAMS + s] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stream_total[s] = carry_s;
+}
+void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_stream_offsets, dim3(SFQ_NSTREAMS), dim3(256), 0, st, blocks, nblocks, blk_stream_off, stream_total);
+}
+// grid = (nblocks, SFQ_NSTREAMS); stream_base[s] = offset of stream s in out
+__global__ __launch_bounds__(256) void k_compact(const BlockDesc* blocks, const u8* arena, const u64* blk_stream_off,
+                                                 const u64* stream_base, u8* out) {
+    const u32 b = blockIdx.x, s = blockIdx.y;
+    const u32 n = blocks[b].size[s];
+    if (!n) return;
+    const u8* src = arena + blocks[b].out_off[s];
+    u8* dst = out + stream_base[s] + blk_stream_off[(u64)b * SFQ_NSTREAMS + s];
+    // src is 16-byte aligned; dst is not.  Copy dwords where dst allows, bytes at the edges.
+    u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3); if (head > n) head = n;
+    for (u32 i = threadIdx.x; i < head; i += 256) dst[i] = src[i];
+    const u32 nd = (n - head) / 4;
+    u32* d4 = reinterpret_cast<u32*>(dst + head);
+    for (u32 i = threadIdx.x; i < nd; i += 256) {
+        const u8* p = src + head + 4 * (u64)i;
+        d4[i] = (u32)p[0] | (u32)p[1] << 8 | (u32)p[2] << 16 | (u32)p[3] << 24;
+    }
+    for (u32 i = head + nd * 4 + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
+                    const u64* stream_base, u8* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact, dim3(nblocks, SFQ_NSTREAMS), dim3(256), 0, st, blocks, arena, blk_stream_off, stream_base, out);
+}
+
+// ---- first headers ("rec.first", recs.cpp:68-75): one per block, gathered into a blob -----------------
+__global__ __launch_bounds__(256) void k_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens) {
+    u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b < nblocks) lens[b] = blocks[b].first_hdr_len;
+}
+__global__ __launch_bounds__(64) void k_gather_first_hdrs(const BlockDesc* blocks, u32 nblocks, const u8* fq,
+                                                          const u64* blob_off, u8* blob, u64 cap) {
+    u32 b = blockIdx.x;                       // one wave per block
+    if (b >= nblocks) return;
+    const u32 n = blocks[b].first_hdr_len;
+    const u64 o = blob_off[b];
+    if (o + n > cap) return;
+    const u8* src = fq + blocks[b].first_hdr_off;
+    for (u32 i = threadIdx.x; i < n; i += 64) blob[o + i] = src[i];
+}
+void launch_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens, hipStream_t st) {
+    hipLaunchKernelGGL(k_first_hdr_lens, dim3((nblocks + 255) / 256), dim3(256), 0, st, blocks, nblocks, lens);
+}
+void launch_gather_first_hdrs(const BlockDesc* blocks, u32 nblocks, const u8* fq, const u64* blob_off, u8* blob, u64 cap, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_first_hdrs, dim3(nblocks), dim3(64), 0, st, blocks, nblocks, fq, blob_off, blob, cap);
+}

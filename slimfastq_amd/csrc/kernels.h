@@ -1,0 +1,71 @@
+// kernels.h -- launch wrappers exported by the .hip translation units to the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_common.h"
+
+// Arguments shared by every model kernel.  Block b of a launch uses table slot (b - batch0).
+struct ModelArgs {
+    const u8*  fq;          // FASTQ text (encode) -- device
+    const u64* line_off;    // line_off[k] = offset of line k; line_off[nlines] = nbytes
+    BlockDesc* blocks;
+    u32 nblocks;            // total
+    u32 batch0, nbatch;     // this launch covers blocks [batch0, batch0+nbatch)
+    u8* arena;              // per-block stream regions (BlockDesc::out_off/out_cap)
+    i32 level;
+    u32 epoch_base;         // block b runs with epoch epoch_base + b + 1
+    // tables
+    u32* q_slots; RowHdr* q_hdr; u32 q_rows;     // Log64 rows per slot: 4096 (level 1) or 65536
+    u32* p_slots; RowHdr* p_hdr;                 // PR_ROWS PowerRanger rows per slot
+    u32* g_tab;   u32 g_bits;                    // (1 << g_bits) Base2 dwords per slot
+};
+
+// Decode-side extras.
+struct DecodeArgs {
+    ModelArgs m;
+    const u8*  streams;                     // compact streams (device)
+    const u64* blk_stream_off;              // [nblocks][SFQ_NSTREAMS] absolute offsets into streams
+    const u8*  first_hdrs;                  // blob (device)
+    u32* slen; u32* qlen;                   // per record (device), filled by the usr kernel
+    u8*  pfg;  u8* pfq;                     // per record solid prefixes
+    const u64* soff; const u64* qoff;       // exclusive scans of slen/qlen
+    u8*  seq_stage; u8* qual_stage;         // decoded bases / qualities
+    u8*  hdr_stage; u32* hlen;              // decoded headers, back to back per block
+    const u64* hdr_stage_off;               // per block base into hdr_stage
+    const u32* hdr_stage_cap;
+    u64* hoff;                              // per record offset into hdr_stage (filled by rec decode)
+    u32  block_reads;                       // records per block (uniform; the last block may be short)
+    u32  version;                           // archive format version (recs.cpp:400: < 5 takes load_pre5)
+};
+
+// framing
+void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
+void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status, hipStream_t st);
+void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
+                          u64 nbytes, i32 level, i32 gen_bits_req, hipStream_t st);
+#define FRAME_CHUNK 16384u
+
+// generic exclusive scan u32 -> u64 (out has n+1 entries)
+void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp /* >= n/1024+2 */, hipStream_t st);
+
+// models, lane-per-block reference kernels
+void launch_qlt_encode_l(const ModelArgs& a, hipStream_t st);
+void launch_gen_encode_l(const ModelArgs& a, hipStream_t st);
+void launch_rec_encode_l(const ModelArgs& a, hipStream_t st);
+void launch_usr_encode_l(const ModelArgs& a, hipStream_t st);
+void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
+
+void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
+void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);
+void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);
+void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st);
+void launch_gen_fixup(const DecodeArgs& a, u64 nrec, hipStream_t st);
+
+// packing
+void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, hipStream_t st);
+void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
+                    const u64* stream_base, u8* out, hipStream_t st);
+void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st);
+void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st);
+void launch_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens, hipStream_t st);
+void launch_gather_first_hdrs(const BlockDesc* blocks, u32 nblocks, const u8* fq, const u64* blob_off, u8* blob, u64 cap, hipStream_t st);

@@ -1,0 +1,356 @@
+// models_l.hip -- lane-per-block kernels: every lane owns one record block and runs that block's
+// serial model + range-coder chains exactly as the reference does on a CPU thread, with the model
+// tables in HBM.  These are the bit-exactness anchor on the device (selected with
+// sfq_params.kernel = 1) and the only decode path so far; the throughput kernels (models_w.hip) must
+// reproduce their bytes.
+//
+//   quality  : QltSave::save_1/2/3, QltLoad::load_1/2/3      qlts.cpp:74-136, 163-234
+//   bases    : GenSave::save_x / normalize_gen, GenLoad      gens.cpp:91-159, 200-249
+//   headers  : RecSave::save, RecLoad::load                  recs.cpp:141-461
+//   framing exceptions : UsrSave::get_record / update, UsrLoad::update   usrs.cpp:126-160, 303-390, 471-510
+#include "kernels.h"
+#include "dev_models.h"
+
+#define LAST_QLT 63u     // log64_ranger.hpp:34
+
+struct Slot {
+    u32 b;          // block index
+    u32 epoch;
+    u32* q_slots; RowHdr* q_hdr;
+    PwTab pw;
+    u32* g_tab;
+};
+__device__ __forceinline__ bool slot_init(const ModelArgs& a, Slot& s) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nbatch) return false;
+    s.b = a.batch0 + t;
+    s.epoch = a.epoch_base + s.b + 1;
+    s.q_slots = a.q_slots ? a.q_slots + (size_t)t * a.q_rows * L64_NSYM : nullptr;
+    s.q_hdr   = a.q_hdr ? a.q_hdr + (size_t)t * a.q_rows : nullptr;
+    s.pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM;
+    s.pw.hdr   = a.p_hdr + (size_t)t * PR_ROWS;
+    s.pw.epoch = s.epoch;
+    s.g_tab = a.g_tab ? a.g_tab + ((size_t)t << a.g_bits) : nullptr;
+    return true;
+}
+__device__ __forceinline__ void set_status(BlockDesc* d, int code) { atomicMax(&d->status, (u32)(-code)); }
+__device__ __forceinline__ void finish_stream(BlockDesc* d, int s, const ByteSink& k, u32 err) {
+    d->size[s] = k.pos;
+    if (k.pos > k.cap) set_status(d, SFQ_E_OVERFLOW);
+    if (err) set_status(d, SFQ_E_CORRUPT);
+}
+
+// qlts.hpp:62-74
+__device__ __forceinline__ u32 calc_last_delta(u32& delta, u32 q, u32 q1, u32 q2) {
+    if (q1 > q) delta += q1 - q;
+    u32 d3 = delta >> 3;
+    return (q | ((q1 < q2 ? q2 : q1) << 6) | ((u32)(q1 == q2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+}
+
+// ===================================================================================================
+// quality encode
+// ===================================================================================================
+__global__ __launch_bounds__(64) void k_qlt_encode_l(ModelArgs a) {
+    Slot sl;
+    if (!slot_init(a, sl)) return;
+    BlockDesc* d = &a.blocks[sl.b];
+    ByteSink snk = { a.arena + d->out_off[SFQ_S_QLT], 0, d->out_cap[SFQ_S_QLT] };
+    RcEnc rc; rc.init();
+    u32 extra_hi = 0;
+    const u32 solid = d->solid;
+    const int level = a.level;
+    for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
+        const u64 q0 = a.line_off[4 * r + 3] + solid;
+        const u64 q1e = a.line_off[4 * r + 4] - 1;
+        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u8* p = a.fq + q0;
+        u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
+        for (u32 i = 0; i < n; i++) {
+            const u32 bsym = (u32)(u8)(p[i] - '!');
+            u32* row = sl.q_slots + (size_t)last * L64_NSYM;
+            RowHdr* hp = sl.q_hdr + last;
+            if (bsym < LAST_QLT) Log64::put(row, hp, sl.epoch, rc, snk, bsym);        // qlts.cpp:79-86
+            else {
+                Log64::put(row, hp, sl.epoch, rc, snk, LAST_QLT);
+                sl.pw.put(PR_EXQ_ROW, rc, snk, bsym);
+                extra_hi++;
+            }
+            if (level == 1)      last = (bsym | (last << 6)) & 0xFFFu;                  // qlts.hpp:52-54
+            else if (level == 2) last = (bsym | (last << 6)) & 0xFFFFu;                 // qlts.hpp:55-57
+            else if (++di & 1) { last = calc_last_delta(delta, bsym, q1, q2); q2 = bsym; }   // qlts.cpp:127-134
+            else               { last = calc_last_delta(delta, bsym, q2, q1); q1 = bsym; }
+        }
+    }
+    rc.done(snk);
+    d->extra_hi = extra_hi;
+    finish_stream(d, SFQ_S_QLT, snk, rc.err);
+}
+void launch_qlt_encode_l(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_l, dim3((a.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ===================================================================================================
+// base encode
+// ===================================================================================================
+// gens.cpp:72-77 : 0..3 bases, 4 = N-like, 0x10 = illegal
+__device__ __forceinline__ u32 gencode(u32 c) {
+    switch (c) {
+    case '0': case 'A': case 'a': return 0;
+    case '1': case 'C': case 'c': return 1;
+    case '2': case 'G': case 'g': return 2;
+    case '3': case 'T': case 't': return 3;
+    case '.': case 'N': case 'n': return 4;
+    default: return 0x10;
+    }
+}
+__global__ __launch_bounds__(64) void k_gen_encode_l(ModelArgs a) {
+    Slot sl;
+    if (!slot_init(a, sl)) return;
+    BlockDesc* d = &a.blocks[sl.b];
+    ByteSink snk = { a.arena + d->out_off[SFQ_S_GEN], 0, d->out_cap[SFQ_S_GEN] };
+    RcEnc rc; rc.init();
+    XfEnc x_ns, x_nn;
+    x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
+    x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+    const u32 solid = d->solid;
+    const u32 mask = (1u << d->gen_bits) - 1u;
+    u64 genofs = 0, ns_index = 0, nn_index = 0;       // g_genofs_count, m_last.{Ns,Nn}_index (block-relative)
+    u32 n_byte = 0; int bad = 0;
+    for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
+        const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1;
+        const u64 q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
+        const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
+        const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
+        u32 last = 0x007616c7u;                                                   // gens.cpp:139
+        for (u32 i = 0; i < llen; i++) {
+            const u32 gch = gp[i];
+            const u32 qch = (i < qlen) ? qp[i] : 40u;                             // gens.cpp:153
+            u32 n = gencode(gch);                                                 // normalize_gen gens.cpp:116-136
+            const bool bad_q = qch == '!';
+            bool bad_n = false;
+            if (n > 3) { if (n > 4) bad = SFQ_E_GENCHAR; bad_n = true; n = 0; }
+            genofs++;
+            if (bad_n || bad_q) {                                                 // bad_q_or_bad_n gens.cpp:91-114
+                if (!bad_n) { x_nn.put(sl.pw, genofs - nn_index); nn_index = genofs; }
+                else {
+                    if (!n_byte) n_byte = gch;
+                    if (gch != n_byte) bad = SFQ_E_GENCHAR;
+                    if (!bad_q) { x_ns.put(sl.pw, genofs - ns_index); ns_index = genofs; }
+                }
+            }
+            last &= mask;
+            sl.g_tab[last] = b2_put(sl.g_tab[last], rc, snk, n);
+            last = (last << 2) | n;
+        }
+    }
+    rc.done(snk);
+    d->n_byte = n_byte;
+    finish_stream(d, SFQ_S_GEN, snk, rc.err);
+    d->size[SFQ_S_GEN_NS] = x_ns.finish(sl.pw);
+    d->size[SFQ_S_GEN_NN] = x_nn.finish(sl.pw);
+    if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) set_status(d, SFQ_E_OVERFLOW);
+    if (x_ns.rc.err | x_nn.rc.err) set_status(d, SFQ_E_CORRUPT);
+    if (bad) set_status(d, bad);
+}
+void launch_gen_encode_l(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_encode_l, dim3((a.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ===================================================================================================
+// header encode
+// ===================================================================================================
+enum {  // recs.cpp:159-190
+    ST_DGT = 0, ST_DLT = 1, ST_STR = 2, ST_HGT = 3, ST_HLT = 4, ST_HGT_Z = 5, ST_HLT_Z = 6,
+    ST_HGTC = 7, ST_HLTC = 8, ST_HGTC_Z = 9, ST_HLTC_Z = 10, ST_DGT_Z = 11, ST_DLT_Z = 12
+};
+struct SpaceMap { u16 off[66]; u16 wln[66]; u8 str[66]; u32 len; };   // recs.hpp:68-73
+__device__ __forceinline__ bool isword(u32 c) { return (c - '0' < 10u) || ((c | 0x20) - 'a' < 26u); }   // recs.cpp:139
+__device__ __forceinline__ bool isdig(u32 c) { return c - '0' < 10u; }
+
+// map_space recs.cpp:141-157 over text p[0..n) (the terminator '\n' is at p[n]).  false = > 64 separators.
+__device__ bool map_space(const u8* p, u32 n, SpaceMap& m) {
+    m.len = 0; m.off[0] = 0;
+    for (u32 i = 0; ; i++) {
+        u32 c = i < n ? p[i] : '\n';
+        if (!isword(c)) {
+            m.wln[m.len] = (u16)(i - m.off[m.len]);
+            m.str[m.len++] = (u8)c;
+            m.off[m.len] = (u16)(i + 1);
+            if (i >= n || c == 0) break;
+            if (m.len > 64) return false;
+        }
+    }
+    return m.len <= 64;
+}
+// numberwang recs.cpp:192-262.  p[len] is readable (separator).
+__device__ u32 numberwang(const u8* p, int len, u64& num, u32 pctype) {
+    int i = 0;
+    const bool has_z = p[0] == '0';
+    if (has_z) if (p[++i] == '0') return ST_STR;
+    u32 caps = 0;
+    num = 0;
+    while (pctype != 2) {
+        if (i >= len) return has_z ? ST_DGT_Z : ST_DGT;
+        u32 c = p[i];
+        if (isdig(c)) {
+            u64 tnum = (num << 3) + (num << 1) + c - '0';
+            i++;
+            if (tnum < num) return ST_STR;
+            num = tnum;
+            continue;
+        }
+        if ((c | 0x20) < 'a' || (c | 0x20) > 'f') return ST_STR;
+        caps = 1 + (c < 'a');
+        i = has_z;
+        num = 0;
+        break;
+    }
+    if (len > 16) return ST_STR;
+    for (; i < len; i++) {
+        u32 c = p[i], nib;
+        if (isdig(c)) nib = c - '0';
+        else if (c >= 'a' && c <= 'f') { if (caps == 2) return ST_STR; caps = 1; nib = 10 + (c - 'a'); }
+        else if (c >= 'A' && c <= 'F') { if (caps == 1) return ST_STR; caps = 2; nib = 10 + (c - 'A'); }
+        else return ST_STR;
+        num = (num << 4) + nib;
+    }
+    return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
+}
+__device__ __forceinline__ bool bytes_differ(const u8* x, const u8* y, u32 n) {
+    for (u32 i = 0; i < n; i++) if (x[i] != y[i]) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_rec_encode_l(ModelArgs a) {
+    Slot sl;
+    if (!slot_init(a, sl)) return;
+    BlockDesc* d = &a.blocks[sl.b];
+    ByteSink snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
+    RcEnc rc; rc.init();
+    XfEnc x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    SpaceMap sm[2];
+    u8  ctype[2][66];
+    u64 cnumb[2][66];
+    u32 imap = 0; int bad = 0;
+    u64 last_index = 0;                       // m_last.index recs.hpp:54
+    u32 hdr_bytes = 0;
+    const u8* prev = nullptr;
+    for (u32 k = 0; k < d->nrec; k++) {
+        const u64 r = d->rec0 + k;
+        const u64 record_count = (u64)k + 1;  // g_record_count, block-relative
+        const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
+        const u8* buf = a.fq + h0;
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        hdr_bytes += n;
+        if (k == 0) {                                                         // recs.cpp:279-287 (first line -> "rec.first")
+            imap = 0;
+            if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
+            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+            prev = buf;
+            continue;
+        }
+        const u32 pmap = imap;
+        imap ^= 1;
+        if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
+        SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
+        bool shape = mi.len != mp.len;
+        if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
+        if (shape) {                                                          // recs.cpp:292-305
+            x_rec.put(sl.pw, record_count - last_index);
+            last_index = record_count;
+            x_rec.put_str(sl.pw, buf, n);
+            for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            prev = buf;
+            continue;
+        }
+        u64 map = 0;
+        for (u32 i = 0; i < mi.len; i++)
+            if (mi.wln[i] != mp.wln[i] || bytes_differ(buf + mi.off[i], prev + mp.off[i], mi.wln[i])) map |= 1ULL << i;
+        sl.pw.put_u(0 * 16 + 2, rc, snk, map);                               // put_num(0, map) recs.cpp:313
+        for (u32 i = 0; i < mi.len; i++) {
+            if (map & (1ULL << i)) {
+                const u8* bp = buf + mi.off[i];
+                u64 bnum;
+                u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                const u32 rr = (i + 1) * 16;
+                if (type == ST_STR) {                                         // recs.cpp:324-331
+                    sl.pw.put(rr + 0, rc, snk, type);
+                    sl.pw.put_u(rr + 2, rc, snk, mi.wln[i]);
+                    for (u32 j = 0; j < mi.wln[i]; j++) sl.pw.put(rr + 1, rc, snk, bp[j]);
+                    ctype[imap][i] = 0;
+                    continue;
+                }
+                u64 pnum = ctype[pmap][i] ? cnumb[pmap][i] : 0;                // recs.cpp:333-348
+                u64 gap;
+                ctype[imap][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+                cnumb[imap][i] = bnum;
+                if (bnum < pnum) { gap = pnum - bnum; type++; }
+                else gap = bnum - pnum;
+                sl.pw.put(rr + 0, rc, snk, type);
+                sl.pw.put_u(rr + 2, rc, snk, gap);
+            } else {
+                ctype[imap][i] = ctype[pmap][i];
+                cnumb[imap][i] = cnumb[pmap][i];
+            }
+        }
+        prev = buf;
+    }
+    rc.done(snk);
+    d->hdr_bytes = hdr_bytes;
+    finish_stream(d, SFQ_S_REC, snk, rc.err);
+    d->size[SFQ_S_REC_X] = x_rec.finish(sl.pw);
+    if (x_rec.sink.pos > x_rec.sink.cap) set_status(d, SFQ_E_OVERFLOW);
+    if (x_rec.rc.err) set_status(d, SFQ_E_CORRUPT);
+    if (bad) set_status(d, bad);
+}
+void launch_rec_encode_l(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_encode_l, dim3((a.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// ===================================================================================================
+// framing exceptions: the bookkeeping half of UsrSave::get_record (usrs.cpp:322-375) + update (126-160)
+// ===================================================================================================
+__global__ __launch_bounds__(64) void k_usr_encode_l(ModelArgs a) {
+    Slot sl;
+    if (!slot_init(a, sl)) return;
+    BlockDesc* d = &a.blocks[sl.b];
+    XfEnc x_llen, x_qlen, x_sgen, x_sqlt;
+    x_llen.init(a.arena + d->out_off[SFQ_S_USR_X],   d->out_cap[SFQ_S_USR_X],   XF_USR_X);
+    x_qlen.init(a.arena + d->out_off[SFQ_S_USR_XQ],  d->out_cap[SFQ_S_USR_XQ],  XF_USR_XQ);
+    x_sgen.init(a.arena + d->out_off[SFQ_S_USR_PFG], d->out_cap[SFQ_S_USR_PFG], XF_USR_PFG);
+    x_sqlt.init(a.arena + d->out_off[SFQ_S_USR_PFQ], d->out_cap[SFQ_S_USR_PFQ], XF_USR_PFQ);
+    const u32 solid = d->solid;
+    u32 llen = d->llen;
+    u64 i_llen = 0, i_qlen = 0, i_sgen = 0, i_sqlt = 0;
+    u32 pf_gen = 0, pf_qlt = 0;
+    for (u32 k = 0; k < d->nrec; k++) {
+        const u64 r = d->rec0 + k;
+        const u64 rcnt = (u64)k + 1;
+        const u64 g0 = a.line_off[4 * r + 1], g1 = a.line_off[4 * r + 2] - 1;
+        const u64 q0 = a.line_off[4 * r + 3], q1 = a.line_off[4 * r + 4] - 1;
+        if (solid) {
+            const u32 c = a.fq[g0];                                            // usrs.cpp:323-327, 339-340
+            if (c != pf_gen) { x_sgen.put(sl.pw, rcnt - i_sgen); x_sgen.put_chr(sl.pw, c); i_sgen = rcnt; pf_gen = c; }
+        }
+        const u32 sl_len = (u32)(g1 - g0) - solid;
+        if (sl_len != llen) {                                                  // usrs.cpp:342-343
+            x_llen.put(sl.pw, rcnt - i_llen); x_llen.put(sl.pw, (u16)sl_len); i_llen = rcnt; llen = sl_len;
+        }
+        if (solid) {
+            const u32 c = a.fq[q0];                                            // usrs.cpp:356-360
+            if (c != pf_qlt) { x_sqlt.put(sl.pw, rcnt - i_sqlt); x_sqlt.put_chr(sl.pw, c); i_sqlt = rcnt; pf_qlt = c; }
+        }
+        const u32 ql = (q1 - q0) >= solid ? (u32)(q1 - q0) - solid : 0;
+        if (ql != llen) { x_qlen.put(sl.pw, rcnt - i_qlen); x_qlen.put(sl.pw, (u16)ql); i_qlen = rcnt; }   // usrs.cpp:371-372
+    }
+    d->size[SFQ_S_USR_X]   = x_llen.finish(sl.pw);
+    d->size[SFQ_S_USR_XQ]  = x_qlen.finish(sl.pw);
+    d->size[SFQ_S_USR_PFG] = x_sgen.finish(sl.pw);
+    d->size[SFQ_S_USR_PFQ] = x_sqlt.finish(sl.pw);
+    if (x_llen.sink.pos > x_llen.sink.cap || x_qlen.sink.pos > x_qlen.sink.cap ||
+        x_sgen.sink.pos > x_sgen.sink.cap || x_sqlt.sink.pos > x_sqlt.sink.cap) set_status(d, SFQ_E_OVERFLOW);
+    if (x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) set_status(d, SFQ_E_CORRUPT);
+}
+void launch_usr_encode_l(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_usr_encode_l, dim3((a.nbatch + 63) / 64), dim3(64), 0, st, a);
+}

@@ -1,0 +1,145 @@
+"""GPU: the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+Bit-exact everywhere: this is integer/byte work."""
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle as O
+from slimfastq_amd import capi
+
+pytestmark = pytest.mark.gpu
+LEVEL_BITS = {1: 18, 2: 22, 3: 24, 4: 26}
+KERNELS = (0, 1)          # 0 = throughput kernels, 1 = lane-per-block reference kernels
+
+
+def assert_streams_equal(enc, want: dict, block=None, ctxmsg=""):
+    for name in capi.STREAM_NAMES:
+        got = enc.stream(name, block)
+        exp = want.get(name, b"")
+        assert got == exp, "%s stream %s: got %d bytes, want %d" % (ctxmsg, name, len(got), len(exp))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("level", (1, 2, 3, 4))
+def test_single_block_equals_reference_streams_synthetic(ctx, level, kernel):
+    fq = capi.synth_fastq(3000, 150, seed=level)
+    enc = ctx.encode_host(fq, level=level, block_reads=0, kernel=kernel)
+    want = O.compress(fq, level).streams
+    assert enc.res.n_blocks == 1 and enc.res.n_records == 3000
+    assert_streams_equal(enc, want, ctxmsg="level %d" % level)
+    b = enc.blocks[0]
+    assert (b.llen, b.solid, b.two_id, b.gen_bits) == (150, 0, 0, LEVEL_BITS[level])
+    assert enc.first_hdrs == fq[1:fq.index(b"\n")]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", util.golden_names())
+def test_single_block_equals_reference_golden(ctx, name, kernel):
+    fq = util.golden_fastq(name)
+    for level in (1, 3) if len(fq) > 300000 else (1, 2, 3, 4):
+        gold = util.golden_streams(name, level)
+        enc = ctx.encode_host(fq, level=level, block_reads=0, kernel=kernel)
+        assert_streams_equal(enc, gold, ctxmsg="%s l%d" % (name, level))
+        info = util.info_of(gold)
+        b = enc.blocks[0]
+        assert b.n_records == int(info["num_records"]) and b.llen == int(info["llen"])
+        assert b.solid == int(info.get("usr.solid", 0)) and b.two_id == int(info["usr.2id"])
+        assert b.n_byte == int(info.get("gen.N_byte", b.n_byte if b.n_byte in (0, ord("N")) else -1))
+        assert enc.first_hdrs.decode("latin1") == info["rec.first"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_blocks_equal_reference_run_per_chunk(ctx, kernel):
+    """The block format's definition: block b's streams == the reference's streams for a FASTQ holding
+    only that block's records (counters restart per block)."""
+    fq = capi.synth_fastq(5300, 150, seed=21)
+    for level, br in ((3, 1000), (1, 2500), (4, 700)):
+        enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel)
+        chunks = util.split_records(fq, br)
+        assert enc.res.n_blocks == len(chunks)
+        for b, chunk in enumerate(chunks):
+            want = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            assert_streams_equal(enc, want, block=b, ctxmsg="level %d block %d" % (level, b))
+            assert enc.blocks[b].n_records == chunk.count(b"\n") // 4
+
+
+@pytest.mark.parametrize("name", ["tst1", "fast5.to", "tsta", "edge_hdr", "edge_len"])
+def test_blocks_on_real_samples(ctx, name):
+    fq = util.golden_fastq(name)
+    nrec = fq.count(b"\n") // 4
+    br = max(2, nrec // 7)
+    enc = ctx.encode_host(fq, level=3, block_reads=br)
+    for b, chunk in enumerate(util.split_records(fq, br)):
+        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        assert_streams_equal(enc, want, block=b, ctxmsg="%s block %d" % (name, b))
+
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_decode_reference_written_streams(ctx, name):
+    """North-star requirement: a reference-written archive decodes to what the reference itself decodes."""
+    fq = util.golden_fastq(name)
+    for level in (3,) if len(fq) > 300000 else (1, 2, 3, 4):
+        gold = util.golden_streams(name, level)
+        info = util.info_of(gold)
+        bi = capi.BlockInfo()
+        bi.first_record = 0
+        bi.n_records = int(info["num_records"]); bi.llen = int(info["llen"])
+        bi.solid = int(info.get("usr.solid", 0)); bi.two_id = int(info["usr.2id"])
+        bi.n_byte = int(info.get("gen.N_byte", 0)); bi.gen_bits = LEVEL_BITS[level]
+        first = info["rec.first"].encode("latin1")
+        bi.first_hdr_off = 0; bi.first_hdr_len = len(first)
+        data = b""; soff = []
+        for i, s in enumerate(capi.STREAM_NAMES):
+            soff.append(len(data)); data += gold.get(s, b""); bi.size[i] = len(gold.get(s, b""))
+        blocks = (capi.BlockInfo * 1)(bi)
+        out = ctx.decode_host((blocks, first, data, soff), level=level, version=int(info["version"]), out_cap=len(fq) * 2 + 4096)
+        assert out == gold.get("<decoded>", fq), (name, level)
+
+
+@pytest.mark.parametrize("level", (1, 2, 3, 4))
+def test_roundtrip_blocks(ctx, level):
+    fq = capi.synth_fastq(4100, 150, seed=30 + level)
+    for br in (0, 512):
+        enc = ctx.encode_host(fq, level=level, block_reads=br)
+        assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+
+
+def test_roundtrip_long_reads_and_samples(ctx):
+    lr = capi.synth_fastq(12, 0, seed=9, kind=1)
+    for br in (0, 5):
+        enc = ctx.encode_host(lr, level=3, block_reads=br)
+        assert ctx.decode_host(enc, level=3, out_cap=len(lr) + 4096) == lr
+    for name in ("small", "solid", "tstc", "tstd", "badqlt", "edge_len", "edge_n", "edge_hiq"):
+        fq = util.golden_fastq(name)
+        nrec = fq.count(b"\n") // 4
+        enc = ctx.encode_host(fq, level=2, block_reads=max(1, nrec // 3))
+        assert ctx.decode_host(enc, level=2, out_cap=len(fq) * 2 + 4096) == fq, name
+
+
+def test_ragged_and_error_inputs(ctx):
+    one = b"@only 1\nACGT\n+\nIIII\n"
+    enc = ctx.encode_host(one, level=3)
+    assert ctx.decode_host(enc, level=3, out_cap=4096) == one
+    for bad, code in ((b"", -4), (b"@x\nACGT\n+\nIIII", -4), (b"@x\nACGT\n+\n", -4), (b"x\nACGT\n+\nIIII\n", -4),
+                      (b"@x\nACGT\n-\nIIII\n", -4), (b"@x\nACXT\n+\nIIII\n", -8), (b"@x\nAC.TN\n+\nIIIII\n", -8)):
+        with pytest.raises(capi.SfqError) as e:
+            ctx.encode_host(bad, level=3)
+        assert e.value.code == code, bad
+    # a record over the model path's 65535-base limit is refused, not mangled
+    big = b"@big\n" + b"A" * 70000 + b"\n+\n" + b"I" * 70000 + b"\n"
+    with pytest.raises(capi.SfqError) as e:
+        ctx.encode_host(big, level=3)
+    assert e.value.code == -7
+
+
+def test_qlt_only_entry_point(ctx):
+    import torch
+    fq = capi.synth_fastq(2000, 150, seed=77)
+    t = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda()
+    out = torch.empty(len(fq), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    res = ctx.encode_device(t.data_ptr(), len(fq), out.data_ptr(), out.numel(), level=3, block_reads=500, qlt_only=True)
+    assert res.n_blocks == 4 and res.stream_bytes[capi.STREAM_NAMES.index("gen")] == 0
+    got = bytes(out[:res.total_bytes].cpu().numpy())
+    want = b"".join(O.compress(c, 3).streams["qlt"] for c in util.split_records(fq, 500))
+    assert got == want

@@ -1,0 +1,100 @@
+"""CPU: the oracle (oracle/sfq_oracle.c) against the reference's golden vectors, and -- when the
+compiled reference is present (build container) -- against the reference itself."""
+import glob
+import os
+
+import pytest
+
+import util
+from oracle import oracle as O
+
+LEVELS = (1, 2, 3, 4)
+
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_oracle_streams_match_reference_golden(name):
+    fq = util.golden_fastq(name)
+    for level in LEVELS:
+        gold = util.golden_streams(name, level)
+        mine = O.compress(fq, level, quiet=True)
+        want = {k: v for k, v in gold.items() if k != "<decoded>"}
+        assert list(mine.streams.keys()) == list(want.keys()), (name, level)
+        for k in want:
+            assert mine.streams[k] == want[k], (name, level, k, len(mine.streams[k]), len(want[k]))
+        # decode of the reference's archive == what the reference itself decodes (== input unless lossy)
+        expect = gold.get("<decoded>", fq)
+        assert O.decompress(mine.image) == expect, (name, level)
+
+
+def test_golden_sizes_match_survey_table():
+    # rec / gen / qlt sizes measured from the reference
+    t = {"tst1": {1: (5968, 61644, 85735), 3: (5968, 62221, 89043), 4: (5968, 62375, 89043)},
+         "small": {2: (630, 4715, 7477), 3: (630, 4716, 7161)},
+         "fast5.to": {3: (2455, 78159, 249309)},
+         "tstb": {3: (45, 122, 209)}}
+    for name, lv in t.items():
+        for level, (r, g, q) in lv.items():
+            s = util.golden_streams(name, level)
+            assert (len(s["rec"]), len(s["gen"]), len(s["qlt"])) == (r, g, q)
+
+
+def test_stream_level_entry_points_agree_with_whole_file():
+    fq = util.golden_fastq("small")
+    lines = fq.split(b"\n")[:-1]
+    import numpy as np
+    offs = np.cumsum([0] + [len(l) + 1 for l in lines])
+    nrec = len(lines) // 4
+    hoff = offs[0:4 * nrec:4] + 1
+    hlen = np.array([len(l) - 1 for l in lines[0::4]])
+    goff = offs[1:4 * nrec:4]; glen = np.array([len(l) for l in lines[1::4]])
+    qoff = offs[3:4 * nrec:4]; qlen = np.array([len(l) for l in lines[3::4]])
+    for level in LEVELS:
+        a = O.compress(fq, level)
+        q, _ = O.qlt_encode(fq, qoff, qlen, level)
+        assert q == a.streams["qlt"]
+        bits = {1: 18, 2: 22, 3: 24, 4: 26}[level]
+        g, ns, nn, nb = O.gen_encode(fq, goff, glen, qoff, qlen, bits)
+        assert g == a.streams["gen"]
+        r, x = O.rec_encode(fq, hoff, hlen)
+        assert r == a.streams["rec"]
+        assert O.qlt_decode(q, qoff, qlen, len(fq), level)[qoff[0]:qoff[0] + qlen[0]] == lines[3]
+
+
+def test_xfile_roundtrip_boundaries():
+    # the reference's utest.cpp:187-355 boundaries for put_u/get_u (self-consistency, no golden bytes there)
+    import numpy as np
+    vals = list(range(300)) + [i * 77 for i in range(300)] + [0x7f, 0x80, 0x7ffd, 0x7ffe, 0x7fff, 0xffff, 0xfffe,
+            (1 << 32) - 1, 1 << 32, (1 << 40) + 5, (1 << 52) + 7, (1 << 64) - 1, (1 << 64) - 122]
+    s = O.xfile_encode_u(vals)
+    back = O.xfile_decode_u(s, len(vals))
+    assert [int(v) for v in back] == [v & ((1 << 64) - 1) for v in vals]
+
+
+@pytest.mark.skipif(O.ref_binary() is None or not os.path.isdir("/root/reference/samples"),
+                    reason="compiled reference / samples only exist in the build container")
+def test_oracle_vs_compiled_reference_all_samples():
+    for f in sorted(glob.glob("/root/reference/samples/*.fq")):
+        fq = open(f, "rb").read()
+        if len(fq) > 1_000_000:
+            levels = (3,)
+        else:
+            levels = (1, 2, 3, 4)
+        for level in levels:
+            ref_img = O.ref_compress(fq, level, quiet=True)
+            mine = O.compress(fq, level, quiet=True)
+            assert mine.image == ref_img, (f, level)          # whole container, byte for byte
+            assert O.decompress(ref_img) == fq
+            assert O.ref_decompress(mine.image) == fq
+
+
+@pytest.mark.skipif(O.ref_binary() is None, reason="compiled reference only exists in the build container")
+def test_oracle_vs_compiled_reference_synthetic_and_chunks():
+    from slimfastq_amd import capi
+    fq = capi.synth_fastq(6000, 150, seed=7)
+    for level in (1, 3):
+        assert O.compress(fq, level).image == O.ref_compress(fq, level)
+    # chunk-as-standalone-file (the block format's definition) incl. a non-default context size
+    for chunk in util.split_records(fq, 2500):
+        assert O.compress(chunk, 3).image == O.ref_compress(chunk, 3)
+    lr = capi.synth_fastq(6, 0, seed=3, kind=1)
+    assert O.compress(lr, 3).image == O.ref_compress(lr, 3)
