@@ -47,11 +47,31 @@ class SfqError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7).  If this library pulled in /opt/rocm's copy first, a later `import torch` would
+    load a second runtime and see no GPU.  Pre-loading torch's copy makes the dynamic linker bind our
+    DT_NEEDED libamdhip64.so.7 to it.  Set SFQ_HIP_RUNTIME=system to skip (e.g. torch-free processes
+    that must use /opt/rocm)."""
+    if os.environ.get("SFQ_HIP_RUNTIME") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -m slimfastq_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, u64, u8p = C.c_void_p, C.c_uint64, C.c_void_p
         L.sfq_stream_name.restype = C.c_char_p

@@ -68,7 +68,7 @@ int reserve(sfq_ctx* ctx, DevBuf& b, size_t bytes, bool zero_new = false) {
     if (zero_new) HIPC(hipMemsetAsync(b.p, 0, want, ctx->st));
     return SFQ_OK;
 }
-void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+void release(DevBuf& b) { if (b.p) { (void)hipDeviceSynchronize(); (void)hipFree(b.p); } b.p = nullptr; b.cap = 0; }
 
 int level_gen_bits(int level) {   // gens.hpp:43-53
     switch (level) { case 1: return 18; case 2: return 22; case 3: return 24; default: return 26; }
@@ -86,22 +86,19 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
                               (unsigned long long)ctx->table_budget, (unsigned long long)per);
     u32 slots = (u32)std::min<u64>(want, fit);
     Tables& t = ctx->tab;
-    // Row tables are epoch-tagged: they must be zero when first used and whenever their geometry changes.
-    const bool regeom = t.q_rows != q_rows;
+    // Row tables are epoch-tagged and epochs only grow, so stale rows of any earlier geometry can never
+    // match: slot storage needs no clearing, and a header array is zeroed only when it is (re)allocated.
     int rc;
     if (per_q) {
         const size_t need_s = (size_t)slots * q_rows * L64_NSYM * 4, need_h = (size_t)slots * q_rows * sizeof(RowHdr);
-        if (regeom || need_s > t.q_slots.cap) {
-            if ((rc = reserve(ctx, t.q_slots, need_s))) return rc;
-            release(t.q_hdr);
-        }
-        if (!t.q_hdr.p) { if ((rc = reserve(ctx, t.q_hdr, need_h, true))) return rc; }
+        if ((rc = reserve(ctx, t.q_slots, need_s))) return rc;
+        if (need_h > t.q_hdr.cap || !t.q_hdr.p) { release(t.q_hdr); if ((rc = reserve(ctx, t.q_hdr, need_h, true))) return rc; }
         t.q_rows = q_rows;
     }
     {
         const size_t need_s = (size_t)slots * PR_ROWS * PW_NSYM * 4, need_h = (size_t)slots * PR_ROWS * sizeof(RowHdr);
-        if (need_s > t.p_slots.cap) { if ((rc = reserve(ctx, t.p_slots, need_s))) return rc; release(t.p_hdr); }
-        if (!t.p_hdr.p) { if ((rc = reserve(ctx, t.p_hdr, need_h, true))) return rc; }
+        if ((rc = reserve(ctx, t.p_slots, need_s))) return rc;
+        if (need_h > t.p_hdr.cap || !t.p_hdr.p) { release(t.p_hdr); if ((rc = reserve(ctx, t.p_hdr, need_h, true))) return rc; }
     }
     if (per_g) { if ((rc = reserve(ctx, t.g_tab, (size_t)slots * per_g))) return rc; t.g_bits = g_bits; }
     t.slots = slots;
