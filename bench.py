@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: MB/s of raw FASTQ compressed (+ ratio vs reference) on synthetic
+150 bp Illumina reads at -l 3, full qlts+gens+recs path, one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (framing + quality/base/header models + range coders + packing) over
+the rank's FASTQ text, which is already resident in HBM when the timed region starts.  For N > 1 each
+rank codes its own shard of records (weak scaling: per-GPU work fixed) and the step ends with the RCCL
+gather of the compressed streams to rank 0.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from slimfastq_amd import capi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="records per GPU (BASELINE config: 10M x 150 bp)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
+    ap.add_argument("--workload", choices=["full", "qlt"], default="full")
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seed):
+    """The reference's single-thread CPU path on a bounded sample of the same workload (rank 0, N=1).
+    kind "reference" = oracle/_ref/slimfastq_ref (the compiled reference) when it travelled with the
+    tree; else kind "port" = oracle/sfq_oracle.c.  Both are test infrastructure, used here only as the
+    reported baseline."""
+    from oracle import oracle as O
+    n = args.cpu_sample_reads
+    fq = capi.synth_fastq(n, args.read_len, seed=seed)
+    out = {"cores": 1, "sample": "%d x %d bp reads (%.1f MB), -l %d, first records of the same synthetic stream"
+           % (n, args.read_len, len(fq) / 1e6, args.level), "unit": "MB/s"}
+    t0 = time.perf_counter()
+    a = O.compress(fq, args.level)
+    t_port = time.perf_counter() - t0
+    ref_payload = a.payload_bytes() - len(a.streams["<info>"])
+    out.update(kind="port", value=round(len(fq) / 1e6 / t_port, 2), port_MBps=round(len(fq) / 1e6 / t_port, 2))
+    if O.ref_binary():
+        try:
+            t0 = time.perf_counter()
+            img = O.ref_compress(fq, args.level)
+            t_ref = time.perf_counter() - t0
+            assert O.parse(img).streams == a.streams
+            out.update(kind="reference", value=round(len(fq) / 1e6 / t_ref, 2))
+        except Exception as e:  # the binary may not run on this host; keep the port number
+            out["reference_error"] = str(e)[:100]
+    return out, fq, ref_payload
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    seed = 1
+    models = 0 if args.workload == "full" else capi.M_QLT
+
+    # ---- synthetic input, resident in HBM before anything is timed ----
+    t0 = time.perf_counter()
+    fq = capi.synth_fastq(args.reads, args.read_len, seed=seed, first_read=rank * args.reads)
+    t_gen = time.perf_counter() - t0
+    nbytes = len(fq)
+    d_in = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda(non_blocking=False)
+    del fq
+    ctx = capi.Context(local_rank)
+    cap = capi.lib().sfq_encode_bound(nbytes)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    gather_bufs = None
+
+    def step():
+        res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=args.level,
+                                block_reads=args.block_reads, models=models, kernel=args.kernel)
+        if world > 1:
+            # the path's one exchange step: compressed streams (+ sizes) to the writer rank, over RCCL/xGMI
+            nonlocal gather_bufs
+            sz = torch.tensor([res.total_bytes], dtype=torch.int64, device="cuda")
+            sizes = torch.empty(world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(sizes, sz)
+            hs = sizes.cpu().tolist()
+            if rank == 0:
+                if gather_bufs is None:
+                    gather_bufs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(world - 1)]
+                ops = [dist.P2POp(dist.irecv, gather_bufs[r - 1][:hs[r]], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, d_out[:res.total_bytes], 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    phase = np.zeros(8)
+    for _ in range(args.steps):
+        res = step()
+        phase += np.array(list(res.kernel_ms))
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phase /= max(args.steps, 1)
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([nbytes, res.total_bytes], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        all_in, all_out = float(tot[0].item()), float(tot[1].item())
+    else:
+        all_in, all_out = float(nbytes), float(res.total_bytes)
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = all_in * args.steps / dt / 1e6
+
+    # ---- roofline for the dominant kernel (device time measured with HIP events on the context's stream) ----
+    names = {capi.T_QLT: "qlt", capi.T_GEN: "gen", capi.T_REC: "rec"}
+    sb = list(res.stream_bytes)
+    nq = args.reads * args.read_len
+    hdr_bytes = nbytes - args.reads * (2 * args.read_len + 6)
+    alg = {capi.T_QLT: nq + sb[2], capi.T_GEN: nq + sb[1] + sb[3] + sb[4], capi.T_REC: hdr_bytes + sb[0] + sb[5]}
+    dom = max(names, key=lambda k: phase[k])
+    achieved = alg[dom] / (phase[dom] * 1e-3) / 1e9 if phase[dom] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": names[dom] + "_encode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "alg_bytes_per_launch": int(alg[dom]), "avg_ms": round(float(phase[dom]), 3),
+                "whole_path_GBps": round((nbytes + res.total_bytes) / (phase[capi.T_TOTAL] * 1e-3) / 1e9, 3)}
+
+    out = {"metric": "MB/s FASTQ compressed", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+           "config": {"workload": ("synthetic %dM x %d bp Illumina reads per GPU, %s, -l %d" %
+                                   (args.reads // 1_000_000, args.read_len,
+                                    "full qlts+gens+recs" if args.workload == "full" else "qlts-only kernel", args.level))
+                      if args.reads >= 1_000_000 else "synthetic %d x %d bp reads" % (args.reads, args.read_len),
+                      "level": args.level, "block_reads": args.block_reads, "blocks_per_gpu": int(res.n_blocks),
+                      "raw_bytes_per_gpu": nbytes, "parallelism": "blocks sharded x%d, RCCL gather" % world if world > 1 else "1 GPU"},
+           "ratio": round(all_in / all_out, 4),
+           "phase_ms": {"frame": round(phase[capi.T_FRAME], 3), "qlt": round(phase[capi.T_QLT], 3), "gen": round(phase[capi.T_GEN], 3),
+                        "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
+                        "device_total": round(phase[capi.T_TOTAL], 3)},
+           "roofline": roofline, "synth_s": round(t_gen, 2)}
+    if world == 1 and not args.no_cpu_baseline:
+        cb, sample, ref_payload = cpu_baseline(args, seed)
+        out["cpu_baseline"] = cb
+        # ratio vs the reference on the same sample: ours in blocks vs the reference's single adaptive stream
+        enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel)
+        ours = enc.payload_bytes + int(enc.res.first_hdr_bytes) + 16 * int(enc.res.n_blocks)   # + first headers + ~index entry
+        if args.workload == "full":
+            out["ratio_vs_reference"] = {"sample_raw": len(sample), "reference_stream_bytes": int(ref_payload),
+                                         "ours_stream_bytes": int(ours), "ours_over_reference": round(ours / ref_payload, 4)}
+    print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
