@@ -42,6 +42,8 @@ __device__ __forceinline__ u32 b2_get(u32 v, RcDec& rc, ByteSrc& s, u32& sym_out
 // Log64Ranger / PowerRanger share one scheme (log64_ranger.hpp:51-138, power_ranger.hpp:49-131);
 // they differ in NSYM / STEP / MAX_FREQ and in the saturation slack (20 vs 256).
 // ---------------------------------------------------------------------------------------------------
+struct Triple { u32 cum, freq, tot; };    // RCoder::Encode(cumFreq, freq, totFreq) coder.hpp:66
+
 template <int NSYM, int STEP, int MAXF, int SAT>
 struct Ranger {
     // open a row: a stale epoch means the all-zero state of a fresh table
@@ -85,8 +87,9 @@ struct Ranger {
         }
         slots[i] = ns;
     }
-    // put (log64_ranger.hpp:98-112 / power_ranger.hpp:91-104)
-    static __device__ __forceinline__ void put(u32* slots, RowHdr* hp, u32 epoch, RcEnc& rc, ByteSink& snk, u32 sym) {
+    // the model half of put (log64_ranger.hpp:98-107,111 / power_ranger.hpp:91-100,103): find the symbol's
+    // slot, return what RCoder::Encode needs, update the row.
+    static __device__ __forceinline__ Triple model(u32* slots, RowHdr* hp, u32 epoch, u32 sym, u32& err) {
         u32 total, iend, count;
         open(hp, epoch, total, iend, count);
         if (iend <= sym) { for (u32 k = iend; k <= sym; k++) slots[k] = k << 16; iend = sym + 1; }
@@ -95,11 +98,17 @@ struct Ranger {
             s = slots[i];
             if ((s >> 16) == sym) break;
             sumf += s & 0xffff;
-            if (++i >= (u32)NSYM) { rc.err = 1; i = NSYM - 1; s = slots[i]; break; }   // unreachable on sane tables
+            if (++i >= (u32)NSYM) { err = 1; i = NSYM - 1; s = slots[i]; break; }   // unreachable on sane tables
         }
-        rc.encode(snk, sumf + i, (s & 0xffff) + 1, total + NSYM);
+        Triple t; t.cum = sumf + i; t.freq = (s & 0xffff) + 1; t.tot = total + NSYM;
         update(slots, i, s, total, iend, count);
         close(hp, epoch, total, iend, count);
+        return t;
+    }
+    // put (log64_ranger.hpp:98-112 / power_ranger.hpp:91-104)
+    static __device__ __forceinline__ void put(u32* slots, RowHdr* hp, u32 epoch, RcEnc& rc, ByteSink& snk, u32 sym) {
+        Triple t = model(slots, hp, epoch, sym, rc.err);
+        rc.encode(snk, t.cum, t.freq, t.tot);
     }
     // get (log64_ranger.hpp:114-138 / power_ranger.hpp:106-130)
     static __device__ __forceinline__ u32 get(u32* slots, RowHdr* hp, u32 epoch, RcDec& rc, ByteSrc& src) {

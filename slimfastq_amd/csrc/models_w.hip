@@ -1,0 +1,246 @@
+// models_w.hip -- wave-per-block throughput kernels (the default path).
+//
+// One 64-lane wavefront owns one record block: its adaptive tables, its range-coder state and its
+// output cursor.  The work of a symbol is split in three stages so that only what is inherently
+// serial runs serially:
+//   (1) lane-parallel : 64 symbols are loaded coalesced, and their model contexts are computed across
+//                       lanes (the quality model's running `delta` is a wave prefix sum)
+//   (2) wave-serial   : the adaptive row of each symbol is searched/updated with lane i holding slot i
+//                       of the row (NSYM = 64 = wave width): find by ballot, cumulative frequency by a
+//                       DPP prefix sum.  The (cum, freq, tot) triple is parked in lane k of a register.
+//   (3) scalar-serial : the range coder consumes the parked triples.  Its one divide per symbol
+//                       (coder.hpp:68) becomes a multiply-high by a per-triple reciprocal computed for all
+//                       64 triples at once in stage 3a, plus an exact fix-up -- bit-exact with range/tot.
+// The bytes produced are identical to models_l.hip (and so to the reference); tests compare both.
+#include "kernels.h"
+#include "dev_models.h"
+
+#define LAST_QLT 63u
+
+// ---- wave primitives (gfx950 = wave64, GFX9 DPP controls) --------------------------------------------
+#define DPP_ROW_SHR(n)  (0x110 + (n))
+#define DPP_WAVE_SHR1   0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+__device__ __forceinline__ u32 rl(u32 v, u32 lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// write a uniform value into one lane (this clang has no writelane builtin: compare + select)
+__device__ __forceinline__ u32 wl(u32 old, u32 val, u32 lane) { return (threadIdx.x == lane) ? val : old; }
+// lane 0's value.  Deliberately NOT readfirstlane: hipcc may sink a readfirstlane into a divergent
+// select (`lane == k ? rfl(x) : y`), where it would read lane k instead; readlane(.., 0) ignores EXEC.
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 0); }
+
+// inclusive prefix sum across the 64 lanes (6 DPP adds); lane 63 ends up with the wave total
+__device__ __forceinline__ u32 wave_incl_scan(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(1), 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(2), 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(4), 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(8), 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST15, 0xa, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return x;
+}
+// value of the previous lane; lane 0 receives `first`
+__device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+// ---- the wave's output window: lane k holds byte k of the current 64-byte window ------------------------
+struct WaveOut {
+    u8* p;
+    u32 pos, cap;      // uniform
+    u32 win;           // per lane
+    __device__ __forceinline__ void init(u8* ptr, u32 c) { p = ptr; pos = 0; cap = c; win = 0; }
+    __device__ __forceinline__ void put(u32 byte, u32 lane) {     // byte uniform
+        win = wl(win, byte, pos & 63);
+        pos++;
+        if ((pos & 63) == 0) {
+            const u32 at = pos - 64 + lane;
+            if (at < cap) p[at] = (u8)win;
+        }
+    }
+    __device__ __forceinline__ void flush(u32 lane) {
+        const u32 pend = pos & 63;
+        const u32 at = pos - pend + lane;
+        if (lane < pend && at < cap) p[at] = (u8)win;
+    }
+};
+
+// ---- stage 3: scalar range coder over the parked triples -------------------------------------------------
+struct WaveCoder {
+    u64 low;        // uniform
+    u32 range;      // uniform
+    u32 err;
+    __device__ __forceinline__ void init() { low = 0; range = 0xFFFFFFFFu; err = 0; }
+
+    // encode triples [0, nt) held one per lane in (tcum, tfreq, ttot)
+    __device__ __forceinline__ void run(u32 tcum, u32 tfreq, u32 ttot, u32 nt, WaveOut& out, u32 lane) {
+        // 3a. reciprocals for all triples at once: m = floor((2^32-1) / tot)  (tot >= 4 always)
+        const u32 minv = 0xFFFFFFFFu / (lane < nt ? ttot : 1u);
+        // 3b. the serial chain, on uniform values
+        for (u32 k = 0; k < nt; k++) {
+            const u32 cum = rl(tcum, k), freq = rl(tfreq, k), tot = rl(ttot, k), m = rl(minv, k);
+            // r = range / tot, exactly: the multiply-high estimate is never above and at most 2 below
+            u32 r = __umulhi(range, m);
+            u32 rem = range - r * tot;
+            while (rem >= tot) { r++; rem -= tot; }
+            low += (u64)(u32)(cum * r);                                  // coder.hpp:69
+            range = r * freq;                                            // coder.hpp:70
+            int guard = 0;
+            while (range < RC_TOP) {                                     // coder.hpp:74-80
+                if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
+                out.put((u32)(low >> 56), lane);
+                range <<= 8;
+                low <<= 8;
+                if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+            }
+        }
+    }
+    __device__ __forceinline__ void done(WaveOut& out, u32 lane) {       // coder.hpp:52-61
+        for (int i = 0; i < 8; i++) { out.put((u32)(low >> 56), lane); low <<= 8; }
+    }
+};
+
+// ---- stage 2: a Log64Ranger row spread over the wave (lane i = slot i) -------------------------------------
+struct WaveRow {
+    u32* slots; RowHdr* hdr;   // the block slot's table
+    u32 epoch;
+    u32 cur;                   // row held in registers (0xFFFFFFFF = none) -- uniform
+    u32 v;                     // per lane: freq | sym << 16
+    u32 total, iend, count;    // uniform
+    __device__ __forceinline__ void init(u32* s, RowHdr* h, u32 e) { slots = s; hdr = h; epoch = e; cur = 0xFFFFFFFFu; v = 0; total = iend = count = 0; }
+    __device__ __forceinline__ void writeback(u32 lane) {
+        if (cur == 0xFFFFFFFFu) return;
+        slots[(size_t)cur * L64_NSYM + lane] = v;
+        if (lane == 0) {
+            RowHdr h; h.total = total; h.iend = (u16)iend; h.count = (u8)count; h.pad = 0; h.epoch = epoch; h.pad2 = 0;
+            hdr[cur] = h;
+        }
+    }
+    __device__ __forceinline__ void select(u32 ctx, u32 lane) {
+        if (ctx == cur) return;
+        writeback(lane);
+        cur = ctx;
+        v = slots[(size_t)ctx * L64_NSYM + lane];
+        const RowHdr h = hdr[ctx];                        // same address in every lane: one broadcast load
+        const bool live = rfl(h.epoch) == epoch;          // a stale epoch = the all-zero row of a fresh table
+        total = live ? rfl(h.total) : 0u;
+        iend  = live ? rfl((u32)h.iend) : 0u;
+        count = live ? rfl((u32)h.count) : 0u;
+    }
+    // Log64Ranger::put minus the Encode call (log64_ranger.hpp:98-112); sym < 64, uniform
+    __device__ __forceinline__ void model(u32 sym, u32 lane, u32& cum, u32& freq, u32& tot) {
+        if (iend <= sym) {                                            // :103-105
+            if (lane >= iend && lane <= sym) v = lane << 16;
+            iend = sym + 1;
+        }
+        const u64 hit = __ballot(lane < iend && (v >> 16) == sym);
+        const u32 i = (u32)__ffsll((long long)hit) - 1u;              // :107 (syms[0..iend) is a permutation: exactly one hit)
+        u32 f = rl(v, i) & 0xffffu;
+        u32 sumf = 0;
+        if (i != 0) {
+            const u32 inc = wave_incl_scan(lane < i ? (v & 0xffffu) : 0u);
+            sumf = rl(inc, 63);
+        }
+        cum = sumf + i; freq = f + 1; tot = total + L64_NSYM;         // :109
+        // update_freq (log64_ranger.hpp:69-87)
+        if (f > (u32)((1 << 16) - 64 - 6)) {
+            if (i == 0 && f + 20u > total) return;
+            if (lane < iend) v = (v & 0xffff0000u) | ((v & 0xffffu) >> 1);     // normalize :51-54
+            total = rl(wave_incl_scan(lane < iend ? (v & 0xffffu) : 0u), 63);
+            f >>= 1;
+        }
+        f += 6; total += 6;
+        if (lane == i) v = (v & 0xffff0000u) | f;
+        if (i != 0) {
+            count = (count + 1) & 0xffu;
+            if ((count & 0xfu) == 0) {
+                const u32 pv = rl(v, i - 1), nv = rl(v, i);
+                if (f > (pv & 0xffffu)) { v = wl(v, nv, i - 1); v = wl(v, pv, i); }   // down_level :56-67
+            }
+        }
+    }
+};
+
+// =========================================================================================================
+// quality encode: QltSave::save_1/2/3 (qlts.cpp:74-136) for every record of the block
+// =========================================================================================================
+__global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a) {
+    const u32 lane = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    const u32 epoch = a.epoch_base + b + 1;
+    BlockDesc* d = &a.blocks[b];
+    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
+    WaveCoder rc; rc.init();
+    WaveRow row; row.init(a.q_slots + (size_t)t * a.q_rows * L64_NSYM, a.q_hdr + (size_t)t * a.q_rows, epoch);
+    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
+    const u32 solid = d->solid;
+    const int level = a.level;
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    u32 tcum = 0, tfreq = 0, ttot = 1, nt = 0;      // parked triples
+    u32 extra_hi = 0, perr = 0;
+
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k;
+        const u64 q0 = a.line_off[4 * r + 3] + solid;
+        const u64 q1e = a.line_off[4 * r + 4] - 1;
+        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u8* p = a.fq + q0;
+        u32 p1 = 0, p2 = 0, p3 = 0, carry_d = 0;       // the three previous symbols and the running delta - 5
+        for (u32 base = 0; base < n; base += 64) {
+            const u32 m = n - base < 64 ? n - base : 64;
+            // ---- stage 1: symbols and contexts, across lanes ----
+            const u32 bv = lane < m ? (u32)(u8)(p[base + lane] - '!') : 0u;
+            const u32 v1 = wave_shr1(bv, p1);           // symbol k-1
+            const u32 v2 = wave_shr1(v1, p2);           // symbol k-2
+            const u32 v3 = wave_shr1(v2, p3);           // symbol k-3
+            u32 ctxv;
+            if (level == 1)      ctxv = (v1 | ((v2 & 63u) << 6)) & 0xFFFu;                                  // qlts.hpp:52-54 unrolled
+            else if (level == 2) ctxv = (v1 | (((v2 | ((v3 & 15u) << 6)) & 0x3FFu) << 6)) & 0xFFFFu;       // qlts.hpp:55-57 unrolled
+            else {                                                                                         // qlts.hpp:62-74
+                // delta after symbol j = 5 + sum_{i<=j} max(0, sym[i-1] - sym[i]); symbol k's context uses delta after k-1
+                const u32 drop = (lane < m && v1 > bv) ? v1 - bv : 0u;
+                const u32 inc = wave_incl_scan(drop);
+                const u32 dprev = 5u + carry_d + inc - drop;
+                const u32 d3 = dprev >> 3;
+                ctxv = (v1 | ((v2 < v3 ? v3 : v2) << 6) | ((u32)(v2 == v3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                if (base == 0 && lane == 0) ctxv = 0;   // qlts.cpp:109: last = 0 for the first symbol
+                carry_d += rl(inc, 63);
+            }
+            p3 = m >= 3 ? rl(bv, m - 3) : (m == 2 ? p1 : p2);
+            p2 = m >= 2 ? rl(bv, m - 2) : p1;
+            p1 = rl(bv, m - 1);
+            // ---- stage 2: adaptive rows, one symbol at a time ----
+            for (u32 j = 0; j < m; j++) {
+                const u32 ctx = rl(ctxv, j), sym = rl(bv, j);
+                row.select(ctx, lane);
+                u32 cum, freq, tot;
+                row.model(sym < LAST_QLT ? sym : LAST_QLT, lane, cum, freq, tot);     // qlts.cpp:79-86
+                { const bool me = lane == nt; tcum = me ? cum : tcum; tfreq = me ? freq : tfreq; ttot = me ? tot : ttot; nt++; }
+                if (sym >= LAST_QLT) {                   // escape: the raw value through the PowerRanger row
+                    Triple e; e.cum = 0; e.freq = 1; e.tot = 1;
+                    if (lane == 0) e = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, epoch, sym, perr);
+                    const u32 ec = rfl(e.cum), ef = rfl(e.freq), et = rfl(e.tot);
+                    { const bool me = lane == nt; tcum = me ? ec : tcum; tfreq = me ? ef : tfreq; ttot = me ? et : ttot; nt++; }
+                    extra_hi++;
+                }
+                if (nt >= 62) { rc.run(tcum, tfreq, ttot, nt, out, lane); nt = 0; }    // ---- stage 3 ----
+            }
+        }
+    }
+    row.writeback(lane);
+    rc.run(tcum, tfreq, ttot, nt, out, lane);
+    rc.done(out, lane);
+    out.flush(lane);
+    if (lane == 0) {
+        d->extra_hi = extra_hi;
+        d->size[SFQ_S_QLT] = out.pos;
+        if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (rc.err | rfl(perr)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    }
+}
+void launch_qlt_encode_w(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+}
