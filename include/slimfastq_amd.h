@@ -118,7 +118,7 @@ typedef struct sfq_result {
 int  sfq_ctx_create(sfq_ctx** out, int hip_device);
 void sfq_ctx_destroy(sfq_ctx* ctx);
 const char* sfq_last_error(const sfq_ctx* ctx);         /* replaces croak() text (config.cpp:54-68) */
-/* Upper bound on device bytes the context may hold for model tables (default: 1/3 of the device). */
+/* Upper bound on device bytes the context may hold for model tables (default: 70 % of the device). */
 int  sfq_ctx_set_table_budget(sfq_ctx* ctx, uint64_t bytes);
 /* The HIP stream the context launches on (a hipStream_t), for callers that order work against it. */
 void* sfq_ctx_stream(sfq_ctx* ctx);

@@ -158,7 +158,7 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
     ctx->dev_total = tot;
-    ctx->table_budget = tot / 3;
+    ctx->table_budget = tot / 10 * 7;
     *out = ctx;
     return SFQ_OK;
 }
@@ -260,24 +260,31 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ModelArgs a;
     fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
     a.fq = d_fastq;
-    // one event pair per model (kernels of one model over all batches are contiguous on the stream)
+    // The four models are independent chains over the same text: each runs on its own HIP stream, forked
+    // from / joined to the context's stream with events, so their kernels overlap on the chip.
     const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
+    hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
     for (int m = 0; m < 4; m++) {
-        HIPC(hipEventRecord(ctx->ev[2 + m], st));
-        if (!(models & order[m])) continue;
-        for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
-            a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
-            switch (order[m]) {
-            case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, st); else launch_qlt_encode_w(a, st); break;
-            case SFQ_M_GEN:
-                launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, st);   // base2_ranger.hpp:68-71
-                launch_gen_encode_l(a, st); break;
-            case SFQ_M_REC: launch_rec_encode_l(a, st); break;
-            case SFQ_M_USR: launch_usr_encode_l(a, st); break;
+        if (m) HIPC(hipStreamWaitEvent(mst[m], ctx->ev[1], 0));
+        HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m]));
+        if (models & order[m]) {
+            for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+                a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
+                switch (order[m]) {
+                case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, mst[m]); else launch_qlt_encode_w(a, mst[m]); break;
+                case SFQ_M_GEN:
+                    launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);   // base2_ranger.hpp:68-71
+                    if (p.kernel == 1) launch_gen_encode_l(a, mst[m]); else launch_gen_encode_w(a, mst[m]);
+                    break;
+                case SFQ_M_REC: if (p.kernel == 1) launch_rec_encode_l(a, mst[m]); else launch_rec_encode_w(a, mst[m]); break;
+                case SFQ_M_USR: launch_usr_encode_l(a, mst[m]); break;
+                }
             }
         }
+        HIPC(hipEventRecord(ctx->ev[3 + 2 * m], mst[m]));
+        if (m) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
     }
-    HIPC(hipEventRecord(ctx->ev[6], st));
+    HIPC(hipEventRecord(ctx->ev[10], st));
     ctx->epoch_base += nblocks;
 
     // ---- pack ----------------------------------------------------------------------------------
@@ -311,7 +318,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
     launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
                    (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-    HIPC(hipEventRecord(ctx->ev[7], st));
+    HIPC(hipEventRecord(ctx->ev[11], st));
     ctx->first_hdrs.resize((size_t)hboff[nblocks]);
     if (hboff[nblocks] > blob_cap) return fail(ctx, SFQ_E_OVERFLOW, "first-header blob overflow");
     if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
@@ -330,12 +337,12 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     res->n_records = nrec; res->n_blocks = nblocks; res->first_hdr_bytes = hboff[nblocks];
     res->kernel_ms[SFQ_T_FRAME] = ev_ms(ctx->ev[0], ctx->ev[1]);
-    res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
-    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[3], ctx->ev[4]);
-    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[4], ctx->ev[5]);
-    res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[5], ctx->ev[6]);
-    res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[6], ctx->ev[7]);
-    res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[7]);
+    res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);     // the models overlap: these do not add up
+    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[4], ctx->ev[5]);
+    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[6], ctx->ev[7]);
+    res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[8], ctx->ev[9]);
+    res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
+    res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
     return SFQ_OK;
 }
 

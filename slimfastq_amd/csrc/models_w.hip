@@ -244,3 +244,152 @@ __global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a) {
 void launch_qlt_encode_w(const ModelArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_qlt_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
 }
+
+// =========================================================================================================
+// base encode: GenSave::save_x + normalize_gen (gens.cpp:91-159) for every record of the block
+//
+// Bases are the one model whose symbols can be modelled across lanes: the context of base k is a hash
+// of the previous 9..13 bases only (gens.cpp:138-148), so 64 consecutive bases gather their 4-byte
+// Base2Ranger rows at once, each lane computes its own (cum, freq, tot) and row update, and the rows are
+// scattered back.  Two bases of one 64-window that share a context would have to chain through the same
+// row; a bitonic sort of (context, lane) keys detects that exactly, and such a window falls back to 64
+// serial steps.  The range coder then consumes the 64 triples (stage 3 above).
+// =========================================================================================================
+__device__ __forceinline__ u32 gencode_w(u32 c) {                      // gens.cpp:72-77
+    const u32 l = c | 0x20u;
+    u32 n = 0x10u;
+    n = (l == 'a' || c == '0') ? 0u : n;
+    n = (l == 'c' || c == '1') ? 1u : n;
+    n = (l == 'g' || c == '2') ? 2u : n;
+    n = (l == 't' || c == '3') ? 3u : n;
+    n = (l == 'n' || c == '.') ? 4u : n;
+    return n;
+}
+__device__ __forceinline__ u32 shfl_up0(u32 x, u32 d, u32 lane) {      // lane-d's value, 0 for lanes < d
+    const u32 y = (u32)__shfl_up((int)x, d, 64);
+    return lane >= d ? y : 0u;
+}
+__device__ __forceinline__ u32 bitonic_sort64(u32 key, u32 lane) {
+#pragma unroll
+    for (u32 k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)key, j, 64);
+            const bool up = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const u32 lo = key < other ? key : other, hi = key < other ? other : key;
+            key = (lower == up) ? lo : hi;
+        }
+    }
+    return key;
+}
+// Base2Ranger::put minus the Encode call, on a row value (base2_ranger.hpp:74-84)
+__device__ __forceinline__ u32 b2_model(u32 v, u32 sym, u32& cum, u32& freq, u32& tot) {
+    const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+    tot = (f0 + f1) + (f2 + f3);
+    cum = sym == 0 ? 0u : sym == 1 ? f0 : sym == 2 ? f0 + f1 : f0 + f1 + f2;
+    freq = (v >> (8 * sym)) & 0xff;
+    return b2_update(v, sym);
+}
+
+__global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a) {
+    const u32 lane = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    const u32 epoch = a.epoch_base + b + 1;
+    BlockDesc* d = &a.blocks[b];
+    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_GEN], d->out_cap[SFQ_S_GEN]);
+    WaveCoder rc; rc.init();
+    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
+    XfEnc x_ns, x_nn;                                  // side-stream coders: lane 0 only
+    x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
+    x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+    u32* tab = a.g_tab + ((size_t)t << a.g_bits);
+    const u32 solid = d->solid;
+    const u32 mask = (1u << d->gen_bits) - 1u;
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    u64 genofs = 0, ns_index = 0, nn_index = 0;        // g_genofs_count, m_last.{Ns,Nn}_index (block-relative)
+    u32 n_byte = 0; int bad = 0;
+
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k;
+        const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1;
+        const u64 q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
+        const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
+        const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
+        u32 carry = 0x007616c7u;                                                      // gens.cpp:139
+        for (u32 base = 0; base < llen; base += 64) {
+            const u32 m = llen - base < 64 ? llen - base : 64;
+            const u32 idx = base + lane;
+            const bool in = lane < m;
+            const u32 gch = in ? gp[idx] : 'A';
+            const u32 qch = (in && idx < qlen) ? qp[idx] : 40u;                       // gens.cpp:153
+            const u32 n = gencode_w(gch);                                             // normalize_gen gens.cpp:116-136
+            const bool bad_n = in && n == 4, bad_q = in && qch == '!';
+            if (__ballot(in && n > 4)) bad = SFQ_E_GENCHAR;
+            const u32 code = n & 3u;                                                  // N is coded as 0 (A)
+            const u64 mN = __ballot(bad_n), mQ = __ballot(bad_q);
+            u64 mx = mN | mQ;
+            while (mx) {                                                              // bad_q_or_bad_n gens.cpp:91-114, in order
+                const u32 bit = (u32)__ffsll((long long)mx) - 1u;
+                mx &= mx - 1;
+                const u64 pos = genofs + bit + 1;
+                const bool is_n = (mN >> bit) & 1, is_q = (mQ >> bit) & 1;
+                if (!is_n) {
+                    if (lane == 0) x_nn.put(pw, pos - nn_index);
+                    nn_index = pos;
+                } else {
+                    const u32 ch = rl(gch, bit);
+                    if (!n_byte) n_byte = ch;
+                    if (ch != n_byte) bad = SFQ_E_GENCHAR;
+                    if (!is_q) { if (lane == 0) x_ns.put(pw, pos - ns_index); ns_index = pos; }
+                }
+            }
+            genofs += m;
+            // contexts: a 32-bit shift register of 2-bit codes; lane k sees the codes of lanes < k, then the carry
+            u32 w = wave_shr1(code, 0u);                            // code[k-1]
+            w |= wave_shr1(w, 0u) << 2;                             // 2 symbols
+            w |= shfl_up0(w, 2, lane) << 4;                         // 4
+            w |= shfl_up0(w, 4, lane) << 8;                         // 8
+            w |= shfl_up0(w, 8, lane) << 16;                        // 16
+            const u32 ctx = ((lane < 16 ? carry << (2 * lane) : 0u) | w) & mask;
+            carry = (rl(w, 63) << 2) | rl(code, 63);                // only meaningful (and only used) after a full window
+            // rows
+            u32 row = in ? tab[ctx] : 0u;
+            const u32 key = in ? ((ctx << 6) | lane) : (0x80000000u | (lane << 6) | lane);
+            const u32 sk = bitonic_sort64(key, lane);
+            const u32 skp = (u32)__shfl_up((int)sk, 1, 64);
+            const bool dup = lane > 0 && (sk >> 6) == (skp >> 6);
+            u32 cum = 0, freq = 1, tot = 1;
+            if (!__ballot(dup)) {
+                const u32 nrow = b2_model(row, code, cum, freq, tot);
+                if (in) tab[ctx] = nrow;
+            } else {
+                for (u32 j = 0; j < m; j++) {                       // same-context bases in one window: chain them in order
+                    const u32 c = rl(ctx, j), s = rl(code, j);
+                    u32 cj, fj, tj;
+                    const u32 nrow = b2_model(tab[c], s, cj, fj, tj);
+                    if (lane == 0) tab[c] = nrow;
+                    if (lane == j) { cum = cj; freq = fj; tot = tj; }
+                }
+            }
+            rc.run(cum, freq, tot, m, out, lane);
+        }
+    }
+    rc.done(out, lane);
+    out.flush(lane);
+    if (lane == 0) {
+        d->n_byte = n_byte;
+        d->size[SFQ_S_GEN] = out.pos;
+        d->size[SFQ_S_GEN_NS] = x_ns.finish(pw);
+        d->size[SFQ_S_GEN_NN] = x_nn.finish(pw);
+        if (out.pos > out.cap || x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (rc.err | x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        if (bad) atomicMax(&d->status, (u32)(-bad));
+    }
+}
+void launch_gen_encode_w(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+}
+void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) { launch_rec_encode_l(a, st); }   // header model: lane-per-block for now

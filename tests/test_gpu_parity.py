@@ -143,3 +143,36 @@ def test_qlt_only_entry_point(ctx):
     got = bytes(out[:res.total_bytes].cpu().numpy())
     want = b"".join(O.compress(c, 3).streams["qlt"] for c in util.split_records(fq, 500))
     assert got == want
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_low_complexity_bases_same_context_in_one_window(ctx, kernel):
+    """Homopolymers / short tandem repeats put the same base context many times into one 64-base window:
+    the wave kernel must chain those updates in order (its serial fallback)."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i in range(400):
+        kind = i % 5
+        n = rnd.choice([30, 64, 65, 150, 200])
+        if kind == 0:
+            seq = rnd.choice("ACGT") * n
+        elif kind == 1:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([2, 3, 5, 13])))
+            seq = (unit * (n // len(unit) + 1))[:n]
+        elif kind == 2:
+            seq = "".join(rnd.choice("ACGT") for _ in range(n))
+        elif kind == 3:
+            seq = "".join(rnd.choice("AAAAAAAC") for _ in range(n))
+        else:
+            seq = "N" * (n // 2) + "ACGT" * (n // 8 + 1)
+            seq = seq[:n]
+        qual = "".join(rnd.choice("!#5II") if c == "N" else rnd.choice("II5I!") if rnd.random() < 0.02 else "I" for c in seq)
+        recs.append("@lc.%d\n%s\n+\n%s\n" % (i, seq, qual))
+    fq = "".join(recs).encode()
+    for level, br in ((1, 0), (3, 0), (4, 0), (3, 64)):
+        enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel)
+        for b, chunk in enumerate(util.split_records(fq, br) if br else [fq]):
+            want = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            assert_streams_equal(enc, want, block=b, ctxmsg="lowcomplexity l%d b%d" % (level, b))
+        assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
