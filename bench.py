@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -89,6 +90,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     seed = 1
     models = 0 if args.workload == "full" else capi.M_QLT
+    if args.models:
+        models = args.models
 
     # ---- synthetic input, resident in HBM before anything is timed ----
     t0 = time.perf_counter()

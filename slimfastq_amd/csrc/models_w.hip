@@ -392,4 +392,243 @@ __global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a) {
 void launch_gen_encode_w(const ModelArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
 }
-void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) { launch_rec_encode_l(a, st); }   // header model: lane-per-block for now
+
+// =========================================================================================================
+// header encode: RecSave::save (recs.cpp:277-372) for every record of the block
+//
+// The header model is control-heavy and light on symbols (~10 coded bytes per record): tokenise at
+// non-alphanumerics, diff against the previous header, type each changed field.  All of that runs
+// wave-uniformly (every lane computes the same scalars; its loads are single broadcast requests).  What
+// the wave buys is the PowerRanger row: 256 slots = 4 per lane, searched with one ballot and summed
+// with one DPP scan instead of a 256-step dependent walk through HBM.
+// =========================================================================================================
+#include "dev_rec.h"
+
+struct Sink0 {                 // uniform cursor; lane 0 stores
+    u8* p; u32 pos, cap;
+    __device__ __forceinline__ void put(u32 b) { if (threadIdx.x == 0 && pos < cap) p[pos] = (u8)b; pos++; }
+};
+struct RcEncU {                // RCoder (coder.hpp) on uniform values, one symbol at a time
+    u64 low; u32 range, err;
+    __device__ __forceinline__ void init() { low = 0; range = 0xFFFFFFFFu; err = 0; }
+    __device__ __forceinline__ void encode(Sink0& s, u32 cum, u32 freq, u32 tot) {      // coder.hpp:66-81
+        const u32 r = range / tot;
+        low += (u64)(u32)(cum * r);
+        range = r * freq;
+        int guard = 0;
+        while (range < RC_TOP) {
+            if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
+            s.put((u32)(low >> 56));
+            range <<= 8; low <<= 8;
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+    __device__ __forceinline__ void done(Sink0& s) { for (int i = 0; i < 8; i++) { s.put((u32)(low >> 56)); low <<= 8; } }
+};
+
+// A block slot's PowerRanger rows with lane l holding slots 4l..4l+3 (power_ranger.hpp:36-131).
+struct WavePw {
+    u32* slots; RowHdr* hdr; u32 epoch;
+    __device__ __forceinline__ u32 comp(const uint4& v, u32 c) const { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+    // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
+    __device__ Triple model(u32 row, u32 sym, u32 lane) {
+        u32* rs = slots + (size_t)row * PW_NSYM;
+        const RowHdr h = hdr[row];
+        const bool live = rl(h.epoch, 0) == epoch;
+        u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
+        const u32 i0 = 4 * lane;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);       // only the lanes that hold live slots
+        u64 dirty = 0;                                                     // lanes to store back
+        if (iend <= sym) {                                                 // :94-96
+            if (i0 + 0 >= iend && i0 + 0 <= sym) v.x = (i0 + 0) << 16;
+            if (i0 + 1 >= iend && i0 + 1 <= sym) v.y = (i0 + 1) << 16;
+            if (i0 + 2 >= iend && i0 + 2 <= sym) v.z = (i0 + 2) << 16;
+            if (i0 + 3 >= iend && i0 + 3 <= sym) v.w = (i0 + 3) << 16;
+            dirty |= __ballot(i0 + 3 >= iend && i0 <= sym);
+            iend = sym + 1;
+        }
+        const u32 mc = ((i0 + 0 < iend && (v.x >> 16) == sym) ? 1u : 0u) | ((i0 + 1 < iend && (v.y >> 16) == sym) ? 2u : 0u) |
+                       ((i0 + 2 < iend && (v.z >> 16) == sym) ? 4u : 0u) | ((i0 + 3 < iend && (v.w >> 16) == sym) ? 8u : 0u);
+        const u64 hit = __ballot(mc != 0);
+        const u32 hl = (u32)__ffsll((long long)hit) - 1u;                  // :98 (exactly one slot holds sym)
+        const u32 c = (u32)__ffs((int)rl(mc, hl)) - 1u;
+        const u32 i = 4 * hl + c;
+        const u32 part = ((i0 + 0 < i) ? (v.x & 0xffffu) : 0u) + ((i0 + 1 < i) ? (v.y & 0xffffu) : 0u) +
+                         ((i0 + 2 < i) ? (v.z & 0xffffu) : 0u) + ((i0 + 3 < i) ? (v.w & 0xffffu) : 0u);
+        const u32 sumf = i ? rl(wave_incl_scan(part), 63) : 0u;
+        u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
+        u32 f = cur & 0xffffu;
+        Triple t; t.cum = sumf + i; t.freq = f + 1; t.tot = total + PW_NSYM;               // :100
+        bool upd = true;
+        if (f > (u32)((1 << 15) - 32 - 14)) {                              // update_freq :66-84
+            if (i == 0 && f + 256u > total) upd = false;
+            else {
+                if (i0 + 0 < iend) v.x = (v.x & 0xffff0000u) | ((v.x & 0xffffu) >> 1);     // normalize :49-52
+                if (i0 + 1 < iend) v.y = (v.y & 0xffff0000u) | ((v.y & 0xffffu) >> 1);
+                if (i0 + 2 < iend) v.z = (v.z & 0xffff0000u) | ((v.z & 0xffffu) >> 1);
+                if (i0 + 3 < iend) v.w = (v.w & 0xffff0000u) | ((v.w & 0xffffu) >> 1);
+                const u32 p2 = ((i0 + 0 < iend) ? (v.x & 0xffffu) : 0u) + ((i0 + 1 < iend) ? (v.y & 0xffffu) : 0u) +
+                               ((i0 + 2 < iend) ? (v.z & 0xffffu) : 0u) + ((i0 + 3 < iend) ? (v.w & 0xffffu) : 0u);
+                total = rl(wave_incl_scan(p2), 63);
+                f >>= 1;
+                dirty |= __ballot(i0 < iend);
+            }
+        }
+        if (upd) {
+            f += 14; total += 14;
+            u32 ns = (cur & 0xffff0000u) | f;
+            u32 at = i;                                                    // where ns lands
+            if (i != 0) {
+                count = (count + 1) & 0xffu;
+                if ((count & 0xfu) == 0) {
+                    const u32 pl = (i - 1) >> 2, pc = (i - 1) & 3;
+                    const u32 pv = pc == 0 ? rl(v.x, pl) : pc == 1 ? rl(v.y, pl) : pc == 2 ? rl(v.z, pl) : rl(v.w, pl);
+                    if (f > (pv & 0xffffu)) {                              // down_level :54-64
+                        if (lane == hl) { if (c == 0) v.x = pv; else if (c == 1) v.y = pv; else if (c == 2) v.z = pv; else v.w = pv; }
+                        at = i - 1;
+                        dirty |= 1ull << hl;
+                    }
+                }
+            }
+            const u32 al = at >> 2, ac = at & 3;
+            if (lane == al) { if (ac == 0) v.x = ns; else if (ac == 1) v.y = ns; else if (ac == 2) v.z = ns; else v.w = ns; }
+            dirty |= 1ull << al;
+        }
+        if ((dirty >> lane) & 1) *reinterpret_cast<uint4*>(rs + i0) = v;
+        if (lane == 0) {
+            RowHdr nh; nh.total = total; nh.iend = (u16)iend; nh.count = (u8)count; nh.pad = 0; nh.epoch = epoch; nh.pad2 = 0;
+            hdr[row] = nh;
+        }
+        return t;
+    }
+    __device__ __forceinline__ void put(u32 row, RcEncU& rc, Sink0& s, u32 sym, u32 lane) {
+        const Triple t = model(row, rl(sym, 0), lane);
+        rc.encode(s, t.cum, t.freq, t.tot);
+    }
+    // PowerRangerU::put_u (power_ranger.hpp:138-163)
+    __device__ void put_u(u32 row0, RcEncU& rc, Sink0& s, u64 num, u32 lane) {
+        if (num <= 0x7f) { put(row0, rc, s, (u32)num, lane); return; }
+        if (num < 0x7ffe) {
+            put(row0, rc, s, 0xff & (0x80 | (u32)(num >> 8)), lane);
+            put(row0 + 1, rc, s, 0xff & (u32)num, lane);
+            return;
+        }
+        put(row0, rc, s, 0xff, lane);
+        if (num < (1ULL << 32)) {
+            put(row0 + 1, rc, s, 0xfe, lane);
+            for (int sh = 0, i = 2; sh < 32; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh), lane);
+            return;
+        }
+        put(row0 + 1, rc, s, 0xff, lane);
+        for (int sh = 0, i = 6; sh < 64; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh), lane);
+    }
+};
+struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
+    RcEncU rc; Sink0 sink; u32 row0, opened;
+    __device__ __forceinline__ void init(u8* p, u32 cap, u32 xf) { sink.p = p; sink.pos = 0; sink.cap = cap; row0 = PR_XF_BASE + xf * PR_XF_ROWS; opened = 0; rc.init(); }
+    __device__ __forceinline__ void put(WavePw& t, u64 gap, u32 lane) { opened = 1; t.put_u(row0, rc, sink, gap, lane); }
+    __device__ __forceinline__ void put_str(WavePw& t, const u8* p, u32 len, u32 lane) {
+        put(t, len, lane);
+        for (u32 j = 0; j < len; j++) t.put(row0 + 14, rc, sink, p[j], lane);
+    }
+    __device__ __forceinline__ u32 finish(WavePw& t, u32 lane) {
+        if (!opened) return 0;
+        put(t, 0, lane);
+        rc.done(sink);
+        return sink.pos;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_rec_encode_w(ModelArgs a) {
+    const u32 lane = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    BlockDesc* d = &a.blocks[b];
+    WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = a.epoch_base + b + 1;
+    Sink0 snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
+    RcEncU rc; rc.init();
+    XfEncW x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    SpaceMap sm[2];
+    u8  ctype[2][66];
+    u64 cnumb[2][66];
+    u32 imap = 0; int bad = 0;
+    u64 last_index = 0;
+    u32 hdr_bytes = 0;
+    const u8* prev = nullptr;
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k;
+        const u64 record_count = (u64)k + 1;
+        const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
+        const u8* buf = a.fq + h0;
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        hdr_bytes += n;
+        if (k == 0) {                                                         // recs.cpp:279-287
+            imap = 0;
+            if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
+            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+            prev = buf;
+            continue;
+        }
+        const u32 pmap = imap;
+        imap ^= 1;
+        if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
+        SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
+        bool shape = mi.len != mp.len;
+        if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
+        if (shape) {                                                          // recs.cpp:292-305
+            x_rec.put(pw, record_count - last_index, lane);
+            last_index = record_count;
+            x_rec.put_str(pw, buf, n, lane);
+            for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            prev = buf;
+            continue;
+        }
+        u64 map = 0;
+        for (u32 i = 0; i < mi.len; i++)
+            if (mi.wln[i] != mp.wln[i] || bytes_differ(buf + mi.off[i], prev + mp.off[i], mi.wln[i])) map |= 1ULL << i;
+        pw.put_u(0 * 16 + 2, rc, snk, map, lane);                             // put_num(0, map) recs.cpp:313
+        for (u32 i = 0; i < mi.len; i++) {
+            if (map & (1ULL << i)) {
+                const u8* bp = buf + mi.off[i];
+                u64 bnum;
+                u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                const u32 rr = (i + 1) * 16;
+                if (type == ST_STR) {                                         // recs.cpp:324-331
+                    pw.put(rr + 0, rc, snk, type, lane);
+                    pw.put_u(rr + 2, rc, snk, mi.wln[i], lane);
+                    for (u32 j = 0; j < mi.wln[i]; j++) pw.put(rr + 1, rc, snk, bp[j], lane);
+                    ctype[imap][i] = 0;
+                    continue;
+                }
+                u64 pnum = ctype[pmap][i] ? cnumb[pmap][i] : 0;                // recs.cpp:333-348
+                u64 gap;
+                ctype[imap][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+                cnumb[imap][i] = bnum;
+                if (bnum < pnum) { gap = pnum - bnum; type++; }
+                else gap = bnum - pnum;
+                pw.put(rr + 0, rc, snk, type, lane);
+                pw.put_u(rr + 2, rc, snk, gap, lane);
+            } else {
+                ctype[imap][i] = ctype[pmap][i];
+                cnumb[imap][i] = cnumb[pmap][i];
+            }
+        }
+        prev = buf;
+    }
+    rc.done(snk);
+    const u32 xsz = x_rec.finish(pw, lane);
+    if (lane == 0) {
+        d->hdr_bytes = hdr_bytes;
+        d->size[SFQ_S_REC] = snk.pos;
+        d->size[SFQ_S_REC_X] = xsz;
+        if (snk.pos > snk.cap || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (rc.err | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        if (bad) atomicMax(&d->status, (u32)(-bad));
+    }
+}
+void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+}
