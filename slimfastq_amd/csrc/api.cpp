@@ -91,7 +91,7 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     int rc;
     if (per_q) {
         const size_t need_s = (size_t)slots * q_rows * L64_NSYM * 4, need_h = (size_t)slots * q_rows * sizeof(RowHdr);
-        if ((rc = reserve(ctx, t.q_slots, need_s))) return rc;
+        if ((rc = reserve(ctx, t.q_slots, need_s, true))) return rc;      // zeroed: the wave kernel keeps its row tags inside
         if (need_h > t.q_hdr.cap || !t.q_hdr.p) { release(t.q_hdr); if ((rc = reserve(ctx, t.q_hdr, need_h, true))) return rc; }
         t.q_rows = q_rows;
     }
@@ -122,8 +122,9 @@ void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_b
 
 // epochs are unique per (context lifetime, block); on wrap the row headers are cleared
 int advance_epoch(sfq_ctx* ctx, u32 nblocks) {
-    if ((u64)ctx->epoch_base + nblocks + 2 >= 0xFFFFFFFFull) {
+    if ((u64)ctx->epoch_base + nblocks + 2 >= 0x3FFFFFFFull) {
         Tables& t = ctx->tab;
+        if (t.q_slots.p) HIPC(hipMemsetAsync(t.q_slots.p, 0, t.q_slots.cap, ctx->st));
         if (t.q_hdr.p) HIPC(hipMemsetAsync(t.q_hdr.p, 0, t.q_hdr.cap, ctx->st));
         if (t.p_hdr.p) HIPC(hipMemsetAsync(t.p_hdr.p, 0, t.p_hdr.cap, ctx->st));
         ctx->epoch_base = 0;

@@ -21,7 +21,7 @@ __device__ __forceinline__ bool dslot_init(const ModelArgs& a, DSlot& s) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.nbatch) return false;
     s.b = a.batch0 + t;
-    s.epoch = a.epoch_base + s.b + 1;
+    s.epoch = EPOCH_L(a.epoch_base + s.b + 1);
     s.q_slots = a.q_slots ? a.q_slots + (size_t)t * a.q_rows * L64_NSYM : nullptr;
     s.q_hdr   = a.q_hdr ? a.q_hdr + (size_t)t * a.q_rows : nullptr;
     s.pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM;

@@ -31,6 +31,12 @@ struct RowHdr {
     u32 pad2;
 };
 
+// Epoch tags: plain row kernels and the wave quality kernel lay rows out differently inside the same
+// table memory, so their tags live in disjoint ranges, and neither range can collide with slot data
+// (freq | sym << 16 < 0x00400000).  Raw epochs stay below 2^30 (api.cpp advance_epoch).
+#define EPOCH_L(e) (0x40000000u | (e))
+#define EPOCH_W(e) (0x80000000u | (e))
+
 #define L64_NSYM 64
 #define PW_NSYM  256
 
