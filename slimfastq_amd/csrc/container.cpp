@@ -1,0 +1,218 @@
+// container.cpp -- see container.h.  Host-side file plumbing only; no entropy coding here.
+#include "container.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace sfqc {
+
+static const size_t PAGE = 0x2000;            // filer.hpp:34
+static const size_t NODE_IDS = PAGE / 4 - 1;  // filer.hpp:39 : 2047 ids, then the next-node id
+static const size_t MAX_FILES = PAGE / 24;    // filer.cpp:49 : 341
+
+#pragma pack(push, 1)
+struct DirEnt { char name[8]; uint64_t size; uint32_t first; uint32_t node; };
+#pragma pack(pop)
+static_assert(sizeof(DirEnt) == 24, "directory entry is 24 bytes (filer.cpp:42-47)");
+
+const char* Archive::get(const std::string& key) const {
+    for (auto& kv : info) if (kv.first == key) return kv.second.c_str();
+    return "";
+}
+long long Archive::get_long(const std::string& key, long long dflt) const {
+    const char* s = get(key);
+    return *s ? atoll(s) : dflt;                                       // config.cpp:127-130
+}
+void Archive::set(const std::string& key, const std::string& val) { info.emplace_back(key, val); }
+void Archive::set(const std::string& key, long long val) { info.emplace_back(key, std::to_string(val)); }
+const std::vector<uint8_t>* Archive::find(const std::string& name) const {
+    for (auto& s : streams) if (s.first == name) return &s.second;
+    return nullptr;
+}
+void Archive::add(const std::string& name, std::vector<uint8_t> bytes) { streams.emplace_back(name, std::move(bytes)); }
+uint64_t Archive::payload_bytes() const {
+    uint64_t n = 0;
+    for (auto& kv : info) n += kv.first.size() + kv.second.size() + 2;
+    for (auto& s : streams) n += s.second.size();
+    return n;
+}
+
+// ---- reading ------------------------------------------------------------------------------------------
+static bool read_chain(const uint8_t* img, size_t npages, const DirEnt& e, bool is_info, std::vector<uint8_t>& out, std::string& err) {
+    out.clear();
+    out.reserve((size_t)e.size);
+    uint64_t left = e.size;
+    auto page = [&](uint32_t id) -> const uint8_t* { return id < npages ? img + (size_t)id * PAGE : nullptr; };
+    const uint8_t* pg = page(is_info ? 0 : e.first);
+    const uint32_t* node = e.node ? (const uint32_t*)page(e.node) : nullptr;
+    size_t ni = 0;
+    while (left) {
+        if (!pg) { err = "container: page chain leaves the file"; return false; }
+        size_t take = left < PAGE ? (size_t)left : PAGE;
+        out.insert(out.end(), pg, pg + take);
+        left -= take;
+        if (!left) break;
+        if (!node) { err = "container: stream longer than its page chain"; return false; }
+        if (ni == NODE_IDS) { node = (const uint32_t*)page(node[NODE_IDS]); ni = 0; if (!node) { err = "container: bad node chain"; return false; } }
+        pg = page(node[ni++]);
+    }
+    return true;
+}
+
+bool parse_image(const uint8_t* img, size_t n, Archive& a, std::string& err) {
+    a.info.clear(); a.streams.clear();
+    if (n < 2 * PAGE) { err = "container: file too small"; return false; }
+    const size_t npages = n / PAGE;
+    const DirEnt* dir = (const DirEnt*)(img + PAGE);
+    uint32_t count = dir[0].first;                                     // filer.cpp:95-96
+    if (count == 0 || count > MAX_FILES) { err = "container: bad directory"; return false; }
+    std::vector<uint8_t> text;
+    if (!read_chain(img, npages, dir[0], true, text, err)) return false;
+    size_t p = 0;                                                      // config.cpp:87-107
+    while (p < text.size()) {
+        size_t e = p;
+        while (e < text.size() && text[e] != '\n' && text[e] != 0) e++;
+        std::string line((const char*)&text[p], e - p);
+        size_t eq = line.find('=');
+        if (eq != std::string::npos) {
+            std::string k = line.substr(0, eq);
+            bool dup = false;
+            for (auto& kv : a.info) if (kv.first == k) dup = true;     // std::map::insert keeps the first
+            if (!dup) a.info.emplace_back(k, line.substr(eq + 1));
+        }
+        p = e + 1;
+    }
+    for (uint32_t i = 1; i < count; i++) {
+        char nm[9]; memcpy(nm, dir[i].name, 8); nm[8] = 0;
+        std::vector<uint8_t> bytes;
+        if (!read_chain(img, npages, dir[i], false, bytes, err)) return false;
+        a.streams.emplace_back(nm, std::move(bytes));
+    }
+    return true;
+}
+
+bool read_file(const std::string& path, Archive& a, std::string& err) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Can't read file '" + path + "'"; return false; }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> img((size_t)n);
+    size_t got = n ? fread(img.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (got != (size_t)n) { err = "short read on '" + path + "'"; return false; }
+    if (!parse_image(img.data(), img.size(), a, err)) return false;
+    long long cs = a.get_long("comp.size", 0);                         // config.cpp:366-371
+    if (cs > 0 && (unsigned long long)cs != (unsigned long long)n) { err = "expected compressed file size to be " + std::to_string(cs); return false; }
+    return true;
+}
+
+// ---- writing ------------------------------------------------------------------------------------------
+std::vector<uint8_t> build_image(const Archive& a) {
+    // page budget: 2 + per stream (data pages + node pages)
+    struct Lay { size_t pages, nodes; };
+    std::vector<Lay> lay;
+    size_t total = 2;
+    for (auto& s : a.streams) {
+        size_t pages = (s.second.size() + PAGE - 1) / PAGE;
+        if (pages == 0) pages = 1;
+        size_t nodes = pages > 1 ? (pages - 1 + NODE_IDS - 1) / NODE_IDS : 0;
+        lay.push_back({pages, nodes});
+        total += pages + nodes;
+    }
+    std::string text;
+    bool has_size = false;
+    for (auto& kv : a.info) { if (kv.first == "comp.size") has_size = true; }
+    for (auto& kv : a.info) text += kv.first + "=" + kv.second + "\n";
+    if (!has_size) text += "comp.size=" + std::to_string((unsigned long long)total * PAGE) + "\n";   // config.cpp:381-389
+    std::vector<uint8_t> img(total * PAGE, 0);
+    if (text.size() > PAGE) text.resize(PAGE);                        // (info beyond one page is not produced by this writer)
+    memcpy(img.data(), text.data(), text.size());
+    DirEnt* dir = (DirEnt*)(img.data() + PAGE);
+    memset(dir, 0, PAGE);
+    dir[0].size = text.size();
+    dir[0].first = (uint32_t)(a.streams.size() + 1);
+    size_t next = 2;
+    for (size_t i = 0; i < a.streams.size() && i + 1 < MAX_FILES; i++) {
+        const auto& s = a.streams[i];
+        DirEnt& e = dir[i + 1];
+        memset(e.name, 0, 8);
+        memcpy(e.name, s.first.data(), s.first.size() < 8 ? s.first.size() : 8);
+        e.size = s.second.size();
+        const size_t pages = lay[i].pages, nodes = lay[i].nodes;
+        const size_t data0 = next, node0 = next + pages;
+        e.first = (uint32_t)data0;
+        e.node = nodes ? (uint32_t)node0 : 0;
+        for (size_t p = 0; p < pages; p++) {
+            size_t off = p * PAGE, take = s.second.size() > off ? s.second.size() - off : 0;
+            if (take > PAGE) take = PAGE;
+            if (take) memcpy(img.data() + (data0 + p) * PAGE, s.second.data() + off, take);
+        }
+        for (size_t q = 0; q < nodes; q++) {
+            uint32_t* node = (uint32_t*)(img.data() + (node0 + q) * PAGE);
+            for (size_t k = 0; k < NODE_IDS; k++) {
+                size_t pi = 1 + q * NODE_IDS + k;                      // page index within the stream
+                node[k] = pi < pages ? (uint32_t)(data0 + pi) : 0;
+            }
+            node[NODE_IDS] = q + 1 < nodes ? (uint32_t)(node0 + q + 1) : 0;
+        }
+        next += pages + nodes;
+    }
+    return img;
+}
+
+bool write_file(const std::string& path, const Archive& a, std::string& err) {
+    if (a.streams.size() + 1 > MAX_FILES) { err = "too many streams"; return false; }
+    std::vector<uint8_t> img = build_image(a);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "Can't write file '" + path + "'"; return false; }
+    bool ok = fwrite(img.data(), 1, img.size(), f) == img.size();
+    ok = fclose(f) == 0 && ok;
+    if (!ok) err = "write error on '" + path + "'";
+    return ok;
+}
+
+// ---- block index ----------------------------------------------------------------------------------------
+static void put_v(std::vector<uint8_t>& o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
+static bool get_v(const std::vector<uint8_t>& b, size_t& p, uint64_t& v) {
+    v = 0;
+    for (int sh = 0; sh < 64; sh += 7) {
+        if (p >= b.size()) return false;
+        uint8_t c = b[p++];
+        v |= (uint64_t)(c & 0x7f) << sh;
+        if (!(c & 0x80)) return true;
+    }
+    return false;
+}
+std::vector<uint8_t> pack_block_index(const std::vector<sfq_block_info>& blocks) {
+    std::vector<uint8_t> o;
+    put_v(o, blocks.size());
+    for (auto& b : blocks) {
+        put_v(o, b.n_records); put_v(o, b.llen);
+        put_v(o, (uint64_t)b.solid | ((uint64_t)b.two_id << 1)); put_v(o, b.n_byte); put_v(o, b.gen_bits);
+        put_v(o, b.extra_hi); put_v(o, b.first_hdr_len); put_v(o, b.hdr_bytes);
+        for (int s = 0; s < SFQ_NSTREAMS; s++) put_v(o, b.size[s]);
+    }
+    return o;
+}
+bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks) {
+    size_t p = 0; uint64_t n, v;
+    if (!get_v(bytes, p, n) || n > (1u << 24)) return false;
+    blocks.assign((size_t)n, sfq_block_info());
+    uint64_t rec = 0, hoff = 0;
+    for (auto& b : blocks) {
+        memset(&b, 0, sizeof b);
+        b.first_record = rec;
+        if (!get_v(bytes, p, v)) return false; b.n_records = (uint32_t)v; rec += v;
+        if (!get_v(bytes, p, v)) return false; b.llen = (uint32_t)v;
+        if (!get_v(bytes, p, v)) return false; b.solid = v & 1; b.two_id = (v >> 1) & 1;
+        if (!get_v(bytes, p, v)) return false; b.n_byte = (uint8_t)v;
+        if (!get_v(bytes, p, v)) return false; b.gen_bits = (uint8_t)v;
+        if (!get_v(bytes, p, v)) return false; b.extra_hi = (uint32_t)v;
+        if (!get_v(bytes, p, v)) return false; b.first_hdr_len = (uint32_t)v; b.first_hdr_off = hoff; hoff += v;
+        if (!get_v(bytes, p, v)) return false; b.hdr_bytes = (uint32_t)v;
+        for (int s = 0; s < SFQ_NSTREAMS; s++) { if (!get_v(bytes, p, v)) return false; b.size[s] = (uint32_t)v; }
+    }
+    return true;
+}
+
+}  // namespace sfqc

@@ -176,3 +176,43 @@ def test_low_complexity_bases_same_context_in_one_window(ctx, kernel):
             want = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, want, block=b, ctxmsg="lowcomplexity l%d b%d" % (level, b))
         assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+
+
+def _cli():
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimfastq_amd", "bin", "slimfastq-amd")
+
+
+def test_cli_roundtrip_and_reference_compatibility(tmp_path):
+    """The C++ CLI (same flags as the reference) against the reference's container format, both ways:
+    it decodes archives written by the reference algorithm, and its -B 0 archives decode with the reference."""
+    import subprocess
+    cli = _cli()
+    for name in ("small", "tstc", "solid", "edge_len"):
+        fq = util.golden_fastq(name)
+        src = tmp_path / (name + ".fq"); src.write_bytes(fq)
+        # block format round trip
+        sfq = tmp_path / (name + ".sfq"); out = tmp_path / (name + ".out")
+        subprocess.check_call([cli, "-u", str(src), "-f", str(sfq), "-O", "-l", "3", "-B", "100"])
+        subprocess.check_call([cli, "-d", "-f", str(sfq), "-u", str(out), "-O"])
+        assert out.read_bytes() == fq, name
+        # legacy (-B 0): a format-6 file; the oracle (== reference, see test_oracle.py) must decode it
+        leg = tmp_path / (name + ".v6.sfq")
+        subprocess.check_call([cli, "-u", str(src), "-f", str(leg), "-O", "-l", "2", "-B", "0", "-q"])
+        img = leg.read_bytes()
+        assert O.decompress(img) == fq, name
+        got = O.parse(img)
+        want = O.compress(fq, 2)
+        assert {k: v for k, v in got.streams.items() if k != "<info>"} == {k: v for k, v in want.streams.items() if k != "<info>"}
+        if O.ref_binary():
+            assert O.ref_decompress(img) == fq, name           # the compiled reference itself, when it travelled with the tree
+        # an archive written by the reference algorithm decodes with the CLI
+        refimg = tmp_path / (name + ".ref.sfq"); refimg.write_bytes(want.image)
+        p = subprocess.run([cli, "-d", "-f", str(refimg)], capture_output=True, check=True)
+        assert p.stdout == fq, name
+    # -s lists the info page and the streams; errors keep the reference's wording
+    p = subprocess.run([cli, "-s", "-f", str(tmp_path / "small.sfq")], capture_output=True)
+    assert b"whoami" in p.stderr and b"qlt" in p.stderr
+    bad = tmp_path / "bad.fq"; bad.write_bytes(b"@x\nACXT\n+\nIIII\n")
+    p = subprocess.run([cli, "-u", str(bad), "-f", str(tmp_path / "bad.sfq"), "-O"], capture_output=True)
+    assert p.returncode == 1 and b"slimfastq: encoding" in p.stderr
