@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from slimfastq_amd import capi  # noqa: E402
+from slimfastq_amd import dist as sdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--prior-step", type=int, default=-1, help="-1 = auto warm start (default), 0 = cold blocks, N = every N-th record")
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +91,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     seed = 1
+    prior_step = capi.PRIOR_AUTO if args.prior_step < 0 else args.prior_step
     models = 0 if args.workload == "full" else capi.M_QLT
     if args.models:
         models = args.models
@@ -105,26 +108,12 @@ def main():
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
 
-    gather_bufs = None
-
     def step():
         res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=args.level,
-                                block_reads=args.block_reads, models=models, kernel=args.kernel)
+                                block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step)
         if world > 1:
-            # the path's one exchange step: compressed streams (+ sizes) to the writer rank, over RCCL/xGMI
-            nonlocal gather_bufs
-            sz = torch.tensor([res.total_bytes], dtype=torch.int64, device="cuda")
-            sizes = torch.empty(world, dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(sizes, sz)
-            hs = sizes.cpu().tolist()
-            if rank == 0:
-                if gather_bufs is None:
-                    gather_bufs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(world - 1)]
-                ops = [dist.P2POp(dist.irecv, gather_bufs[r - 1][:hs[r]], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, d_out[:res.total_bytes], 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            # the path's one exchange step: compressed streams to the writer rank, over RCCL/xGMI
+            sdist.gather_bytes(d_out[:res.total_bytes], dst=0)
         return res
 
     for _ in range(args.warmup):
@@ -179,7 +168,7 @@ def main():
                                    (args.reads // 1_000_000, args.read_len,
                                     "full qlts+gens+recs" if args.workload == "full" else "qlts-only kernel", args.level))
                       if args.reads >= 1_000_000 else "synthetic %d x %d bp reads" % (args.reads, args.read_len),
-                      "level": args.level, "block_reads": args.block_reads, "blocks_per_gpu": int(res.n_blocks),
+                      "level": args.level, "block_reads": args.block_reads, "prior_step": args.prior_step, "blocks_per_gpu": int(res.n_blocks),
                       "raw_bytes_per_gpu": nbytes, "parallelism": "blocks sharded x%d, RCCL gather" % world if world > 1 else "1 GPU"},
            "ratio": round(all_in / all_out, 4),
            "phase_ms": {"frame": round(phase[capi.T_FRAME], 3), "qlt": round(phase[capi.T_QLT], 3), "gen": round(phase[capi.T_GEN], 3),
@@ -190,8 +179,8 @@ def main():
         cb, sample, ref_payload = cpu_baseline(args, seed)
         out["cpu_baseline"] = cb
         # ratio vs the reference on the same sample: ours in blocks vs the reference's single adaptive stream
-        enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel)
-        ours = enc.payload_bytes + int(enc.res.first_hdr_bytes) + 16 * int(enc.res.n_blocks)   # + first headers + ~index entry
+        enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step)
+        ours = enc.archive_bytes                                   # streams + first headers + prior + block index
         if args.workload == "full":
             out["ratio_vs_reference"] = {"sample_raw": len(sample), "reference_stream_bytes": int(ref_payload),
                                          "ours_stream_bytes": int(ours), "ours_over_reference": round(ours / ref_payload, 4)}

@@ -71,8 +71,12 @@ typedef struct sfq_params {
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks) */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
-    uint32_t reserved[2];
+    uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);
+                              N > 0 = warm start: quality rows start from a prior counted over every N-th record
+                              (SFQ_PRIOR_AUTO picks N from the input size)                                      */
+    uint32_t reserved[1];
 } sfq_params;
+#define SFQ_PRIOR_AUTO 0xFFFFFFFFu
 
 /* One entry per block: what a decoder needs besides the stream bytes (the "block index").
  * The per-block stream bytes are the reference's streams for a FASTQ consisting of that block alone,
@@ -144,6 +148,12 @@ int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes
 /* Block index / first headers of the LAST encode call on this context (host copies). */
 int sfq_get_block_index(sfq_ctx* ctx, sfq_block_info* h_blocks, uint32_t cap);
 int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
+
+/* Quality warm-start prior of the LAST encode call (the "qlt.pri" stream): returns its size, copies it if
+ * cap allows; 0 = the call used cold blocks. */
+int64_t sfq_get_qlt_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
+/* Install the prior the next sfq_decode_blocks call must start its quality rows from (n = 0: cold). */
+int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n);
 
 /* ---- decompress ----------------------------------------------------------------------------
  * Replaces UsrLoad::decode()'s loop (usrs.cpp:555-571: rec.load / qlt.load / gen.load / save).

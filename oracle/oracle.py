@@ -270,3 +270,42 @@ def ref_decompress(image: bytes) -> bytes:
         if p.returncode != 0:
             raise OracleError("reference failed: " + p.stderr.decode("latin1"))
         return p.stdout
+
+
+# ---- format-7 warm start (this project's rule, restated in sfq_oracle.c) -------------------------------------
+def qlt_histogram(buf: bytes, off, length, level=3, first=0, step=1):
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    q_rows = 4096 if level == 1 else 65536
+    counts = np.zeros(q_rows * 64, np.uint32)
+    L.sfqo_qlt_histogram.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.sfqo_qlt_histogram(buf, po, pl, len(off), level, first, step, counts.ctypes.data_as(C.c_void_p))
+    return counts
+
+
+def qlt_prior_rows(counts):
+    """-> uint32 [q_rows, 66]: slot[64] (freq | sym << 16), total, iend."""
+    L = lib()
+    q_rows = len(counts) // 64
+    rows = np.zeros(q_rows * 66, np.uint32)
+    L.sfqo_qlt_prior_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sfqo_qlt_prior_rows(counts.ctypes.data_as(C.c_void_p), q_rows, rows.ctypes.data_as(C.c_void_p))
+    return rows.reshape(q_rows, 66)
+
+
+def qlt_encode_blocks(buf: bytes, off, length, level=3, block_reads=1024, prior_rows=None):
+    """-> (concatenated per-block qlt streams, per-block sizes); prior_rows None = cold (== the reference per chunk)."""
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    nb = (len(off) + block_reads - 1) // block_reads
+    sizes = np.zeros(nb, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    pr = None
+    if prior_rows is not None:
+        prior_rows = np.ascontiguousarray(prior_rows, np.uint32)
+        pr = prior_rows.ctypes.data_as(C.c_void_p)
+    L.sfqo_qlt_encode_blocks.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
+                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p]
+    if L.sfqo_qlt_encode_blocks(buf, po, pl, len(off), level, block_reads, pr, C.byref(out), C.byref(n), sizes.ctypes.data_as(C.c_void_p)) != 0:
+        raise _err()
+    return _take(out, n), sizes

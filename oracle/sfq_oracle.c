@@ -1423,3 +1423,101 @@ int sfqo_xfile_decode_u(const u8* stream, size_t n, u64* vals, size_t nvals) {
     xl_close(x);
     return g_failed ? -1 : 0;
 }
+
+/* ================================================================================================
+ * Block format 7 extension: quality tables that start from a shared PRIOR instead of all-zero rows.
+ * This is NOT reference behaviour (the reference has one cold adaptive state per file); it restates
+ * this project's own rule (DESIGN.md "warm start") so that the GPU path has a CPU checker for it.
+ * The arithmetic per symbol is the pinned Log64Ranger/RCoder code above; only the initial rows differ.
+ * ============================================================================================== */
+
+/* contexts of one quality line, exactly as qlt_save walks them; cb(ctx, sym) per symbol */
+static void qlt_walk(const u8* buf, size_t size, int level, void (*cb)(void*, u32, u8), void* arg) {
+    if (level <= 2) {
+        u32 mask = level == 1 ? 0xFFF : 0xFFFF, last = 0;
+        for (const u8* p = buf; p < buf + size; p++) { u8 b = (u8)(*p - '!'); cb(arg, last, b); last = (b | (last << 6)) & mask; }
+        return;
+    }
+    u32 last = 0, delta = 5, di = 0; u8 q1 = 0, q2 = 0;
+    for (const u8* p = buf; p < buf + size; p++) {
+        u8 b = (u8)(*p - '!');
+        cb(arg, last, b);
+        if (++di & 1) { last = calc_last_delta(&delta, b, q1, q2); q2 = b; }
+        else          { last = calc_last_delta(&delta, b, q2, q1); q1 = b; }
+    }
+}
+static void hist_cb(void* arg, u32 ctx, u8 b) { ((u32*)arg)[(size_t)ctx * 64 + (b < LAST_QLT ? b : LAST_QLT)]++; }
+
+/* counts[q_rows][64] over records first, first+step, ... */
+int sfqo_qlt_histogram(const u8* base, const u64* off, const u32* len, size_t nrec, int level,
+                       size_t first, size_t step, u32* counts) {
+    if (!step) step = 1;
+    for (size_t i = first; i < nrec; i += step) qlt_walk(base + off[i], len[i], level, hist_cb, counts);
+    return 0;
+}
+
+/* The prior-row rule: symbols by (count desc, symbol asc); freq = (6 * count) >> s with the
+ * smallest s that brings the largest to <= 32000; iend = highest seen symbol + 1; total = sum; count = 0.
+ * rows: q_rows x { u32 slot[64] (freq | sym << 16), u32 total, u32 iend } = 66 dwords per row. */
+int sfqo_qlt_prior_rows(const u32* counts, size_t q_rows, u32* rows) {
+    for (size_t c = 0; c < q_rows; c++) {
+        const u32* cn = counts + c * 64;
+        u32* r = rows + c * 66;
+        memset(r, 0, 66 * sizeof(u32));
+        int iend = 0; u32 mx = 0;
+        u32 cl[64];                                            /* counts saturate at 2^26-1 (the device sort key has 26 bits) */
+        for (int s = 0; s < 64; s++) { cl[s] = cn[s] > 0x3FFFFFFu ? 0x3FFFFFFu : cn[s]; }
+        cn = cl;
+        for (int s = 0; s < 64; s++) if (cn[s]) { iend = s + 1; if (cn[s] > mx) mx = cn[s]; }
+        if (!iend) continue;
+        int sh = 0;
+        while ((((u64)mx * 6) >> sh) > 32000) sh++;
+        int order[64];
+        for (int s = 0; s < iend; s++) order[s] = s;
+        for (int i = 1; i < iend; i++) {                       /* stable insertion sort: count desc, symbol asc */
+            int k = order[i], j = i;
+            while (j > 0 && cn[order[j - 1]] < cn[k]) { order[j] = order[j - 1]; j--; }
+            order[j] = k;
+        }
+        u32 total = 0;
+        for (int j = 0; j < iend; j++) {
+            u32 f = (u32)(((u64)cn[order[j]] * 6) >> sh);
+            r[j] = f | ((u32)order[j] << 16);
+            total += f;
+        }
+        r[64] = total; r[65] = (u32)iend;
+    }
+    return 0;
+}
+
+static void row_from_prior(log64* r, const u32* pr) {
+    memset(r, 0, sizeof *r);
+    r->total = pr[64]; r->iend = (u16)pr[65];
+    for (int j = 0; j < 64; j++) { r->freq[j] = (u16)(pr[j] & 0xffff); r->syms[j] = (u8)(pr[j] >> 16); }
+}
+
+/* qlt streams of consecutive blocks of block_reads records, every block starting from `prior_rows`
+ * (NULL = cold, i.e. the reference's own per-chunk result).  out = the blocks' streams back to back,
+ * sizes[b] = each block's length. */
+int sfqo_qlt_encode_blocks(const u8* base, const u64* off, const u32* len, size_t nrec, int level, size_t block_reads,
+                           const u32* prior_rows, u8** out, size_t* out_len, u32* sizes) {
+    g_failed = 0; g_err[0] = 0;
+    obuf o = { 0, 0, 0 };
+    qltm q; qlt_alloc(&q, level);
+    size_t nb = 0;
+    for (size_t r0 = 0; r0 < nrec; r0 += block_reads, nb++) {
+        size_t r1 = r0 + block_reads < nrec ? r0 + block_reads : nrec;
+        if (prior_rows) for (size_t c = 0; c < q.cnt; c++) row_from_prior(&q.ranger[c], prior_rows + c * 66);
+        else memset(q.ranger, 0, q.cnt * sizeof(log64));
+        memset(&q.exranger, 0, sizeof q.exranger);
+        wr* w = wr_new_plain(); rc_init_save(&q.rc, w);
+        for (size_t i = r0; i < r1 && !g_failed; i++) qlt_save(&q, base + off[i], len[i]);
+        rc_done(&q.rc);
+        ob_write(&o, w->data, w->n);
+        if (sizes) sizes[nb] = (u32)w->n;
+        wr_close(w);
+    }
+    free(q.ranger);
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : 0;
+}

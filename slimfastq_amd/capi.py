@@ -11,18 +11,19 @@ NSTREAMS = 10
 STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"]
 M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
+PRIOR_AUTO = 0xFFFFFFFF
 
 EXPORTS = [
     "sfq_stream_name", "sfq_ctx_create", "sfq_ctx_destroy", "sfq_last_error", "sfq_ctx_set_table_budget",
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
-    "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version",
+    "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
 ]
 
 
 class Params(C.Structure):
     _fields_ = [("level", C.c_int32), ("block_reads", C.c_uint32), ("gen_bits", C.c_int32), ("models", C.c_uint32),
-                ("kernel", C.c_uint32), ("version", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("kernel", C.c_uint32), ("version", C.c_uint32), ("prior_step", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class BlockInfo(C.Structure):
@@ -94,6 +95,9 @@ def lib():
                                         C.POINTER(u64), u8p, u64, C.POINTER(u64), C.POINTER(Result)]
         L.sfq_decode_blocks_host.argtypes = [vp, C.POINTER(Params), C.POINTER(BlockInfo), C.c_uint32, u8p, u64, u8p, u64,
                                              C.POINTER(u64), u8p, u64, C.POINTER(u64), C.POINTER(Result)]
+        L.sfq_get_qlt_prior.argtypes = [vp, u8p, u64]
+        L.sfq_get_qlt_prior.restype = C.c_int64
+        L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_synth_fastq.argtypes = [u64, u64, C.c_uint32, u64, C.c_int, u8p, u64]
         L.sfq_synth_fastq.restype = C.c_int64
         _lib = L
@@ -116,8 +120,8 @@ def synth_fastq(n_reads, read_len=150, seed=1, kind=0, first_read=0) -> bytes:
 class Encoded:
     """Host copy of one sfq_encode_blocks result."""
 
-    def __init__(self, res, blocks, first_hdrs, data):
-        self.res, self.blocks, self.first_hdrs, self.data = res, blocks, first_hdrs, data
+    def __init__(self, res, blocks, first_hdrs, data, prior=b""):
+        self.res, self.blocks, self.first_hdrs, self.data, self.prior = res, blocks, first_hdrs, data, prior
 
     def stream(self, s, block=None) -> bytes:
         """Bytes of stream s (an id or a name): the whole concatenation, or one block's part."""
@@ -133,6 +137,11 @@ class Encoded:
     @property
     def payload_bytes(self):
         return int(self.res.total_bytes)
+
+    @property
+    def archive_bytes(self):
+        """Everything a decoder needs: streams + first headers + quality prior + ~the block index."""
+        return int(self.res.total_bytes) + len(self.first_hdrs) + len(self.prior) + 14 * len(self.blocks)
 
 
 class Context:
@@ -175,9 +184,17 @@ class Context:
         self._check(lib().sfq_get_first_headers(self._h, buf, nbytes))
         return buf.raw[:nbytes]
 
-    def encode_host(self, fastq: bytes, level=3, block_reads=0, gen_bits=0, models=0, kernel=0) -> Encoded:
+    def prior(self) -> bytes:
+        n = lib().sfq_get_qlt_prior(self._h, None, 0)
+        if n <= 0:
+            return b""
+        buf = C.create_string_buffer(n)
+        lib().sfq_get_qlt_prior(self._h, buf, n)
+        return buf.raw[:n]
+
+    def encode_host(self, fastq: bytes, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, prior_step=0) -> Encoded:
         L = lib()
-        p = Params(level, block_reads, gen_bits, models, kernel, 0)
+        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step)
         res = Result()
         cap = L.sfq_encode_bound(len(fastq))
         out = np.empty(cap, np.uint8)
@@ -185,12 +202,13 @@ class Context:
         self._check(L.sfq_encode_blocks_host(self._h, src.ctypes.data_as(C.c_void_p), len(fastq), C.byref(p),
                                              out.ctypes.data_as(C.c_void_p), cap, C.byref(res)))
         blocks = self.index(res.n_blocks)
-        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy())
+        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy(), self.prior())
 
-    def encode_device(self, d_ptr, nbytes, d_out, out_cap, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, qlt_only=False):
+    def encode_device(self, d_ptr, nbytes, d_out, out_cap, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, qlt_only=False,
+                      prior_step=0):
         """Device-pointer entry point (ints from torch .data_ptr()). Returns the Result struct."""
         L = lib()
-        p = Params(level, block_reads, gen_bits, models, kernel, 0)
+        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step)
         res = Result()
         f = L.sfq_encode_qlt_blocks if qlt_only else L.sfq_encode_blocks
         self._check(f(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p), C.c_void_p(d_out), out_cap, C.byref(res)))
@@ -199,12 +217,16 @@ class Context:
     def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()
+        prior = b""
         if isinstance(enc_or_parts, Encoded):
-            blocks, first, data = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data
+            blocks, first, data, prior = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data, enc_or_parts.prior
             soff = (C.c_uint64 * NSTREAMS)(*list(enc_or_parts.res.stream_offset))
         else:
-            blocks, first, data, so = enc_or_parts
+            blocks, first, data, so = enc_or_parts[:4]
+            if len(enc_or_parts) > 4:
+                prior = enc_or_parts[4]
             soff = (C.c_uint64 * NSTREAMS)(*so)
+        self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
         p = Params(level, 0, 0, 0, 0, version)
         res = Result()

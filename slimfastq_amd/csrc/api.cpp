@@ -43,6 +43,10 @@ struct sfq_ctx {
            lens, blob_off, blob, in_stage, out_stage;
     // decode scratch
     DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
+    // quality warm start
+    DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh;
+    bool prior_on = false;                 // the device prior tables are valid for the running call
+    std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
     std::vector<sfq_block_info> index;
     std::vector<u8> first_hdrs;
@@ -118,6 +122,10 @@ void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_b
     a.q_slots = (u32*)t.q_slots.p; a.q_hdr = (RowHdr*)t.q_hdr.p; a.q_rows = t.q_rows;
     a.p_slots = (u32*)t.p_slots.p; a.p_hdr = (RowHdr*)t.p_hdr.p;
     a.g_tab = (u32*)t.g_tab.p; a.g_bits = g_bits;
+    if (ctx->prior_on) {
+        a.prior_w = (const u32*)ctx->prior_w.p; a.prior_wovf = (const u32*)ctx->prior_wovf.p;
+        a.prior_ls = (const u32*)ctx->prior_ls.p; a.prior_lh = (const RowHdr*)ctx->prior_lh.p;
+    }
 }
 
 // epochs are unique per (context lifetime, block); on wrap the row headers are cleared
@@ -129,6 +137,71 @@ int advance_epoch(sfq_ctx* ctx, u32 nblocks) {
         if (t.p_hdr.p) HIPC(hipMemsetAsync(t.p_hdr.p, 0, t.p_hdr.cap, ctx->st));
         ctx->epoch_base = 0;
     }
+    return SFQ_OK;
+}
+
+// ---- "qlt.pri": the prior's exchange form (66 dwords per context: slot[64], total, iend) <-> bytes.
+// Per non-empty context, in order: varint(ctx delta), iend, nnz, then nnz x { symbol byte, varint(freq) } for
+// the leading non-zero slots; the remaining slots are the unused symbols below iend in ascending order.
+void put_v(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
+bool get_v(const u8* b, size_t n, size_t& p, u64& v) {
+    v = 0;
+    for (int sh = 0; sh < 64; sh += 7) { if (p >= n) return false; u8 c = b[p++]; v |= (u64)(c & 0x7f) << sh; if (!(c & 0x80)) return true; }
+    return false;
+}
+std::vector<u8> pack_prior(const u32* rows66, u32 q_rows) {
+    std::vector<u8> o;
+    put_v(o, q_rows);
+    u32 prev = 0;
+    for (u32 c = 0; c < q_rows; c++) {
+        const u32* r = rows66 + (size_t)c * 66;
+        const u32 iend = r[65];
+        if (!iend) continue;
+        u32 nnz = 0;
+        while (nnz < iend && (r[nnz] & 0xffff)) nnz++;
+        put_v(o, c - prev + 1); prev = c;
+        o.push_back((u8)iend); o.push_back((u8)nnz);
+        for (u32 j = 0; j < nnz; j++) { o.push_back((u8)(r[j] >> 16)); put_v(o, r[j] & 0xffff); }
+    }
+    put_v(o, 0);
+    return o;
+}
+bool unpack_prior(const u8* b, size_t n, u32 q_rows, std::vector<u32>& rows66) {
+    size_t p = 0; u64 v;
+    if (!get_v(b, n, p, v) || v != q_rows) return false;
+    rows66.assign((size_t)q_rows * 66, 0);
+    u64 c = 0; bool first = true;
+    for (;;) {
+        if (!get_v(b, n, p, v)) return false;
+        if (v == 0) break;
+        c = first ? v - 1 : c + v - 1; first = false;
+        // deltas are stored +1 so that 0 terminates; each is relative to the previous context (the first to 0)
+        if (c >= q_rows || p + 2 > n) return false;
+        u32* r = rows66.data() + (size_t)c * 66;
+        const u32 iend = b[p++], nnz = b[p++];
+        if (iend > 64 || nnz > iend) return false;
+        bool used[64] = {false};
+        u32 total = 0;
+        for (u32 j = 0; j < nnz; j++) {
+            if (p >= n) return false;
+            const u32 sym = b[p++];
+            if (sym >= iend || used[sym] || !get_v(b, n, p, v) || v > 0xffff) return false;
+            used[sym] = true; r[j] = (u32)v | (sym << 16); total += (u32)v;
+        }
+        u32 j = nnz;
+        for (u32 s = 0; s < iend; s++) if (!used[s]) r[j++] = s << 16;
+        r[64] = total; r[65] = iend;
+    }
+    return true;
+}
+int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
+    int rc;
+    if ((rc = reserve(ctx, ctx->hist, (size_t)q_rows * 64 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rows66, (size_t)q_rows * 66 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->prior_w, (size_t)q_rows * 64 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->prior_wovf, (size_t)q_rows * 4 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->prior_ls, (size_t)q_rows * 64 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->prior_lh, (size_t)q_rows * sizeof(RowHdr)))) return rc;
     return SFQ_OK;
 }
 
@@ -172,7 +245,8 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->chunk_counts, &ctx->chunk_base, &ctx->scan_tmp, &ctx->line_off, &ctx->status, &ctx->blocks, &ctx->arena,
         &ctx->blk_stream_off, &ctx->stream_total, &ctx->lens, &ctx->blob_off, &ctx->blob, &ctx->in_stage, &ctx->out_stage,
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
-        &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first };
+        &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
+        &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -255,6 +329,23 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
 
     // ---- models --------------------------------------------------------------------------------
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);       // qlts.hpp:36-40
+    // warm start (format 7 only): count a sample, build the prior rows, keep a host copy for "qlt.pri"
+    ctx->prior_on = false;
+    ctx->prior_blob.clear();
+    std::vector<u32> h_rows66;
+    u32 prior_step = p.block_reads ? p.prior_step : 0;
+    if (prior_step == SFQ_PRIOR_AUTO) prior_step = (u32)std::max<u64>(1, nrec / 400000);   // ~<= 400 k sampled records
+    if (prior_step && (models & SFQ_M_QLT)) {
+        if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
+        HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
+        launch_qlt_hist(d_fastq, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, (u32*)ctx->hist.p, st);
+        launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
+                          (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
+        h_rows66.resize((size_t)q_rows * 66);
+        HIPC(hipMemcpyAsync(h_rows66.data(), ctx->rows66.p, h_rows66.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
+        ctx->prior_on = true;
+    }
     u32 slots = 0;
     if ((rc = ensure_tables(ctx, nblocks, q_rows, (u32)g_bits, models, &slots))) return rc;
     if ((rc = advance_epoch(ctx, nblocks))) return rc;
@@ -325,6 +416,8 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
 
+    if (ctx->prior_on) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
+    ctx->prior_on = false;
     ctx->index.resize(nblocks);
     for (u32 b = 0; b < nblocks; b++) {
         sfq_block_info& bi = ctx->index[b];
@@ -382,6 +475,17 @@ int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
     if (!ctx || !h_blob) return SFQ_E_ARG;
     if (cap < ctx->first_hdrs.size()) return fail(ctx, SFQ_E_ARG, "blob has %zu bytes", ctx->first_hdrs.size());
     if (!ctx->first_hdrs.empty()) memcpy(h_blob, ctx->first_hdrs.data(), ctx->first_hdrs.size());
+    return SFQ_OK;
+}
+
+int64_t sfq_get_qlt_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
+    if (!ctx) return SFQ_E_ARG;
+    if (h_blob && cap >= ctx->prior_blob.size() && !ctx->prior_blob.empty()) memcpy(h_blob, ctx->prior_blob.data(), ctx->prior_blob.size());
+    return (int64_t)ctx->prior_blob.size();
+}
+int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
+    if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    ctx->prior_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
 
@@ -451,9 +555,20 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     if ((rc = reserve(ctx, ctx->roff, ((size_t)nrec + 1) * 8))) return rc;
     if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
 
+    ctx->prior_on = false;
+    if (!ctx->prior_blob.empty()) {
+        std::vector<u32> rows;
+        if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
+        if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
+        HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
+        HIPC(hipStreamSynchronize(st));            // `rows` is a local
+        ctx->prior_on = true;
+    }
     DecodeArgs da;
     memset(&da, 0, sizeof da);
     fill_model_args(ctx, da.m, nblocks, p.level, (u32)g_bits);
+    ctx->prior_on = false;
     da.streams = d_streams;
     da.blk_stream_off = (const u64*)ctx->blk_stream_off.p;
     da.first_hdrs = (const u8*)ctx->d_first.p;

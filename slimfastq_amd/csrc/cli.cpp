@@ -126,6 +126,7 @@ int main(int argc, char** argv) {
         if (in != stdin) fclose(in);
         sfq_params p; memset(&p, 0, sizeof p);
         p.level = level; p.block_reads = (uint32_t)block_reads;
+        p.prior_step = block_reads ? SFQ_PRIOR_AUTO : 0;               // warm start needs the block format
         std::vector<uint8_t> out((size_t)sfq_encode_bound(fq.size()));
         sfq_result res;
         rc = sfq_encode_blocks_host(ctx, fq.data(), fq.size(), &p, out.data(), out.size(), &res);
@@ -166,6 +167,8 @@ int main(int argc, char** argv) {
         if (!legacy) {
             a.add("blk.idx", sfqc::pack_block_index(blocks));
             a.add("blk.hdr", first);
+            const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
+            if (pn > 0) { std::vector<uint8_t> pri((size_t)pn); sfq_get_qlt_prior(ctx, pri.data(), pri.size()); a.add("qlt.pri", pri); }
         }
         if (!sfqc::write_file(fil, a, err)) croak("%s", err.c_str());
     } else {
@@ -200,6 +203,7 @@ int main(int argc, char** argv) {
             soff[s] = data.size();
             if (auto* v = a.find(sfq_stream_name(s))) data.insert(data.end(), v->begin(), v->end());
         }
+        if (const std::vector<uint8_t>* pri = a.find("qlt.pri")) sfq_set_qlt_prior(ctx, pri->data(), pri->size());
         sfq_params p; memset(&p, 0, sizeof p);
         p.level = level; p.version = version >= kBlockVersion ? kInternalVersion : (uint32_t)version;
         uint64_t cap = (uint64_t)a.get_long("orig.size", 0), got = 0;

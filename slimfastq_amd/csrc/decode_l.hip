@@ -83,6 +83,8 @@ __global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
         u8* p = a.qual_stage + a.qoff[r];
         u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
         for (u32 i = 0; i < n; i++) {
+            l64_touch(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch,
+                      a.m.prior_ls ? a.m.prior_ls + (size_t)last * L64_NSYM : nullptr, a.m.prior_lh + last);
             u32 b = Log64::get(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch, rc, src);
             if (b == LAST_QLT) b = sl.pw.get(PR_EXQ_ROW, rc, src);                          // qlts.cpp:168-171
             p[i] = (u8)('!' + b);

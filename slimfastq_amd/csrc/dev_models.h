@@ -133,6 +133,16 @@ struct Ranger {
 };
 
 typedef Ranger<64, 6, (1 << 16) - 64, 20>    Log64;   // log64_ranger.hpp:37-42, 72
+
+// Format-7 warm start: the first touch of a quality row in a block copies the shared prior row
+// (prior.hip) into the block's private row instead of leaving it all-zero.
+__device__ __forceinline__ void l64_touch(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php) {
+    if (!pslots || hp->epoch == epoch) return;
+    RowHdr h = *php;
+    for (u32 k = 0; k < h.iend; k++) slots[k] = pslots[k];
+    h.epoch = epoch;
+    *hp = h;
+}
 typedef Ranger<256, 14, (1 << 15) - 32, 256> Power;   // power_ranger.hpp:37-41, 70
 
 // A block slot's PowerRanger rows.

@@ -17,6 +17,9 @@ struct ModelArgs {
     u32* q_slots; RowHdr* q_hdr; u32 q_rows;     // Log64 rows per slot: 4096 (level 1) or 65536
     u32* p_slots; RowHdr* p_hdr;                 // PR_ROWS PowerRanger rows per slot
     u32* g_tab;   u32 g_bits;                    // (1 << g_bits) Base2 dwords per slot
+    // quality warm start (prior.hip); all null = cold rows, the reference's behaviour
+    const u32* prior_w; const u32* prior_wovf;   // wave layout [q_rows][64] + overflow [q_rows][4]
+    const u32* prior_ls; const RowHdr* prior_lh; // lane-per-block layout
 };
 
 // Decode-side extras.
@@ -74,3 +77,9 @@ void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t 
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st);
 void launch_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens, hipStream_t st);
 void launch_gather_first_hdrs(const BlockDesc* blocks, u32 nblocks, const u8* fq, const u64* blob_off, u8* blob, u64 cap, hipStream_t st);
+
+// quality prior (prior.hip)
+void launch_qlt_hist(const u8* fq, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
+                     int level, u32* hist, hipStream_t st);
+void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);
+void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64) void k_qlt_encode_l(ModelArgs a) {
             const u32 bsym = (u32)(u8)(p[i] - '!');
             u32* row = sl.q_slots + (size_t)last * L64_NSYM;
             RowHdr* hp = sl.q_hdr + last;
+            l64_touch(row, hp, sl.epoch, a.prior_ls ? a.prior_ls + (size_t)last * L64_NSYM : nullptr, a.prior_lh + last);
             if (bsym < LAST_QLT) Log64::put(row, hp, sl.epoch, rc, snk, bsym);        // qlts.cpp:79-86
             else {
                 Log64::put(row, hp, sl.epoch, rc, snk, LAST_QLT);

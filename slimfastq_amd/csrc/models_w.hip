@@ -115,8 +115,9 @@ struct WaveRow {
     u32 total, iend, count;    // uniform
     u64 dirty;                 // lanes whose slot changed since the row was loaded
     u32 nxt, vn;               // one-row-ahead prefetch: row id and its 64 dwords (in flight)
+    const u32* prior; const u32* prior_ovf;   // shared warm-start rows (null = cold)
     __device__ __forceinline__ void init(u32* r, u32* o, u32 e) {
-        rows = r; ovf = o; epoch = e; cur = 0xFFFFFFFFu; nxt = 0xFFFFFFFFu; v = vn = 0; total = iend = count = 0; dirty = 0;
+        rows = r; ovf = o; epoch = e; prior = nullptr; prior_ovf = nullptr; cur = 0xFFFFFFFFu; nxt = 0xFFFFFFFFu; v = vn = 0; total = iend = count = 0; dirty = 0;
     }
     __device__ __forceinline__ void writeback(u32 lane) {
         if (cur == 0xFFFFFFFFu) return;
@@ -145,8 +146,14 @@ struct WaveRow {
         iend  = live ? (h1 & 0xffffu) : 0u;
         count = live ? (h1 >> 16) : 0u;
         v = raw;
-        if (iend > 60) { if (lane < 4) v = ovf[(size_t)ctx * 4 + lane]; }
         dirty = 0;
+        if (!live && prior) {                              // first touch in this block: start from the shared prior row
+            v = prior[(size_t)ctx * 64 + lane];
+            total = rl(v, 0);
+            iend = rl(v, 1) & 0xffffu;
+            if (iend > 60) { if (lane < 4) v = prior_ovf[(size_t)ctx * 4 + lane]; }
+            dirty = __ballot(((lane + 60) & 63) < iend);   // the private copy holds nothing yet: write every live slot back
+        } else if (iend > 60) { if (lane < 4) v = ovf[(size_t)ctx * 4 + lane]; }
     }
     // Log64Ranger::put minus the Encode call (log64_ranger.hpp:98-112); sym < 64, uniform
     __device__ __forceinline__ void model(u32 sym, u32 lane, u32& cum, u32& freq, u32& tot) {
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a) {
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
     WaveCoder rc; rc.init();
     WaveRow row; row.init(a.q_slots + (size_t)t * a.q_rows * L64_NSYM, reinterpret_cast<u32*>(a.q_hdr + (size_t)t * a.q_rows), epoch);
+    row.prior = a.prior_w; row.prior_ovf = a.prior_wovf;
     PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
     const u32 solid = d->solid;
     const int level = a.level;

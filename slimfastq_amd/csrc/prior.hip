@@ -1,0 +1,116 @@
+// prior.hip -- warm start for the quality model (block format 7 only; DESIGN.md "warm start").
+//
+// The reference keeps ONE adaptive state per file, so cutting a file into independent blocks costs it
+// its learning again in every block (+25 % on the quality stream at 1024-record blocks).  Format 7 lets
+// every block start from a shared PRIOR instead of from all-zero rows:
+//   1. histogram: count (context, symbol) over a sample of the records       -- parallel, atomics
+//   2. rows     : per context, symbols ordered by count and frequencies scaled -- one wave per context
+// The prior is stored once in the archive ("qlt.pri"); encoder and decoder build identical tables from
+// it, and a block's first touch of a row copies the prior row instead of starting from zero.  With it a
+// 256-record block codes as well as the reference's whole-file state (oracle/sfq_oracle.c restates the
+// rule for the tests).  One block and no prior stays byte-identical to the reference.
+#include "kernels.h"
+
+// ---- 1. histogram --------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 q2) {   // qlts.hpp:62-74
+    if (q1 > q) delta += q1 - q;
+    u32 d3 = delta >> 3;
+    return (q | ((q1 < q2 ? q2 : q1) << 6) | ((u32)(q1 == q2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+}
+// one lane per sampled record: walk its quality line with the model's context function, count (ctx, symbol)
+__global__ __launch_bounds__(256) void k_qlt_hist(const u8* fq, const u64* line_off, const BlockDesc* blocks, u32 block_reads,
+                                                 u64 nrec, u32 step, int level, u32* hist) {
+    const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) * step;
+    if (r >= nrec) return;
+    const u32 solid = blocks[r / block_reads].solid;
+    const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
+    const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+    const u8* p = fq + q0;
+    u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
+    for (u32 i = 0; i < n; i++) {
+        const u32 b = (u32)(u8)(p[i] - '!');
+        atomicAdd(&hist[(size_t)last * 64 + (b < 63u ? b : 63u)], 1u);
+        if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
+        else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
+        else if (++di & 1) { last = p_calc_last_delta(delta, b, q1, q2); q2 = b; }
+        else               { last = p_calc_last_delta(delta, b, q2, q1); q1 = b; }
+    }
+}
+void launch_qlt_hist(const u8* fq, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
+                     int level, u32* hist, hipStream_t st) {
+    const u64 nsamp = (nrec + step - 1) / step;
+    hipLaunchKernelGGL(k_qlt_hist, dim3((u32)((nsamp + 255) / 256)), dim3(256), 0, st, fq, line_off, blocks, block_reads, nrec, step, level, hist);
+}
+
+// ---- 2. rows -------------------------------------------------------------------------------------------
+// The rule (also oracle/sfq_oracle.c sfqo_qlt_prior_rows): symbols below iend = highest seen symbol + 1,
+// ordered by (count desc, symbol asc); freq = (6 * count) >> s with the smallest s that brings the largest
+// to <= 32000; total = sum of freq; count = 0.  Output, 66 dwords per context: slot[64] (freq | sym << 16),
+// total, iend -- the exchange form the host packs into "qlt.pri" -- plus the two device layouts.
+__device__ __forceinline__ u32 pr_sort64(u32 key, u32 lane) {
+#pragma unroll
+    for (u32 k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)key, j, 64);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            const u32 lo = key < other ? key : other, hi = key < other ? other : key;
+            key = (lower == up) ? lo : hi;
+        }
+    }
+    return key;
+}
+__global__ __launch_bounds__(256) void k_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf,
+                                                   u32* l_slots, RowHdr* l_hdr) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    u32 c = hist[(size_t)ctx * 64 + lane];
+    if (c > 0x3FFFFFFu) c = 0x3FFFFFFu;
+    const u64 seen = __ballot(c != 0);
+    const u32 iend = seen ? 64u - (u32)__clzll((long long)seen) : 0u;
+    // ascending sort of (~count, symbol) = count descending, symbol ascending; unseen lanes beyond iend last
+    const u32 key = lane < iend ? (((0x3FFFFFFu - c) << 6) | lane) : (0xFFFFFFC0u | lane);
+    const u32 sk = pr_sort64(key, lane);
+    const u32 cnt = lane < iend ? 0x3FFFFFFu - (sk >> 6) : 0u;
+    const u32 sym = sk & 63u;
+    const u32 mx = (u32)__builtin_amdgcn_readlane((int)cnt, 0);       // largest count sits in slot 0
+    u32 sh = 0;
+    while ((((u64)mx * 6) >> sh) > 32000) sh++;
+    const u32 f = (u32)(((u64)cnt * 6) >> sh);
+    const u32 slot = lane < iend ? (f | (sym << 16)) : 0u;
+    u32 tot = lane < iend ? f : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) tot += (u32)__shfl_xor((int)tot, d, 64);
+    // exchange form
+    u32* r = rows66 + (size_t)ctx * 66;
+    r[lane] = slot;
+    if (lane == 0) { r[64] = tot; r[65] = iend; }
+    // lane-per-block layout (dev_common.h RowHdr); epoch 0 never matches a running block
+    l_slots[(size_t)ctx * 64 + lane] = slot;
+    if (lane == 0) { RowHdr h; h.total = tot; h.iend = (u16)iend; h.count = 0; h.pad = 0; h.epoch = 0; h.pad2 = 0; l_hdr[ctx] = h; }
+    // wave layout (models_w.hip WaveRow): dwords 0..2 header, 4..63 slots 0..59, overflow slots 60..63
+    u32* w = w_rows + (size_t)ctx * 64;
+    if (lane < 60) w[4 + lane] = slot; else w_ovf[(size_t)ctx * 4 + (lane - 60)] = slot;
+    if (lane == 0) { w[0] = tot; w[1] = iend; w[2] = 0; w[3] = 0; }
+}
+void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st) {
+    hipLaunchKernelGGL(k_prior_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, rows66, w_rows, w_ovf, l_slots, l_hdr);
+}
+
+// decode side: the host unpacked "qlt.pri" into the exchange form; spread it into the device layouts
+__global__ __launch_bounds__(256) void k_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    const u32* r = rows66 + (size_t)ctx * 66;
+    const u32 slot = r[lane], tot = r[64], iend = r[65];
+    l_slots[(size_t)ctx * 64 + lane] = slot;
+    if (lane == 0) { RowHdr h; h.total = tot; h.iend = (u16)iend; h.count = 0; h.pad = 0; h.epoch = 0; h.pad2 = 0; l_hdr[ctx] = h; }
+    u32* w = w_rows + (size_t)ctx * 64;
+    if (lane < 60) w[4 + lane] = slot; else w_ovf[(size_t)ctx * 4 + (lane - 60)] = slot;
+    if (lane == 0) { w[0] = tot; w[1] = iend; w[2] = 0; w[3] = 0; }
+}
+void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st) {
+    hipLaunchKernelGGL(k_prior_spread, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, w_rows, w_ovf, l_slots, l_hdr);
+}

@@ -1,0 +1,91 @@
+"""CPU, world_size 2, gloo: the N>1 path's plumbing -- record sharding, the variable-size gather of the
+per-rank compressed streams to the writer rank, and the merge of the block indexes.  The encoder inside
+each rank is a stand-in here (the oracle, run per block, exactly what the GPU kernels are proven to equal
+in test_gpu_parity.py); what this test checks is that shards + gather + merge reproduce the single-process
+result byte for byte."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BLOCK = 300
+NREC = 2000
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _encode_blocks(fq: bytes, level: int):
+    """stand-in for sfq_encode_blocks: per block, the reference's streams for that block alone"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    from oracle import oracle as O
+    blocks, payload, firsts = [], {}, []
+    names = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"]
+    per_stream = {n: [] for n in names}
+    for chunk in util.split_records(fq, BLOCK):
+        a = O.compress(chunk, level, gen_bits=18)
+        first = a.info["rec.first"].encode("latin1")
+        firsts.append(first)
+        blocks.append({"n_records": chunk.count(b"\n") // 4, "first_hdr_len": len(first),
+                       "size": [len(a.streams.get(n, b"")) for n in names]})
+        for n in names:
+            per_stream[n].append(a.streams.get(n, b""))
+    return blocks, b"".join(firsts), b"".join(b"".join(per_stream[n]) for n in names), [sum(map(len, per_stream[n])) for n in names]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from slimfastq_amd import capi, dist as sdist
+    lo, hi = sdist.shard_records(NREC, rank, world, BLOCK)
+    fq = capi.synth_fastq(hi - lo, 100, seed=3, first_read=lo)        # every rank generates only its shard
+    blocks, firsts, payload, totals = _encode_blocks(fq, 3)
+    bufs = sdist.gather_bytes(torch.frombuffer(bytearray(payload), dtype=torch.uint8), dst=0)
+    meta = [None] * world
+    dist.gather_object((blocks, firsts, totals), meta if rank == 0 else None, dst=0)
+    if rank == 0:
+        index, first_blob = sdist.merge_indexes([m[0] for m in meta], [m[1] for m in meta])
+        q.put((index, first_blob, [bytes(b.numpy()) for b in bufs], [m[2] for m in meta], (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_gather_merge_equals_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    index, first_blob, payloads, totals, _ = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from slimfastq_amd import capi, dist as sdist
+    whole = capi.synth_fastq(NREC, 100, seed=3)
+    blocks1, firsts1, payload1, totals1 = _encode_blocks(whole, 3)
+    # shards are block aligned and cover the records exactly once
+    assert sdist.shard_records(NREC, 0, 2, BLOCK)[1] == sdist.shard_records(NREC, 1, 2, BLOCK)[0]
+    assert [b["n_records"] for b in index] == [b["n_records"] for b in blocks1]
+    assert [b["size"] for b in index] == [b["size"] for b in blocks1]
+    assert first_blob == firsts1
+    assert index[0]["first_record"] == 0 and index[-1]["first_record"] == NREC - index[-1]["n_records"]
+    # per stream: rank 0's part followed by rank 1's part == the single-process stream
+    off = [0, 0]; single_off = 0
+    for s in range(10):
+        merged = b""
+        for r in range(world):
+            merged += payloads[r][off[r]:off[r] + totals[r][s]]
+            off[r] += totals[r][s]
+        assert merged == payload1[single_off:single_off + totals1[s]], s
+        single_off += totals1[s]

@@ -216,3 +216,47 @@ def test_cli_roundtrip_and_reference_compatibility(tmp_path):
     bad = tmp_path / "bad.fq"; bad.write_bytes(b"@x\nACXT\n+\nIIII\n")
     p = subprocess.run([cli, "-u", str(bad), "-f", str(tmp_path / "bad.sfq"), "-O"], capture_output=True)
     assert p.returncode == 1 and b"slimfastq: encoding" in p.stderr
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("level", (1, 3))
+def test_warm_start_prior_matches_oracle_rule(ctx, level, kernel):
+    """Format 7 warm start: the prior counted over every N-th record, the rows built from it and the blocks
+    coded from it equal the oracle's restatement of the same rule; decode restores the text."""
+    fq = capi.synth_fastq(6100, 150, seed=40 + level)
+    step, br = 3, 500
+    enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel, prior_step=step)
+    starts, lens = util.line_table(fq)
+    qoff, qlen = starts[3::4], lens[3::4]
+    counts = O.qlt_histogram(fq, qoff, qlen, level, 0, step)
+    rows = O.qlt_prior_rows(counts)
+    got_rows = util.unpack_prior(enc.prior, 4096 if level == 1 else 65536)
+    assert np.array_equal(got_rows, rows)
+    want, sizes = O.qlt_encode_blocks(fq, qoff, qlen, level, br, rows)
+    assert enc.stream("qlt") == want
+    assert [b.size[2] for b in enc.blocks] == list(sizes)
+    # the other streams are untouched by the prior: still the reference's per-chunk result
+    chunks = util.split_records(fq, br)
+    for b in (0, len(chunks) - 1):
+        ref = O.compress(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
+        assert enc.stream("gen", b) == ref["gen"] and enc.stream("rec", b) == ref["rec"]
+    assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+    # and it pays: within a fraction of a percent of the whole-file (reference) quality stream
+    whole = len(O.compress(fq, level).streams["qlt"])
+    cold = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel).res.stream_bytes[2]
+    assert len(want) < cold and len(want) < whole * 1.03
+
+
+def test_warm_start_with_escapes_and_real_samples(ctx):
+    for name in ("tst1", "fast5.to", "badqlt", "edge_hiq"):
+        fq = util.golden_fastq(name)
+        nrec = fq.count(b"\n") // 4
+        br = max(2, nrec // 9)
+        enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=1)
+        starts, lens = util.line_table(fq)
+        solid = enc.blocks[0].solid
+        qoff, qlen = starts[3::4] + solid, lens[3::4] - solid
+        rows = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, qlen, 3, 0, 1))
+        want, _ = O.qlt_encode_blocks(fq, qoff, qlen, 3, br, rows)
+        assert enc.stream("qlt") == want, name
+        assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq, name

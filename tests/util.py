@@ -46,3 +46,46 @@ def info_of(streams: dict) -> dict:
             k, v = line.split("=", 1)
             info.setdefault(k, v)
     return info
+
+
+def line_table(fastq: bytes):
+    """(offsets, lengths) of every line of a 4-line FASTQ, as numpy arrays."""
+    a = np.frombuffer(fastq, np.uint8)
+    nl = np.flatnonzero(a == 10)
+    starts = np.concatenate([[0], nl[:-1] + 1]).astype(np.uint64)
+    return starts, (nl - starts).astype(np.uint32)
+
+
+def unpack_prior(blob: bytes, q_rows: int):
+    """"qlt.pri" -> uint32 [q_rows, 66] (slot[64], total, iend); mirrors api.cpp pack_prior."""
+    rows = np.zeros((q_rows, 66), np.uint32)
+    p = 0
+
+    def vint():
+        nonlocal p
+        v = sh = 0
+        while True:
+            c = blob[p]; p += 1
+            v |= (c & 0x7f) << sh; sh += 7
+            if not c & 0x80:
+                return v
+    assert vint() == q_rows
+    c = 0; first = True
+    while True:
+        v = vint()
+        if v == 0:
+            break
+        c = v - 1 if first else c + v - 1
+        first = False
+        iend, nnz = blob[p], blob[p + 1]; p += 2
+        used = set(); total = 0
+        for j in range(nnz):
+            sym = blob[p]; p += 1
+            f = vint()
+            rows[c, j] = f | (sym << 16); used.add(sym); total += f
+        j = nnz
+        for s in range(iend):
+            if s not in used:
+                rows[c, j] = s << 16; j += 1
+        rows[c, 64] = total; rows[c, 65] = iend
+    return rows
