@@ -338,7 +338,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
-        launch_qlt_hist(d_fastq, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, (u32*)ctx->hist.p, st);
+        launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, (u32*)ctx->hist.p, st);
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
         h_rows66.resize((size_t)q_rows * 66);

@@ -17,29 +17,74 @@ __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 
     u32 d3 = delta >> 3;
     return (q | ((q1 < q2 ? q2 : q1) << 6) | ((u32)(q1 == q2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
 }
-// one lane per sampled record: walk its quality line with the model's context function, count (ctx, symbol)
-__global__ __launch_bounds__(256) void k_qlt_hist(const u8* fq, const u64* line_off, const BlockDesc* blocks, u32 block_reads,
-                                                 u64 nrec, u32 step, int level, u32* hist) {
-    const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) * step;
-    if (r >= nrec) return;
-    const u32 solid = blocks[r / block_reads].solid;
-    const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
-    const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
-    const u8* p = fq + q0;
-    u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
-    for (u32 i = 0; i < n; i++) {
-        const u32 b = (u32)(u8)(p[i] - '!');
-        atomicAdd(&hist[(size_t)last * 64 + (b < 63u ? b : 63u)], 1u);
-        if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
-        else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
-        else if (++di & 1) { last = p_calc_last_delta(delta, b, q1, q2); q2 = b; }
-        else               { last = p_calc_last_delta(delta, b, q2, q1); q1 = b; }
+// One lane per sampled record walks its quality line with the model's context function and counts
+// (ctx, symbol).  Plain global atomics serialise on the few very hot counters (memory-side atomics:
+// ~30 ns each on one address), so every workgroup first aggregates in an LDS hash table and flushes each
+// distinct key once.
+#define HIST_SLOTS 8192u            // 64 KiB of LDS: keys + counts
+#define HIST_READS_PER_LANE 4u
+#define HIST_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 key) {
+    u32 slot = (key * 2654435761u) >> 19;                 // 13 bits
+    for (int probe = 0; probe < 8; probe++) {
+        const u32 old = atomicCAS(&keys[slot], HIST_EMPTY, key);
+        if (old == HIST_EMPTY || old == key) { atomicAdd(&cnts[slot], 1u); return; }
+        slot = (slot + 1) & (HIST_SLOTS - 1);
     }
+    atomicAdd(&hist[key], 1u);                            // table crowded: count directly
 }
-void launch_qlt_hist(const u8* fq, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
+__global__ __launch_bounds__(256) void k_qlt_hist(const u8* __restrict__ fq, u64 nbytes, const u64* __restrict__ line_off,
+                                                 const BlockDesc* __restrict__ blocks, u32 block_reads,
+                                                 u64 nrec, u32 step, int level, u32* __restrict__ hist) {
+    __shared__ u32 keys[HIST_SLOTS];
+    __shared__ u32 cnts[HIST_SLOTS];
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
+    __syncthreads();
+    for (u32 rr = 0; rr < HIST_READS_PER_LANE; rr++) {
+        const u64 r = (((u64)blockIdx.x * HIST_READS_PER_LANE + rr) * 256 + threadIdx.x) * step;
+        if (r >= nrec) break;
+        const u32 solid = blocks[r / block_reads].solid;
+        const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
+        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        // read the line as aligned dwords, four at a time: one memory latency per 16 symbols
+        const u64 a0 = q0 & ~3ull;
+        const u32 skip = (u32)(q0 - a0);
+        const u32* wp = reinterpret_cast<const u32*>(fq + a0);
+        const u64 wmax = (nbytes - a0) / 4;              // whole dwords available from a0
+        u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
+        u32 done = 0;                                    // symbols consumed
+        for (u64 w = 0; done < n; w += 4) {
+            u32 wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (w + k < wmax) wd[k] = wp[w + k];
+                else { wd[k] = 0; for (int j = 0; j < 4; j++) { const u64 at = a0 + (w + k) * 4 + j; if (at < nbytes) wd[k] |= (u32)fq[at] << (8 * j); } }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32 pos = (u32)(w + k) * 4 + j;    // byte index from a0
+                    if (pos < skip || done >= n) continue;
+                    const u32 b = (u32)(u8)(((wd[k] >> (8 * j)) & 0xff) - '!');
+                    hist_add(keys, cnts, hist, last * 64 + (b < 63u ? b : 63u));
+                    if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
+                    else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
+                    else if (++di & 1) { last = p_calc_last_delta(delta, b, q1, q2); q2 = b; }
+                    else               { last = p_calc_last_delta(delta, b, q2, q1); q1 = b; }
+                    done++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) if (cnts[i]) atomicAdd(&hist[keys[i]], cnts[i]);
+}
+void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
                      int level, u32* hist, hipStream_t st) {
     const u64 nsamp = (nrec + step - 1) / step;
-    hipLaunchKernelGGL(k_qlt_hist, dim3((u32)((nsamp + 255) / 256)), dim3(256), 0, st, fq, line_off, blocks, block_reads, nrec, step, level, hist);
+    const u64 per_wg = 256ull * HIST_READS_PER_LANE;
+    hipLaunchKernelGGL(k_qlt_hist, dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
 }
 
 // ---- 2. rows -------------------------------------------------------------------------------------------
