@@ -581,12 +581,8 @@ struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
     }
 };
 
-__global__ __launch_bounds__(64) void k_rec_encode_w(ModelArgs a) {
-    const u32 lane = threadIdx.x;
-    const u32 t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
-    BlockDesc* d = &a.blocks[b];
+// general path: any header length (tokenising and field state in per-lane scratch)
+__device__ void rec_encode_block_slow(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
     WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
     Sink0 snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
     RcEncU rc; rc.init();
@@ -670,6 +666,206 @@ __global__ __launch_bounds__(64) void k_rec_encode_w(ModelArgs a) {
         if (bad) atomicMax(&d->status, (u32)(-bad));
     }
 }
+
+// Header bytes held two per lane: register c0 = bytes 0..63, c1 = bytes 64..127 (lane j <-> byte 64*k + j).
+struct HdrRegs {
+    u32 c0, c1;
+    __device__ __forceinline__ u32 at(u32 pos) const { return pos < 64 ? rl(c0, pos) : rl(c1, pos - 64); }   // pos uniform
+};
+// numberwang (recs.cpp:192-262) over a field [off, off+len) of such a header
+__device__ u32 nw_lanes(const HdrRegs& h, u32 off, int len, u64& num, u32 pctype) {
+    int i = 0;
+    const bool has_z = h.at(off) == '0';
+    if (has_z) if (h.at(off + (++i)) == '0') return ST_STR;
+    u32 caps = 0;
+    num = 0;
+    while (pctype != 2) {
+        if (i >= len) return has_z ? ST_DGT_Z : ST_DGT;
+        const u32 c = h.at(off + i);
+        if (isdig(c)) {
+            const u64 tnum = (num << 3) + (num << 1) + c - '0';
+            i++;
+            if (tnum < num) return ST_STR;
+            num = tnum;
+            continue;
+        }
+        if ((c | 0x20) < 'a' || (c | 0x20) > 'f') return ST_STR;
+        caps = 1 + (c < 'a');
+        i = has_z;
+        num = 0;
+        break;
+    }
+    if (len > 16) return ST_STR;
+    for (; i < len; i++) {
+        const u32 c = h.at(off + i); u32 nib;
+        if (isdig(c)) nib = c - '0';
+        else if (c >= 'a' && c <= 'f') { if (caps == 2) return ST_STR; caps = 1; nib = 10 + (c - 'a'); }
+        else if (c >= 'A' && c <= 'F') { if (caps == 1) return ST_STR; caps = 2; nib = 10 + (c - 'A'); }
+        else return ST_STR;
+        num = (num << 4) + nib;
+    }
+    return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
+}
+// bits [a, b) of a 128-bit mask, as two 64-bit halves (per lane)
+__device__ __forceinline__ void mask128(u32 a, u32 b, u64& m0, u64& m1) {
+    const u64 lo_b = b >= 64 ? ~0ull : ((1ull << b) - 1), lo_a = a >= 64 ? ~0ull : ((1ull << a) - 1);
+    m0 = lo_b & ~lo_a;
+    const u32 a1 = a > 64 ? a - 64 : 0, b1 = b > 64 ? b - 64 : 0;
+    const u64 hi_b = b1 >= 64 ? ~0ull : ((1ull << b1) - 1), hi_a = a1 >= 64 ? ~0ull : ((1ull << a1) - 1);
+    m1 = hi_b & ~hi_a;
+}
+
+// fast path: every header of the block fits two bytes per lane (<= 126 bytes + terminator, <= 64 fields).
+// Tokenising is two ballots, field tables are lanes (lane k = field k), the field diff against the previous
+// header is a cross-lane gather; only the few coded symbols per record run serially.
+#define REC_FAST_MAX 126u
+__device__ void rec_encode_block_fast(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
+    WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
+    Sink0 snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
+    RcEncU rc; rc.init();
+    XfEncW x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    const u64 lt = (1ull << lane) - 1;                    // lanes below this one
+    HdrRegs pb = {0, 0};                                  // previous header
+    u32 psep = 0, pspos = 0, pnf = 0;                     // its k-th separator char / position (lane k), field count
+    u32 ct = 0, cn_lo = 0, cn_hi = 0;                     // per field (lane k): ctype, cnumb (recs.hpp:75-76)
+    u64 last_index = 0;
+    u32 hdr_bytes = 0;
+    int bad = 0;
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k;
+        const u64 record_count = (u64)k + 1;
+        const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        hdr_bytes += n;
+        HdrRegs cb;
+        cb.c0 = lane < n ? (u32)a.fq[h0 + lane] : 0u;
+        cb.c1 = lane + 64 < n ? (u32)a.fq[h0 + 64 + lane] : 0u;
+        if (lane == n) cb.c0 = '\n';                     // the terminator is a separator too (recs.cpp:148-150)
+        if (lane + 64 == n) cb.c1 = '\n';
+        u64 cm0 = __ballot(lane <= n && !isword(cb.c0));  // map_space: separators
+        u64 cm1 = __ballot(lane + 64 <= n && !isword(cb.c1));
+        // a NUL inside the text ends the reference's scan early (recs.cpp:148): cut there
+        const u64 nul0 = __ballot(lane < n && cb.c0 == 0), nul1 = __ballot(lane + 64 < n && cb.c1 == 0);
+        if (nul0) { const u32 z = (u32)__ffsll((long long)nul0) - 1u; cm0 &= z >= 63 ? ~0ull : ((2ull << z) - 1); cm1 = 0; }
+        else if (nul1) { const u32 z = (u32)__ffsll((long long)nul1) - 1u; cm1 &= z >= 63 ? ~0ull : ((2ull << z) - 1); }
+        const u32 nf0 = (u32)__popcll(cm0), nf = nf0 + (u32)__popcll(cm1);   // fields = separators (the last is the terminator)
+        if (nf > 64) { bad = SFQ_E_FORMAT; break; }       // recs.cpp:153-154
+        // field index of each byte, and the k-th separator's char / position gathered into lane k
+        const bool sep0 = (cm0 >> lane) & 1, sep1 = (cm1 >> lane) & 1;
+        const u32 rank0 = (u32)__popcll(cm0 & lt), rank1 = nf0 + (u32)__popcll(cm1 & lt);
+        // (pushes from non-separator lanes go to lane 63 with value 0; a real 64th field only exists when
+        //  every position is a separator, so nothing else lands there)
+        u32 sepc = (u32)__builtin_amdgcn_ds_permute((int)((sep0 ? rank0 : 63u) * 4), (int)(sep0 ? cb.c0 : 0u));
+        u32 spos = (u32)__builtin_amdgcn_ds_permute((int)((sep0 ? rank0 : 63u) * 4), (int)(sep0 ? lane : 0u));
+        sepc |= (u32)__builtin_amdgcn_ds_permute((int)((sep1 ? (rank1 & 63) : 63u) * 4), (int)(sep1 ? cb.c1 : 0u));
+        spos |= (u32)__builtin_amdgcn_ds_permute((int)((sep1 ? (rank1 & 63) : 63u) * 4), (int)(sep1 ? lane + 64 : 0u));
+        if (nf == 64) {                                   // lane 63 is then a real field: its entry is the last separator
+            const u32 tpos = cm1 ? 127u - (u32)__clzll((long long)cm1) : 63u - (u32)__clzll((long long)cm0);
+            const u32 tch = cb.at(tpos);
+            if (lane == 63) { sepc = tch; spos = tpos; }
+        }
+        if (k == 0) {                                     // first header -> "rec.first" (recs.cpp:279-287)
+            ct = 0;
+            pb = cb; psep = sepc; pspos = spos; pnf = nf;
+            continue;
+        }
+        const bool shape = nf != pnf || __ballot(lane < nf && sepc != psep) != 0;
+        if (shape) {                                      // recs.cpp:292-305
+            x_rec.put(pw, record_count - last_index, lane);
+            last_index = record_count;
+            x_rec.put(pw, n, lane);                       // put_str: length, then the characters
+            for (u32 j = 0; j < n; j++) pw.put(x_rec.row0 + 14, x_rec.rc, x_rec.sink, cb.at(j), lane);
+            ct = 0;
+            pb = cb; psep = sepc; pspos = spos; pnf = nf;
+            continue;
+        }
+        // field tables: lane f = field f.  (Cross-lane ops stay out of lane-dependent conditionals:
+        // `c ? dpp : x` would run the DPP under a partial EXEC.)
+        const u32 offv = wave_shr1(spos, 0xFFFFFFFFu) + 1;          // lane 0: 0xFFFFFFFF + 1 = 0
+        const u32 wlnv = spos - offv;
+        const u32 poffv = wave_shr1(pspos, 0xFFFFFFFFu) + 1;
+        const u32 pwlnv = pspos - poffv;
+        // byte diff: byte at position p of field f against the previous header's byte at p + (poff_f - off_f)
+        const u32 dv = poffv - offv;
+        const u32 d0 = (u32)__builtin_amdgcn_ds_bpermute((int)((rank0 & 63) * 4), (int)dv);
+        const u32 d1 = (u32)__builtin_amdgcn_ds_bpermute((int)((rank1 & 63) * 4), (int)dv);
+        const u32 pp0 = lane + d0, pp1 = lane + 64 + d1;            // positions in the previous header
+        const u32 g00 = (u32)__builtin_amdgcn_ds_bpermute((int)((pp0 & 63) * 4), (int)pb.c0), g01 = (u32)__builtin_amdgcn_ds_bpermute((int)((pp0 & 63) * 4), (int)pb.c1);
+        const u32 g10 = (u32)__builtin_amdgcn_ds_bpermute((int)((pp1 & 63) * 4), (int)pb.c0), g11 = (u32)__builtin_amdgcn_ds_bpermute((int)((pp1 & 63) * 4), (int)pb.c1);
+        const u32 pby0 = (pp0 & 64) ? g01 : g00, pby1 = (pp1 & 64) ? g11 : g10;
+        const u64 dm0 = __ballot(lane < n && !sep0 && cb.c0 != pby0);
+        const u64 dm1 = __ballot(lane + 64 < n && !sep1 && cb.c1 != pby1);
+        u64 f0, f1;
+        mask128(offv, offv + wlnv, f0, f1);
+        const u64 map = __ballot(lane < nf && (wlnv != pwlnv || ((dm0 & f0) | (dm1 & f1)) != 0));
+        pw.put_u(0 * 16 + 2, rc, snk, map, lane);         // put_num(0, map) recs.cpp:313
+        u64 todo = map;
+        while (todo) {
+            const u32 i = (u32)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            const u32 off = rl(offv, i), wln = rl(wlnv, i), pct = rl(ct, i);
+            u64 bnum;
+            u32 type = nw_lanes(cb, off, (int)wln, bnum, pct);
+            const u32 rr = (i + 1) * 16;
+            if (type == ST_STR) {                         // recs.cpp:324-331
+                pw.put(rr + 0, rc, snk, type, lane);
+                pw.put_u(rr + 2, rc, snk, wln, lane);
+                for (u32 j = 0; j < wln; j++) pw.put(rr + 1, rc, snk, cb.at(off + j), lane);
+                if (lane == i) ct = 0;
+                continue;
+            }
+            const u64 pnum = pct ? ((u64)rl(cn_hi, i) << 32 | rl(cn_lo, i)) : 0;       // recs.cpp:333-348
+            u64 gap;
+            const u32 nct = (type < ST_STR || type >= ST_DGT_Z) ? 1u : 2u;
+            if (lane == i) { ct = nct; cn_lo = (u32)bnum; cn_hi = (u32)(bnum >> 32); }
+            if (bnum < pnum) { gap = pnum - bnum; type++; }
+            else gap = bnum - pnum;
+            pw.put(rr + 0, rc, snk, type, lane);
+            pw.put_u(rr + 2, rc, snk, gap, lane);
+        }
+        pb = cb; psep = sepc; pspos = spos; pnf = nf;
+    }
+    rc.done(snk);
+    const u32 xsz = x_rec.finish(pw, lane);
+    if (lane == 0) {
+        d->hdr_bytes = hdr_bytes;
+        d->size[SFQ_S_REC] = snk.pos;
+        d->size[SFQ_S_REC_X] = xsz;
+        if (snk.pos > snk.cap || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (rc.err | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        if (bad) atomicMax(&d->status, (u32)(-bad));
+    }
+}
+
+// longest header of the block decides the path; two kernels (so each keeps its own register budget),
+// each of which returns at once for the blocks that belong to the other
+__device__ __forceinline__ bool rec_block_is_short(const ModelArgs& a, const BlockDesc* d, u32 lane) {
+    u32 longest = 0;
+    for (u32 k = lane; k < d->nrec; k += 64) {
+        const u64 r = d->rec0 + k;
+        const u32 n = (u32)(a.line_off[4 * r + 1] - a.line_off[4 * r] - 2);
+        longest = n > longest ? n : longest;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { const u32 o = (u32)__shfl_xor((int)longest, s, 64); longest = o > longest ? o : longest; }
+    return rl(longest, 0) <= REC_FAST_MAX;
+}
+__global__ __launch_bounds__(64) void k_rec_encode_w_fast(ModelArgs a) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    BlockDesc* d = &a.blocks[b];
+    if (rec_block_is_short(a, d, lane)) rec_encode_block_fast(a, t, b, d, lane);
+}
+__global__ __launch_bounds__(64) void k_rec_encode_w_slow(ModelArgs a) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    BlockDesc* d = &a.blocks[b];
+    if (!rec_block_is_short(a, d, lane)) rec_encode_block_slow(a, t, b, d, lane);
+}
 void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_rec_encode_w_fast, dim3(a.nbatch), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_rec_encode_w_slow, dim3(a.nbatch), dim3(64), 0, st, a);
 }

@@ -260,3 +260,22 @@ def test_warm_start_with_escapes_and_real_samples(ctx):
         want, _ = O.qlt_encode_blocks(fq, qoff, qlen, 3, br, rows)
         assert enc.stream("qlt") == want, name
         assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq, name
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_headers_longer_than_one_wave_of_bytes(ctx, kernel):
+    """64..126-byte headers take the two-bytes-per-lane path of the header kernel; longer ones its general path."""
+    fq = capi.synth_fastq(2500, 100, seed=9, first_read=123_456_789)     # 68-byte headers
+    assert max(len(l) for l in fq.split(b"\n")[0::4]) > 64
+    enc = ctx.encode_host(fq, level=3, block_reads=0, kernel=kernel)
+    assert_streams_equal(enc, O.compress(fq, 3).streams, ctxmsg="long headers")
+    # mixed: some blocks short, some long, a shape change and a > 126-byte header in between
+    lines = fq.split(b"\n")
+    lines[4 * 700] = b"@" + b"x" * 140 + b":1:2"
+    lines[4 * 1500] = b"@only_two fields"
+    fq2 = b"\n".join(lines)
+    enc = ctx.encode_host(fq2, level=3, block_reads=600, kernel=kernel)
+    for b, chunk in enumerate(util.split_records(fq2, 600)):
+        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        assert_streams_equal(enc, want, block=b, ctxmsg="mixed headers block %d" % b)
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq2) + 4096) == fq2
