@@ -68,7 +68,8 @@ typedef struct sfq_params {
                               byte-identical to the reference's own (format 6)                        */
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
-    uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks) */
+    uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks);
+                              2 = wave-per-row quality kernel (the earlier default, kept for A/B runs)       */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);

@@ -363,7 +363,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
                 a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
                 switch (order[m]) {
-                case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, mst[m]); else launch_qlt_encode_w(a, mst[m]); break;
+                case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, mst[m]); else if (p.kernel == 2) launch_qlt_encode_w(a, mst[m]); else launch_qlt_encode_s(a, mst[m]); break;
                 case SFQ_M_GEN:
                     launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);   // base2_ranger.hpp:68-71
                     if (p.kernel == 1) launch_gen_encode_l(a, mst[m]); else launch_gen_encode_w(a, mst[m]);

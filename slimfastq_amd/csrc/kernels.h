@@ -60,6 +60,7 @@ void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
 
 // models, wave-per-block throughput kernels
 void launch_qlt_encode_w(const ModelArgs& a, hipStream_t st);
+void launch_qlt_encode_s(const ModelArgs& a, hipStream_t st);
 void launch_gen_encode_w(const ModelArgs& a, hipStream_t st);
 void launch_rec_encode_w(const ModelArgs& a, hipStream_t st);
 

@@ -869,3 +869,173 @@ void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_encode_w_fast, dim3(a.nbatch), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_rec_encode_w_slow, dim3(a.nbatch), dim3(64), 0, st, a);
 }
+
+// =========================================================================================================
+// quality encode, symbol-parallel rows  (default quality kernel)
+//
+// k_qlt_encode_w above spends ~90 instructions per symbol walking one row at a time with the whole wave.
+// The rows of different contexts are independent state machines, so the 64 symbols of a window can be
+// modelled side by side, one per lane, as long as symbols that share a context are applied in their
+// original order.  A bitonic sort of (context, position) keys gives every symbol its rank inside its
+// context; round t applies the rank-t symbol of every context at once (each lane runs the Log64Ranger
+// search/update on its own row in HBM).  A window needs as many rounds as its most repeated context
+// (~10 on Illumina-like data) instead of 64 serial steps.  The triples are un-sorted back into position
+// order and the scalar range coder (stage 3) consumes them as before.  Rows use the plain layout
+// (slots[64] + RowHdr), shared with the lane-per-block kernels and decoders.
+// =========================================================================================================
+__device__ __forceinline__ u32 wave_incl_scan_max(u32 x) {
+    u32 y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(1), 0xf, 0xf, false); x = x > y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(2), 0xf, 0xf, false); x = x > y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(4), 0xf, 0xf, false); x = x > y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(8), 0xf, 0xf, false); x = x > y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST15, 0xa, 0xf, false); x = x > y ? x : y;
+    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST31, 0xc, 0xf, false); x = x > y ? x : y;
+    return x;
+}
+
+// Log64Ranger::put minus Encode on one row, by one lane (log64_ranger.hpp:69-112); 16-byte accesses.
+// A row whose tag is stale starts from the shared prior row (format 7) or from zeros.
+__device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php, u32 sym, u32& err) {
+    const uint4 hq = *reinterpret_cast<const uint4*>(hp);          // {total, iend | count<<16 | pad<<24, epoch, pad2}
+    u32 total, iend, count;
+    if (hq.z == epoch) { total = hq.x; iend = hq.y & 0xffffu; count = (hq.y >> 16) & 0xffu; }
+    else if (pslots) {
+        const uint4 ph = *reinterpret_cast<const uint4*>(php);
+        total = ph.x; iend = ph.y & 0xffffu; count = 0;
+        for (u32 k = 0; k < iend; k += 4) *reinterpret_cast<uint4*>(slots + k) = *reinterpret_cast<const uint4*>(pslots + k);
+    } else { total = 0; iend = 0; count = 0; }
+    if (iend <= sym) { for (u32 k = iend; k <= sym; k++) slots[k] = k << 16; iend = sym + 1; }          // :103-105
+    u32 i = 0, sumf = 0, s = 0;
+    for (;;) {                                                                                        // :107
+        const uint4 q = *reinterpret_cast<const uint4*>(slots + i);
+        if ((q.x >> 16) == sym) { s = q.x; break; }
+        sumf += q.x & 0xffffu;
+        if ((q.y >> 16) == sym && i + 1 < iend) { s = q.y; i += 1; break; }
+        sumf += q.y & 0xffffu;
+        if ((q.z >> 16) == sym && i + 2 < iend) { s = q.z; i += 2; break; }
+        sumf += q.z & 0xffffu;
+        if ((q.w >> 16) == sym && i + 3 < iend) { s = q.w; i += 3; break; }
+        sumf += q.w & 0xffffu;
+        i += 4;
+        if (i >= 64) { err = 1; i = 63; s = slots[63]; break; }
+    }
+    Triple t; t.cum = sumf + i; t.freq = (s & 0xffffu) + 1; t.tot = total + 64;                        // :109
+    Log64::update(slots, i, s, total, iend, count);
+    uint4 nh; nh.x = total; nh.y = iend | (count << 16); nh.z = epoch; nh.w = 0;
+    *reinterpret_cast<uint4*>(hp) = nh;
+    return t;
+}
+
+__global__ __launch_bounds__(64) void k_qlt_encode_s(ModelArgs a) {
+    const u32 lane = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= a.nbatch) return;
+    const u32 b = a.batch0 + t;
+    const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
+    BlockDesc* d = &a.blocks[b];
+    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
+    WaveCoder rc; rc.init();
+    u32* const qs = a.q_slots + (size_t)t * a.q_rows * L64_NSYM;
+    RowHdr* const qh = a.q_hdr + (size_t)t * a.q_rows;
+    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
+    const u32 solid = d->solid;
+    const int level = a.level;
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    u32 extra_hi = 0, perr = 0;
+
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k;
+        const u64 q0 = a.line_off[4 * r + 3] + solid;
+        const u64 q1e = a.line_off[4 * r + 4] - 1;
+        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u8* p = a.fq + q0;
+        u32 p1 = 0, p2 = 0, p3 = 0, carry_d = 0;
+        for (u32 base = 0; base < n; base += 64) {
+            const u32 m = n - base < 64 ? n - base : 64;
+            // ---- stage 1: symbols and contexts, across lanes (as in k_qlt_encode_w) ----
+            const u32 bv = lane < m ? (u32)(u8)(p[base + lane] - '!') : 0u;
+            const u32 v1 = wave_shr1(bv, p1);
+            const u32 v2 = wave_shr1(v1, p2);
+            const u32 v3 = wave_shr1(v2, p3);
+            u32 ctxv;
+            if (level == 1)      ctxv = (v1 | ((v2 & 63u) << 6)) & 0xFFFu;
+            else if (level == 2) ctxv = (v1 | (((v2 | ((v3 & 15u) << 6)) & 0x3FFu) << 6)) & 0xFFFFu;
+            else {
+                const u32 drop = (lane < m && v1 > bv) ? v1 - bv : 0u;
+                const u32 inc = wave_incl_scan(drop);
+                const u32 dprev = 5u + carry_d + inc - drop;
+                const u32 d3 = dprev >> 3;
+                ctxv = (v1 | ((v2 < v3 ? v3 : v2) << 6) | ((u32)(v2 == v3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                if (base == 0 && lane == 0) ctxv = 0;
+                carry_d += rl(inc, 63);
+            }
+            p3 = m >= 3 ? rl(bv, m - 3) : (m == 2 ? p1 : p2);
+            p2 = m >= 2 ? rl(bv, m - 2) : p1;
+            p1 = rl(bv, m - 1);
+            u32 tcum = 0, tfreq = 1, ttot = 1;
+            const u64 esc = __ballot(lane < m && bv >= LAST_QLT);
+            if (!esc) {
+                // ---- stage 2: rank every symbol inside its context, then one round per rank ----
+                const u32 key = lane < m ? ((ctxv << 6) | lane) : (0x80000000u | (lane << 6) | lane);
+                const u32 sk = bitonic_sort64(key, lane);                 // sorted lane: (context, original position)
+                const u32 sctx = sk >> 6, spos = sk & 63u;
+                const bool valid = !(sk >> 31);
+                const u32 ssym = (u32)__builtin_amdgcn_ds_bpermute((int)(spos * 4), (int)bv);
+                const u32 prevctx = wave_shr1(sctx, 0xFFFFFFFFu);
+                const u32 start = wave_incl_scan_max(sctx != prevctx ? lane : 0u);     // first sorted lane of this context's run
+                const u32 rank = lane - start;
+                u32* const row = qs + (size_t)(sctx & 0xFFFFu) * L64_NSYM;
+                RowHdr* const hp = qh + (sctx & 0xFFFFu);
+                const u32* const prow = a.prior_ls ? a.prior_ls + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
+                const RowHdr* const php = a.prior_lh + (sctx & 0xFFFFu);
+                u32 scum = 0, sfreq = 1, stot = 1;
+                for (u32 round = 0; ; round++) {
+                    const u64 act = __ballot(valid && rank == round);
+                    if (!act) break;
+                    if (valid && rank == round) {
+                        const Triple tr = l64_model_lane(row, hp, epoch, prow, php, ssym, perr);
+                        scum = tr.cum; sfreq = tr.freq; stot = tr.tot;
+                    }
+                }
+                // back to position order
+                tcum  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)scum);
+                tfreq = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)sfreq);
+                ttot  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)stot);
+                rc.run(tcum, tfreq, ttot, m, out, lane);                  // ---- stage 3 ----
+            } else {
+                // a window holding escape symbols (quality >= 63: qlts.cpp:80-86) is walked in order on lane 0;
+                // each symbol contributes one triple, an escape a second one from the PowerRanger row
+                for (u32 j = 0; j < m; j++) {
+                    const u32 ctx = rl(ctxv, j), sym = rl(bv, j);
+                    Triple t1; t1.cum = 0; t1.freq = 1; t1.tot = 1;
+                    Triple t2 = t1;
+                    if (lane == 0) {
+                        t1 = l64_model_lane(qs + (size_t)ctx * L64_NSYM, qh + ctx, epoch,
+                                            a.prior_ls ? a.prior_ls + (size_t)ctx * L64_NSYM : nullptr, a.prior_lh + ctx,
+                                            sym < LAST_QLT ? sym : LAST_QLT, perr);
+                        if (sym >= LAST_QLT) t2 = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, epoch, sym, perr);
+                    }
+                    const u32 c1 = rfl(t1.cum), f1 = rfl(t1.freq), o1 = rfl(t1.tot);
+                    const u32 c2 = rfl(t2.cum), f2 = rfl(t2.freq), o2 = rfl(t2.tot);
+                    const u32 cnt = sym >= LAST_QLT ? 2u : 1u;
+                    tcum = lane == 0 ? c1 : c2; tfreq = lane == 0 ? f1 : f2; ttot = lane == 0 ? o1 : o2;
+                    rc.run(tcum, tfreq, ttot, cnt, out, lane);
+                    if (sym >= LAST_QLT) extra_hi++;
+                }
+            }
+        }
+    }
+    rc.done(out, lane);
+    out.flush(lane);
+    const u64 anyerr = __ballot(perr != 0);
+    if (lane == 0) {
+        d->extra_hi = extra_hi;
+        d->size[SFQ_S_QLT] = out.pos;
+        if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    }
+}
+void launch_qlt_encode_s(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_s, dim3(a.nbatch), dim3(64), 0, st, a);
+}

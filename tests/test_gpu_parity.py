@@ -9,7 +9,7 @@ from slimfastq_amd import capi
 
 pytestmark = pytest.mark.gpu
 LEVEL_BITS = {1: 18, 2: 22, 3: 24, 4: 26}
-KERNELS = (0, 1)          # 0 = throughput kernels, 1 = lane-per-block reference kernels
+KERNELS = (0, 1, 2)       # 0 = default kernels, 1 = lane-per-block reference kernels, 2 = wave-per-row quality kernel
 
 
 def assert_streams_equal(enc, want: dict, block=None, ctxmsg=""):
