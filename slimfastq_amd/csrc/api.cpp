@@ -356,6 +356,12 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
     const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
     hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
+    // The first batch's Base2 tables are initialised (base2_ranger.hpp:68-71) before the streams fork, while
+    // the chip is otherwise idle: a streaming fill that has to compete with the model kernels is starved.
+    if (models & SFQ_M_GEN) {
+        launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)std::min(slots, nblocks) << g_bits, 0x03030303u, st);
+        HIPC(hipEventRecord(ctx->ev[1], st));
+    }
     for (int m = 0; m < 4; m++) {
         if (m) HIPC(hipStreamWaitEvent(mst[m], ctx->ev[1], 0));
         HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m]));
@@ -365,7 +371,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 switch (order[m]) {
                 case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, mst[m]); else if (p.kernel == 2) launch_qlt_encode_w(a, mst[m]); else launch_qlt_encode_s(a, mst[m]); break;
                 case SFQ_M_GEN:
-                    launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);   // base2_ranger.hpp:68-71
+                    if (b0) launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);
                     if (p.kernel == 1) launch_gen_encode_l(a, mst[m]); else launch_gen_encode_w(a, mst[m]);
                     break;
                 case SFQ_M_REC: if (p.kernel == 1) launch_rec_encode_l(a, mst[m]); else launch_rec_encode_w(a, mst[m]); break;
