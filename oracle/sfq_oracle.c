@@ -1456,8 +1456,8 @@ int sfqo_qlt_histogram(const u8* base, const u64* off, const u32* len, size_t nr
     return 0;
 }
 
-/* The prior-row rule: symbols by (count desc, symbol asc); freq = (6 * count) >> s with the
- * smallest s that brings the largest to <= 32000; iend = highest seen symbol + 1; total = sum; count = 0.
+/* The prior-row rule: iend = highest seen symbol + 1; freq = (6 * count) >> s with the smallest s
+ * that brings the context's largest to <= 32000; symbols by (freq desc, symbol asc); total = sum; count = 0.
  * rows: q_rows x { u32 slot[64] (freq | sym << 16), u32 total, u32 iend } = 66 dwords per row. */
 int sfqo_qlt_prior_rows(const u32* counts, size_t q_rows, u32* rows) {
     for (size_t c = 0; c < q_rows; c++) {
@@ -1465,25 +1465,21 @@ int sfqo_qlt_prior_rows(const u32* counts, size_t q_rows, u32* rows) {
         u32* r = rows + c * 66;
         memset(r, 0, 66 * sizeof(u32));
         int iend = 0; u32 mx = 0;
-        u32 cl[64];                                            /* counts saturate at 2^26-1 (the device sort key has 26 bits) */
-        for (int s = 0; s < 64; s++) { cl[s] = cn[s] > 0x3FFFFFFu ? 0x3FFFFFFu : cn[s]; }
-        cn = cl;
         for (int s = 0; s < 64; s++) if (cn[s]) { iend = s + 1; if (cn[s] > mx) mx = cn[s]; }
         if (!iend) continue;
         int sh = 0;
         while ((((u64)mx * 6) >> sh) > 32000) sh++;
-        int order[64];
-        for (int s = 0; s < iend; s++) order[s] = s;
-        for (int i = 1; i < iend; i++) {                       /* stable insertion sort: count desc, symbol asc */
+        u32 fs[64]; int order[64];
+        for (int s = 0; s < iend; s++) { fs[s] = (u32)(((u64)cn[s] * 6) >> sh); order[s] = s; }
+        for (int i = 1; i < iend; i++) {                       /* stable insertion sort: scaled freq desc, symbol asc */
             int k = order[i], j = i;
-            while (j > 0 && cn[order[j - 1]] < cn[k]) { order[j] = order[j - 1]; j--; }
+            while (j > 0 && fs[order[j - 1]] < fs[k]) { order[j] = order[j - 1]; j--; }
             order[j] = k;
         }
         u32 total = 0;
         for (int j = 0; j < iend; j++) {
-            u32 f = (u32)(((u64)cn[order[j]] * 6) >> sh);
-            r[j] = f | ((u32)order[j] << 16);
-            total += f;
+            r[j] = fs[order[j]] | ((u32)order[j] << 16);
+            total += fs[order[j]];
         }
         r[64] = total; r[65] = (u32)iend;
     }

@@ -88,9 +88,9 @@ void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockD
 }
 
 // ---- 2. rows -------------------------------------------------------------------------------------------
-// The rule (also oracle/sfq_oracle.c sfqo_qlt_prior_rows): symbols below iend = highest seen symbol + 1,
-// ordered by (count desc, symbol asc); freq = (6 * count) >> s with the smallest s that brings the largest
-// to <= 32000; total = sum of freq; count = 0.  Output, 66 dwords per context: slot[64] (freq | sym << 16),
+// The rule (also oracle/sfq_oracle.c sfqo_qlt_prior_rows): iend = highest seen symbol + 1; freq = (6 * count) >> s
+// with the smallest s that brings the context's largest to <= 32000; symbols below iend ordered by (freq desc,
+// symbol asc); total = sum of freq; count = 0.  Output, 66 dwords per context: slot[64] (freq | sym << 16),
 // total, iend -- the exchange form the host packs into "qlt.pri" -- plus the two device layouts.
 __device__ __forceinline__ u32 pr_sort64(u32 key, u32 lane) {
 #pragma unroll
@@ -110,19 +110,20 @@ __global__ __launch_bounds__(256) void k_prior_rows(const u32* hist, u32 q_rows,
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
-    u32 c = hist[(size_t)ctx * 64 + lane];
-    if (c > 0x3FFFFFFu) c = 0x3FFFFFFu;
+    const u32 c = hist[(size_t)ctx * 64 + lane];
     const u64 seen = __ballot(c != 0);
     const u32 iend = seen ? 64u - (u32)__clzll((long long)seen) : 0u;
-    // ascending sort of (~count, symbol) = count descending, symbol ascending; unseen lanes beyond iend last
-    const u32 key = lane < iend ? (((0x3FFFFFFu - c) << 6) | lane) : (0xFFFFFFC0u | lane);
-    const u32 sk = pr_sort64(key, lane);
-    const u32 cnt = lane < iend ? 0x3FFFFFFu - (sk >> 6) : 0u;
-    const u32 sym = sk & 63u;
-    const u32 mx = (u32)__builtin_amdgcn_readlane((int)cnt, 0);       // largest count sits in slot 0
+    u32 mx = c;                                                       // largest count of the context
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)mx, dd, 64); mx = o > mx ? o : mx; }
     u32 sh = 0;
     while ((((u64)mx * 6) >> sh) > 32000) sh++;
-    const u32 f = (u32)(((u64)cnt * 6) >> sh);
+    const u32 fq = (u32)(((u64)c * 6) >> sh);                          // this symbol's scaled frequency (<= 32000)
+    // ascending sort of (~freq, symbol) = scaled frequency descending, symbol ascending; lanes beyond iend last
+    const u32 key = lane < iend ? (((0xFFFFu - fq) << 6) | lane) : (0xFFFFFFC0u | lane);
+    const u32 sk = pr_sort64(key, lane);
+    const u32 f = lane < iend ? 0xFFFFu - (sk >> 6) : 0u;
+    const u32 sym = sk & 63u;
     const u32 slot = lane < iend ? (f | (sym << 16)) : 0u;
     u32 tot = lane < iend ? f : 0u;
 #pragma unroll

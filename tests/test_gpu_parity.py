@@ -279,3 +279,17 @@ def test_headers_longer_than_one_wave_of_bytes(ctx, kernel):
         want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
         assert_streams_equal(enc, want, block=b, ctxmsg="mixed headers block %d" % b)
     assert ctx.decode_host(enc, level=3, out_cap=len(fq2) + 4096) == fq2
+
+
+def test_warm_start_prior_with_heavily_scaled_counts(ctx):
+    """Big samples scale the prior's frequencies down to zero for rare symbols; the zero-frequency tail must
+    have a canonical order (the prior is transmitted as its non-zero head only)."""
+    fq = capi.synth_fastq(40000, 150, seed=77)
+    enc = ctx.encode_host(fq, level=3, block_reads=2500, prior_step=1)
+    starts, lens = util.line_table(fq)
+    rows = O.qlt_prior_rows(O.qlt_histogram(fq, starts[3::4], lens[3::4], 3, 0, 1))
+    assert int(((rows[:, :64] & 0xffff) == 0).sum()) > 0 and int(rows[:, 64].max()) > 30000
+    assert np.array_equal(util.unpack_prior(enc.prior, 65536), rows)
+    want, _ = O.qlt_encode_blocks(fq, starts[3::4], lens[3::4], 3, 2500, rows)
+    assert enc.stream("qlt") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
