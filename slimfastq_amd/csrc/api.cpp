@@ -596,13 +596,17 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
 
-    // 2. quality, then bases (the N rule reads the decoded qualities)
+    // 2. quality, then bases (the N rule reads the decoded qualities); the header chain (3.) is independent of
+    //    both and runs on a second stream
     HIPC(hipEventRecord(ctx->ev[2], st));
+    HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
+    hipStream_t st_rec = ctx->st_aux[0];
+    launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)std::min(slots, nblocks) << g_bits, 0x03030303u, st);
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
     HIPC(hipEventRecord(ctx->ev[3], st));
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
-        launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st);
+        if (b0) launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st);
         launch_gen_decode_l(da, st);
     }
     HIPC(hipEventRecord(ctx->ev[4], st));
@@ -623,13 +627,15 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         }
         hso[nblocks] = o;
         if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
-        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nblocks + 1) * 8, hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, st));
-        HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st));
-        HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st));
+        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nblocks + 1) * 8, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
+        HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
         if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; ctx->epoch_base += nblocks; da.m.epoch_base = ctx->epoch_base; }
-        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st); }
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
+        HIPC(hipStreamSynchronize(st_rec));
+        HIPC(hipStreamSynchronize(st));
         HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         bool overflow = false; int worst = 0;

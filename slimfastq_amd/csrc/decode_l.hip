@@ -83,9 +83,8 @@ __global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
         u8* p = a.qual_stage + a.qoff[r];
         u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
         for (u32 i = 0; i < n; i++) {
-            l64_touch(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch,
-                      a.m.prior_ls ? a.m.prior_ls + (size_t)last * L64_NSYM : nullptr, a.m.prior_lh + last);
-            u32 b = Log64::get(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch, rc, src);
+            u32 b = l64_get_lane(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch,
+                                 a.m.prior_ls ? a.m.prior_ls + (size_t)last * L64_NSYM : nullptr, a.m.prior_lh + last, rc, src);
             if (b == LAST_QLT) b = sl.pw.get(PR_EXQ_ROW, rc, src);                          // qlts.cpp:168-171
             p[i] = (u8)('!' + b);
             if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
@@ -119,13 +118,21 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
         const u32 llen = a.slen[r], qlen = a.qlen[r];
         u8* g = a.seq_stage + a.soff[r];
         const u8* q = a.qual_stage + a.qoff[r];
-        u32 last = 0x007616c7u;
+        u32 last = 0x007616c7u & mask;
+        u32 row = llen ? sl.g_tab[last] : 0u;
         for (u32 i = 0; i < llen; i++) {
-            last &= mask;
+            // the next context is (last << 2) + b: its four candidate rows are one aligned 16-byte piece, fetched
+            // while this base is being decoded (the context needs at least 2 bits: gen_bits >= 2)
+            const u32 nbase = (last << 2) & mask;
+            const uint4 cand = *reinterpret_cast<const uint4*>(sl.g_tab + nbase);
             u32 b;
-            sl.g_tab[last] = b2_get(sl.g_tab[last], rc, src, b);
+            const u32 nrow = b2_get(row, rc, src, b);
+            sl.g_tab[last] = nrow;
             u32 ch = (code >> (8 * b)) & 0xff;
-            last = (last << 2) + b;
+            const u32 nlast = nbase + b;
+            row = b == 0 ? cand.x : b == 1 ? cand.y : b == 2 ? cand.z : cand.w;
+            if (nlast == last) row = nrow;                                                  // the row just updated is its own successor
+            last = nlast;
             const u32 qc = i < qlen ? q[i] : 40u;
             genofs++;                                                                       // normalize_gen gens.cpp:200-213
             if (nn_index == genofs) nn_index += x_nn.get(sl.pw);

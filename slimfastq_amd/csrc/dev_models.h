@@ -145,6 +145,43 @@ __device__ __forceinline__ void l64_touch(u32* slots, RowHdr* hp, u32 epoch, con
 }
 typedef Ranger<256, 14, (1 << 15) - 32, 256> Power;   // power_ranger.hpp:37-41, 70
 
+// Log64Ranger::get (log64_ranger.hpp:114-138) by one lane with 16-byte accesses; a stale row starts from the
+// shared prior row (format 7) or from zeros.
+__device__ __forceinline__ u32 l64_get_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php, RcDec& rc, ByteSrc& src) {
+    const uint4 hq = *reinterpret_cast<const uint4*>(hp);          // {total, iend | count<<16, epoch, pad}
+    u32 total, iend, count;
+    if (hq.z == epoch) { total = hq.x; iend = hq.y & 0xffffu; count = (hq.y >> 16) & 0xffu; }
+    else if (pslots) {
+        const uint4 ph = *reinterpret_cast<const uint4*>(php);
+        total = ph.x; iend = ph.y & 0xffffu; count = 0;
+        for (u32 k = 0; k < iend; k += 4) *reinterpret_cast<uint4*>(slots + k) = *reinterpret_cast<const uint4*>(pslots + k);
+    } else { total = 0; iend = 0; count = 0; }
+    const u32 vtot = total + 64;
+    const u32 prob = rc.get_freq(vtot);
+    u32 i = 0, sumf = 0, s = 0;
+    bool found = false;
+    while (!found && i < 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(slots + i);
+        u32 e[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (found) break;
+            const u32 idx = i + c;
+            if (iend == idx) { e[c] = idx << 16; slots[idx] = e[c]; iend++; }          // :124-125
+            const u32 f1 = (e[c] & 0xffffu) + 1;
+            if (sumf + f1 <= prob) sumf += f1; else { s = e[c]; i = idx; found = true; }
+        }
+        if (!found) i += 4;
+    }
+    if (!found) { rc.err = 1; i = 63; s = slots[63]; sumf -= (s & 0xffffu) + 1; }
+    rc.decode(src, sumf, (s & 0xffffu) + 1);
+    const u32 sym = (s >> 16) & 0xffu;
+    Log64::update(slots, i, s, total, iend, count);
+    uint4 nh; nh.x = total; nh.y = iend | (count << 16); nh.z = epoch; nh.w = 0;
+    *reinterpret_cast<uint4*>(hp) = nh;
+    return sym;
+}
+
 // A block slot's PowerRanger rows.
 struct PwTab {
     u32*    slots;   // [PR_ROWS][256]
