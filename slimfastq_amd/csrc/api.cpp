@@ -44,7 +44,7 @@ struct sfq_ctx {
     // decode scratch
     DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
     // quality warm start
-    DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh;
+    DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
@@ -88,7 +88,7 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     u64 fit = ctx->table_budget / per;
     if (fit == 0) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B too small for one block slot (%llu B)",
                               (unsigned long long)ctx->table_budget, (unsigned long long)per);
-    u32 slots = (u32)std::min<u64>(want, fit);
+    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), 12288);      // more slots than resident waves buys nothing
     Tables& t = ctx->tab;
     // Row tables are epoch-tagged and epochs only grow, so stale rows of any earlier geometry can never
     // match: slot storage needs no clearing, and a header array is zeroed only when it is (re)allocated.
@@ -246,7 +246,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->blk_stream_off, &ctx->stream_total, &ctx->lens, &ctx->blob_off, &ctx->blob, &ctx->in_stage, &ctx->out_stage,
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
-        &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh };
+        &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -356,26 +356,38 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
     const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
     hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
-    // The first batch's Base2 tables are initialised (base2_ranger.hpp:68-71) before the streams fork, while
-    // the chip is otherwise idle: a streaming fill that has to compete with the model kernels is starved.
-    if (models & SFQ_M_GEN) {
+    // Default kernels are persistent: one workgroup per table slot, blocks handed out through ticket counters.
+    // The lane-per-block reference kernels (kernel = 1, and usr) run in batches of `slots` blocks.
+    if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
+    HIPC(hipMemsetAsync(ctx->tickets.p, 0, 64, st));
+    u32* tickets = (u32*)ctx->tickets.p;
+    if ((models & SFQ_M_GEN) && p.kernel == 1)   // first batch's Base2 tables (base2_ranger.hpp:68-71), while the chip is idle
         launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)std::min(slots, nblocks) << g_bits, 0x03030303u, st);
-        HIPC(hipEventRecord(ctx->ev[1], st));
-    }
+    HIPC(hipEventRecord(ctx->ev[1], st));
     for (int m = 0; m < 4; m++) {
         if (m) HIPC(hipStreamWaitEvent(mst[m], ctx->ev[1], 0));
         HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m]));
         if (models & order[m]) {
-            for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
-                a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
+            const bool batched = p.kernel == 1 || order[m] == SFQ_M_USR;
+            if (!batched) {
+                a.batch0 = 0; a.nbatch = std::min(slots, nblocks);
                 switch (order[m]) {
-                case SFQ_M_QLT: if (p.kernel == 1) launch_qlt_encode_l(a, mst[m]); else if (p.kernel == 2) launch_qlt_encode_w(a, mst[m]); else launch_qlt_encode_s(a, mst[m]); break;
-                case SFQ_M_GEN:
-                    if (b0) launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);
-                    if (p.kernel == 1) launch_gen_encode_l(a, mst[m]); else launch_gen_encode_w(a, mst[m]);
-                    break;
-                case SFQ_M_REC: if (p.kernel == 1) launch_rec_encode_l(a, mst[m]); else launch_rec_encode_w(a, mst[m]); break;
-                case SFQ_M_USR: launch_usr_encode_l(a, mst[m]); break;
+                case SFQ_M_QLT: if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]); else launch_qlt_encode_s(a, tickets + 0, mst[m]); break;
+                case SFQ_M_GEN: launch_gen_encode_w(a, tickets + 1, mst[m]); break;
+                case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
+                }
+            } else {
+                for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+                    a.batch0 = b0; a.nbatch = std::min(slots, nblocks - b0);
+                    switch (order[m]) {
+                    case SFQ_M_QLT: launch_qlt_encode_l(a, mst[m]); break;
+                    case SFQ_M_GEN:
+                        if (b0) launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)a.nbatch << g_bits, 0x03030303u, mst[m]);
+                        launch_gen_encode_l(a, mst[m]);
+                        break;
+                    case SFQ_M_REC: launch_rec_encode_l(a, mst[m]); break;
+                    case SFQ_M_USR: launch_usr_encode_l(a, mst[m]); break;
+                    }
                 }
             }
         }

@@ -59,10 +59,11 @@ void launch_usr_encode_l(const ModelArgs& a, hipStream_t st);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
 
 // models, wave-per-block throughput kernels
-void launch_qlt_encode_w(const ModelArgs& a, hipStream_t st);
-void launch_qlt_encode_s(const ModelArgs& a, hipStream_t st);
-void launch_gen_encode_w(const ModelArgs& a, hipStream_t st);
-void launch_rec_encode_w(const ModelArgs& a, hipStream_t st);
+// (persistent: grid = a.nbatch table slots; blocks 0..a.nblocks-1 are handed out through *ticket, which must be 0)
+void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);
 
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);

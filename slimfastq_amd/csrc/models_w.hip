@@ -45,6 +45,14 @@ __device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
     return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
 
+// Persistent launch: a workgroup (= one wave = one table slot) takes blocks off a shared ticket counter until
+// none are left, so the grid never exceeds the table slots and long and short blocks balance themselves.
+__device__ __forceinline__ u32 next_block(u32* ticket) {
+    u32 b = 0;
+    if (threadIdx.x == 0) b = atomicAdd(ticket, 1u);
+    return rl(b, 0);
+}
+
 // ---- the wave's output window: lane k holds byte k of the current 64-byte window ------------------------
 struct WaveOut {
     u8* p;
@@ -197,11 +205,7 @@ struct WaveRow {
 // =========================================================================================================
 // quality encode: QltSave::save_1/2/3 (qlts.cpp:74-136) for every record of the block
 // =========================================================================================================
-__global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a) {
-    const u32 lane = threadIdx.x;
-    const u32 t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
+__device__ __forceinline__ void k_qlt_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_W(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
@@ -282,8 +286,11 @@ __global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a) {
         if (rc.err | rfl(perr)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
     }
 }
-void launch_qlt_encode_w(const ModelArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+__global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a, u32* ticket) {
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_w_block(a, blockIdx.x, b, threadIdx.x);
+}
+void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }
 
 // =========================================================================================================
@@ -333,11 +340,7 @@ __device__ __forceinline__ u32 b2_model(u32 v, u32 sym, u32& cum, u32& freq, u32
     return b2_update(v, sym);
 }
 
-__global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a) {
-    const u32 lane = threadIdx.x;
-    const u32 t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
+__device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_GEN], d->out_cap[SFQ_S_GEN]);
@@ -430,8 +433,19 @@ __global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a) {
         if (bad) atomicMax(&d->status, (u32)(-bad));
     }
 }
-void launch_gen_encode_w(const ModelArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+__global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a, u32* ticket) {
+    const u32 lane = threadIdx.x;
+    u32* const tab = a.g_tab + ((size_t)blockIdx.x << a.g_bits);
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        // Base2Ranger rows start at 3,3,3,3 (base2_ranger.hpp:68-71): the slot's table is re-initialised per block
+        const u32 n4 = 1u << (a.g_bits - 2);
+#pragma unroll 4
+        for (u32 i = lane; i < n4; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(B2_INIT, B2_INIT, B2_INIT, B2_INIT);
+        k_gen_encode_w_block(a, blockIdx.x, b, lane);
+    }
+}
+void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }
 
 // =========================================================================================================
@@ -582,7 +596,7 @@ struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
 };
 
 // general path: any header length (tokenising and field state in per-lane scratch)
-__device__ void rec_encode_block_slow(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
+__device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
     WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
     Sink0 snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
     RcEncU rc; rc.init();
@@ -719,7 +733,7 @@ __device__ __forceinline__ void mask128(u32 a, u32 b, u64& m0, u64& m1) {
 // Tokenising is two ballots, field tables are lanes (lane k = field k), the field diff against the previous
 // header is a cross-lane gather; only the few coded symbols per record run serially.
 #define REC_FAST_MAX 126u
-__device__ void rec_encode_block_fast(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
+__device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
     WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
     Sink0 snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
     RcEncU rc; rc.init();
@@ -851,23 +865,23 @@ __device__ __forceinline__ bool rec_block_is_short(const ModelArgs& a, const Blo
     for (int s = 32; s > 0; s >>= 1) { const u32 o = (u32)__shfl_xor((int)longest, s, 64); longest = o > longest ? o : longest; }
     return rl(longest, 0) <= REC_FAST_MAX;
 }
-__global__ __launch_bounds__(64) void k_rec_encode_w_fast(ModelArgs a) {
+__global__ __launch_bounds__(64) void k_rec_encode_w_fast(ModelArgs a, u32* ticket) {
     const u32 lane = threadIdx.x, t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
-    BlockDesc* d = &a.blocks[b];
-    if (rec_block_is_short(a, d, lane)) rec_encode_block_fast(a, t, b, d, lane);
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        BlockDesc* d = &a.blocks[b];
+        if (rec_block_is_short(a, d, lane)) rec_encode_block_fast(a, t, b, d, lane);
+    }
 }
-__global__ __launch_bounds__(64) void k_rec_encode_w_slow(ModelArgs a) {
+__global__ __launch_bounds__(64) void k_rec_encode_w_slow(ModelArgs a, u32* ticket) {
     const u32 lane = threadIdx.x, t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
-    BlockDesc* d = &a.blocks[b];
-    if (!rec_block_is_short(a, d, lane)) rec_encode_block_slow(a, t, b, d, lane);
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        BlockDesc* d = &a.blocks[b];
+        if (!rec_block_is_short(a, d, lane)) rec_encode_block_slow(a, t, b, d, lane);
+    }
 }
-void launch_rec_encode_w(const ModelArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_encode_w_fast, dim3(a.nbatch), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_rec_encode_w_slow, dim3(a.nbatch), dim3(64), 0, st, a);
+void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_encode_w_fast, dim3(a.nbatch), dim3(64), 0, st, a, ticket_fast);
+    hipLaunchKernelGGL(k_rec_encode_w_slow, dim3(a.nbatch), dim3(64), 0, st, a, ticket_slow);
 }
 
 // =========================================================================================================
@@ -927,11 +941,7 @@ __device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epo
     return t;
 }
 
-__global__ __launch_bounds__(64) void k_qlt_encode_s(ModelArgs a) {
-    const u32 lane = threadIdx.x;
-    const u32 t = blockIdx.x;
-    if (t >= a.nbatch) return;
-    const u32 b = a.batch0 + t;
+__device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
@@ -1036,6 +1046,9 @@ __global__ __launch_bounds__(64) void k_qlt_encode_s(ModelArgs a) {
         if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
     }
 }
-void launch_qlt_encode_s(const ModelArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_encode_s, dim3(a.nbatch), dim3(64), 0, st, a);
+__global__ __launch_bounds__(64) void k_qlt_encode_s(ModelArgs a, u32* ticket) {
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block(a, blockIdx.x, b, threadIdx.x);
+}
+void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }

@@ -293,3 +293,21 @@ def test_warm_start_prior_with_heavily_scaled_counts(ctx):
     want, _ = O.qlt_encode_blocks(fq, starts[3::4], lens[3::4], 3, 2500, rows)
     assert enc.stream("qlt") == want
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
+def test_small_table_budget_forces_batches():
+    """When the table budget holds fewer block slots than there are blocks, blocks run in batches that reuse
+    the slots (epoch tags make the rows self-clearing; the Base2 tables are refilled per batch)."""
+    c = capi.Context(0, table_budget=3 * (65536 * 272 + 1192 * 1040 + (4 << 18)) + (1 << 20))    # ~3 slots at level 3
+    try:
+        fq = capi.synth_fastq(4000, 150, seed=123)
+        for kernel in KERNELS:
+            enc = c.encode_host(fq, level=3, block_reads=400, kernel=kernel, prior_step=2)       # 10 blocks, 3-4 batches
+            cold = c.encode_host(fq, level=3, block_reads=400, kernel=kernel)
+            for b, chunk in enumerate(util.split_records(fq, 400)):
+                want = O.compress(chunk, 3, gen_bits=cold.blocks[b].gen_bits).streams
+                assert_streams_equal(cold, want, block=b, ctxmsg="batched kernel %d block %d" % (kernel, b))
+            assert c.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+            assert c.decode_host(cold, level=3, out_cap=len(fq) + 4096) == fq
+    finally:
+        c.close()
