@@ -193,22 +193,18 @@ struct PwTab {
     __device__ __forceinline__ u32 get(u32 row, RcDec& rc, ByteSrc& s) const {
         return Power::get(slots + (size_t)row * PW_NSYM, hdr + row, epoch, rc, s);
     }
-    // PowerRangerU::put_u (power_ranger.hpp:138-163); rows row0 .. row0+13
+    // PowerRangerU::put_u (power_ranger.hpp:138-163); rows row0 .. row0+13.  One loop, one inlined put: the
+    // byte sequence is 1 byte (<= 0x7f), 2 bytes (< 0x7ffe), 0xff 0xfe + 4 LE bytes, or 0xff 0xff + 8 LE bytes.
     __device__ void put_u(u32 row0, RcEnc& rc, ByteSink& s, u64 num) const {
-        if (num <= 0x7f) { put(row0, rc, s, (u32)num); return; }
-        if (num < 0x7ffe) {
-            put(row0, rc, s, 0xff & (0x80 | (u32)(num >> 8)));
-            put(row0 + 1, rc, s, 0xff & (u32)num);
-            return;
+        const u32 n = num <= 0x7f ? 1u : num < 0x7ffe ? 2u : num < (1ULL << 32) ? 6u : 10u;
+#pragma nounroll
+        for (u32 j = 0; j < n; j++) {
+            u32 row, sym;
+            if (j == 0)      { row = row0;     sym = n == 1 ? (u32)num : n == 2 ? (0xff & (0x80 | (u32)(num >> 8))) : 0xffu; }
+            else if (j == 1) { row = row0 + 1; sym = n == 2 ? (0xff & (u32)num) : n == 6 ? 0xfeu : 0xffu; }
+            else             { row = row0 + (n == 6 ? 2 : 6) + (j - 2); sym = 0xff & (u32)(num >> (8 * (j - 2))); }
+            put(row, rc, s, sym);
         }
-        put(row0, rc, s, 0xff);
-        if (num < (1ULL << 32)) {
-            put(row0 + 1, rc, s, 0xfe);
-            for (int sh = 0, i = 2; sh < 32; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh));
-            return;
-        }
-        put(row0 + 1, rc, s, 0xff);
-        for (int sh = 0, i = 6; sh < 64; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh));
     }
     // PowerRangerU::get_u (power_ranger.hpp:165-190)
     __device__ u64 get_u(u32 row0, RcDec& rc, ByteSrc& s) const {

@@ -85,7 +85,8 @@ struct WaveCoder {
     __device__ __forceinline__ void run(u32 tcum, u32 tfreq, u32 ttot, u32 nt, WaveOut& out, u32 lane) {
         // 3a. reciprocals for all triples at once: m = floor((2^32-1) / tot)  (tot >= 4 always)
         const u32 minv = 0xFFFFFFFFu / (lane < nt ? ttot : 1u);
-        // 3b. the serial chain, on uniform values
+        // 3b. the serial chain, on uniform values (not unrolled: the kernels share a small instruction cache)
+#pragma nounroll
         for (u32 k = 0; k < nt; k++) {
             const u32 cum = rl(tcum, k), freq = rl(tfreq, k), tot = rl(ttot, k), m = rl(minv, k);
             // r = range / tot, exactly: the multiply-high estimate is never above and at most 2 below
@@ -95,6 +96,7 @@ struct WaveCoder {
             low += (u64)(u32)(cum * r);                                  // coder.hpp:69
             range = r * freq;                                            // coder.hpp:70
             int guard = 0;
+#pragma nounroll
             while (range < RC_TOP) {                                     // coder.hpp:74-80
                 if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
                 out.put((u32)(low >> 56), lane);
@@ -103,6 +105,43 @@ struct WaveCoder {
                 if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
             }
         }
+    }
+    // The same chain on the VECTOR unit (every lane computes the identical values).  The scalar form above is
+    // pure SALU, and the chip issues one instruction per type per SIMD slot: with the quality kernel's coder on
+    // the scalar pipe and the base kernel's on the vector pipe, the two kernels' waves interleave on a SIMD
+    // instead of queueing for the same pipe.
+    __device__ __forceinline__ void run_v(u32 tcum, u32 tfreq, u32 ttot, u32 nt, WaveOut& out, u32 lane) {
+        // exact reciprocals m = floor(2^32 / tot): the multiply-high estimate is then at most 1 below
+        const u32 td = lane < nt ? ttot : 1u;
+        const u32 m0 = 0xFFFFFFFFu / td;
+        const u32 minv = m0 + ((0xFFFFFFFFu - m0 * td) == td - 1 ? 1u : 0u);
+        u32 vr, vlo, vhi;                                      // range / low, laundered into VGPRs
+        asm volatile("v_mov_b32 %0, %1" : "=v"(vr) : "s"(range));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"((u32)low));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"((u32)(low >> 32)));
+#pragma nounroll
+        for (u32 k = 0; k < nt; k++) {
+            const u32 cum = rl(tcum, k), freq = rl(tfreq, k), tot = rl(ttot, k), m = rl(minv, k);
+            u32 r = __umulhi(vr, m);
+            const u32 rem = vr - r * tot;
+            r += rem >= tot ? 1u : 0u;
+            u64 lo64 = (((u64)vhi << 32) | vlo) + (u64)cum * r;          // cum * r < range: no truncation (coder.hpp:69)
+            vr = r * freq;                                               // coder.hpp:70
+            if (rl(vr, 0) < RC_TOP) {                                    // coder.hpp:74-80
+                int guard = 0;
+#pragma nounroll
+                do {
+                    if ((lo64 ^ (lo64 + vr)) >> 56) vr = (((u32)lo64 | (RC_TOP - 1)) - (u32)lo64);
+                    out.put(rl((u32)(lo64 >> 56), 0), lane);
+                    vr <<= 8;
+                    lo64 <<= 8;
+                    if (++guard > 12) { err = 1; vr = 0xFFFFFFFFu; break; }
+                } while (rl(vr, 0) < RC_TOP);
+            }
+            vlo = (u32)lo64; vhi = (u32)(lo64 >> 32);
+        }
+        range = rl(vr, 0);
+        low = ((u64)rl(vhi, 0) << 32) | rl(vlo, 0);
     }
     __device__ __forceinline__ void done(WaveOut& out, u32 lane) {       // coder.hpp:52-61
         for (int i = 0; i < 8; i++) { out.put((u32)(low >> 56), lane); low <<= 8; }
@@ -418,7 +457,7 @@ __device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u
                     if (lane == j) { cum = cj; freq = fj; tot = tj; }
                 }
             }
-            rc.run(cum, freq, tot, m, out, lane);
+            rc.run_v(cum, freq, tot, m, out, lane);
         }
     }
     rc.done(out, lane);
@@ -433,7 +472,7 @@ __device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u
         if (bad) atomicMax(&d->status, (u32)(-bad));
     }
 }
-__global__ __launch_bounds__(64) void k_gen_encode_w(ModelArgs a, u32* ticket) {
+__global__ __launch_bounds__(64, 8) void k_gen_encode_w(ModelArgs a, u32* ticket) {
     const u32 lane = threadIdx.x;
     u32* const tab = a.g_tab + ((size_t)blockIdx.x << a.g_bits);
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
@@ -561,22 +600,17 @@ struct WavePw {
         const Triple t = model(row, rl(sym, 0), lane);
         rc.encode(s, t.cum, t.freq, t.tot);
     }
-    // PowerRangerU::put_u (power_ranger.hpp:138-163)
+    // PowerRangerU::put_u (power_ranger.hpp:138-163), as one loop around one inlined put (see PwTab::put_u)
     __device__ void put_u(u32 row0, RcEncU& rc, Sink0& s, u64 num, u32 lane) {
-        if (num <= 0x7f) { put(row0, rc, s, (u32)num, lane); return; }
-        if (num < 0x7ffe) {
-            put(row0, rc, s, 0xff & (0x80 | (u32)(num >> 8)), lane);
-            put(row0 + 1, rc, s, 0xff & (u32)num, lane);
-            return;
+        const u32 n = num <= 0x7f ? 1u : num < 0x7ffe ? 2u : num < (1ULL << 32) ? 6u : 10u;
+#pragma nounroll
+        for (u32 j = 0; j < n; j++) {
+            u32 row, sym;
+            if (j == 0)      { row = row0;     sym = n == 1 ? (u32)num : n == 2 ? (0xff & (0x80 | (u32)(num >> 8))) : 0xffu; }
+            else if (j == 1) { row = row0 + 1; sym = n == 2 ? (0xff & (u32)num) : n == 6 ? 0xfeu : 0xffu; }
+            else             { row = row0 + (n == 6 ? 2 : 6) + (j - 2); sym = 0xff & (u32)(num >> (8 * (j - 2))); }
+            put(row, rc, s, sym, lane);
         }
-        put(row0, rc, s, 0xff, lane);
-        if (num < (1ULL << 32)) {
-            put(row0 + 1, rc, s, 0xfe, lane);
-            for (int sh = 0, i = 2; sh < 32; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh), lane);
-            return;
-        }
-        put(row0 + 1, rc, s, 0xff, lane);
-        for (int sh = 0, i = 6; sh < 64; sh += 8, i++) put(row0 + i, rc, s, 0xff & (u32)(num >> sh), lane);
     }
 };
 struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
@@ -865,7 +899,7 @@ __device__ __forceinline__ bool rec_block_is_short(const ModelArgs& a, const Blo
     for (int s = 32; s > 0; s >>= 1) { const u32 o = (u32)__shfl_xor((int)longest, s, 64); longest = o > longest ? o : longest; }
     return rl(longest, 0) <= REC_FAST_MAX;
 }
-__global__ __launch_bounds__(64) void k_rec_encode_w_fast(ModelArgs a, u32* ticket) {
+__global__ __launch_bounds__(64, 8) void k_rec_encode_w_fast(ModelArgs a, u32* ticket) {
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
@@ -1046,7 +1080,7 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
         if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
     }
 }
-__global__ __launch_bounds__(64) void k_qlt_encode_s(ModelArgs a, u32* ticket) {
+__global__ __launch_bounds__(64, 8) void k_qlt_encode_s(ModelArgs a, u32* ticket) {
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block(a, blockIdx.x, b, threadIdx.x);
 }
 void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
