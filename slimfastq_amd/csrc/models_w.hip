@@ -14,44 +14,9 @@
 // The bytes produced are identical to models_l.hip (and so to the reference); tests compare both.
 #include "kernels.h"
 #include "dev_models.h"
+#include "dev_wave.h"
 
 #define LAST_QLT 63u
-
-// ---- wave primitives (gfx950 = wave64, GFX9 DPP controls) --------------------------------------------
-#define DPP_ROW_SHR(n)  (0x110 + (n))
-#define DPP_WAVE_SHR1   0x138
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-
-__device__ __forceinline__ u32 rl(u32 v, u32 lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane); }
-// write a uniform value into one lane (this clang has no writelane builtin: compare + select)
-__device__ __forceinline__ u32 wl(u32 old, u32 val, u32 lane) { return (threadIdx.x == lane) ? val : old; }
-// lane 0's value.  Deliberately NOT readfirstlane: hipcc may sink a readfirstlane into a divergent
-// select (`lane == k ? rfl(x) : y`), where it would read lane k instead; readlane(.., 0) ignores EXEC.
-__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 0); }
-
-// inclusive prefix sum across the 64 lanes (6 DPP adds); lane 63 ends up with the wave total
-__device__ __forceinline__ u32 wave_incl_scan(u32 x) {
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(1), 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(2), 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(4), 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(8), 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST15, 0xa, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST31, 0xc, 0xf, false);
-    return x;
-}
-// value of the previous lane; lane 0 receives `first`
-__device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
-    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, DPP_WAVE_SHR1, 0xf, 0xf, false);
-}
-
-// Persistent launch: a workgroup (= one wave = one table slot) takes blocks off a shared ticket counter until
-// none are left, so the grid never exceeds the table slots and long and short blocks balance themselves.
-__device__ __forceinline__ u32 next_block(u32* ticket) {
-    u32 b = 0;
-    if (threadIdx.x == 0) b = atomicAdd(ticket, 1u);
-    return rl(b, 0);
-}
 
 // ---- the wave's output window: lane k holds byte k of the current 64-byte window ------------------------
 struct WaveOut {
@@ -342,43 +307,6 @@ void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
 // row; a bitonic sort of (context, lane) keys detects that exactly, and such a window falls back to 64
 // serial steps.  The range coder then consumes the 64 triples (stage 3 above).
 // =========================================================================================================
-__device__ __forceinline__ u32 gencode_w(u32 c) {                      // gens.cpp:72-77
-    const u32 l = c | 0x20u;
-    u32 n = 0x10u;
-    n = (l == 'a' || c == '0') ? 0u : n;
-    n = (l == 'c' || c == '1') ? 1u : n;
-    n = (l == 'g' || c == '2') ? 2u : n;
-    n = (l == 't' || c == '3') ? 3u : n;
-    n = (l == 'n' || c == '.') ? 4u : n;
-    return n;
-}
-__device__ __forceinline__ u32 shfl_up0(u32 x, u32 d, u32 lane) {      // lane-d's value, 0 for lanes < d
-    const u32 y = (u32)__shfl_up((int)x, d, 64);
-    return lane >= d ? y : 0u;
-}
-__device__ __forceinline__ u32 bitonic_sort64(u32 key, u32 lane) {
-#pragma unroll
-    for (u32 k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            const u32 other = (u32)__shfl_xor((int)key, j, 64);
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            const u32 lo = key < other ? key : other, hi = key < other ? other : key;
-            key = (lower == up) ? lo : hi;
-        }
-    }
-    return key;
-}
-// Base2Ranger::put minus the Encode call, on a row value (base2_ranger.hpp:74-84)
-__device__ __forceinline__ u32 b2_model(u32 v, u32 sym, u32& cum, u32& freq, u32& tot) {
-    const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-    tot = (f0 + f1) + (f2 + f3);
-    cum = sym == 0 ? 0u : sym == 1 ? f0 : sym == 2 ? f0 + f1 : f0 + f1 + f2;
-    freq = (v >> (8 * sym)) & 0xff;
-    return b2_update(v, sym);
-}
-
 __device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
@@ -931,17 +859,6 @@ void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow,
 // order and the scalar range coder (stage 3) consumes them as before.  Rows use the plain layout
 // (slots[64] + RowHdr), shared with the lane-per-block kernels and decoders.
 // =========================================================================================================
-__device__ __forceinline__ u32 wave_incl_scan_max(u32 x) {
-    u32 y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(1), 0xf, 0xf, false); x = x > y ? x : y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(2), 0xf, 0xf, false); x = x > y ? x : y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(4), 0xf, 0xf, false); x = x > y ? x : y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR(8), 0xf, 0xf, false); x = x > y ? x : y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST15, 0xa, 0xf, false); x = x > y ? x : y;
-    y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_BCAST31, 0xc, 0xf, false); x = x > y ? x : y;
-    return x;
-}
-
 // Log64Ranger::put minus Encode on one row, by one lane (log64_ranger.hpp:69-112); 16-byte accesses.
 // A row whose tag is stale starts from the shared prior row (format 7) or from zeros.
 __device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php, u32 sym, u32& err) {
