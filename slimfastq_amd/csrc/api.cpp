@@ -347,8 +347,10 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         ctx->prior_on = true;
     }
     u32 slots = 0;
-    if ((rc = ensure_tables(ctx, nblocks + (nblocks & 1), q_rows, (u32)g_bits, models, &slots))) return rc;
-    if (slots > 1) slots &= ~1u;
+    const u32 KR = 8;                                                  // the multi-chain kernels take table slots in groups of up to 8
+    const u32 nblocks_r = (nblocks + KR - 1) / KR * KR;
+    if ((rc = ensure_tables(ctx, nblocks_r, q_rows, (u32)g_bits, models, &slots))) return rc;
+    if (slots >= KR) slots &= ~(KR - 1);
     if ((rc = advance_epoch(ctx, nblocks))) return rc;
     ModelArgs a;
     fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
@@ -371,10 +373,10 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         if (models & order[m]) {
             const bool batched = p.kernel == 1 || order[m] == SFQ_M_USR;
             if (!batched) {
-                a.batch0 = 0; a.nbatch = std::min(slots, nblocks + (nblocks & 1));      // even: the two-chain kernels take slot pairs
+                a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
                 switch (order[m]) {
                 case SFQ_M_QLT: if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]); else launch_qlt_encode_s(a, tickets + 0, mst[m]); break;
-                case SFQ_M_GEN: if (p.kernel == 2 || slots < 2) launch_gen_encode_w(a, tickets + 1, mst[m]); else launch_gen_encode_k(a, tickets + 1, mst[m]); break;
+                case SFQ_M_GEN: if (p.kernel == 2 || slots < KR) launch_gen_encode_w(a, tickets + 1, mst[m]); else launch_gen_encode_k(a, tickets + 1, mst[m]); break;
                 case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
                 }
             } else {
