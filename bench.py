@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")
+    ap.add_argument("--kind", type=int, default=0, help="0 = 150 bp-style Illumina reads, 1 = 10-50 kb long reads (BASELINE config 5)")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--prior-step", type=int, default=-1, help="-1 = auto warm start (default), 0 = cold blocks, N = every N-th record")
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
@@ -55,7 +56,7 @@ def cpu_baseline(args, seed):
     reported baseline."""
     from oracle import oracle as O
     n = args.cpu_sample_reads
-    fq = capi.synth_fastq(n, args.read_len, seed=seed)
+    fq = capi.synth_fastq(n, args.read_len, seed=seed, kind=args.kind)
     out = {"cores": 1, "sample": "%d x %d bp reads (%.1f MB), -l %d, first records of the same synthetic stream"
            % (n, args.read_len, len(fq) / 1e6, args.level), "unit": "MB/s"}
     t0 = time.perf_counter()
@@ -98,7 +99,7 @@ def main():
 
     # ---- synthetic input, resident in HBM before anything is timed ----
     t0 = time.perf_counter()
-    fq = capi.synth_fastq(args.reads, args.read_len, seed=seed, first_read=rank * args.reads)
+    fq = capi.synth_fastq(args.reads, args.read_len, seed=seed, first_read=rank * args.reads, kind=args.kind)
     t_gen = time.perf_counter() - t0
     nbytes = len(fq)
     d_in = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda(non_blocking=False)

@@ -334,7 +334,9 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ctx->prior_blob.clear();
     std::vector<u32> h_rows66;
     u32 prior_step = p.block_reads ? p.prior_step : 0;
-    if (prior_step == SFQ_PRIOR_AUTO) prior_step = (u32)std::max<u64>(1, nrec / 400000);   // ~<= 400 k sampled records
+    // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
+    // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
+    if (prior_step == SFQ_PRIOR_AUTO) prior_step = (u32)std::min<u64>(std::max<u64>(1, (nbytes / 2) / 60000000ull), 0x7FFFFFFFull);
     if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));

@@ -22,7 +22,6 @@ __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 
 // ~30 ns each on one address), so every workgroup first aggregates in an LDS hash table and flushes each
 // distinct key once.
 #define HIST_SLOTS 8192u            // 64 KiB of LDS: keys + counts
-#define HIST_READS_PER_LANE 4u
 #define HIST_EMPTY 0xFFFFFFFFu
 __device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 key) {
     u32 slot = (key * 2654435761u) >> 19;                 // 13 bits
@@ -33,15 +32,16 @@ __device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 ke
     }
     atomicAdd(&hist[key], 1u);                            // table crowded: count directly
 }
-__global__ __launch_bounds__(256) void k_qlt_hist(const u8* __restrict__ fq, u64 nbytes, const u64* __restrict__ line_off,
+template <u32 THREADS, u32 READS_PER_LANE>
+__global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq, u64 nbytes, const u64* __restrict__ line_off,
                                                  const BlockDesc* __restrict__ blocks, u32 block_reads,
                                                  u64 nrec, u32 step, int level, u32* __restrict__ hist) {
     __shared__ u32 keys[HIST_SLOTS];
     __shared__ u32 cnts[HIST_SLOTS];
-    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
     __syncthreads();
-    for (u32 rr = 0; rr < HIST_READS_PER_LANE; rr++) {
-        const u64 r = (((u64)blockIdx.x * HIST_READS_PER_LANE + rr) * 256 + threadIdx.x) * step;
+    for (u32 rr = 0; rr < READS_PER_LANE; rr++) {
+        const u64 r = (((u64)blockIdx.x * READS_PER_LANE + rr) * THREADS + threadIdx.x) * step;
         if (r >= nrec) break;
         const u32 solid = blocks[r / block_reads].solid;
         const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
@@ -78,13 +78,19 @@ __global__ __launch_bounds__(256) void k_qlt_hist(const u8* __restrict__ fq, u64
         }
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) if (cnts[i]) atomicAdd(&hist[keys[i]], cnts[i]);
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) if (cnts[i]) atomicAdd(&hist[keys[i]], cnts[i]);
 }
 void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
                      int level, u32* hist, hipStream_t st) {
     const u64 nsamp = (nrec + step - 1) / step;
-    const u64 per_wg = 256ull * HIST_READS_PER_LANE;
-    hipLaunchKernelGGL(k_qlt_hist, dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
+    // long records (one lane walks a whole record): few records per workgroup, so that many workgroups share the work
+    if (nbytes / (nrec ? nrec : 1) > 4000) {
+        const u64 per_wg = 64;
+        hipLaunchKernelGGL((k_qlt_hist<64, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(64), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
+    } else {
+        const u64 per_wg = 256ull * 4;
+        hipLaunchKernelGGL((k_qlt_hist<256, 4>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
+    }
 }
 
 // ---- 2. rows -------------------------------------------------------------------------------------------

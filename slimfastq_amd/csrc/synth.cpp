@@ -29,7 +29,7 @@ struct Rng {
 void put_u(std::string& o, uint64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v); o.append(b, (size_t)n); }
 
 // 150 bp-style Illumina read: '@SIM.<i> M7:<run>:<flowcell>:<lane>:<tile>:<x>:<y> 1:N:0:<idx>'
-void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o) {
+void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o, bool binned = false) {
     Rng r(seed ^ (idx * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
     o += "@SIM."; put_u(o, idx + 1);
     o += " M7:42:000000000-A7XYZ:"; put_u(o, 1 + (idx / 2500000) % 8);
@@ -58,7 +58,9 @@ void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o) {
             }
             if (cur <= 4 && i > knee) tail = true;
         }
-        q[i] = (char)('!' + (tail ? 2 : cur));
+        const int qv = tail ? 2 : cur;
+        // kind 2: NovaSeq-style 4-level binning (Q2, Q12, Q23, Q37)
+        q[i] = (char)('!' + (binned ? (qv < 3 ? 2 : qv < 15 ? 12 : qv < 30 ? 23 : 37) : qv));
         const uint32_t v = (uint32_t)(r.next() >> 40);
         char base = "ACGT"[v & 3];
         if ((v >> 2) % 1000 == 0) { base = 'N'; q[i] = '#'; }   // P(N) = 1e-3, N gets quality '#'
@@ -109,8 +111,8 @@ void long_read(uint64_t idx, uint64_t seed, std::string& o) {
 
 extern "C" int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed, int kind,
                                    uint8_t* h_out, uint64_t cap) {
-    if (kind != 0 && kind != 1) return SFQ_E_ARG;
-    if (kind == 0 && (read_len == 0 || read_len > 65000)) return SFQ_E_ARG;
+    if (kind < 0 || kind > 2) return SFQ_E_ARG;
+    if (kind != 1 && (read_len == 0 || read_len > 65000)) return SFQ_E_ARG;
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
     if (nt > 32) nt = 32;
@@ -122,10 +124,10 @@ extern "C" int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32
         th.emplace_back([&, t]() {
             const uint64_t a = std::min<uint64_t>(n_reads, (uint64_t)t * per), b = std::min<uint64_t>(n_reads, a + per);
             std::string& o = parts[t];
-            if (kind == 0) o.reserve((size_t)(b - a) * (2 * read_len + 64));
+            if (kind != 1) o.reserve((size_t)(b - a) * (2 * read_len + 64));
             for (uint64_t i = a; i < b; i++) {
-                if (kind == 0) illumina_read(first_read + i, read_len, seed, o);
-                else long_read(first_read + i, seed, o);
+                if (kind == 1) long_read(first_read + i, seed, o);
+                else illumina_read(first_read + i, read_len, seed, o, kind == 2);
             }
         });
     }
