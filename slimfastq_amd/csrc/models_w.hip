@@ -892,6 +892,33 @@ __device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epo
     return t;
 }
 
+// A RUN of L consecutive hits of one symbol in one row, by one lane: triples go to out[0..L).  When the symbol sits
+// in the front slot (the usual case for long runs: the dominant symbol bubbles to the front) the repeats are
+// the closed form of update_freq(0) -- freq += 6, total += 6, no count / swap (log64_ranger.hpp:69-87) -- with
+// the row state in registers; otherwise every repeat is a full put.
+__device__ __forceinline__ void l64_model_run_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php,
+                                                   u32 sym, u32 L, uint4* out, u32& err) {
+    const Triple t0 = l64_model_lane(slots, hp, epoch, pslots, php, sym, err);
+    out[0] = make_uint4(t0.cum, t0.freq, t0.tot, 0u);
+    u32 r = 1;
+    if (L > 1 && (slots[0] >> 16) == sym) {
+        const uint4 hq = *reinterpret_cast<const uint4*>(hp);
+        u32 total = hq.x, s0 = slots[0], f = s0 & 0xffffu;
+        for (; r < L; r++) {
+            if (f > (u32)((1 << 16) - 64 - 6)) break;                     // saturation / normalize: leave to the full path
+            out[r] = make_uint4(0u, f + 1, total + 64, 0u);
+            f += 6; total += 6;
+        }
+        slots[0] = (s0 & 0xffff0000u) | f;
+        uint4 nh = hq; nh.x = total;
+        *reinterpret_cast<uint4*>(hp) = nh;
+    }
+    for (; r < L; r++) {
+        const Triple t = l64_model_lane(slots, hp, epoch, pslots, php, sym, err);
+        out[r] = make_uint4(t.cum, t.freq, t.tot, 0u);
+    }
+}
+
 __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
@@ -904,6 +931,7 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
     const int level = a.level;
     const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
     u32 extra_hi = 0, perr = 0;
+    __shared__ uint4 strip[64];                        // triples of the window in sorted order
 
     for (u32 k = 0; k < nrec; k++) {
         const u64 r = rec0 + k;
@@ -943,22 +971,30 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
                 const u32 sctx = sk >> 6, spos = sk & 63u;
                 const bool valid = !(sk >> 31);
                 const u32 ssym = (u32)__builtin_amdgcn_ds_bpermute((int)(spos * 4), (int)bv);
-                const u32 prevctx = wave_shr1(sctx, 0xFFFFFFFFu);
-                const u32 start = wave_incl_scan_max(sctx != prevctx ? lane : 0u);     // first sorted lane of this context's run
-                const u32 rank = lane - start;
+                // symbols of one context are contiguous and in position order; consecutive equal symbols form a RUN.
+                // A context's runs are applied one per round, each by the lane of its first symbol.
+                const u32 prevctx = wave_shr1(sctx, 0xFFFFFFFFu), prevsym = wave_shr1(ssym, 0xFFFFFFFFu);
+                const bool ctx_head = sctx != prevctx;
+                const bool run_head = ctx_head || ssym != prevsym;
+                const u32 cstart = wave_incl_scan_max(ctx_head ? lane : 0u);          // first sorted lane of this context
+                const u32 nheads = wave_incl_scan(run_head ? 1u : 0u);
+                const u32 runidx = nheads - (u32)__builtin_amdgcn_ds_bpermute((int)(cstart * 4), (int)nheads);
+                const u64 heads = __ballot(run_head);
+                const u64 above = lane >= 63 ? 0ull : (heads >> (lane + 1));
+                const u32 runlen = above ? (u32)__ffsll((long long)above) : 64u - lane;   // distance to the next run head
                 u32* const row = qs + (size_t)(sctx & 0xFFFFu) * L64_NSYM;
                 RowHdr* const hp = qh + (sctx & 0xFFFFu);
                 const u32* const prow = a.prior_ls ? a.prior_ls + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
                 const RowHdr* const php = a.prior_lh + (sctx & 0xFFFFu);
-                u32 scum = 0, sfreq = 1, stot = 1;
+                __syncthreads();                                          // one wave per workgroup: LDS ordering across lanes
                 for (u32 round = 0; ; round++) {
-                    const u64 act = __ballot(valid && rank == round);
-                    if (!act) break;
-                    if (valid && rank == round) {
-                        const Triple tr = l64_model_lane(row, hp, epoch, prow, php, ssym, perr);
-                        scum = tr.cum; sfreq = tr.freq; stot = tr.tot;
-                    }
+                    const bool mine = valid && run_head && runidx == round;
+                    if (!__ballot(mine)) break;
+                    if (mine) l64_model_run_lane(row, hp, epoch, prow, php, ssym, runlen, &strip[lane], perr);
                 }
+                __syncthreads();
+                const uint4 tr = valid ? strip[lane] : make_uint4(0u, 1u, 1u, 0u);
+                const u32 scum = tr.x, sfreq = tr.y, stot = tr.z;
                 // back to position order
                 tcum  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)scum);
                 tfreq = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)sfreq);
