@@ -69,7 +69,10 @@ typedef struct sfq_params {
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks);
-                              2 = wave-per-row quality kernel (the earlier default, kept for A/B runs)       */
+                              2 = wave-per-row quality kernel (the earlier default, kept for A/B runs);
+                              3 = split form: the model kernels park their (cum, freq, tot) triples and a second
+                              kernel runs the range coder one block per lane (measured slower, DESIGN.md section 4;
+                              falls back to 0 by itself when a block's triples do not fit their scratch)        */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);

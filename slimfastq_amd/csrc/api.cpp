@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -45,6 +46,8 @@ struct sfq_ctx {
     DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
+    // parked triples of the split kernels
+    DevBuf trip_q, trip_g, ntrip;
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
@@ -88,7 +91,7 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     u64 fit = ctx->table_budget / per;
     if (fit == 0) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B too small for one block slot (%llu B)",
                               (unsigned long long)ctx->table_budget, (unsigned long long)per);
-    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), 12288);      // more slots than resident waves buys nothing
+    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), 12288);      // the chip holds 8192 waves; the multi-chain base kernel takes 2 slots per wave
     Tables& t = ctx->tab;
     // Row tables are epoch-tagged and epochs only grow, so stale rows of any earlier geometry can never
     // match: slot storage needs no clearing, and a header array is zeroed only when it is (re)allocated.
@@ -226,8 +229,18 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     if (hipSetDevice(hip_device) != hipSuccess) return SFQ_E_HIP;
     sfq_ctx* ctx = new sfq_ctx();
     ctx->dev = hip_device;
-    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
-    for (auto& s : ctx->st_aux) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    // queue priorities of the four model streams (quality, bases, headers, framing): experiment hook SFQ_PRIO="q,g,r,u",
+    // each -1 (high), 0, 1 (low)
+    int prio[4] = { 0, 0, 0, 0 };
+    if (const char* e = getenv("SFQ_PRIO")) sscanf(e, "%d,%d,%d,%d", &prio[0], &prio[1], &prio[2], &prio[3]);
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    auto mk = [&](hipStream_t* s, int pr) {
+        const int v = pr < 0 ? greatest : pr > 0 ? least : (least + greatest) / 2;
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, v);
+    };
+    if (mk(&ctx->st, prio[0]) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    for (int i = 0; i < 3; i++) if (mk(&ctx->st_aux[i], prio[i + 1]) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
@@ -246,7 +259,8 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->blk_stream_off, &ctx->stream_total, &ctx->lens, &ctx->blob_off, &ctx->blob, &ctx->in_stage, &ctx->out_stage,
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
-        &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets };
+        &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
+        &ctx->trip_q, &ctx->trip_g, &ctx->ntrip };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -268,7 +282,8 @@ uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
 // -------------------------------------------------------------------------------------------------
 // compress
 // -------------------------------------------------------------------------------------------------
-static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+#define RETRY_FUSED 1   // encode_core: a block's triples did not fit their scratch region; repeat with the fused kernels
+static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
                        sfq_result* res, u32 force_models) {
     if (!ctx || !d_fastq || !pp || !d_out || !res) return fail(ctx, SFQ_E_ARG, "null argument");
     if (nbytes == 0) return fail(ctx, SFQ_E_FORMAT, "empty input");
@@ -357,6 +372,14 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ModelArgs a;
     fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
     a.fq = d_fastq;
+    const bool split = p.kernel == 3;
+    if (split) {
+        // 8 bytes per quality triple, 4 per base triple, at most one of each per two text bytes (dev_common.h trip_base)
+        if (models & SFQ_M_QLT) { if ((rc = reserve(ctx, ctx->trip_q, ((size_t)nbytes / 2 + 8) * 8))) return rc; a.trip_q = (u64*)ctx->trip_q.p; }
+        if (models & SFQ_M_GEN) { if ((rc = reserve(ctx, ctx->trip_g, ((size_t)nbytes / 2 + 8) * 4))) return rc; a.trip_g = (u32*)ctx->trip_g.p; }
+        if ((rc = reserve(ctx, ctx->ntrip, (size_t)nblocks * 8))) return rc;
+        a.ntrip_q = (u32*)ctx->ntrip.p; a.ntrip_g = a.ntrip_q + nblocks;
+    }
     // The four models are independent chains over the same text: each runs on its own HIP stream, forked
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
     const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
@@ -376,9 +399,22 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             const bool batched = p.kernel == 1 || order[m] == SFQ_M_USR;
             if (!batched) {
                 a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
+                {   // experiment hook: waves (table slots) per model kernel
+                    static const char* const names[3] = { "SFQ_GRID_Q", "SFQ_GRID_G", "SFQ_GRID_R" };
+                    const char* e = m < 3 ? getenv(names[m]) : nullptr;
+                    if (e && atoi(e) >= (int)KR) a.nbatch = std::min<u32>(a.nbatch, (u32)atoi(e) & ~(KR - 1));
+                }
                 switch (order[m]) {
-                case SFQ_M_QLT: if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]); else launch_qlt_encode_s(a, tickets + 0, mst[m]); break;
-                case SFQ_M_GEN: if (p.kernel == 2 || slots < KR) launch_gen_encode_w(a, tickets + 1, mst[m]); else launch_gen_encode_k(a, tickets + 1, mst[m]); break;
+                case SFQ_M_QLT:
+                    if (split) { launch_qlt_model_s(a, tickets + 0, mst[m]); launch_rc_lanes(a, true, mst[m]); }
+                    else if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]);
+                    else launch_qlt_encode_s(a, tickets + 0, mst[m]);
+                    break;
+                case SFQ_M_GEN:
+                    if (split) { launch_gen_model_w(a, tickets + 1, mst[m]); launch_rc_lanes(a, false, mst[m]); }
+                    else if (p.kernel == 2 || slots < KR) launch_gen_encode_w(a, tickets + 1, mst[m]);
+                    else launch_gen_encode_k(a, tickets + 1, mst[m]);
+                    break;
                 case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
                 }
             } else {
@@ -427,6 +463,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // per-block status first: an overflowed block has a meaningless size
     int worst = 0;
     for (u32 b = 0; b < nblocks; b++) if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
+    if (worst == (int)ST_TRIP_OVERFLOW) return RETRY_FUSED;
     if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
                            -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" : "see status codes");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
@@ -461,6 +498,18 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
     return SFQ_OK;
+}
+
+static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+                       sfq_result* res, u32 force_models) {
+    int rc = encode_core(ctx, d_fastq, nbytes, pp, d_out, out_cap, res, force_models);
+    if (rc == RETRY_FUSED) {            // e.g. Phred+64 qualities: most symbols are escapes with two triples each
+        sfq_params p = *pp;
+        p.kernel = 0;
+        rc = encode_core(ctx, d_fastq, nbytes, &p, d_out, out_cap, res, force_models);
+        if (rc == RETRY_FUSED) rc = fail(ctx, SFQ_E_HIP, "internal: fused kernels reported a triple overflow");
+    }
+    return rc;
 }
 
 int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void k_block_prepare(const u8* fq, const u64* l
     // scratch-arena regions: sized from the block's text bytes (overflow is detected, never silent)
     const u64 t0 = l0, t1 = line_off[4 * rend];
     const u64 bb = t1 - t0;
-    u64 off = t0 * 7 + (u64)b * 1024;
+    u64 off = (t0 * 7 + (u64)b * 1024 + 15) & ~15ull;
     const u32 caps[SFQ_NSTREAMS] = {
         (u32)(bb + bb / 2 + 64),   // rec
         (u32)(bb * 3 / 4 + 64),    // gen

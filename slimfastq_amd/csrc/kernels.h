@@ -20,6 +20,8 @@ struct ModelArgs {
     // quality warm start (prior.hip); all null = cold rows, the reference's behaviour
     const u32* prior_w; const u32* prior_wovf;   // wave layout [q_rows][64] + overflow [q_rows][4]
     const u32* prior_ls; const RowHdr* prior_lh; // lane-per-block layout
+    // parked triples of the split kernels (dev_common.h TRIP_*): entries per block at trip_base(); counts per block
+    u64* trip_q; u32* trip_g; u32* ntrip_q; u32* ntrip_g;
 };
 
 // Decode-side extras.
@@ -65,6 +67,10 @@ void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // K blocks per wave (SFQ_GEN_CHAINS = 2/4/8); a.nbatch a multiple of 8
 void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);
+// split form (default): the model kernels park (cum, freq, tot) triples, launch_rc_lanes codes them, one block per lane
+void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_gen_model_w(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_rc_lanes(const ModelArgs& a, bool quality, hipStream_t st);
 
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);

@@ -307,11 +307,14 @@ void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
 // row; a bitonic sort of (context, lane) keys detects that exactly, and such a window falls back to 64
 // serial steps.  The range coder then consumes the 64 triples (stage 3 above).
 // =========================================================================================================
+template <bool SPLIT>
 __device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_GEN], d->out_cap[SFQ_S_GEN]);
     WaveCoder rc; rc.init();
+    u32* const trip = SPLIT ? a.trip_g + trip_base(a.line_off, d->rec0) : nullptr;
+    const u32 tcap = SPLIT ? trip_cap(a.line_off, d->rec0, d->nrec) : 0u;
     PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
     XfEnc x_ns, x_nn;                                  // side-stream coders: lane 0 only
     x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
@@ -385,18 +388,27 @@ __device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u
                     if (lane == j) { cum = cj; freq = fj; tot = tj; }
                 }
             }
-            rc.run_v(cum, freq, tot, m, out, lane);
+            if constexpr (SPLIT) {                                 // genofs already counts this window
+                const u64 at = genofs - m + lane;
+                if (in && at < tcap) trip[at] = TRIP_G_PACK(cum, freq, tot);
+            } else rc.run_v(cum, freq, tot, m, out, lane);
         }
     }
-    rc.done(out, lane);
-    out.flush(lane);
+    if constexpr (!SPLIT) { rc.done(out, lane); out.flush(lane); }
     if (lane == 0) {
         d->n_byte = n_byte;
-        d->size[SFQ_S_GEN] = out.pos;
+        if constexpr (SPLIT) {
+            a.ntrip_g[b] = genofs <= tcap ? (u32)genofs : 0u;
+            if (genofs > tcap) atomicMax(&d->status, ST_TRIP_OVERFLOW);
+        } else {
+            d->size[SFQ_S_GEN] = out.pos;
+            if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        }
         d->size[SFQ_S_GEN_NS] = x_ns.finish(pw);
         d->size[SFQ_S_GEN_NN] = x_nn.finish(pw);
-        if (out.pos > out.cap || x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-        if (rc.err | x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
         if (bad) atomicMax(&d->status, (u32)(-bad));
     }
 }
@@ -408,11 +420,24 @@ __global__ __launch_bounds__(64, 8) void k_gen_encode_w(ModelArgs a, u32* ticket
         const u32 n4 = 1u << (a.g_bits - 2);
 #pragma unroll 4
         for (u32 i = lane; i < n4; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(B2_INIT, B2_INIT, B2_INIT, B2_INIT);
-        k_gen_encode_w_block(a, blockIdx.x, b, lane);
+        k_gen_encode_w_block<false>(a, blockIdx.x, b, lane);
     }
 }
 void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
+}
+__global__ __launch_bounds__(64, 8) void k_gen_model_w(ModelArgs a, u32* ticket) {
+    const u32 lane = threadIdx.x;
+    u32* const tab = a.g_tab + ((size_t)blockIdx.x << a.g_bits);
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        const u32 n4 = 1u << (a.g_bits - 2);
+#pragma unroll 4
+        for (u32 i = lane; i < n4; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(B2_INIT, B2_INIT, B2_INIT, B2_INIT);
+        k_gen_encode_w_block<true>(a, blockIdx.x, b, lane);
+    }
+}
+void launch_gen_model_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_model_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }
 
 // =========================================================================================================
@@ -919,11 +944,16 @@ __device__ __forceinline__ void l64_model_run_lane(u32* slots, RowHdr* hp, u32 e
     }
 }
 
+// SPLIT: stage 3 is not run here; the triples are parked for coder_l.hip (launch_rc_lanes)
+template <bool SPLIT>
 __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
     const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
     WaveCoder rc; rc.init();
+    u64* const trip = SPLIT ? a.trip_q + trip_base(a.line_off, d->rec0) : nullptr;
+    const u32 tcap = SPLIT ? trip_cap(a.line_off, d->rec0, d->nrec) : 0u;
+    u32 ntr = 0;                                       // triples parked so far (uniform)
     u32* const qs = a.q_slots + (size_t)t * a.q_rows * L64_NSYM;
     RowHdr* const qh = a.q_hdr + (size_t)t * a.q_rows;
     PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
@@ -996,10 +1026,17 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
                 const uint4 tr = valid ? strip[lane] : make_uint4(0u, 1u, 1u, 0u);
                 const u32 scum = tr.x, sfreq = tr.y, stot = tr.z;
                 // back to position order
-                tcum  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)scum);
-                tfreq = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)sfreq);
-                ttot  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)stot);
-                rc.run(tcum, tfreq, ttot, m, out, lane);                  // ---- stage 3 ----
+                if constexpr (SPLIT) {
+                    const u32 plo = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)TRIP_Q_PACK_LO(scum, sfreq));
+                    const u32 phi = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)TRIP_Q_PACK_HI(sfreq, stot));
+                    if (lane < m && ntr + lane < tcap) trip[ntr + lane] = ((u64)phi << 32) | plo;
+                    ntr += m;
+                } else {
+                    tcum  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)scum);
+                    tfreq = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)sfreq);
+                    ttot  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)stot);
+                    rc.run(tcum, tfreq, ttot, m, out, lane);              // ---- stage 3 ----
+                }
             } else {
                 // a window holding escape symbols (quality >= 63: qlts.cpp:80-86) is walked in order on lane 0;
                 // each symbol contributes one triple, an escape a second one from the PowerRanger row
@@ -1016,26 +1053,49 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
                     const u32 c1 = rfl(t1.cum), f1 = rfl(t1.freq), o1 = rfl(t1.tot);
                     const u32 c2 = rfl(t2.cum), f2 = rfl(t2.freq), o2 = rfl(t2.tot);
                     const u32 cnt = sym >= LAST_QLT ? 2u : 1u;
-                    tcum = lane == 0 ? c1 : c2; tfreq = lane == 0 ? f1 : f2; ttot = lane == 0 ? o1 : o2;
-                    rc.run(tcum, tfreq, ttot, cnt, out, lane);
+                    if constexpr (SPLIT) {
+                        if (lane == 0 && ntr + cnt <= tcap) {
+                            trip[ntr] = ((u64)TRIP_Q_PACK_HI(f1, o1) << 32) | TRIP_Q_PACK_LO(c1, f1);
+                            if (cnt == 2) trip[ntr + 1] = ((u64)TRIP_Q_PACK_HI(f2, o2) << 32) | TRIP_Q_PACK_LO(c2, f2);
+                        }
+                        ntr += cnt;
+                    } else {
+                        tcum = lane == 0 ? c1 : c2; tfreq = lane == 0 ? f1 : f2; ttot = lane == 0 ? o1 : o2;
+                        rc.run(tcum, tfreq, ttot, cnt, out, lane);
+                    }
                     if (sym >= LAST_QLT) extra_hi++;
                 }
             }
         }
     }
-    rc.done(out, lane);
-    out.flush(lane);
     const u64 anyerr = __ballot(perr != 0);
-    if (lane == 0) {
-        d->extra_hi = extra_hi;
-        d->size[SFQ_S_QLT] = out.pos;
-        if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-        if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    if constexpr (SPLIT) {
+        if (lane == 0) {
+            d->extra_hi = extra_hi;
+            a.ntrip_q[b] = ntr <= tcap ? ntr : 0u;
+            if (ntr > tcap) atomicMax(&d->status, ST_TRIP_OVERFLOW);
+            if (anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        }
+    } else {
+        rc.done(out, lane);
+        out.flush(lane);
+        if (lane == 0) {
+            d->extra_hi = extra_hi;
+            d->size[SFQ_S_QLT] = out.pos;
+            if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        }
     }
 }
 __global__ __launch_bounds__(64, 8) void k_qlt_encode_s(ModelArgs a, u32* ticket) {
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block(a, blockIdx.x, b, threadIdx.x);
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block<false>(a, blockIdx.x, b, threadIdx.x);
 }
 void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
     hipLaunchKernelGGL(k_qlt_encode_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
+}
+__global__ __launch_bounds__(64, 8) void k_qlt_model_s(ModelArgs a, u32* ticket) {
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block<true>(a, blockIdx.x, b, threadIdx.x);
+}
+void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_model_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }

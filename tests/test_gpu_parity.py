@@ -9,7 +9,7 @@ from slimfastq_amd import capi
 
 pytestmark = pytest.mark.gpu
 LEVEL_BITS = {1: 18, 2: 22, 3: 24, 4: 26}
-KERNELS = (0, 1, 2)       # 0 = default kernels, 1 = lane-per-block reference kernels, 2 = wave-per-row quality kernel
+KERNELS = (0, 1, 2, 3)    # 0 = default kernels, 1 = lane-per-block, 2 = wave-per-row quality, 3 = split model / lane-per-block coder
 
 
 def assert_streams_equal(enc, want: dict, block=None, ctxmsg=""):
@@ -311,3 +311,20 @@ def test_small_table_budget_forces_batches():
             assert c.decode_host(cold, level=3, out_cap=len(fq) + 4096) == fq
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("kernel", (0, 3))
+def test_escape_heavy_qualities(ctx, kernel):
+    """Phred+64-style files: nearly every quality is an escape symbol (two coder triples each).  That does not fit
+    the split kernels' (kernel 3) triple scratch; the library repeats the call with the default kernels by itself."""
+    fq = capi.synth_fastq(3000, 100, seed=5)
+    lines = fq.split(b"\n")
+    for i in range(3, len(lines), 4):
+        lines[i] = bytes(min(c + 45, 126) for c in lines[i])
+    fq = b"\n".join(lines)
+    assert sum(c >= 96 for c in lines[3]) > 50
+    enc = ctx.encode_host(fq, level=3, block_reads=1000, kernel=kernel)
+    for b, chunk in enumerate(util.split_records(fq, 1000)):
+        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        assert_streams_equal(enc, want, block=b, ctxmsg="escape-heavy block %d" % b)
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
