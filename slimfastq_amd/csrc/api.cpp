@@ -662,20 +662,22 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
 
-    // 2. quality, then bases (the N rule reads the decoded qualities); the header chain (3.) is independent of
-    //    both and runs on a second stream
+    // 2. quality, bases and (3.) headers are independent chains: three streams.  (The one rule that ties bases to
+    //    qualities -- quality '!' means N -- is applied when the records are assembled.)
     HIPC(hipEventRecord(ctx->ev[2], st));
     HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
-    hipStream_t st_rec = ctx->st_aux[0];
-    launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)std::min(slots, nblocks) << g_bits, 0x03030303u, st);
+    HIPC(hipStreamWaitEvent(ctx->st_aux[1], ctx->ev[2], 0));
+    hipStream_t st_rec = ctx->st_aux[0], st_gen = ctx->st_aux[1];
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
     HIPC(hipEventRecord(ctx->ev[3], st));
+    HIPC(hipEventRecord(ctx->ev[7], st_gen));
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
-        if (b0) launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st);
-        launch_gen_decode_l(da, st);
+        launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st_gen);
+        launch_gen_decode_l(da, st_gen);
     }
-    HIPC(hipEventRecord(ctx->ev[4], st));
+    HIPC(hipEventRecord(ctx->ev[4], st_gen));
+    HIPC(hipStreamWaitEvent(st, ctx->ev[4], 0));
 
     // 3. headers; the staging size comes from the index when known, else grows on overflow
     std::vector<u64> hso((size_t)nblocks + 1);
@@ -732,8 +734,8 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     res->n_records = nrec; res->n_blocks = nblocks; res->total_bytes = total;
     res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[0], ctx->ev[1]);
     res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
-    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[3], ctx->ev[4]);
-    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[4], ctx->ev[5]);
+    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[7], ctx->ev[4]);
+    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[2], ctx->ev[5]);          // the chains overlap: these do not add up
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[5], ctx->ev[6]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[6]);
     return SFQ_OK;

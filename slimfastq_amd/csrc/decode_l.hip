@@ -115,9 +115,8 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
     const u32 mask = (1u << d->gen_bits) - 1u;
     u64 genofs = 0;
     for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
-        const u32 llen = a.slen[r], qlen = a.qlen[r];
+        const u32 llen = a.slen[r];
         u8* g = a.seq_stage + a.soff[r];
-        const u8* q = a.qual_stage + a.qoff[r];
         u32 last = 0x007616c7u & mask;
         u32 row = llen ? sl.g_tab[last] : 0u;
         for (u32 i = 0; i < llen; i++) {
@@ -133,10 +132,13 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
             row = b == 0 ? cand.x : b == 1 ? cand.y : b == 2 ? cand.z : cand.w;
             if (nlast == last) row = nrow;                                                  // the row just updated is its own successor
             last = nlast;
-            const u32 qc = i < qlen ? q[i] : 40u;
-            genofs++;                                                                       // normalize_gen gens.cpp:200-213
-            if (nn_index == genofs) nn_index += x_nn.get(sl.pw);
-            else if (qc == '!') ch = n_byte;
+            // normalize_gen gens.cpp:200-213: a listed "not N" position keeps its base whatever its quality; an N
+            // whose quality is not '!' is listed; every other base under quality '!' is N.  The last rule needs the
+            // decoded qualities, so it is applied when the record is assembled (k_assemble): a "not N" base is
+            // staged with bit 7 set, and the two decoders run side by side.  (The encoder lists an N only where the
+            // quality is not '!', gens.cpp:91-114, so looking the list up first consumes it at the same positions.)
+            genofs++;
+            if (nn_index == genofs) { nn_index += x_nn.get(sl.pw); ch |= 0x80u; }
             else if (ns_index == genofs) { ch = n_byte; ns_index += x_ns.get(sl.pw); }
             g[i] = (u8)ch;
         }
@@ -355,7 +357,14 @@ __global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const 
     o += 1 + h;
     if (lane == 0) { o[0] = '\n'; if (s) o[1] = a.pfg[r]; }
     o += 1 + s;
-    wave_copy(o, a.seq_stage + a.soff[r], sl, lane);
+    {   // bases, with the quality-'!'-means-N rule of normalize_gen (gens.cpp:206-208)
+        const u8* sp = a.seq_stage + a.soff[r]; const u8* qp = a.qual_stage + a.qoff[r];
+        const u32 n_byte = d->n_byte ? d->n_byte : 'N';
+        for (u32 i = lane; i < sl; i += 64) {
+            const u32 c = sp[i];
+            o[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
+        }
+    }
     o += sl;
     if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
     o += 2;
