@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")
-    ap.add_argument("--kind", type=int, default=0, help="0 = 150 bp-style Illumina reads, 1 = 10-50 kb long reads (BASELINE config 5)")
+    ap.add_argument("--kind", type=int, default=0, help="0 = 150 bp-style Illumina reads, 1 = 10-50 kb long reads (BASELINE config 5), 2 = 4-level binned qualities, "
+                    "3 = bases sampled from a 10 Mbp genome (coverage = reads x length / 1e7)")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--prior-step", type=int, default=-1, help="-1 = auto warm start (default), 0 = cold blocks, N = every N-th record")
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")

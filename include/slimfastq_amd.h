@@ -177,7 +177,8 @@ int sfq_decode_blocks_host(sfq_ctx* ctx, const sfq_params* params, const sfq_blo
 /* ---- utilities (host only, no GPU) ----------------------------------------------------------- */
 /* Deterministic synthetic FASTQ. kind 0 = 150 bp-style Illumina reads of
  * read_len bases; kind 1 = long reads, lengths log-uniform in [10000, 50000] (read_len ignored);
- * kind 2 = kind 0 with NovaSeq-style 4-level binned qualities.
+ * kind 2 = kind 0 with NovaSeq-style 4-level binned qualities; kind 3 = kind 0 with the bases sampled (either
+ * strand, 0.5 % substitutions) from a seeded random 10 Mbp genome: 30x coverage at 2 M reads of 150 bp.
  * Returns bytes written, or the required size when h_out == NULL, or <0. */
 int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed, int kind,
                         uint8_t* h_out, uint64_t cap);

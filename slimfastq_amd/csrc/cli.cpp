@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,14 +23,18 @@ static const int   kBlockVersion = 7;
 static const char* kUserVersion = "2.04-amd";
 
 static bool g_encode = true;
+static bool g_batch = false;                  // -b: jobs from stdin, one context for all of them; errors end the job, not the process
 static std::string g_usr;
 
+struct JobError { std::string msg; };
+
 [[noreturn]] static void croak(const char* fmt, ...) {                 // config.cpp:54-68
+    char msg[1024];
     va_list ap; va_start(ap, fmt);
-    fprintf(stderr, "slimfastq: %s %s: ", g_encode ? "encoding" : "decoding", g_usr.empty() ? "<< stdin >>" : g_usr.c_str());
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(msg, sizeof msg, fmt, ap);
     va_end(ap);
+    if (g_batch) throw JobError{msg};
+    fprintf(stderr, "slimfastq: %s %s: %s\n", g_encode ? "encoding" : "decoding", g_usr.empty() ? "<< stdin >>" : g_usr.c_str(), msg);
     exit(1);
 }
 
@@ -42,7 +47,9 @@ static void usage() {
            "-l level         : compression level 1 to 4 (default is 3 ) \n"
            "-1, -2, -3, -4   : alias for -l 1, -l 2, etc \n"
            "-B reads         : records per independent GPU block (default 1024; 0 = single block, reference-compatible file)\n"
+           "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 2048)\n"
            "-g device        : HIP device index (default 0)\n"
+           "-b               : batch: read '<fastq>\\t<sfq>' jobs (with -d: '<sfq>\\t<fastq>') from stdin, answer 'ok|fail\\t...' per job on stdout\n"
            "-v               : version : internal version \n"
            "-h               : help : this message \n"
            "-s               : stat : information about a compressed file \n"
@@ -51,40 +58,289 @@ static void usage() {
     exit(0);
 }
 
-static bool read_all(FILE* f, std::vector<uint8_t>& out) {
-    uint8_t buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
-    return !ferror(f);
-}
-
 static int clamp_level(int l) { return l > 4 ? 4 : l < 1 ? 1 : l; }   // config.cpp:232-237
 static int level_gen_bits(int level) { switch (level) { case 1: return 18; case 2: return 22; case 3: return 24; default: return 26; } }
 
-int main(int argc, char** argv) {
-    std::string fil;
-    bool overwrite = false, statistics = false, quiet = false;
+struct Opts {
     int level = 3, device = 0;
     long block_reads = 1024;
+    bool overwrite = false, quiet = false;
+    uint64_t slab_bytes = 2048ull << 20;
+};
+
+// "seg.idx": an archive is a sequence of SEGMENTS, each the result of one library call (one slab of a large
+// input, or one rank of a multi-GPU job): its blocks, its share of every stream, its own quality prior.
+struct Segment { uint64_t nblocks, prior_bytes, raw_bytes; };
+static void put_v(std::vector<uint8_t>& o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
+static bool get_v(const std::vector<uint8_t>& b, size_t& p, uint64_t& v) {
+    v = 0;
+    for (int sh = 0; sh < 64; sh += 7) { if (p >= b.size()) return false; const uint8_t c = b[p++]; v |= (uint64_t)(c & 0x7f) << sh; if (!(c & 0x80)) return true; }
+    return false;
+}
+
+// Fill `buf` (which may hold a carried-over tail) up to `want` bytes; returns false on a read error.
+static bool fill(FILE* f, std::vector<uint8_t>& buf, size_t want, bool& eof) {
+    size_t have = buf.size();
+    buf.resize(want);
+    while (have < want) {
+        const size_t n = fread(buf.data() + have, 1, want - have, f);
+        if (n == 0) { eof = true; break; }
+        have += n;
+    }
+    buf.resize(have);
+    return !ferror(f);
+}
+// Bytes of `buf` that hold whole records (a record is four lines), given that buf starts at a record.
+static size_t whole_records(const std::vector<uint8_t>& buf) {
+    size_t nl = 0;
+    const uint8_t* p = buf.data();
+    for (size_t i = 0; i < buf.size(); i++) nl += p[i] == '\n';
+    size_t drop = nl & 3, end = buf.size();
+    while (end > 0 && p[end - 1] != '\n') end--;                    // the partial last line
+    while (drop && end > 0) { end--; while (end > 0 && p[end - 1] != '\n') end--; drop--; }
+    return end;
+}
+
+static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, const std::string& fil) {
+    if (!o.overwrite && access(fil.c_str(), F_OK) == 0) {
+        if (g_batch) croak("Can't write file '%s': File exists", fil.c_str());
+        fprintf(stderr, "Can't write file '%s': File exists\n", fil.c_str()); exit(1);
+    }
+    FILE* in = usr.empty() ? stdin : fopen(usr.c_str(), "rb");
+    if (!in) {
+        if (g_batch) croak("Can't read file '%s'", usr.c_str());
+        fprintf(stderr, "Can't read file '%s'\n", usr.c_str()); exit(1);
+    }
+    const bool legacy = o.block_reads == 0;
+    sfq_params p; memset(&p, 0, sizeof p);
+    p.level = o.level; p.block_reads = (uint32_t)o.block_reads;
+    p.prior_step = legacy ? 0 : SFQ_PRIOR_AUTO;                        // warm start needs the block format
+
+    std::vector<uint8_t> fq, out, streams[SFQ_NSTREAMS], first_all, prior_all;
+    std::vector<sfq_block_info> blocks_all;
+    std::vector<Segment> segs;
+    uint64_t total_in = 0, total_records = 0;
+    bool eof = false;
+    while (!eof || !fq.empty()) {
+        // the reference's single adaptive state (format 6) cannot be cut: one slab holds the whole file
+        size_t want = legacy ? std::max<size_t>(fq.size() * 2, 64u << 20) : (size_t)o.slab_bytes;
+        if (want <= fq.size()) want = fq.size() * 2;                   // a record longer than the slab: grow
+        if (!eof && !fill(in, fq, want, eof)) croak("read error");
+        if (legacy && !eof) continue;
+        size_t use = fq.size();
+        if (!eof) { use = whole_records(fq); if (use == 0) continue; }
+        if (use == 0) break;
+        out.resize((size_t)sfq_encode_bound(use));
+        sfq_result res;
+        const int rc = sfq_encode_blocks_host(ctx, fq.data(), use, &p, out.data(), out.size(), &res);
+        if (rc) croak("%s", sfq_last_error(ctx));
+        const size_t b0 = blocks_all.size();
+        blocks_all.resize(b0 + res.n_blocks);
+        sfq_get_block_index(ctx, blocks_all.data() + b0, res.n_blocks);
+        for (size_t b = b0; b < blocks_all.size(); b++) { blocks_all[b].first_record += total_records; blocks_all[b].first_hdr_off += first_all.size(); }
+        const size_t f0 = first_all.size();
+        first_all.resize(f0 + (size_t)res.first_hdr_bytes + 1);
+        sfq_get_first_headers(ctx, first_all.data() + f0, res.first_hdr_bytes);
+        first_all.resize(f0 + (size_t)res.first_hdr_bytes);
+        for (int s = 0; s < SFQ_NSTREAMS; s++)
+            streams[s].insert(streams[s].end(), out.data() + res.stream_offset[s], out.data() + res.stream_offset[s] + res.stream_bytes[s]);
+        Segment sg{res.n_blocks, 0, use};
+        if (!legacy) {
+            const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
+            if (pn > 0) { const size_t q0 = prior_all.size(); prior_all.resize(q0 + (size_t)pn); sfq_get_qlt_prior(ctx, prior_all.data() + q0, (uint64_t)pn); sg.prior_bytes = (uint64_t)pn; }
+        }
+        segs.push_back(sg);
+        total_in += use; total_records += res.n_records;
+        fq.erase(fq.begin(), fq.begin() + (ptrdiff_t)use);             // keep the partial record for the next slab
+    }
+    if (in != stdin) fclose(in);
+    if (segs.empty()) croak("fastq file: empty input");
+
+    sfqc::Archive a;                                                   // info keys in the reference's order (config.cpp:334-347, usrs.cpp:262-266, recs.cpp:71, gens.cpp:104, usrs.cpp:405)
+    a.set("whoami", "slimfastq");
+    a.set("version", legacy ? kInternalVersion : kBlockVersion);
+    a.set("config.level", o.level);
+    a.set("orig.filename", usr.empty() ? "<< stdin >>" : usr);
+    if (!usr.empty() || !legacy) a.set("orig.size", (long long)total_in);
+    if (legacy) {
+        const sfq_block_info& b = blocks_all[0];
+        if (first_all.size() >= 400) croak("first header too long for the reference's info page (recs.cpp:30)");
+        if (b.solid) a.set("usr.solid", 1);
+        a.set("llen", b.llen);
+        a.set("usr.2id", b.two_id);
+        a.set("rec.first", std::string(first_all.begin(), first_all.end()));
+        if (b.n_byte && b.n_byte != 'N') a.set("gen.N_byte", b.n_byte);
+        a.set("num_records", (long long)total_records);
+        if (!o.quiet && b.extra_hi) a.set("qlt.extra.hi", b.extra_hi);
+    } else {
+        a.set("blk.reads", o.block_reads);
+        a.set("blk.count", (long long)blocks_all.size());
+        a.set("num_records", (long long)total_records);
+        if (segs.size() > 1) a.set("seg.count", (long long)segs.size());
+    }
+    for (int s = 0; s < SFQ_NSTREAMS; s++) if (!streams[s].empty()) a.add(sfq_stream_name(s), std::move(streams[s]));
+    if (!legacy) {
+        a.add("blk.idx", sfqc::pack_block_index(blocks_all));
+        a.add("blk.hdr", first_all);
+        if (!prior_all.empty()) a.add("qlt.pri", prior_all);
+        if (segs.size() > 1) {
+            std::vector<uint8_t> si;
+            put_v(si, segs.size());
+            for (auto& g : segs) { put_v(si, g.nblocks); put_v(si, g.prior_bytes); put_v(si, g.raw_bytes); }
+            a.add("seg.idx", si);
+        }
+    }
+    std::string err;
+    if (!sfqc::write_file(fil, a, err)) croak("%s", err.c_str());
+}
+
+static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, const std::string& fil) {
+    std::string err;
+    sfqc::Archive a;
+    if (!sfqc::read_file(fil, a, err)) croak("%s", err.c_str());
+    const int version = (int)a.get_long("version", 0);
+    if (version > kBlockVersion) croak("%s was compressed with slimfastq version %d. My version is %d. Please upgrade me before decoing", fil.c_str(), version, kBlockVersion);
+    if (a.find("usr.lrec")) croak("archive holds oversize records (usr.lrec): not supported by the GPU decoder yet");
+    const int level = clamp_level((int)a.get_long("config.level", 2));       // config.cpp:359
+    std::vector<sfq_block_info> blocks;
+    std::vector<uint8_t> first;
+    std::vector<Segment> segs;
+    const std::vector<uint8_t>* pri = a.find("qlt.pri");
+    if (version >= kBlockVersion) {
+        const std::vector<uint8_t>* idx = a.find("blk.idx");
+        if (!idx || !sfqc::unpack_block_index(*idx, blocks)) croak("bad block index");
+        if (const std::vector<uint8_t>* h = a.find("blk.hdr")) first = *h;
+        if (const std::vector<uint8_t>* si = a.find("seg.idx")) {
+            size_t q = 0; uint64_t n = 0;
+            if (!get_v(*si, q, n) || n == 0 || n > blocks.size()) croak("bad segment index");
+            segs.resize((size_t)n);
+            for (auto& g : segs) if (!get_v(*si, q, g.nblocks) || !get_v(*si, q, g.prior_bytes) || !get_v(*si, q, g.raw_bytes)) croak("bad segment index");
+        } else segs.push_back(Segment{blocks.size(), pri ? pri->size() : 0, (uint64_t)a.get_long("orig.size", 0)});
+    } else {
+        sfq_block_info b; memset(&b, 0, sizeof b);
+        b.n_records = (uint32_t)a.get_long("num_records");
+        if (!b.n_records) croak("Zero records, what's going on?");
+        b.llen = (uint32_t)a.get_long("llen");
+        b.solid = a.get_long("usr.solid") != 0; b.two_id = a.get_long("usr.2id") != 0;
+        b.n_byte = (uint8_t)a.get_long("gen.N_byte", 0);
+        b.gen_bits = (uint8_t)level_gen_bits(level);
+        std::string f = a.get("rec.first");
+        first.assign(f.begin(), f.end());
+        b.first_hdr_len = (uint32_t)first.size();
+        for (int s = 0; s < SFQ_NSTREAMS; s++) if (auto* v = a.find(sfq_stream_name(s))) b.size[s] = (uint32_t)v->size();
+        blocks.push_back(b);
+        segs.push_back(Segment{1, 0, (uint64_t)a.get_long("orig.size", 0)});
+    }
+    FILE* of = stdout;
+    if (!usr.empty()) {
+        if (!o.overwrite && access(usr.c_str(), F_OK) == 0) {
+            if (g_batch) croak("Can't write file '%s': File exists", usr.c_str());
+            fprintf(stderr, "Can't write file '%s': File exists\n", usr.c_str()); exit(1);
+        }
+        of = fopen(usr.c_str(), "wb");
+        if (!of) {
+            if (g_batch) croak("Can't write file '%s'", usr.c_str());
+            fprintf(stderr, "Can't write file '%s'\n", usr.c_str()); exit(1);
+        }
+    }
+    sfq_params p; memset(&p, 0, sizeof p);
+    p.level = level; p.version = version >= kBlockVersion ? kInternalVersion : (uint32_t)version;
+    // walk the segments: each one's blocks, its slice of every stream (streams are segment-major), its prior
+    size_t b0 = 0, pri_off = 0;
+    uint64_t spos[SFQ_NSTREAMS] = {0};
+    std::vector<uint8_t> data, out;
+    for (const Segment& g : segs) {
+        if (b0 + g.nblocks > blocks.size() || (pri ? pri_off + g.prior_bytes > pri->size() : g.prior_bytes != 0)) croak("bad segment index");
+        std::vector<sfq_block_info> sb(blocks.begin() + (ptrdiff_t)b0, blocks.begin() + (ptrdiff_t)(b0 + g.nblocks));
+        const uint64_t rec0 = sb[0].first_record, h0 = sb[0].first_hdr_off;
+        uint64_t need[SFQ_NSTREAMS] = {0}, hbytes = 0;
+        for (auto& b : sb) { b.first_record -= rec0; b.first_hdr_off -= h0; hbytes += b.first_hdr_len; for (int s = 0; s < SFQ_NSTREAMS; s++) need[s] += b.size[s]; }
+        if (h0 + hbytes > first.size()) croak("bad block index (first headers)");
+        data.clear();
+        uint64_t soff[SFQ_NSTREAMS];
+        for (int s = 0; s < SFQ_NSTREAMS; s++) {
+            soff[s] = data.size();
+            if (!need[s]) continue;
+            const std::vector<uint8_t>* v = a.find(sfq_stream_name(s));
+            if (!v || spos[s] + need[s] > v->size()) croak("stream %s is shorter than its block index says", sfq_stream_name(s));
+            data.insert(data.end(), v->begin() + (ptrdiff_t)spos[s], v->begin() + (ptrdiff_t)(spos[s] + need[s]));
+            spos[s] += need[s];
+        }
+        if (g.prior_bytes) { if (sfq_set_qlt_prior(ctx, pri->data() + pri_off, g.prior_bytes)) croak("%s", sfq_last_error(ctx)); }
+        else sfq_set_qlt_prior(ctx, nullptr, 0);
+        uint64_t cap = g.raw_bytes, got = 0;
+        if (!cap) cap = data.size() * 8 + (1 << 20);
+        sfq_result res;
+        int rc = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            out.resize((size_t)cap + 16);
+            rc = sfq_decode_blocks_host(ctx, &p, sb.data(), (uint32_t)sb.size(), first.data() + h0, hbytes,
+                                        data.data(), data.size(), soff, out.data(), cap, &got, &res);
+            if (rc != SFQ_E_OVERFLOW || got <= cap) break;
+            cap = got;                                                 // the call reports the size it needs
+        }
+        if (rc) croak("%s", sfq_last_error(ctx));
+        if (fwrite(out.data(), 1, (size_t)got, of) != got) croak("USR: Error writing output");
+        b0 += g.nblocks; pri_off += g.prior_bytes;
+    }
+    if (of != stdout) fclose(of); else fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    std::string fil;
+    Opts o;
+    bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdO1234u:f:l:B:g:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdOb1234u:f:l:B:g:S:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
-        case 'l': level = (int)strtoll(optarg, 0, 0); break;
-        case '1': case '2': case '3': case '4': level = opt - '0'; break;
+        case 'l': o.level = (int)strtoll(optarg, 0, 0); break;
+        case '1': case '2': case '3': case '4': o.level = opt - '0'; break;
         case 'd': g_encode = false; break;
-        case 'O': overwrite = true; break;
+        case 'O': o.overwrite = true; break;
         case 'P': break;
-        case 'q': quiet = true; break;
-        case 'B': block_reads = strtol(optarg, 0, 0); break;
-        case 'g': device = atoi(optarg); break;
+        case 'q': o.quiet = true; break;
+        case 'B': o.block_reads = strtol(optarg, 0, 0); break;
+        case 'S': o.slab_bytes = (uint64_t)std::max<long long>(1, strtoll(optarg, 0, 0)) << 20; break;
+        case 'g': o.device = atoi(optarg); break;
+        case 'b': g_batch = true; break;
         case 'v': printf("Version %s\nInternal format version=%u (block format %u)\n", kUserVersion, kInternalVersion, kBlockVersion); exit(0);
         case 'h': usage();
         case 's': statistics = true; g_encode = false; break;
-        default: croak("Ilagal args: use -h for help");
+        default: fprintf(stderr, "slimfastq: Ilagal args: use -h for help\n"); exit(1);
         }
     }
+    o.level = clamp_level(o.level);                                    // clamp at parse time (the reference records the clamped value only)
+    if (o.block_reads < 0) o.block_reads = 0;
+
+    if (g_batch) {
+        sfq_ctx* ctx = nullptr;
+        const int rc = sfq_ctx_create(&ctx, o.device);
+        if (rc) { fprintf(stderr, "slimfastq: no usable HIP device (error %d): this build has no CPU path\n", rc); return 1; }
+        char* line = nullptr; size_t cap = 0; ssize_t n;
+        int failed = 0;
+        while ((n = getline(&line, &cap, stdin)) > 0) {
+            while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
+            if (!n) continue;
+            char* tab = strchr(line, '\t');
+            if (!tab) { printf("fail\t%s\texpected '<source>\\t<target>'\n", line); fflush(stdout); failed++; continue; }
+            *tab = 0;
+            const std::string src = line, dst = tab + 1;
+            try {
+                if (g_encode) encode_file(ctx, o, src, dst); else decode_file(ctx, o, dst, src);
+                printf("ok\t%s\t%s\n", src.c_str(), dst.c_str());
+            } catch (const JobError& e) {
+                printf("fail\t%s\t%s\n", src.c_str(), e.msg.c_str());
+                failed++;
+            }
+            fflush(stdout);
+        }
+        free(line);
+        sfq_ctx_destroy(ctx);
+        return failed ? 2 : 0;
+    }
+
     while (optind < argc) {                                            // DWIM, config.cpp:279-325 (simplified)
         const char* file = argv[optind++];
         FILE* fh = fopen(file, "rb");
@@ -98,8 +354,6 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "What am I suppose to do with '%s'?\n (please specify explicitly with -f/-u prefix)\n", file); exit(1); }
     }
     if (fil.empty()) { fprintf(stderr, "Missing essential argument: -f\n"); exit(1); }
-    level = clamp_level(level);                                        // clamp at parse time (the reference records the clamped value only)
-    if (block_reads < 0) block_reads = 0;
 
     std::string err;
     if (statistics) {                                                  // config.cpp:76-85
@@ -114,119 +368,9 @@ int main(int argc, char** argv) {
     }
 
     sfq_ctx* ctx = nullptr;
-    int rc = sfq_ctx_create(&ctx, device);
+    const int rc = sfq_ctx_create(&ctx, o.device);
     if (rc) croak("no usable HIP device (error %d): this build has no CPU path", rc);
-
-    if (g_encode) {
-        if (!overwrite && access(fil.c_str(), F_OK) == 0) { fprintf(stderr, "Can't write file '%s': File exists\n", fil.c_str()); exit(1); }
-        std::vector<uint8_t> fq;
-        FILE* in = g_usr.empty() ? stdin : fopen(g_usr.c_str(), "rb");
-        if (!in) { fprintf(stderr, "Can't read file '%s'\n", g_usr.c_str()); exit(1); }
-        if (!read_all(in, fq)) croak("read error");
-        if (in != stdin) fclose(in);
-        sfq_params p; memset(&p, 0, sizeof p);
-        p.level = level; p.block_reads = (uint32_t)block_reads;
-        p.prior_step = block_reads ? SFQ_PRIOR_AUTO : 0;               // warm start needs the block format
-        std::vector<uint8_t> out((size_t)sfq_encode_bound(fq.size()));
-        sfq_result res;
-        rc = sfq_encode_blocks_host(ctx, fq.data(), fq.size(), &p, out.data(), out.size(), &res);
-        if (rc) croak("%s", sfq_last_error(ctx));
-        std::vector<sfq_block_info> blocks(res.n_blocks);
-        sfq_get_block_index(ctx, blocks.data(), res.n_blocks);
-        std::vector<uint8_t> first((size_t)res.first_hdr_bytes + 1);
-        sfq_get_first_headers(ctx, first.data(), res.first_hdr_bytes);
-        first.resize((size_t)res.first_hdr_bytes);
-
-        sfqc::Archive a;                                               // info keys in the reference's order (config.cpp:334-347, usrs.cpp:262-266, recs.cpp:71, gens.cpp:104, usrs.cpp:405)
-        const bool legacy = block_reads == 0;
-        a.set("whoami", "slimfastq");
-        a.set("version", legacy ? kInternalVersion : kBlockVersion);
-        a.set("config.level", level);
-        a.set("orig.filename", g_usr.empty() ? "<< stdin >>" : g_usr);
-        if (!g_usr.empty() || !legacy) a.set("orig.size", (long long)fq.size());
-        if (legacy) {
-            const sfq_block_info& b = blocks[0];
-            if (first.size() >= 400) croak("first header too long for the reference's info page (recs.cpp:30)");
-            if (b.solid) a.set("usr.solid", 1);
-            a.set("llen", b.llen);
-            a.set("usr.2id", b.two_id);
-            a.set("rec.first", std::string(first.begin(), first.end()));
-            if (b.n_byte && b.n_byte != 'N') a.set("gen.N_byte", b.n_byte);
-            a.set("num_records", (long long)res.n_records);
-            if (!quiet && b.extra_hi) a.set("qlt.extra.hi", b.extra_hi);
-        } else {
-            a.set("blk.reads", block_reads);
-            a.set("blk.count", (long long)res.n_blocks);
-            a.set("num_records", (long long)res.n_records);
-        }
-        for (int s = 0; s < SFQ_NSTREAMS; s++) {
-            if (!res.stream_bytes[s]) continue;
-            const uint8_t* p0 = out.data() + res.stream_offset[s];
-            a.add(sfq_stream_name(s), std::vector<uint8_t>(p0, p0 + res.stream_bytes[s]));
-        }
-        if (!legacy) {
-            a.add("blk.idx", sfqc::pack_block_index(blocks));
-            a.add("blk.hdr", first);
-            const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
-            if (pn > 0) { std::vector<uint8_t> pri((size_t)pn); sfq_get_qlt_prior(ctx, pri.data(), pri.size()); a.add("qlt.pri", pri); }
-        }
-        if (!sfqc::write_file(fil, a, err)) croak("%s", err.c_str());
-    } else {
-        sfqc::Archive a;
-        if (!sfqc::read_file(fil, a, err)) croak("%s", err.c_str());
-        const int version = (int)a.get_long("version", 0);
-        if (version > kBlockVersion) croak("%s was compressed with slimfastq version %d. My version is %d. Please upgrade me before decoing", fil.c_str(), version, kBlockVersion);
-        if (a.find("usr.lrec")) croak("archive holds oversize records (usr.lrec): not supported by the GPU decoder yet");
-        level = clamp_level((int)a.get_long("config.level", 2));       // config.cpp:359
-        std::vector<sfq_block_info> blocks;
-        std::vector<uint8_t> first;
-        if (version >= kBlockVersion) {
-            const std::vector<uint8_t>* idx = a.find("blk.idx");
-            if (!idx || !sfqc::unpack_block_index(*idx, blocks)) croak("bad block index");
-            if (const std::vector<uint8_t>* h = a.find("blk.hdr")) first = *h;
-        } else {
-            sfq_block_info b; memset(&b, 0, sizeof b);
-            b.n_records = (uint32_t)a.get_long("num_records");
-            if (!b.n_records) croak("Zero records, what's going on?");
-            b.llen = (uint32_t)a.get_long("llen");
-            b.solid = a.get_long("usr.solid") != 0; b.two_id = a.get_long("usr.2id") != 0;
-            b.n_byte = (uint8_t)a.get_long("gen.N_byte", 0);
-            b.gen_bits = (uint8_t)level_gen_bits(level);
-            std::string f = a.get("rec.first");
-            first.assign(f.begin(), f.end());
-            b.first_hdr_len = (uint32_t)first.size();
-            for (int s = 0; s < SFQ_NSTREAMS; s++) if (auto* v = a.find(sfq_stream_name(s))) b.size[s] = (uint32_t)v->size();
-            blocks.push_back(b);
-        }
-        std::vector<uint8_t> data; uint64_t soff[SFQ_NSTREAMS];
-        for (int s = 0; s < SFQ_NSTREAMS; s++) {
-            soff[s] = data.size();
-            if (auto* v = a.find(sfq_stream_name(s))) data.insert(data.end(), v->begin(), v->end());
-        }
-        if (const std::vector<uint8_t>* pri = a.find("qlt.pri")) sfq_set_qlt_prior(ctx, pri->data(), pri->size());
-        sfq_params p; memset(&p, 0, sizeof p);
-        p.level = level; p.version = version >= kBlockVersion ? kInternalVersion : (uint32_t)version;
-        uint64_t cap = (uint64_t)a.get_long("orig.size", 0), got = 0;
-        if (!cap) cap = data.size() * 8 + (1 << 20);
-        std::vector<uint8_t> out;
-        sfq_result res;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            out.resize((size_t)cap + 16);
-            rc = sfq_decode_blocks_host(ctx, &p, blocks.data(), (uint32_t)blocks.size(), first.data(), first.size(),
-                                        data.data(), data.size(), soff, out.data(), cap, &got, &res);
-            if (rc != SFQ_E_OVERFLOW || got <= cap) break;
-            cap = got;                                                 // the call reports the size it needs
-        }
-        if (rc) croak("%s", sfq_last_error(ctx));
-        FILE* o = stdout;
-        if (!g_usr.empty()) {
-            if (!overwrite && access(g_usr.c_str(), F_OK) == 0) { fprintf(stderr, "Can't write file '%s': File exists\n", g_usr.c_str()); exit(1); }
-            o = fopen(g_usr.c_str(), "wb");
-            if (!o) { fprintf(stderr, "Can't write file '%s'\n", g_usr.c_str()); exit(1); }
-        }
-        if (fwrite(out.data(), 1, (size_t)got, o) != got) croak("USR: Error writing output");
-        if (o != stdout) fclose(o);
-    }
+    if (g_encode) encode_file(ctx, o, g_usr, fil); else decode_file(ctx, o, g_usr, fil);
     sfq_ctx_destroy(ctx);
     return 0;
 }

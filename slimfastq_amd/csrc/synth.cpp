@@ -28,8 +28,20 @@ struct Rng {
 
 void put_u(std::string& o, uint64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v); o.append(b, (size_t)n); }
 
+// kind 3: the bases come from a seeded random genome of GENOME_BP bases (never stored: base p is a hash of p),
+// read = a uniformly placed window, either strand, 0.5 % substitutions -- coverage = reads x length / GENOME_BP
+// (30x at 2 M reads of 150 bp).  This is the honest stress of the base model: the reference's file-wide
+// context table learns the genome as coverage accumulates, an independent block cannot.
+const uint64_t GENOME_BP = 10000000ull;
+inline uint32_t genome_base(uint64_t seed, uint64_t p) {
+    uint64_t z = (seed * 0x9E3779B97F4A7C15ull) ^ (p * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull);
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    return (uint32_t)(z >> 61) & 3u;
+}
+
 // 150 bp-style Illumina read: '@SIM.<i> M7:<run>:<flowcell>:<lane>:<tile>:<x>:<y> 1:N:0:<idx>'
-void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o, bool binned = false) {
+void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o, bool binned = false, bool genome = false) {
     Rng r(seed ^ (idx * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
     o += "@SIM."; put_u(o, idx + 1);
     o += " M7:42:000000000-A7XYZ:"; put_u(o, 1 + (idx / 2500000) % 8);
@@ -44,6 +56,9 @@ void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o, bo
     // terminal "B-tail" of Q2 once the read has collapsed
     int cur = 34 + (int)r.below(7);
     const uint32_t knee = len / 3 + r.below(len);          // where the decline starts
+    const uint64_t gspan = GENOME_BP > len ? GENOME_BP - len : 1;
+    const uint64_t gpos = genome ? r.next() % gspan : 0;
+    const bool rev = genome && (r.next() >> 63);
     bool tail = false;
     for (uint32_t i = 0; i < len; i++) {
         if (!tail) {
@@ -63,6 +78,11 @@ void illumina_read(uint64_t idx, uint32_t len, uint64_t seed, std::string& o, bo
         q[i] = (char)('!' + (binned ? (qv < 3 ? 2 : qv < 15 ? 12 : qv < 30 ? 23 : 37) : qv));
         const uint32_t v = (uint32_t)(r.next() >> 40);
         char base = "ACGT"[v & 3];
+        if (genome) {
+            uint32_t g = rev ? 3u - genome_base(seed, gpos + (len - 1 - i)) : genome_base(seed, gpos + i);
+            if (((v >> 12) % 200) == 0) g = (g + 1 + ((v >> 2) & 3) % 3) & 3;       // 0.5 % substitutions
+            base = "ACGT"[g];
+        }
         if ((v >> 2) % 1000 == 0) { base = 'N'; q[i] = '#'; }   // P(N) = 1e-3, N gets quality '#'
         o[b0 + i] = base;
     }
@@ -111,7 +131,7 @@ void long_read(uint64_t idx, uint64_t seed, std::string& o) {
 
 extern "C" int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed, int kind,
                                    uint8_t* h_out, uint64_t cap) {
-    if (kind < 0 || kind > 2) return SFQ_E_ARG;
+    if (kind < 0 || kind > 3) return SFQ_E_ARG;
     if (kind != 1 && (read_len == 0 || read_len > 65000)) return SFQ_E_ARG;
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
@@ -127,7 +147,7 @@ extern "C" int64_t sfq_synth_fastq(uint64_t first_read, uint64_t n_reads, uint32
             if (kind != 1) o.reserve((size_t)(b - a) * (2 * read_len + 64));
             for (uint64_t i = a; i < b; i++) {
                 if (kind == 1) long_read(first_read + i, seed, o);
-                else illumina_read(first_read + i, read_len, seed, o, kind == 2);
+                else illumina_read(first_read + i, read_len, seed, o, kind == 2, kind == 3);
             }
         });
     }

@@ -328,3 +328,56 @@ def test_escape_heavy_qualities(ctx, kernel):
         want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
         assert_streams_equal(enc, want, block=b, ctxmsg="escape-heavy block %d" % b)
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
+def test_cli_slabs_make_segments_and_batch_mode(tmp_path):
+    """Large inputs are compressed slab by slab (-S MiB), one archive segment per slab with its own quality prior;
+    -b keeps one context for a list of jobs and reports per job."""
+    import subprocess
+    cli = _cli()
+    fq = capi.synth_fastq(12000, 150, seed=21)                    # ~4.4 MB -> 5 slabs of 1 MiB
+    src = tmp_path / "big.fq"; src.write_bytes(fq)
+    sfq = tmp_path / "big.sfq"; out = tmp_path / "big.out"
+    subprocess.check_call([cli, "-u", str(src), "-f", str(sfq), "-O", "-S", "1", "-B", "500"])
+    p = subprocess.run([cli, "-s", "-f", str(sfq)], capture_output=True)
+    assert b"seg.count" in p.stderr and b"seg.idx" in p.stderr
+    subprocess.check_call([cli, "-d", "-f", str(sfq), "-u", str(out), "-O"])
+    assert out.read_bytes() == fq
+    # from stdin, slabs again
+    p = subprocess.run([cli, "-f", str(tmp_path / "stdin.sfq"), "-O", "-S", "2"], input=fq, capture_output=True, check=True)
+    p = subprocess.run([cli, "-d", "-f", str(tmp_path / "stdin.sfq")], capture_output=True, check=True)
+    assert p.stdout == fq
+    # one slab = no segment keys: the archive of a small file is unchanged
+    one = tmp_path / "one.sfq"
+    subprocess.check_call([cli, "-u", str(src), "-f", str(one), "-O", "-B", "500"])
+    p = subprocess.run([cli, "-s", "-f", str(one)], capture_output=True)
+    assert b"seg.count" not in p.stderr
+    # batch mode: two good jobs and a bad one; the process survives the bad one
+    small = tmp_path / "small.fq"; small.write_bytes(util.golden_fastq("small"))
+    bad = tmp_path / "bad.fq"; bad.write_bytes(b"@x\nACXT\n+\nIIII\n")
+    jobs = "%s\t%s\n%s\t%s\n%s\t%s\n" % (small, tmp_path / "b1.sfq", bad, tmp_path / "b2.sfq", src, tmp_path / "b3.sfq")
+    p = subprocess.run([cli, "-b", "-O"], input=jobs.encode(), capture_output=True)
+    lines = p.stdout.decode().splitlines()
+    assert [l.split("\t")[0] for l in lines] == ["ok", "fail", "ok"] and p.returncode == 2
+    p = subprocess.run([cli, "-b", "-d", "-O"], input=("%s\t%s\n" % (tmp_path / "b3.sfq", tmp_path / "b3.out")).encode(), capture_output=True)
+    assert p.returncode == 0 and (tmp_path / "b3.out").read_bytes() == fq
+
+
+def test_multi_file_driver(tmp_path):
+    """slimfastq_amd.multi (the reference's tools/slimfastq.multi): a directory of FASTQ files -> .sfq and back."""
+    from slimfastq_amd import multi
+    src = tmp_path / "FQ"; src.mkdir()
+    files = {"a.fq": capi.synth_fastq(3000, 100, seed=1), "b.fastq": util.golden_fastq("tst1"), "c.fq": util.golden_fastq("solid"),
+             "notes.txt": b"not a fastq\n"}
+    for n, b in files.items():
+        (src / n).write_bytes(b)
+    assert multi.main(["-t", str(tmp_path / "SFQ"), "-c", "2", str(src)]) == 0
+    assert sorted(p.name for p in (tmp_path / "SFQ").iterdir()) == ["a.sfq", "b.sfq", "c.sfq"]
+    assert multi.main(["-d", "-t", str(tmp_path / "OUT"), str(tmp_path / "SFQ")]) == 0
+    for n in ("a", "b", "c"):
+        want = files[n + (".fastq" if n == "b" else ".fq")]
+        assert (tmp_path / "OUT" / (n + ".fastq")).read_bytes() == want
+    # existing targets are skipped unless -O; a broken file fails its job only
+    (src / "bad.fq").write_bytes(b"@x\nACXT\n+\nIIII\n")
+    assert multi.main(["-t", str(tmp_path / "SFQ"), str(src)]) == 2
+    assert not (tmp_path / "SFQ" / "bad.sfq").exists()
