@@ -163,6 +163,19 @@ def main():
                 "alg_bytes_per_launch": int(alg[dom]), "avg_ms": round(float(phase[dom]), 3),
                 "whole_path_GBps": round((nbytes + res.total_bytes) / (phase[capi.T_TOTAL] * 1e-3) / 1e9, 3)}
 
+    # HBM traffic of that kernel per launch: PMC counters cannot be collected from inside this process, so the
+    # figure comes from the committed rocprofv3 --pmc passes over this very configuration (profiles/), else null
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_pmc_traffic.json")))
+        c = pmc["config"]
+        if (args.reads, args.read_len, args.level, args.kind, args.block_reads, args.kernel, args.workload) == \
+           (c["reads"], c["read_len"], c["level"], c["kind"], c["block_reads"], c["kernel"], "full") and prior_step == capi.PRIOR_AUTO:
+            k = pmc["kernels"][names[dom] + "_encode"]
+            roofline["traffic"] = k["fetch_bytes"] + k["write_bytes"]
+            roofline["traffic_source"] = pmc["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {"metric": "MB/s FASTQ compressed", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
