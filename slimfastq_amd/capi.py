@@ -214,6 +214,19 @@ class Context:
         self._check(f(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p), C.c_void_p(d_out), out_cap, C.byref(res)))
         return res
 
+    def decode_device(self, blocks, first_hdrs: bytes, d_streams, stream_offset, d_out, out_cap, prior=b"", level=3, version=0):
+        """Device-pointer decode (ints from torch .data_ptr()): returns (bytes written, Result)."""
+        L = lib()
+        self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
+        p = Params(level, 0, 0, 0, 0, version)
+        res = Result()
+        n = C.c_uint64()
+        fb = np.frombuffer(first_hdrs if len(first_hdrs) else b"\0", np.uint8)
+        soff = (C.c_uint64 * NSTREAMS)(*list(stream_offset))
+        self._check(L.sfq_decode_blocks(self._h, C.byref(p), blocks, len(blocks), fb.ctypes.data_as(C.c_void_p), len(first_hdrs),
+                                        C.c_void_p(d_streams), soff, C.c_void_p(d_out), out_cap, C.byref(n), C.byref(res)))
+        return n.value, res
+
     def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()

@@ -381,3 +381,44 @@ def test_multi_file_driver(tmp_path):
     (src / "bad.fq").write_bytes(b"@x\nACXT\n+\nIIII\n")
     assert multi.main(["-t", str(tmp_path / "SFQ"), str(src)]) == 2
     assert not (tmp_path / "SFQ" / "bad.sfq").exists()
+
+
+@pytest.mark.parametrize("kind,n,level", [(0, 10_000_000, 3), (2, 4_000_000, 4), (1, 20_000, 3)])
+def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level):
+    """BASELINE-size inputs (C3: 10 M x 150 bp; binned qualities at -l 4; C5 long reads), text resident in HBM.  The
+    oracle cannot run these in seconds, so the checks are the size-independent ones: decode(encode(x)) == x, the
+    block index adds up, a second encode gives the same bytes, the quality-only entry point gives the same stream."""
+    import torch
+    fq = capi.synth_fastq(n, 150, seed=3, kind=kind)
+    nbytes = len(fq)
+    d_in = torch.from_numpy(np.frombuffer(fq, np.uint8).copy()).cuda()
+    del fq
+    cap = capi.lib().sfq_encode_bound(nbytes)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO)
+    torch.cuda.synchronize()
+    blocks = ctx.index(res.n_blocks)
+    first = ctx.first_headers(res.first_hdr_bytes)
+    prior = ctx.prior()
+    assert res.n_records == n and sum(b.n_records for b in blocks) == n and res.n_blocks == (n + 1023) // 1024
+    for s in range(capi.NSTREAMS):
+        assert sum(b.size[s] for b in blocks) == res.stream_bytes[s]
+    assert sum(res.stream_bytes) == res.total_bytes and all(b.status == 0 for b in blocks)
+    if kind == 0:
+        assert 4.5 < nbytes / res.total_bytes < 5.5
+    packed = d_out[:res.total_bytes].clone()
+    soff, sbytes = list(res.stream_offset), list(res.stream_bytes)
+    # same input, same bytes (tables are reused under new epochs)
+    res2 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO)
+    torch.cuda.synchronize()
+    assert res2.total_bytes == res.total_bytes and torch.equal(d_out[:res.total_bytes], packed) and ctx.prior() == prior
+    # the quality model alone (BASELINE config C2) writes the same quality stream
+    res3 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO, qlt_only=True)
+    torch.cuda.synchronize()
+    assert res3.stream_bytes[2] == sbytes[2]
+    assert torch.equal(d_out[res3.stream_offset[2]: res3.stream_offset[2] + sbytes[2]], packed[soff[2]: soff[2] + sbytes[2]])
+    # and back
+    d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
+    got, _ = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=level)
+    torch.cuda.synchronize()
+    assert got == nbytes and torch.equal(d_back[:nbytes], d_in)
