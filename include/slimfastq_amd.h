@@ -72,7 +72,8 @@ typedef struct sfq_params {
                               2 = wave-per-row quality kernel (the earlier default, kept for A/B runs);
                               3 = split form: the model kernels park their (cum, freq, tot) triples and a second
                               kernel runs the range coder one block per lane (measured slower, DESIGN.md section 4;
-                              falls back to 0 by itself when a block's triples do not fit their scratch)        */
+                              falls back to 0 by itself when a block's triples do not fit their scratch);
+                              4 = one block per wave in the quality kernel (the earlier default)                */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);

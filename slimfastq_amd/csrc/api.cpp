@@ -382,7 +382,10 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     // The four models are independent chains over the same text: each runs on its own HIP stream, forked
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
-    const u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
+    u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
+    if (const char* e = getenv("SFQ_ORDER")) {         // experiment hook: launch order of the model kernels, e.g. "rgq"
+        for (int i = 0; i < 3 && e[i]; i++) order[i] = e[i] == 'q' ? SFQ_M_QLT : e[i] == 'g' ? SFQ_M_GEN : SFQ_M_REC;
+    }
     hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
     // Default kernels are persistent: one workgroup per table slot, blocks handed out through ticket counters.
     // The lane-per-block reference kernels (kernel = 1, and usr) run in batches of `slots` blocks.
@@ -408,7 +411,8 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 case SFQ_M_QLT:
                     if (split) { launch_qlt_model_s(a, tickets + 0, mst[m]); launch_rc_lanes(a, true, mst[m]); }
                     else if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]);
-                    else launch_qlt_encode_s(a, tickets + 0, mst[m]);
+                    else if (p.kernel == 4 || slots < KR) launch_qlt_encode_s(a, tickets + 0, mst[m]);
+                    else launch_qlt_encode_k(a, tickets + 0, mst[m]);
                     break;
                 case SFQ_M_GEN:
                     if (split) { launch_gen_model_w(a, tickets + 1, mst[m]); launch_rc_lanes(a, false, mst[m]); }

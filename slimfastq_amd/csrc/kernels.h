@@ -64,6 +64,7 @@ void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
 // (persistent: grid = a.nbatch table slots; blocks 0..a.nblocks-1 are handed out through *ticket, which must be 0)
 void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st);
+void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // 2 blocks per wave; a.nbatch even
 void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // K blocks per wave (SFQ_GEN_CHAINS = 2/4/8); a.nbatch a multiple of 8
 void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);

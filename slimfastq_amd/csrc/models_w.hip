@@ -885,20 +885,27 @@ void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow,
 // (slots[64] + RowHdr), shared with the lane-per-block kernels and decoders.
 // =========================================================================================================
 // Log64Ranger::put minus Encode on one row, by one lane (log64_ranger.hpp:69-112); 16-byte accesses.
-// A row whose tag is stale starts from the shared prior row (format 7) or from zeros.
-__device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php, u32 sym, u32& err) {
-    const uint4 hq = *reinterpret_cast<const uint4*>(hp);          // {total, iend | count<<16 | pad<<24, epoch, pad2}
+// The row is in the WAVE layout (WaveRow above): 64 dwords {total, iend | count << 16, epoch tag, pad, slots 0..59}
+// plus a 16-byte overflow row for slots 60..63.  Header and slots 0..11 share the row's first 64-byte sector, and
+// the hot symbols live in the front slots, so a typical put reads one sector and writes one -- the table traffic
+// is what bounds these kernels.  A row whose tag is stale starts from the shared prior row
+// (format 7) or from zeros.
+__device__ __forceinline__ u32* l64w_at(u32* row, u32* ovf, u32 i) { return i < 60 ? row + 4 + i : ovf + (i - 60); }
+__device__ __forceinline__ Triple l64_model_lane(u32* row, u32* ovf, u32 epoch, const u32* prow, const u32* povf, u32 sym, u32& err) {
+    const uint4 hq = *reinterpret_cast<const uint4*>(row);          // {total, iend | count << 16, epoch, pad}
     u32 total, iend, count;
     if (hq.z == epoch) { total = hq.x; iend = hq.y & 0xffffu; count = (hq.y >> 16) & 0xffu; }
-    else if (pslots) {
-        const uint4 ph = *reinterpret_cast<const uint4*>(php);
+    else if (prow) {
+        const uint4 ph = *reinterpret_cast<const uint4*>(prow);
         total = ph.x; iend = ph.y & 0xffffu; count = 0;
-        for (u32 k = 0; k < iend; k += 4) *reinterpret_cast<uint4*>(slots + k) = *reinterpret_cast<const uint4*>(pslots + k);
+        const u32 n60 = iend < 60 ? iend : 60;
+        for (u32 k = 0; k < n60; k += 4) *reinterpret_cast<uint4*>(row + 4 + k) = *reinterpret_cast<const uint4*>(prow + 4 + k);
+        if (iend > 60) *reinterpret_cast<uint4*>(ovf) = *reinterpret_cast<const uint4*>(povf);
     } else { total = 0; iend = 0; count = 0; }
-    if (iend <= sym) { for (u32 k = iend; k <= sym; k++) slots[k] = k << 16; iend = sym + 1; }          // :103-105
+    if (iend <= sym) { for (u32 k = iend; k <= sym; k++) *l64w_at(row, ovf, k) = k << 16; iend = sym + 1; }   // :103-105
     u32 i = 0, sumf = 0, s = 0;
     for (;;) {                                                                                        // :107
-        const uint4 q = *reinterpret_cast<const uint4*>(slots + i);
+        const uint4 q = *reinterpret_cast<const uint4*>(i < 60 ? row + 4 + i : ovf);
         if ((q.x >> 16) == sym) { s = q.x; break; }
         sumf += q.x & 0xffffu;
         if ((q.y >> 16) == sym && i + 1 < iend) { s = q.y; i += 1; break; }
@@ -908,12 +915,36 @@ __device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epo
         if ((q.w >> 16) == sym && i + 3 < iend) { s = q.w; i += 3; break; }
         sumf += q.w & 0xffffu;
         i += 4;
-        if (i >= 64) { err = 1; i = 63; s = slots[63]; break; }
+        if (i >= 64) { err = 1; i = 63; s = ovf[3]; break; }
     }
     Triple t; t.cum = sumf + i; t.freq = (s & 0xffffu) + 1; t.tot = total + 64;                        // :109
-    Log64::update(slots, i, s, total, iend, count);
-    uint4 nh; nh.x = total; nh.y = iend | (count << 16); nh.z = epoch; nh.w = 0;
-    *reinterpret_cast<uint4*>(hp) = nh;
+    // update_freq (log64_ranger.hpp:69-87), as dev_models.h Ranger::update on this layout
+    u32 f = s & 0xffffu;
+    bool upd = true;
+    if (f > (u32)((1 << 16) - 64 - 6)) {
+        if (i == 0 && f + 20u > total) upd = false;
+        else {
+            u32 tt = 0;
+            for (u32 k = 0; k < iend; k++) { u32* p = l64w_at(row, ovf, k); const u32 nf = (*p & 0xffffu) >> 1; *p = (*p & 0xffff0000u) | nf; tt += nf; }
+            total = tt;
+            f >>= 1;
+        }
+    }
+    if (upd) {
+        f += 6; total += 6;
+        const u32 ns = (s & 0xffff0000u) | f;
+        bool placed = false;
+        if (i != 0) {
+            count = (count + 1) & 0xffu;
+            if ((count & 0xfu) == 0) {
+                u32* pp = l64w_at(row, ovf, i - 1);
+                const u32 pv = *pp;
+                if (f > (pv & 0xffffu)) { *pp = ns; *l64w_at(row, ovf, i) = pv; placed = true; }          // down_level :56-67
+            }
+        }
+        if (!placed) *l64w_at(row, ovf, i) = ns;
+    }
+    *reinterpret_cast<uint4*>(row) = make_uint4(total, iend | (count << 16), epoch, 0u);
     return t;
 }
 
@@ -921,25 +952,23 @@ __device__ __forceinline__ Triple l64_model_lane(u32* slots, RowHdr* hp, u32 epo
 // in the front slot (the usual case for long runs: the dominant symbol bubbles to the front) the repeats are
 // the closed form of update_freq(0) -- freq += 6, total += 6, no count / swap (log64_ranger.hpp:69-87) -- with
 // the row state in registers; otherwise every repeat is a full put.
-__device__ __forceinline__ void l64_model_run_lane(u32* slots, RowHdr* hp, u32 epoch, const u32* pslots, const RowHdr* php,
+__device__ __forceinline__ void l64_model_run_lane(u32* row, u32* ovf, u32 epoch, const u32* prow, const u32* povf,
                                                    u32 sym, u32 L, uint4* out, u32& err) {
-    const Triple t0 = l64_model_lane(slots, hp, epoch, pslots, php, sym, err);
+    const Triple t0 = l64_model_lane(row, ovf, epoch, prow, povf, sym, err);
     out[0] = make_uint4(t0.cum, t0.freq, t0.tot, 0u);
     u32 r = 1;
-    if (L > 1 && (slots[0] >> 16) == sym) {
-        const uint4 hq = *reinterpret_cast<const uint4*>(hp);
-        u32 total = hq.x, s0 = slots[0], f = s0 & 0xffffu;
+    if (L > 1 && (row[4] >> 16) == sym) {
+        u32 total = row[0], s0 = row[4], f = s0 & 0xffffu;
         for (; r < L; r++) {
             if (f > (u32)((1 << 16) - 64 - 6)) break;                     // saturation / normalize: leave to the full path
             out[r] = make_uint4(0u, f + 1, total + 64, 0u);
             f += 6; total += 6;
         }
-        slots[0] = (s0 & 0xffff0000u) | f;
-        uint4 nh = hq; nh.x = total;
-        *reinterpret_cast<uint4*>(hp) = nh;
+        row[4] = (s0 & 0xffff0000u) | f;
+        row[0] = total;
     }
     for (; r < L; r++) {
-        const Triple t = l64_model_lane(slots, hp, epoch, pslots, php, sym, err);
+        const Triple t = l64_model_lane(row, ovf, epoch, prow, povf, sym, err);
         out[r] = make_uint4(t.cum, t.freq, t.tot, 0u);
     }
 }
@@ -947,15 +976,15 @@ __device__ __forceinline__ void l64_model_run_lane(u32* slots, RowHdr* hp, u32 e
 // SPLIT: stage 3 is not run here; the triples are parked for coder_l.hip (launch_rc_lanes)
 template <bool SPLIT>
 __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
-    const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
+    const u32 epoch = EPOCH_L(a.epoch_base + b + 1), epoch_w = EPOCH_W(a.epoch_base + b + 1);
     BlockDesc* d = &a.blocks[b];
     WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
     WaveCoder rc; rc.init();
     u64* const trip = SPLIT ? a.trip_q + trip_base(a.line_off, d->rec0) : nullptr;
     const u32 tcap = SPLIT ? trip_cap(a.line_off, d->rec0, d->nrec) : 0u;
     u32 ntr = 0;                                       // triples parked so far (uniform)
-    u32* const qs = a.q_slots + (size_t)t * a.q_rows * L64_NSYM;
-    RowHdr* const qh = a.q_hdr + (size_t)t * a.q_rows;
+    u32* const qs = a.q_slots + (size_t)t * a.q_rows * L64_NSYM;                    // rows in the wave layout
+    u32* const qo = reinterpret_cast<u32*>(a.q_hdr + (size_t)t * a.q_rows);          // their overflow slots
     PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
     const u32 solid = d->solid;
     const int level = a.level;
@@ -1013,14 +1042,14 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
                 const u64 above = lane >= 63 ? 0ull : (heads >> (lane + 1));
                 const u32 runlen = above ? (u32)__ffsll((long long)above) : 64u - lane;   // distance to the next run head
                 u32* const row = qs + (size_t)(sctx & 0xFFFFu) * L64_NSYM;
-                RowHdr* const hp = qh + (sctx & 0xFFFFu);
-                const u32* const prow = a.prior_ls ? a.prior_ls + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
-                const RowHdr* const php = a.prior_lh + (sctx & 0xFFFFu);
+                u32* const ovf = qo + (size_t)(sctx & 0xFFFFu) * 4;
+                const u32* const prow = a.prior_w ? a.prior_w + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
+                const u32* const povf = a.prior_wovf + (size_t)(sctx & 0xFFFFu) * 4;
                 __syncthreads();                                          // one wave per workgroup: LDS ordering across lanes
                 for (u32 round = 0; ; round++) {
                     const bool mine = valid && run_head && runidx == round;
                     if (!__ballot(mine)) break;
-                    if (mine) l64_model_run_lane(row, hp, epoch, prow, php, ssym, runlen, &strip[lane], perr);
+                    if (mine) l64_model_run_lane(row, ovf, epoch_w, prow, povf, ssym, runlen, &strip[lane], perr);
                 }
                 __syncthreads();
                 const uint4 tr = valid ? strip[lane] : make_uint4(0u, 1u, 1u, 0u);
@@ -1045,8 +1074,8 @@ __device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u
                     Triple t1; t1.cum = 0; t1.freq = 1; t1.tot = 1;
                     Triple t2 = t1;
                     if (lane == 0) {
-                        t1 = l64_model_lane(qs + (size_t)ctx * L64_NSYM, qh + ctx, epoch,
-                                            a.prior_ls ? a.prior_ls + (size_t)ctx * L64_NSYM : nullptr, a.prior_lh + ctx,
+                        t1 = l64_model_lane(qs + (size_t)ctx * L64_NSYM, qo + (size_t)ctx * 4, epoch_w,
+                                            a.prior_w ? a.prior_w + (size_t)ctx * L64_NSYM : nullptr, a.prior_wovf + (size_t)ctx * 4,
                                             sym < LAST_QLT ? sym : LAST_QLT, perr);
                         if (sym >= LAST_QLT) t2 = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, epoch, sym, perr);
                     }
@@ -1098,4 +1127,181 @@ __global__ __launch_bounds__(64, 8) void k_qlt_model_s(ModelArgs a, u32* ticket)
 }
 void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
     hipLaunchKernelGGL(k_qlt_model_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
+}
+
+// =========================================================================================================
+// quality encode, two blocks per wave  (default quality kernel)
+//
+// k_qlt_encode_s spends 19 scalar instructions per symbol in its range coder, every lane idle.  Here a wave owns
+// TWO blocks (two table slots): stages 1-2 run for a window of each block in turn, full width, and stage 3 walks
+// both windows in one instruction stream -- lanes 0..31 carry block A's coder state, lanes 32..63 block B's
+// (dev_multicoder.h), the steps come through LDS.  Same bytes, fewer instructions per symbol.
+// =========================================================================================================
+#include "dev_multicoder.h"
+
+struct QChain {                    // one block's progress; all uniform
+    u32 act, b, k, nrec, base, n, solid, extra_hi, p1, p2, p3, carry_d;
+    u64 rec0;
+    const u8* p;                   // quality line of the current record
+};
+// put the chain on its next record that has quality symbols (or past the end)
+__device__ __forceinline__ void qchain_seek(const ModelArgs& a, QChain& c) {
+    while (c.k < c.nrec) {
+        const u64 r = c.rec0 + c.k;
+        const u64 q0 = a.line_off[4 * r + 3] + c.solid, q1e = a.line_off[4 * r + 4] - 1;
+        c.n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        c.p = a.fq + q0;
+        c.base = 0; c.p1 = c.p2 = c.p3 = 0; c.carry_d = 0;
+        if (c.n) return;
+        c.k++;
+    }
+}
+// stages 1-2 for the chain's next window: steps[0..) = (cum, freq, tot, reciprocal) in coding order, neutral steps
+// behind them.  Returns the number of real steps and moves the chain on.
+__device__ __forceinline__ u32 qlt_window_k(const ModelArgs& a, QChain& c, u32* qs, u32* qo, PwTab& pw, u32 epoch, u32 epoch_w,
+                                            uint4* steps, uint4* strip, u32& perr, const u32 lane) {
+    const int level = a.level;
+    const u32 m = c.n - c.base < 64 ? c.n - c.base : 64;
+    // ---- stage 1 (as k_qlt_encode_s) ----
+    const u32 bv = lane < m ? (u32)(u8)(c.p[c.base + lane] - '!') : 0u;
+    const u32 v1 = wave_shr1(bv, c.p1);
+    const u32 v2 = wave_shr1(v1, c.p2);
+    const u32 v3 = wave_shr1(v2, c.p3);
+    u32 ctxv, inc = 0;
+    if (level == 1)      ctxv = (v1 | ((v2 & 63u) << 6)) & 0xFFFu;
+    else if (level == 2) ctxv = (v1 | (((v2 | ((v3 & 15u) << 6)) & 0x3FFu) << 6)) & 0xFFFFu;
+    else {
+        const u32 drop = (lane < m && v1 > bv) ? v1 - bv : 0u;
+        inc = wave_incl_scan(drop);
+        const u32 dprev = 5u + c.carry_d + inc - drop;
+        const u32 d3 = dprev >> 3;
+        ctxv = (v1 | ((v2 < v3 ? v3 : v2) << 6) | ((u32)(v2 == v3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+        if (c.base == 0 && lane == 0) ctxv = 0;
+    }
+    u32 cons, nsteps;
+    const u64 esc = __ballot(lane < m && bv >= LAST_QLT);
+    if (!esc) {
+        // ---- stage 2: runs of one symbol in one context, one round per run index (as k_qlt_encode_s) ----
+        const u32 key = lane < m ? ((ctxv << 6) | lane) : (0x80000000u | (lane << 6) | lane);
+        const u32 sk = bitonic_sort64(key, lane);
+        const u32 sctx = sk >> 6, spos = sk & 63u;
+        const bool valid = !(sk >> 31);
+        const u32 ssym = (u32)__builtin_amdgcn_ds_bpermute((int)(spos * 4), (int)bv);
+        const u32 prevctx = wave_shr1(sctx, 0xFFFFFFFFu), prevsym = wave_shr1(ssym, 0xFFFFFFFFu);
+        const bool ctx_head = sctx != prevctx;
+        const bool run_head = ctx_head || ssym != prevsym;
+        const u32 cstart = wave_incl_scan_max(ctx_head ? lane : 0u);
+        const u32 nheads = wave_incl_scan(run_head ? 1u : 0u);
+        const u32 runidx = nheads - (u32)__builtin_amdgcn_ds_bpermute((int)(cstart * 4), (int)nheads);
+        const u64 heads = __ballot(run_head);
+        const u64 above = lane >= 63 ? 0ull : (heads >> (lane + 1));
+        const u32 runlen = above ? (u32)__ffsll((long long)above) : 64u - lane;
+        u32* const row = qs + (size_t)(sctx & 0xFFFFu) * L64_NSYM;
+        u32* const ovf = qo + (size_t)(sctx & 0xFFFFu) * 4;
+        const u32* const prow = a.prior_w ? a.prior_w + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
+        const u32* const povf = a.prior_wovf + (size_t)(sctx & 0xFFFFu) * 4;
+        __syncthreads();
+        for (u32 round = 0; ; round++) {
+            const bool mine = valid && run_head && runidx == round;
+            if (!__ballot(mine)) break;
+            if (mine) l64_model_run_lane(row, ovf, epoch_w, prow, povf, ssym, runlen, &strip[lane], perr);
+        }
+        __syncthreads();
+        const uint4 tr = strip[lane];
+        steps[spos] = valid ? make_uint4(tr.x, tr.y, tr.z, recip_exact(tr.z)) : NEUTRAL_TRIPLE;   // invalid keys sit at their own lane >= m
+        cons = m; nsteps = m;
+    } else {
+        // escape symbols (quality >= 63: qlts.cpp:80-86) code two steps each: walk at most 32 symbols in order on lane 0
+        cons = m < 32 ? m : 32;
+        u32 t = 0;
+        __syncthreads();
+        for (u32 j = 0; j < cons; j++) {
+            const u32 ctx = rl(ctxv, j), sym = rl(bv, j);
+            if (lane == 0) {
+                const Triple t1 = l64_model_lane(qs + (size_t)ctx * L64_NSYM, qo + (size_t)ctx * 4, epoch_w,
+                                                 a.prior_w ? a.prior_w + (size_t)ctx * L64_NSYM : nullptr, a.prior_wovf + (size_t)ctx * 4,
+                                                 sym < LAST_QLT ? sym : LAST_QLT, perr);
+                steps[t] = make_uint4(t1.cum, t1.freq, t1.tot, recip_exact(t1.tot));
+                if (sym >= LAST_QLT) {
+                    const Triple t2 = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, epoch, sym, perr);
+                    steps[t + 1] = make_uint4(t2.cum, t2.freq, t2.tot, recip_exact(t2.tot));
+                }
+            }
+            t += sym >= LAST_QLT ? 2u : 1u;
+            if (sym >= LAST_QLT) c.extra_hi++;
+        }
+        if (lane >= t) steps[lane] = NEUTRAL_TRIPLE;
+        nsteps = t;
+    }
+    // ---- the chain moves on by `cons` symbols ----
+    const u32 np3 = cons >= 3 ? rl(bv, cons - 3) : (cons == 2 ? c.p1 : c.p2);
+    const u32 np2 = cons >= 2 ? rl(bv, cons - 2) : c.p1;
+    c.p3 = np3; c.p2 = np2; c.p1 = rl(bv, cons - 1);
+    if (level >= 3) c.carry_d += rl(inc, cons - 1);
+    c.base += cons;
+    if (c.base >= c.n) { c.k++; qchain_seek(a, c); }
+    return nsteps;
+}
+
+__global__ __launch_bounds__(64, 8) void k_qlt_encode_k2(ModelArgs a, u32* ticket) {
+    constexpr u32 K = 2, LPC = 64 / K;
+    __shared__ uint4 steps[K][64];
+    __shared__ uint4 strip[64];
+    const u32 lane = threadIdx.x, h = lane / LPC;
+    const bool lead = (lane % LPC) == 0;
+    MultiCoder dc; dc.lo = 0; dc.vr = 0xFFFFFFFFu; dc.acc = 0; dc.pos = 0; dc.cap = 0; dc.outp = nullptr; dc.err = 0;
+    QChain c[K];
+    u32 perr[K];
+#pragma unroll
+    for (u32 j = 0; j < K; j++) { c[j].act = 0; c[j].k = c[j].nrec = 0; perr[j] = 0; }
+    bool drained = false;
+    for (;;) {
+#pragma unroll
+        for (u32 j = 0; j < K; j++) {
+            if (c[j].act || drained) continue;
+            const u32 b = next_block(ticket);
+            if (b >= a.nblocks) { drained = true; continue; }
+            const BlockDesc* d = &a.blocks[b];
+            c[j].act = 1; c[j].b = b; c[j].k = 0; c[j].nrec = d->nrec; c[j].rec0 = d->rec0; c[j].solid = d->solid; c[j].extra_hi = 0;
+            c[j].n = 0; c[j].base = 0; c[j].p = a.fq;
+            qchain_seek(a, c[j]);
+            dc.reset(h == j, a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
+            perr[j] = 0;
+        }
+        if (!(c[0].act | c[1].act)) break;
+        __syncthreads();                                   // one wave per workgroup: orders the LDS traffic across lanes
+        u32 nmax = 0;
+#pragma unroll
+        for (u32 j = 0; j < K; j++) {
+            if (c[j].act && c[j].k < c[j].nrec) {
+                const size_t slot = (size_t)blockIdx.x * K + j;
+                const u32 epoch = EPOCH_L(a.epoch_base + c[j].b + 1);
+                PwTab pw; pw.slots = a.p_slots + slot * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + slot * PR_ROWS; pw.epoch = epoch;
+                const u32 n = qlt_window_k(a, c[j], a.q_slots + slot * a.q_rows * L64_NSYM, reinterpret_cast<u32*>(a.q_hdr + slot * a.q_rows), pw,
+                                           epoch, EPOCH_W(a.epoch_base + c[j].b + 1), steps[j], strip, perr[j], lane);
+                nmax = n > nmax ? n : nmax;
+            } else steps[j][lane] = NEUTRAL_TRIPLE;
+        }
+        __syncthreads();
+        dc.run(steps, nmax, h, lead);                      // ---- stage 3, both chains ----
+#pragma unroll
+        for (u32 j = 0; j < K; j++) {
+            if (!c[j].act || c[j].k < c[j].nrec) continue;
+            dc.done(h == j, lead);
+            const u32 size = rl(dc.pos, j * LPC), cap = rl(dc.cap, j * LPC), cerr = rl(dc.err, j * LPC);
+            const u64 anyerr = __ballot(perr[j] != 0);
+            if (lane == 0) {
+                BlockDesc* d = &a.blocks[c[j].b];
+                d->extra_hi = c[j].extra_hi;
+                d->size[SFQ_S_QLT] = size;
+                if (size > cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+                if (cerr || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+            }
+            if (h == j) dc.err = 0;
+            c[j].act = 0;
+        }
+    }
+}
+void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_encode_k2, dim3((a.nbatch + 1) / 2), dim3(64), 0, st, a, ticket);
 }

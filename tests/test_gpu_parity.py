@@ -9,7 +9,8 @@ from slimfastq_amd import capi
 
 pytestmark = pytest.mark.gpu
 LEVEL_BITS = {1: 18, 2: 22, 3: 24, 4: 26}
-KERNELS = (0, 1, 2, 3)    # 0 = default kernels, 1 = lane-per-block, 2 = wave-per-row quality, 3 = split model / lane-per-block coder
+KERNELS = (0, 1, 2, 3, 4)  # 0 = default kernels, 1 = lane-per-block, 2 = wave-per-row quality, 3 = split model / lane-per-block coder,
+                           # 4 = one block per wave in the quality kernel
 
 
 def assert_streams_equal(enc, want: dict, block=None, ctxmsg=""):
