@@ -91,7 +91,9 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     u64 fit = ctx->table_budget / per;
     if (fit == 0) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B too small for one block slot (%llu B)",
                               (unsigned long long)ctx->table_budget, (unsigned long long)per);
-    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), 12288);      // the chip holds 8192 waves; the multi-chain base kernel takes 2 slots per wave
+    u32 cap = 12288;
+    if (const char* e = getenv("SFQ_MAX_SLOTS")) cap = (u32)std::max(8, atoi(e));      // experiment hook
+    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), cap);      // the chip holds 8192 waves; the multi-chain base kernel takes 2 slots per wave
     Tables& t = ctx->tab;
     // Row tables are epoch-tagged and epochs only grow, so stale rows of any earlier geometry can never
     // match: slot storage needs no clearing, and a header array is zeroed only when it is (re)allocated.
