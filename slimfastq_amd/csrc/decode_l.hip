@@ -11,6 +11,14 @@
 
 #define LAST_QLT 63u
 
+// Active lanes per decode wavefront.  A wave waits for the slowest of its lanes' table reads, and the chains are
+// few (one per block): fewer lanes per wave = more waves, each waiting on fewer reads.
+#include <cstdlib>
+static u32 decode_lanes() {
+    static const u32 n = [] { const char* e = getenv("SFQ_DECODE_LANES"); const int v = e ? atoi(e) : 16; return (u32)(v == 8 || v == 16 || v == 32 || v == 64 ? v : 16); }();
+    return n;
+}
+
 struct DSlot {
     u32 b, epoch;
     u32* q_slots; RowHdr* q_hdr;
@@ -71,6 +79,73 @@ void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st) {
 }
 
 // ---- QltLoad::load_1/2/3 (qlts.cpp:163-234) ------------------------------------------------------------
+// Log64Ranger::get (log64_ranger.hpp:114-138) by one lane on a row in the WAVE layout (models_w.hip WaveRow:
+// 64 dwords {total, iend | count << 16, epoch tag, pad, slots 0..59} + a 16-byte overflow row): the header and
+// the first four slots are one 32-byte read, so a symbol that sits in the front of its row -- the usual case --
+// costs one memory round trip.  A stale row starts from the shared prior row (format 7) or from zeros.
+__device__ __forceinline__ u32* l64w_slot(u32* row, u32* ovf, u32 i) { return i < 60 ? row + 4 + i : ovf + (i - 60); }
+__device__ __forceinline__ u32 l64w_get_lane(u32* row, u32* ovf, u32 epoch, const u32* prow, const u32* povf, RcDec& rc, ByteSrc& src) {
+    const uint4 hq = *reinterpret_cast<const uint4*>(row);          // {total, iend | count << 16, epoch, pad}
+    uint4 q = *reinterpret_cast<const uint4*>(row + 4);             // slots 0..3, same 64-byte sector
+    u32 total, iend, count;
+    if (hq.z == epoch) { total = hq.x; iend = hq.y & 0xffffu; count = (hq.y >> 16) & 0xffu; }
+    else if (prow) {
+        const uint4 ph = *reinterpret_cast<const uint4*>(prow);
+        total = ph.x; iend = ph.y & 0xffffu; count = 0;
+        const u32 n60 = iend < 60 ? iend : 60;
+        for (u32 k = 0; k < n60; k += 4) *reinterpret_cast<uint4*>(row + 4 + k) = *reinterpret_cast<const uint4*>(prow + 4 + k);
+        if (iend > 60) *reinterpret_cast<uint4*>(ovf) = *reinterpret_cast<const uint4*>(povf);
+        q = *reinterpret_cast<const uint4*>(prow + 4);
+    } else { total = 0; iend = 0; count = 0; }
+    const u32 prob = rc.get_freq(total + 64);
+    u32 i = 0, sumf = 0, s = 0;
+    bool found = false;
+    while (!found && i < 64) {
+        if (i) q = *reinterpret_cast<const uint4*>(i < 60 ? row + 4 + i : ovf);
+        u32 e[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (found) break;
+            const u32 idx = i + c;
+            if (iend == idx) { e[c] = idx << 16; *l64w_slot(row, ovf, idx) = e[c]; iend++; }      // :124-125
+            const u32 f1 = (e[c] & 0xffffu) + 1;
+            if (sumf + f1 <= prob) sumf += f1; else { s = e[c]; i = idx; found = true; }
+        }
+        if (!found) i += 4;
+    }
+    if (!found) { rc.err = 1; i = 63; s = ovf[3]; sumf -= (s & 0xffffu) + 1; }
+    rc.decode(src, sumf, (s & 0xffffu) + 1);
+    const u32 sym = (s >> 16) & 0xffu;
+    // update_freq (log64_ranger.hpp:69-87)
+    u32 f = s & 0xffffu;
+    bool upd = true;
+    if (f > (u32)((1 << 16) - 64 - 6)) {
+        if (i == 0 && f + 20u > total) upd = false;
+        else {
+            u32 tt = 0;
+            for (u32 k = 0; k < iend; k++) { u32* p = l64w_slot(row, ovf, k); const u32 nf = (*p & 0xffffu) >> 1; *p = (*p & 0xffff0000u) | nf; tt += nf; }
+            total = tt;
+            f >>= 1;
+        }
+    }
+    if (upd) {
+        f += 6; total += 6;
+        const u32 ns = (s & 0xffff0000u) | f;
+        bool placed = false;
+        if (i != 0) {
+            count = (count + 1) & 0xffu;
+            if ((count & 0xfu) == 0) {
+                u32* pp = l64w_slot(row, ovf, i - 1);
+                const u32 pv = *pp;
+                if (f > (pv & 0xffffu)) { *pp = ns; *l64w_slot(row, ovf, i) = pv; placed = true; }     // down_level :56-67
+            }
+        }
+        if (!placed) *l64w_slot(row, ovf, i) = ns;
+    }
+    *reinterpret_cast<uint4*>(row) = make_uint4(total, iend | (count << 16), epoch, 0u);
+    return sym;
+}
+
 __global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
     DSlot sl;
     if (!dslot_init(a.m, sl)) return;
@@ -78,13 +153,15 @@ __global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
     ByteSrc src = stream_src(a, d, sl.b, SFQ_S_QLT);
     RcDec rc; rc.init(src);
     const int level = a.m.level;
+    u32* const qo = reinterpret_cast<u32*>(sl.q_hdr);                   // overflow rows of the wave layout
+    const u32 epoch_w = EPOCH_W(a.m.epoch_base + sl.b + 1);
     for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
         const u32 n = a.qlen[r];
         u8* p = a.qual_stage + a.qoff[r];
         u32 last = 0, delta = 5, q1 = 0, q2 = 0, di = 0;
         for (u32 i = 0; i < n; i++) {
-            u32 b = l64_get_lane(sl.q_slots + (size_t)last * L64_NSYM, sl.q_hdr + last, sl.epoch,
-                                 a.m.prior_ls ? a.m.prior_ls + (size_t)last * L64_NSYM : nullptr, a.m.prior_lh + last, rc, src);
+            u32 b = l64w_get_lane(sl.q_slots + (size_t)last * L64_NSYM, qo + (size_t)last * 4, epoch_w,
+                                  a.m.prior_w ? a.m.prior_w + (size_t)last * L64_NSYM : nullptr, a.m.prior_wovf + (size_t)last * 4, rc, src);
             if (b == LAST_QLT) b = sl.pw.get(PR_EXQ_ROW, rc, src);                          // qlts.cpp:168-171
             p[i] = (u8)('!' + b);
             if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
@@ -96,7 +173,8 @@ __global__ __launch_bounds__(64) void k_qlt_decode_l(DecodeArgs a) {
     if (rc.err) dset_status(d, SFQ_E_CORRUPT);
 }
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+    const u32 L = decode_lanes();
+    hipLaunchKernelGGL(k_qlt_decode_l, dim3((a.m.nbatch + L - 1) / L), dim3(L), 0, st, a);
 }
 
 // ---- GenLoad::load_x + normalize_gen (gens.cpp:200-249) ---------------------------------------------------
@@ -146,7 +224,8 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
     if (rc.err | x_ns.rc.err | x_nn.rc.err) dset_status(d, SFQ_E_CORRUPT);
 }
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+    const u32 L = decode_lanes();
+    hipLaunchKernelGGL(k_gen_decode_l, dim3((a.m.nbatch + L - 1) / L), dim3(L), 0, st, a);
 }
 
 // ---- RecLoad::load (recs.cpp:374-461) ----------------------------------------------------------------------
@@ -325,7 +404,8 @@ __global__ __launch_bounds__(64) void k_rec_decode_l(DecodeArgs a) {
     }
 }
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_decode_l, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+    const u32 L = decode_lanes();
+    hipLaunchKernelGGL(k_rec_decode_l, dim3((a.m.nbatch + L - 1) / L), dim3(L), 0, st, a);
 }
 void launch_gen_fixup(const DecodeArgs&, u64, hipStream_t) {}
 
