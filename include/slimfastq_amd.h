@@ -175,6 +175,15 @@ int sfq_decode_blocks_host(sfq_ctx* ctx, const sfq_params* params, const sfq_blo
                            const uint8_t* h_streams, uint64_t streams_bytes, const uint64_t stream_offset[SFQ_NSTREAMS],
                            uint8_t* h_fastq_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* result);
 
+/* ---- the ".sfq" container (host only) ----------------------------------------------------------
+ * Replaces FilerSave + the info page (filer.cpp:217-242, config.cpp:334-347) for hosts that assemble an archive
+ * themselves, e.g. the writer rank of a multi-GPU job (slimfastq_amd/dist_compress.py): info_text is the info
+ * page ("key=value\n" lines), then n_streams named byte streams (names of at most 8 bytes: filer.cpp:42-47). */
+int sfq_archive_write(const char* path, const char* info_text, uint32_t n_streams,
+                      const char* const* names, const uint8_t* const* data, const uint64_t* sizes);
+/* The "blk.idx" stream of a block-format archive from a block index; returns its size (out == NULL: size only). */
+int64_t sfq_pack_block_index(const sfq_block_info* blocks, uint32_t n, uint8_t* out, uint64_t cap);
+
 /* ---- utilities (host only, no GPU) ----------------------------------------------------------- */
 /* Deterministic synthetic FASTQ. kind 0 = 150 bp-style Illumina reads of
  * read_len bases; kind 1 = long reads, lengths log-uniform in [10000, 50000] (read_len ignored);

@@ -58,3 +58,51 @@ def test_multi_pairs_sources_and_targets(tmp_path):
     A.tgt_dir = None
     assert multi.target_of(str(d / "a.fq"), A, [".fastq", ".fq"], ".sfq") == str(d / "a.sfq")
     assert multi.target_of(str(d / "x.sfq"), A, [".sfq"], ".fastq") == str(d / "x.fastq")
+
+
+def test_dist_compress_shards_on_record_boundaries():
+    """Byte ranges of the multi-rank compressor start at records even when quality lines start with '@'."""
+    from slimfastq_amd import dist_compress as dc
+    recs = []
+    for i in range(200):
+        n = 20 + (i * 7) % 30
+        qual = ("@" if i % 3 == 0 else "I") + "@+I#"[i % 4] * (n - 1)      # '@' and '+' as first quality characters
+        recs.append("@r%d x\n%s\n+\n%s\n" % (i, "ACGT" * 12 if False else ("ACGTN"[i % 5]) * n, qual))
+    fq = "".join(recs).encode()
+    starts = set()
+    o = 0
+    for r in recs:
+        starts.add(o); o += len(r)
+    for world in (1, 2, 3, 7):
+        cuts = [dc.shard_bytes(fq, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(fq)
+        for (lo, hi), (lo2, _) in zip(cuts, cuts[1:] + [(len(fq), 0)]):
+            assert hi == lo2 and (lo in starts or lo == len(fq))
+    for pos in range(0, len(fq), 37):
+        p = dc.record_start(fq, pos)
+        assert p >= pos and (p in starts or p == len(fq))
+
+
+def test_dist_compress_assembles_a_segmented_archive(cli, tmp_path):
+    """The writer rank's part: per-rank results -> one archive with a segment per rank (host only; the streams here
+    are placeholders, the layout is what is checked -- `slimfastq-amd -s` walks it)."""
+    from slimfastq_amd import capi, dist_compress as dc
+    parts = []
+    for r in range(3):
+        blocks = (capi.BlockInfo * 2)()
+        for k in range(2):
+            blocks[k].n_records = 10 + k; blocks[k].first_hdr_len = 5
+            for s in range(3):
+                blocks[k].size[s] = 4 + s
+        streams = [bytes([r]) * (2 * (4 + s)) if s < 3 else b"" for s in range(capi.NSTREAMS)]
+        parts.append(dict(streams=streams, blocks=list(blocks), first=b"hdr_%d" % r * 2, prior=b"P" * (r + 1), raw=1000 + r, records=21))
+    parts.append(dict(streams=[b""] * capi.NSTREAMS, blocks=[], first=b"", prior=b"", raw=0, records=0))   # a rank with no records
+    info, streams = dc.assemble(parts, 3, 1024, "x.fq")
+    f = tmp_path / "seg.sfq"
+    dc.write_archive(str(f), info, streams)
+    p = subprocess.run([cli, "-s", "-f", str(f)], capture_output=True)
+    text = p.stderr.decode()
+    assert p.returncode == 0 and "seg.count" in text and "= 3" in text and "blk.count" in text and "= 6" in text
+    d = dict(streams)
+    assert d["qlt.pri"] == b"PPPPPP" and len(d["rec"]) == 3 * 8 and d["seg.idx"][0] == 3
+    assert "num_records      = 63" in text

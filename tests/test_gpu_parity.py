@@ -423,3 +423,26 @@ def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level):
     got, _ = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=level)
     torch.cuda.synchronize()
     assert got == nbytes and torch.equal(d_back[:nbytes], d_in)
+
+
+def test_two_ranks_compress_one_file_into_one_archive(tmp_path):
+    """slimfastq_amd.dist_compress: each rank codes its record-aligned share of the file, rank 0 gathers and writes one
+    archive with a segment per rank; the CLI restores the file.  Two ranks share this box's one GPU, so the exchange
+    runs over gloo here (RCCL needs a GPU per rank; the call pattern is the same)."""
+    import subprocess, sys, os
+    fq = capi.synth_fastq(9000, 150, seed=31) + util.golden_fastq("tst1")
+    src = tmp_path / "in.fq"; src.write_bytes(fq)
+    sfq = tmp_path / "out.sfq"; back = tmp_path / "back.fq"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29533", "-m", "slimfastq_amd.dist_compress", str(src), str(sfq), "-B", "700"],
+                   check=True, cwd=root, env=env, timeout=600)
+    p = subprocess.run([_cli(), "-s", "-f", str(sfq)], capture_output=True)
+    assert b"seg.count" in p.stderr and b"= 2" in p.stderr
+    subprocess.check_call([_cli(), "-d", "-f", str(sfq), "-u", str(back), "-O"])
+    assert back.read_bytes() == fq
+    # one rank: a plain one-segment archive
+    subprocess.run([sys.executable, "-m", "slimfastq_amd.dist_compress", str(src), str(tmp_path / "one.sfq")], check=True, cwd=root, env=env, timeout=600)
+    p = subprocess.run([_cli(), "-d", "-f", str(tmp_path / "one.sfq")], capture_output=True, check=True)
+    assert p.stdout == fq
