@@ -18,6 +18,7 @@ EXPORTS = [
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
+    "sfq_archive_write", "sfq_pack_block_index",
 ]
 
 
@@ -100,6 +101,9 @@ def lib():
         L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_synth_fastq.argtypes = [u64, u64, C.c_uint32, u64, C.c_int, u8p, u64]
         L.sfq_synth_fastq.restype = C.c_int64
+        L.sfq_archive_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(u64)]
+        L.sfq_pack_block_index.argtypes = [C.POINTER(BlockInfo), C.c_uint32, u8p, u64]
+        L.sfq_pack_block_index.restype = C.c_int64
         _lib = L
     return _lib
 
