@@ -478,7 +478,7 @@ struct WavePw {
     u32* slots; RowHdr* hdr; u32 epoch;
     __device__ __forceinline__ u32 comp(const uint4& v, u32 c) const { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
     // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
-    __device__ Triple model(u32 row, u32 sym, u32 lane) {
+    __device__ __forceinline__ Triple model(u32 row, u32 sym, u32 lane) {
         u32* rs = slots + (size_t)row * PW_NSYM;
         const RowHdr h = hdr[row];
         const bool live = rl(h.epoch, 0) == epoch;
@@ -554,7 +554,7 @@ struct WavePw {
         rc.encode(s, t.cum, t.freq, t.tot);
     }
     // PowerRangerU::put_u (power_ranger.hpp:138-163), as one loop around one inlined put (see PwTab::put_u)
-    __device__ void put_u(u32 row0, RcEncU& rc, Sink0& s, u64 num, u32 lane) {
+    __device__ __forceinline__ void put_u(u32 row0, RcEncU& rc, Sink0& s, u64 num, u32 lane) {
         const u32 n = num <= 0x7f ? 1u : num < 0x7ffe ? 2u : num < (1ULL << 32) ? 6u : 10u;
 #pragma nounroll
         for (u32 j = 0; j < n; j++) {
@@ -674,7 +674,7 @@ struct HdrRegs {
     __device__ __forceinline__ u32 at(u32 pos) const { return pos < 64 ? rl(c0, pos) : rl(c1, pos - 64); }   // pos uniform
 };
 // numberwang (recs.cpp:192-262) over a field [off, off+len) of such a header
-__device__ u32 nw_lanes(const HdrRegs& h, u32 off, int len, u64& num, u32 pctype) {
+__device__ __forceinline__ u32 nw_lanes(const HdrRegs& h, u32 off, int len, u64& num, u32 pctype) {
     int i = 0;
     const bool has_z = h.at(off) == '0';
     if (has_z) if (h.at(off + (++i)) == '0') return ST_STR;
@@ -852,7 +852,7 @@ __device__ __forceinline__ bool rec_block_is_short(const ModelArgs& a, const Blo
     for (int s = 32; s > 0; s >>= 1) { const u32 o = (u32)__shfl_xor((int)longest, s, 64); longest = o > longest ? o : longest; }
     return rl(longest, 0) <= REC_FAST_MAX;
 }
-__global__ __launch_bounds__(64, 8) void k_rec_encode_w_fast(ModelArgs a, u32* ticket) {
+__global__ __launch_bounds__(64, 4) void k_rec_encode_w_fast(ModelArgs a, u32* ticket) {
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
@@ -1243,7 +1243,7 @@ __device__ __forceinline__ u32 qlt_window_k(const ModelArgs& a, QChain& c, u32* 
     return nsteps;
 }
 
-__global__ __launch_bounds__(64, 8) void k_qlt_encode_k2(ModelArgs a, u32* ticket) {
+__global__ __launch_bounds__(64, 5) void k_qlt_encode_k2(ModelArgs a, u32* ticket) {
     constexpr u32 K = 2, LPC = 64 / K;
     __shared__ uint4 steps[K][64];
     __shared__ uint4 strip[64];
