@@ -166,7 +166,7 @@ def main():
     # HBM traffic of that kernel per launch: PMC counters cannot be collected from inside this process, so the
     # figure comes from the committed rocprofv3 --pmc passes over this very configuration (profiles/), else null
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01h_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01i_pmc_traffic.json")))
         c = pmc["config"]
         if (args.reads, args.read_len, args.level, args.kind, args.block_reads, args.kernel, args.workload) == \
            (c["reads"], c["read_len"], c["level"], c["kind"], c["block_reads"], c["kernel"], "full") and prior_step == capi.PRIOR_AUTO:
