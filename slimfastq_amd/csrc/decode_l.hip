@@ -40,7 +40,7 @@ __device__ __forceinline__ bool dslot_init(const ModelArgs& a, DSlot& s) {
 }
 __device__ __forceinline__ void dset_status(BlockDesc* d, int code) { atomicMax(&d->status, (u32)(-code)); }
 __device__ __forceinline__ ByteSrc stream_src(const DecodeArgs& a, const BlockDesc* d, u32 b, int s) {
-    ByteSrc r; r.p = a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + s]; r.pos = 0; r.n = d->size[s];
+    ByteSrc r; r.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + s], d->size[s]);
     return r;
 }
 __device__ __forceinline__ u32 calc_last_delta_d(u32& delta, u32 q, u32 q1, u32 q2) {   // qlts.hpp:62-74

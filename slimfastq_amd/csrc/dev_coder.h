@@ -19,13 +19,27 @@ struct ByteSink {
     }
 };
 
-// Byte source replacing FilerLoad::get (filer.hpp:94-97): 0 past the end.
+// Byte source replacing FilerLoad::get (filer.hpp:94-97): 0 past the end.  The decoders are one serial chain per
+// lane and every renormalisation needs the next stream byte, so the bytes are fetched eight at a time: one memory
+// round trip per eight bytes instead of one per byte (the last seven bytes of a stream are read singly, so
+// nothing beyond the stream is ever touched).
 struct ByteSrc {
     const u8* p;
     u32 pos;
     u32 n;
+    u64 buf;      // bytes already fetched, next one in the low byte
+    u32 have;     // how many of them
+    __device__ __forceinline__ void init(const u8* ptr, u32 len) { p = ptr; pos = 0; n = len; buf = 0; have = 0; }
     __device__ __forceinline__ u32 get() {
-        u32 b = pos < n ? p[pos] : 0u;
+        if (have == 0) {
+            if (pos + 8 <= n) {
+                const u32* q = reinterpret_cast<const u32*>(p + pos);      // global loads need no alignment on gfx9
+                buf = (u64)q[0] | ((u64)q[1] << 32);
+                have = 8;
+            } else { buf = pos < n ? p[pos] : 0u; have = 1; }
+        }
+        const u32 b = (u32)buf & 0xffu;
+        buf >>= 8; have--;
         pos++;
         return b;
     }

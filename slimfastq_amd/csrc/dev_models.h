@@ -255,7 +255,7 @@ struct XfDec {
     u32 row0;
     u32 valid;
     __device__ __forceinline__ void init(const u8* p, u32 n, u32 xf) {
-        src.p = p; src.pos = 0; src.n = n; row0 = PR_XF_BASE + xf * PR_XF_ROWS; valid = n > 0;
+        src.init(p, n); row0 = PR_XF_BASE + xf * PR_XF_ROWS; valid = n > 0;
         if (valid) rc.init(src); else { rc.low = rc.code = 0; rc.range = 0xFFFFFFFFu; rc.err = 0; }
     }
     __device__ __forceinline__ u64 get(const PwTab& t) { return valid ? t.get_u(row0, rc, src) : 0; }
