@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="records per GPU (BASELINE config: 10M x 150 bp)")
+    ap.add_argument("--reads", type=int, default=0, help="records per GPU (default: 10M x 150 bp, the BASELINE config; 60k for --kind 1 long reads)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
@@ -47,7 +47,12 @@ def parse():
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.reads <= 0:
+        args.reads = 60_000 if args.kind == 1 else 10_000_000
+    if args.kind == 1:
+        args.cpu_sample_reads = min(args.cpu_sample_reads, 6_000)      # long reads: ~60 kB per record
+    return args
 
 
 def cpu_baseline(args, seed):
@@ -100,6 +105,10 @@ def main():
 
     # ---- synthetic input, resident in HBM before anything is timed ----
     t0 = time.perf_counter()
+    # the synthetic text is built in host memory: bound it (long reads average ~60 kB per record)
+    est = args.reads * (60_000 if args.kind == 1 else 2 * args.read_len + 70)
+    if est > 24 << 30:
+        raise SystemExit("bench.py: %d records of kind %d would need ~%d GB of host memory; lower --reads" % (args.reads, args.kind, est >> 30))
     fq = capi.synth_fastq(args.reads, args.read_len, seed=seed, first_read=rank * args.reads, kind=args.kind)
     t_gen = time.perf_counter() - t0
     nbytes = len(fq)
