@@ -412,7 +412,7 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 // fill whatever is free: the three overlap from the start (measured: 225 -> 207 ms at 10 M reads).
                 if (p.kernel == 0 && (models & (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC)) == (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC) &&
                     (order[m] == SFQ_M_QLT || order[m] == SFQ_M_GEN) && slots >= KR)
-                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * 2) & ~(KR - 1)));
+                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * (order[m] == SFQ_M_GEN ? (u32)gen_chains() : 2u)) & ~(KR - 1)));
                 {   // experiment hook: waves (table slots) per model kernel
                     static const char* const names[3] = { "SFQ_GRID_Q", "SFQ_GRID_G", "SFQ_GRID_R" };
                     const char* e = m < 3 ? getenv(names[m]) : nullptr;

@@ -66,7 +66,8 @@ void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // 2 blocks per wave; a.nbatch even
 void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
-void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // K blocks per wave (SFQ_GEN_CHAINS = 2/4/8); a.nbatch a multiple of 8
+void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);
+int  gen_chains();                                                            // blocks per wave of that kernel (2)   // K blocks per wave (SFQ_GEN_CHAINS = 2/4/8); a.nbatch a multiple of 8
 void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);
 // split form (default): the model kernels park (cum, freq, tot) triples, launch_rc_lanes codes them, one block per lane
 void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st);
