@@ -6,6 +6,7 @@
 //   -g dev    : HIP device
 // All model / coder work happens in libslimfastq_amd.so on the GPU; this file parses arguments, reads and
 // writes files and fills the info page.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdarg>
@@ -27,6 +28,17 @@ static bool g_batch = false;                  // -b: jobs from stdin, one contex
 static std::string g_usr;
 
 struct JobError { std::string msg; };
+
+// SFQ_TIMING=1: where a run spends its wall time (stderr)
+#include <chrono>
+static void tick(const char* what) {
+    static const bool on = getenv("SFQ_TIMING") != nullptr;
+    static auto t0 = std::chrono::steady_clock::now(), last = t0;
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] %-28s +%7.3f s  (%7.3f s)\n", what, std::chrono::duration<double>(now - last).count(), std::chrono::duration<double>(now - t0).count());
+    last = now;
+}
 
 [[noreturn]] static void croak(const char* fmt, ...) {                 // config.cpp:54-68
     char msg[1024];
@@ -78,24 +90,40 @@ static bool get_v(const std::vector<uint8_t>& b, size_t& p, uint64_t& v) {
     return false;
 }
 
-// Fill `buf` (which may hold a carried-over tail) up to `want` bytes; returns false on a read error.
-static bool fill(FILE* f, std::vector<uint8_t>& buf, size_t want, bool& eof) {
-    size_t have = buf.size();
-    buf.resize(want);
-    while (have < want) {
-        const size_t n = fread(buf.data() + have, 1, want - have, f);
-        if (n == 0) { eof = true; break; }
-        have += n;
+// Growable byte buffer that never zero-fills (a std::vector would touch gigabytes just to size them).
+struct Bytes {
+    uint8_t* p = nullptr; size_t n = 0, cap = 0, touched = 0;
+    ~Bytes() { free(p); }
+    // Fault the first `upto` bytes in now: a device-to-host copy into pages the process has never touched goes
+    // through the driver page by page and is ~10x slower than touching them here first (measured).
+    void touch(size_t upto) {
+        if (upto > cap) upto = cap;
+        for (size_t i = touched & ~(size_t)4095; i < upto; i += 4096) p[i] = 0;
+        if (upto > touched) touched = upto;
     }
-    buf.resize(have);
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        uint8_t* q = (uint8_t*)realloc(p, want);
+        if (!q) return false;
+        p = q; cap = want; touched = std::min(touched, n);               // realloc may have moved to fresh pages
+        return true;
+    }
+};
+// Fill `buf` (which may hold a carried-over tail) up to `want` bytes; returns false on a read error.
+static bool fill(FILE* f, Bytes& buf, size_t want, bool& eof) {
+    if (!buf.reserve(want)) return false;
+    while (buf.n < want) {
+        const size_t got = fread(buf.p + buf.n, 1, want - buf.n, f);
+        if (got == 0) { eof = true; break; }
+        buf.n += got;
+    }
     return !ferror(f);
 }
-// Bytes of `buf` that hold whole records (a record is four lines), given that buf starts at a record.
-static size_t whole_records(const std::vector<uint8_t>& buf) {
+// Bytes of [p, p+n) that hold whole records (a record is four lines), given that p starts at a record.
+static size_t whole_records(const uint8_t* p, size_t n) {
     size_t nl = 0;
-    const uint8_t* p = buf.data();
-    for (size_t i = 0; i < buf.size(); i++) nl += p[i] == '\n';
-    size_t drop = nl & 3, end = buf.size();
+    for (size_t i = 0; i < n; i++) nl += p[i] == '\n';
+    size_t drop = nl & 3, end = n;
     while (end > 0 && p[end - 1] != '\n') end--;                    // the partial last line
     while (drop && end > 0) { end--; while (end > 0 && p[end - 1] != '\n') end--; drop--; }
     return end;
@@ -116,24 +144,44 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     p.level = o.level; p.block_reads = (uint32_t)o.block_reads;
     p.prior_step = legacy ? 0 : SFQ_PRIOR_AUTO;                        // warm start needs the block format
 
-    std::vector<uint8_t> fq, out, streams[SFQ_NSTREAMS], first_all, prior_all;
+    std::vector<uint8_t> streams[SFQ_NSTREAMS], first_all, prior_all;
     std::vector<sfq_block_info> blocks_all;
     std::vector<Segment> segs;
     uint64_t total_in = 0, total_records = 0;
+    // (Mapping the file and handing the mapping to the library was measured: the copy engine pins page-cache pages one
+    //  by one, 4-10x slower than reading into an ordinary buffer first.)
+    size_t file_left = SIZE_MAX;                                       // bytes not yet read, when the input is a regular file
+    if (in != stdin) { struct stat st; if (fstat(fileno(in), &st) == 0 && S_ISREG(st.st_mode)) file_left = (size_t)st.st_size; }
+    // A one-shot process pays for every byte of model tables it allocates (device allocations of tens of GB take
+    // seconds), and its time is file I/O anyway: size the tables for a fraction of the block slots the text could use.
+    if (!g_batch) {
+        const uint64_t text = std::min<uint64_t>(file_left == SIZE_MAX ? o.slab_bytes : file_left, legacy ? UINT64_MAX : o.slab_bytes);
+        sfq_ctx_set_table_budget(ctx, std::max<uint64_t>(2ull << 30, 8 * text));
+    }
+    Bytes fq, out;
     bool eof = false;
-    while (!eof || !fq.empty()) {
+    for (;;) {
+        if (eof && fq.n == 0) break;
         // the reference's single adaptive state (format 6) cannot be cut: one slab holds the whole file
-        size_t want = legacy ? std::max<size_t>(fq.size() * 2, 64u << 20) : (size_t)o.slab_bytes;
-        if (want <= fq.size()) want = fq.size() * 2;                   // a record longer than the slab: grow
+        size_t want = legacy ? std::max<size_t>(fq.n * 2, 64u << 20) : (size_t)o.slab_bytes;
+        if (want <= fq.n) want = fq.n * 2;                              // a record longer than the slab: grow
+        if (file_left != SIZE_MAX) want = legacy ? fq.n + file_left + 1 : std::min(want, fq.n + file_left + 1);   // +1: see the end of the file
+        const size_t before = fq.n;
         if (!eof && !fill(in, fq, want, eof)) croak("read error");
+        if (file_left != SIZE_MAX) file_left -= std::min(file_left, fq.n - before);
+        tick("read slab");
         if (legacy && !eof) continue;
-        size_t use = fq.size();
-        if (!eof) { use = whole_records(fq); if (use == 0) continue; }
+        size_t use = fq.n;
+        if (!eof) { use = whole_records(fq.p, fq.n); if (use == 0) continue; }
+        const uint8_t* text = fq.p;
         if (use == 0) break;
-        out.resize((size_t)sfq_encode_bound(use));
+        const size_t bound = (size_t)sfq_encode_bound(use);
+        if (!out.reserve(bound)) croak("out of memory");
+        out.touch(use / 3 + (1 << 20));                                    // the streams rarely exceed a third of the text
         sfq_result res;
-        const int rc = sfq_encode_blocks_host(ctx, fq.data(), use, &p, out.data(), out.size(), &res);
+        const int rc = sfq_encode_blocks_host(ctx, text, use, &p, out.p, bound, &res);
         if (rc) croak("%s", sfq_last_error(ctx));
+        tick("sfq_encode_blocks_host");
         const size_t b0 = blocks_all.size();
         blocks_all.resize(b0 + res.n_blocks);
         sfq_get_block_index(ctx, blocks_all.data() + b0, res.n_blocks);
@@ -143,7 +191,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         sfq_get_first_headers(ctx, first_all.data() + f0, res.first_hdr_bytes);
         first_all.resize(f0 + (size_t)res.first_hdr_bytes);
         for (int s = 0; s < SFQ_NSTREAMS; s++)
-            streams[s].insert(streams[s].end(), out.data() + res.stream_offset[s], out.data() + res.stream_offset[s] + res.stream_bytes[s]);
+            streams[s].insert(streams[s].end(), out.p + res.stream_offset[s], out.p + res.stream_offset[s] + res.stream_bytes[s]);
         Segment sg{res.n_blocks, 0, use};
         if (!legacy) {
             const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
@@ -151,10 +199,11 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         }
         segs.push_back(sg);
         total_in += use; total_records += res.n_records;
-        fq.erase(fq.begin(), fq.begin() + (ptrdiff_t)use);             // keep the partial record for the next slab
+        memmove(fq.p, fq.p + use, fq.n - use); fq.n -= use;               // keep the partial record for the next slab
     }
     if (in != stdin) fclose(in);
     if (segs.empty()) croak("fastq file: empty input");
+    tick("collect streams");
 
     sfqc::Archive a;                                                   // info keys in the reference's order (config.cpp:334-347, usrs.cpp:262-266, recs.cpp:71, gens.cpp:104, usrs.cpp:405)
     a.set("whoami", "slimfastq");
@@ -191,13 +240,17 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         }
     }
     std::string err;
+    tick("build archive");
     if (!sfqc::write_file(fil, a, err)) croak("%s", err.c_str());
+    tick("write file");
 }
 
 static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, const std::string& fil) {
     std::string err;
     sfqc::Archive a;
+    tick("start");
     if (!sfqc::read_file(fil, a, err)) croak("%s", err.c_str());
+    tick("read archive");
     const int version = (int)a.get_long("version", 0);
     if (version > kBlockVersion) croak("%s was compressed with slimfastq version %d. My version is %d. Please upgrade me before decoing", fil.c_str(), version, kBlockVersion);
     if (a.find("usr.lrec")) croak("archive holds oversize records (usr.lrec): not supported by the GPU decoder yet");
@@ -248,7 +301,8 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     // walk the segments: each one's blocks, its slice of every stream (streams are segment-major), its prior
     size_t b0 = 0, pri_off = 0;
     uint64_t spos[SFQ_NSTREAMS] = {0};
-    std::vector<uint8_t> data, out;
+    std::vector<uint8_t> data;
+    Bytes out;
     for (const Segment& g : segs) {
         if (b0 + g.nblocks > blocks.size() || (pri ? pri_off + g.prior_bytes > pri->size() : g.prior_bytes != 0)) croak("bad segment index");
         std::vector<sfq_block_info> sb(blocks.begin() + (ptrdiff_t)b0, blocks.begin() + (ptrdiff_t)(b0 + g.nblocks));
@@ -273,14 +327,17 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         sfq_result res;
         int rc = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
-            out.resize((size_t)cap + 16);
+            if (!out.reserve((size_t)cap + 16)) croak("out of memory");
+            out.touch((size_t)cap);
             rc = sfq_decode_blocks_host(ctx, &p, sb.data(), (uint32_t)sb.size(), first.data() + h0, hbytes,
-                                        data.data(), data.size(), soff, out.data(), cap, &got, &res);
+                                        data.data(), data.size(), soff, out.p, cap, &got, &res);
             if (rc != SFQ_E_OVERFLOW || got <= cap) break;
             cap = got;                                                 // the call reports the size it needs
         }
         if (rc) croak("%s", sfq_last_error(ctx));
-        if (fwrite(out.data(), 1, (size_t)got, of) != got) croak("USR: Error writing output");
+        tick("sfq_decode_blocks_host");
+        if (fwrite(out.p, 1, (size_t)got, of) != got) croak("USR: Error writing output");
+        tick("write output");
         b0 += g.nblocks; pri_off += g.prior_bytes;
     }
     if (of != stdout) fclose(of); else fflush(stdout);
@@ -368,9 +425,13 @@ int main(int argc, char** argv) {
     }
 
     sfq_ctx* ctx = nullptr;
+    tick("process start");
     const int rc = sfq_ctx_create(&ctx, o.device);
     if (rc) croak("no usable HIP device (error %d): this build has no CPU path", rc);
+    tick("sfq_ctx_create");
     if (g_encode) encode_file(ctx, o, g_usr, fil); else decode_file(ctx, o, g_usr, fil);
-    sfq_ctx_destroy(ctx);
-    return 0;
+    tick("done");
+    // a one-shot process: the driver reclaims the context's 10s of GB faster than freeing them one by one
+    fflush(nullptr);
+    _exit(0);
 }
