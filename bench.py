@@ -112,7 +112,10 @@ def main():
     fq = capi.synth_fastq(args.reads, args.read_len, seed=seed, first_read=rank * args.reads, kind=args.kind)
     t_gen = time.perf_counter() - t0
     nbytes = len(fq)
-    d_in = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda(non_blocking=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                       # read-only source: it is only copied to the device
+        d_in = torch.from_numpy(np.frombuffer(fq, np.uint8)).cuda(non_blocking=False)
     del fq
     ctx = capi.Context(local_rank)
     cap = capi.lib().sfq_encode_bound(nbytes)
