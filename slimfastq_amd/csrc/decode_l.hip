@@ -4,8 +4,8 @@
 // owns one block's chain, as in models_l.hip.  The reference interleaves rec.load / qlt.load /
 // gen.load per record (usrs.cpp:555-571); here the chains are independent kernels that write staging
 // buffers, and a last streaming kernel lays the 4-line records out (UsrLoad::save, usrs.cpp:512-535).
-// Order on the stream: usr (line lengths) -> scans -> qlt -> gen (needs the qualities: gens.cpp:200-213)
-// and rec, -> record sizes -> scan -> assemble.
+// Order: usr (line lengths) -> scans -> qlt | gen | rec side by side on three streams -> record sizes -> scan ->
+// assemble (which applies the one rule that ties bases to qualities: quality '!' means N, gens.cpp:206-208).
 #include "kernels.h"
 #include "dev_models.h"
 

@@ -1,6 +1,6 @@
 // models_k.hip -- multi-chain kernels: one wavefront codes K record blocks at once.
 //
-// Measured on MI355X (profiles/r01c): these kernels are bound by instruction ISSUE -- about 4.2 cycles per
+// Measured on MI355X: these kernels are bound by instruction ISSUE -- about 4.4 cycles per
 // wave-instruction per SIMD whatever its type -- and the serial range-coder chain (stage 3 of models_w.hip)
 // is the largest share: ~19 instructions per symbol executed by a whole wave for ONE chain, every lane
 // computing the same value.  Here a wave owns K blocks (K table slots).  Stages 1-2 (contexts, rows,

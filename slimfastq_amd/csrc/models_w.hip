@@ -1,17 +1,22 @@
-// models_w.hip -- wave-per-block throughput kernels (the default path).
+// models_w.hip -- wave-per-block throughput kernels.
 //
-// One 64-lane wavefront owns one record block: its adaptive tables, its range-coder state and its
-// output cursor.  The work of a symbol is split in three stages so that only what is inherently
-// serial runs serially:
+// A 64-lane wavefront owns one record block (two, in the default quality kernel): its adaptive tables, its
+// range-coder state and its output cursor.  The work of a symbol is split in three stages so that only what is
+// inherently serial runs serially:
 //   (1) lane-parallel : 64 symbols are loaded coalesced, and their model contexts are computed across
 //                       lanes (the quality model's running `delta` is a wave prefix sum)
-//   (2) wave-serial   : the adaptive row of each symbol is searched/updated with lane i holding slot i
-//                       of the row (NSYM = 64 = wave width): find by ballot, cumulative frequency by a
-//                       DPP prefix sum.  The (cum, freq, tot) triple is parked in lane k of a register.
-//   (3) scalar-serial : the range coder consumes the parked triples.  Its one divide per symbol
-//                       (coder.hpp:68) becomes a multiply-high by a per-triple reciprocal computed for all
-//                       64 triples at once in stage 3a, plus an exact fix-up -- bit-exact with range/tot.
-// The bytes produced are identical to models_l.hip (and so to the reference); tests compare both.
+//   (2) rows          : the adaptive row of each symbol is searched and updated.  Three forms live here:
+//                       k_qlt_encode_w   whole wave on ONE row, lane i = slot i (find by ballot, cumulative
+//                                        frequency by a DPP prefix sum) -- the first throughput kernel (kernel = 2)
+//                       k_qlt_encode_s   symbol-parallel: rows of different contexts in different lanes, one
+//                                        round per run of one symbol in one context (kernel = 4)
+//                       k_qlt_encode_k2  the same rows, two blocks per wave (the DEFAULT quality kernel)
+//                       k_rec_encode_w_* PowerRanger rows, four slots per lane (the default header kernel)
+//   (3) coder         : the range coder consumes the (cum, freq, tot) triples; its one divide per symbol
+//                       (coder.hpp:68) is a multiply-high by a reciprocal computed for all 64 triples at once plus an
+//                       exact fix-up.  Scalar, one block (WaveCoder), or per lane group, two blocks (MultiCoder).
+// The default base kernel is models_k.hip.  The bytes produced are identical to models_l.hip (and so to the
+// reference); tests compare all of them.
 #include "kernels.h"
 #include "dev_models.h"
 #include "dev_wave.h"
