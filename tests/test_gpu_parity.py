@@ -181,7 +181,11 @@ def test_low_complexity_bases_same_context_in_one_window(ctx, kernel):
 
 def _cli():
     import os
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimfastq_amd", "bin", "slimfastq-amd")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimfastq_amd", "bin", "slimfastq-amd")
+    if not os.access(path, os.X_OK):                 # a build product (not in git): make it if this tree has not been built
+        from slimfastq_amd import build
+        build.build()
+    return path
 
 
 def test_cli_roundtrip_and_reference_compatibility(tmp_path):
