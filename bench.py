@@ -10,6 +10,11 @@ A step = one pass of the hot path (framing + quality/base/header models + range 
 the rank's FASTQ text, which is already resident in HBM when the timed region starts.  For N > 1 each
 rank codes its own shard of records (weak scaling: per-GPU work fixed) and the step ends with the RCCL
 gather of the compressed streams to rank 0.  Prints ONE JSON line on rank 0.
+
+Beside the contract's fields the line carries, at N = 1: `roofline` (the base kernel: algorithmic bytes over its
+launch time, the PMC-measured HBM traffic from profiles/, the practical random-sector peak), `cpu_baseline` (the
+compiled reference, or the oracle port, on a bounded sample on one host core), `ratio_vs_reference` (same sample),
+and `decode` (the same blocks decoded in HBM after the timed steps and compared with the input; never in `value`).
 """
 import argparse
 import ctypes
@@ -47,6 +52,7 @@ def parse():
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode-and-compare leg after the timed steps")
     args = ap.parse_args()
     if args.reads <= 0:
         args.reads = 60_000 if args.kind == 1 else 10_000_000
@@ -209,6 +215,24 @@ def main():
                         "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
                         "device_total": round(phase[capi.T_TOTAL], 3)},
            "roofline": roofline, "synth_s": round(t_gen, 2)}
+    if world == 1 and args.workload == "full" and not args.models and not args.no_decode:
+        # the way back ("decode MB/s secondarily"): the same blocks decoded in HBM and compared with the input;
+        # outside the timed region, never part of `value`
+        blocks = ctx.index(res.n_blocks)
+        first = ctx.first_headers(res.first_hdr_bytes)
+        prior = ctx.prior()
+        packed = d_out[:res.total_bytes].clone()
+        soff = list(res.stream_offset)
+        d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
+        times = []
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            got, _r = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=args.level)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        same = bool(got == nbytes and torch.equal(d_back[:nbytes], d_in))
+        out["decode"] = {"value": round(nbytes / min(times) / 1e6, 2), "unit": "MB/s FASTQ restored", "ms": round(min(times) * 1e3, 3),
+                         "round_trip_identical": same}
+        del d_back, packed
     if world == 1 and not args.no_cpu_baseline:
         cb, sample, ref_payload = cpu_baseline(args, seed)
         out["cpu_baseline"] = cb
