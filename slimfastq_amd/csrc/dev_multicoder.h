@@ -35,11 +35,21 @@ struct MultiCoder {
             if ((pos & 3) == 0 && lead && pos <= cap) *reinterpret_cast<u32*>(outp + pos - 4) = acc;
         }
     }
-    __device__ __forceinline__ void renorm_step(bool lead) {                // one pass of coder.hpp:74-80 where needed
+    // one pass of coder.hpp:74-80 on the lanes that need it, written with selects (no divergent control flow: the
+    // compiler's version of the branchy form spent a third of its instructions moving loop-carried registers)
+    __device__ __forceinline__ void renorm_step(bool lead) {
         const bool pred = vr < RC_TOP;
-        if (pred && ((lo ^ (lo + vr)) >> 56)) vr = (((u32)lo | (RC_TOP - 1)) - (u32)lo);
-        put(pred, (u32)(lo >> 56), lead);
-        if (pred) { vr <<= 8; lo <<= 8; }
+        const u32 lo32 = (u32)lo, hi32 = (u32)(lo >> 32);
+        const u64 sum = lo + vr;
+        const bool clamp = ((((u32)(sum >> 32)) ^ hi32) >> 24) != 0;       // (low ^ (low + range)) >> 56
+        const u32 vrc = clamp ? (~lo32 & (RC_TOP - 1)) : vr;               // ((u32)low | (TOP-1)) - (u32)low
+        const u32 nacc = __builtin_amdgcn_alignbit(hi32 >> 24, acc, 8);    // (acc >> 8) | (byte << 24)
+        const u32 npos = pos + 1;
+        if (pred && lead && (npos & 3) == 0 && npos <= cap) *reinterpret_cast<u32*>(outp + npos - 4) = nacc;
+        acc = pred ? nacc : acc;
+        pos = pred ? npos : pos;
+        vr = pred ? (vrc << 8) : vr;
+        lo = pred ? (lo << 8) : lo;
     }
     // walk nmax steps; trip[h][k] = {cum, freq, tot, recip}; steps past a chain's own count are neutral
     __device__ __forceinline__ void run(const uint4 (*trip)[64], u32 nmax, u32 h, bool lead) {
@@ -51,14 +61,12 @@ struct MultiCoder {
             r += rem >= t.z ? 1u : 0u;
             lo += (u64)t.x * r;                                              // coder.hpp:69 (cum * r < range: no wrap)
             vr = r * t.y;                                                    // coder.hpp:70
-            if (__any(vr < RC_TOP)) {
-                renorm_step(lead);
-                int guard = 0;
+            int guard = 0;
 #pragma nounroll
-                while (__any(vr < RC_TOP)) {
-                    renorm_step(lead);
-                    if (++guard > 12) { err = 1; if (vr < RC_TOP) vr = 0xFFFFFFFFu; break; }
-                }
+            while (__any(vr < RC_TOP)) {
+                renorm_step(lead);
+                // the reference spins forever if the clamp yields range 0; every chain here must drain
+                if (++guard > 13) { err = 1; if (vr < RC_TOP) vr = 0xFFFFFFFFu; break; }
             }
         }
     }
