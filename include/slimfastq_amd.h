@@ -129,6 +129,8 @@ void sfq_ctx_destroy(sfq_ctx* ctx);
 const char* sfq_last_error(const sfq_ctx* ctx);         /* replaces croak() text (config.cpp:54-68) */
 /* Upper bound on device bytes the context may hold for model tables (default: 70 % of the device). */
 int  sfq_ctx_set_table_budget(sfq_ctx* ctx, uint64_t bytes);
+/* Total memory of the context's device, in bytes (to share a GPU between contexts: budget = a fraction of it). */
+uint64_t sfq_ctx_device_memory(const sfq_ctx* ctx);
 /* The HIP stream the context launches on (a hipStream_t), for callers that order work against it. */
 void* sfq_ctx_stream(sfq_ctx* ctx);
 int  sfq_ctx_synchronize(sfq_ctx* ctx);

@@ -18,7 +18,7 @@ EXPORTS = [
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
-    "sfq_archive_write", "sfq_pack_block_index",
+    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory",
 ]
 
 
@@ -83,6 +83,8 @@ def lib():
         L.sfq_last_error.argtypes = [vp]
         L.sfq_last_error.restype = C.c_char_p
         L.sfq_ctx_set_table_budget.argtypes = [vp, u64]
+        L.sfq_ctx_device_memory.argtypes = [vp]
+        L.sfq_ctx_device_memory.restype = u64
         L.sfq_ctx_stream.argtypes = [vp]
         L.sfq_ctx_stream.restype = vp
         L.sfq_ctx_synchronize.argtypes = [vp]

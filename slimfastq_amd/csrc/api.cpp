@@ -273,6 +273,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
 }
 
 const char* sfq_last_error(const sfq_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+uint64_t sfq_ctx_device_memory(const sfq_ctx* ctx) { return ctx ? ctx->dev_total : 0; }
 int sfq_ctx_set_table_budget(sfq_ctx* ctx, uint64_t bytes) { if (!ctx) return SFQ_E_ARG; ctx->table_budget = bytes; return SFQ_OK; }
 void* sfq_ctx_stream(sfq_ctx* ctx) { return ctx ? (void*)ctx->st : nullptr; }
 int sfq_ctx_synchronize(sfq_ctx* ctx) {

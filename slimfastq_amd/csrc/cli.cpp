@@ -61,6 +61,7 @@ static void usage() {
            "-B reads         : records per independent GPU block (default 1024; 0 = single block, reference-compatible file)\n"
            "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 2048)\n"
            "-g device        : HIP device index (default 0)\n"
+           "-T percent       : share of the device memory this process may use for model tables (several processes on one GPU)\n"
            "-b               : batch: read '<fastq>\\t<sfq>' jobs (with -d: '<sfq>\\t<fastq>') from stdin, answer 'ok|fail\\t...' per job on stdout\n"
            "-v               : version : internal version \n"
            "-h               : help : this message \n"
@@ -78,6 +79,7 @@ struct Opts {
     long block_reads = 1024;
     bool overwrite = false, quiet = false;
     uint64_t slab_bytes = 2048ull << 20;
+    int table_pct = 0;                                                 // -T: share of the device memory for model tables (0 = the library's default)
 };
 
 // "seg.idx": an archive is a sequence of SEGMENTS, each the result of one library call (one slab of a large
@@ -156,7 +158,9 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     // seconds), and its time is file I/O anyway: size the tables for a fraction of the block slots the text could use.
     if (!g_batch) {
         const uint64_t text = std::min<uint64_t>(file_left == SIZE_MAX ? o.slab_bytes : file_left, legacy ? UINT64_MAX : o.slab_bytes);
-        sfq_ctx_set_table_budget(ctx, std::max<uint64_t>(2ull << 30, 8 * text));
+        uint64_t budget = std::max<uint64_t>(2ull << 30, 8 * text);
+        if (o.table_pct) budget = std::min<uint64_t>(budget, sfq_ctx_device_memory(ctx) / 100 * (uint64_t)o.table_pct);
+        sfq_ctx_set_table_budget(ctx, budget);
     }
     Bytes fq, out;
     bool eof = false;
@@ -348,7 +352,7 @@ int main(int argc, char** argv) {
     Opts o;
     bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdOb1234u:f:l:B:g:S:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdOb1234u:f:l:B:g:S:T:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
@@ -361,6 +365,7 @@ int main(int argc, char** argv) {
         case 'B': o.block_reads = strtol(optarg, 0, 0); break;
         case 'S': o.slab_bytes = (uint64_t)std::max<long long>(1, strtoll(optarg, 0, 0)) << 20; break;
         case 'g': o.device = atoi(optarg); break;
+        case 'T': o.table_pct = std::min(90, std::max(1, atoi(optarg))); break;
         case 'b': g_batch = true; break;
         case 'v': printf("Version %s\nInternal format version=%u (block format %u)\n", kUserVersion, kInternalVersion, kBlockVersion); exit(0);
         case 'h': usage();
@@ -375,6 +380,7 @@ int main(int argc, char** argv) {
         sfq_ctx* ctx = nullptr;
         const int rc = sfq_ctx_create(&ctx, o.device);
         if (rc) { fprintf(stderr, "slimfastq: no usable HIP device (error %d): this build has no CPU path\n", rc); return 1; }
+        if (o.table_pct) sfq_ctx_set_table_budget(ctx, sfq_ctx_device_memory(ctx) / 100 * (uint64_t)o.table_pct);
         char* line = nullptr; size_t cap = 0; ssize_t n;
         int failed = 0;
         while ((n = getline(&line, &cap, stdin)) > 0) {
@@ -429,6 +435,7 @@ int main(int argc, char** argv) {
     const int rc = sfq_ctx_create(&ctx, o.device);
     if (rc) croak("no usable HIP device (error %d): this build has no CPU path", rc);
     tick("sfq_ctx_create");
+    if (o.table_pct) sfq_ctx_set_table_budget(ctx, sfq_ctx_device_memory(ctx) / 100 * (uint64_t)o.table_pct);
     if (g_encode) encode_file(ctx, o, g_usr, fil); else decode_file(ctx, o, g_usr, fil);
     tick("done");
     // a one-shot process: the driver reclaims the context's 10s of GB faster than freeing them one by one

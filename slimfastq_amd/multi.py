@@ -153,6 +153,9 @@ def main(argv=None):
     gpus = [int(g) for g in args.gpus.split(",") if g.strip() != ""] or visible_gpus()
     nworkers = max(1, min(args.count or len(gpus), jobs.qsize()))
     cmd = [args.exe, "-b", "-l", str(args.level), "-B", str(args.block_reads)] + (["-d"] if args.decompress else []) + (["-O"] if args.overwrite else [])
+    per_gpu = (nworkers + len(gpus) - 1) // len(gpus)
+    if per_gpu > 1:                                  # workers sharing a GPU share its memory: model tables take most of it
+        cmd += ["-T", str(max(5, 60 // per_gpu))]
     results = []
     t0 = time.time()
     workers = [Worker(i, gpus[i % len(gpus)], cmd, jobs, results, args.verbose) for i in range(nworkers)]
