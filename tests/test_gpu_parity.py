@@ -450,3 +450,75 @@ def test_two_ranks_compress_one_file_into_one_archive(tmp_path):
     subprocess.run([sys.executable, "-m", "slimfastq_amd.dist_compress", str(src), str(tmp_path / "one.sfq")], check=True, cwd=root, env=env, timeout=600)
     p = subprocess.run([_cli(), "-d", "-f", str(tmp_path / "one.sfq")], capture_output=True, check=True)
     assert p.stdout == fq
+
+
+def _fuzz_fastq(rng, nrec):
+    """A structurally hostile little FASTQ: ragged lengths, qlen != llen, N with and without quality '!', quality '!' under
+    real bases, escape qualities (>= 63), lowercase bases, header fields that grow, shrink, turn hexadecimal, get leading
+    zeros, change their separators, and a second id on the '+' line for the whole file or not at all."""
+    two_id = rng.random() < 0.3
+    hdr_shapes = [lambda i, a, b: "r%d:%d:%d" % (i, a, b), lambda i, a, b: "run_%x/%d %05d" % (a, i, b % 9973),
+                  lambda i, a, b: "X%d.%d-%X" % (i * 7, 1000 - (i % 900), b), lambda i, a, b: "id%d" % i,
+                  lambda i, a, b: "m%d/%d/%d_%d" % (54006 + (i // 50), a % 97, b % 5000, i)]
+    shape = hdr_shapes[rng.integers(len(hdr_shapes))]
+    base_len = int(rng.integers(1, 260))
+    lines = []
+    a, b = int(rng.integers(1000)), int(rng.integers(100000))
+    for i in range(nrec):
+        if rng.random() < 0.03:
+            shape = hdr_shapes[rng.integers(len(hdr_shapes))]                      # the header's shape changes
+        a += int(rng.integers(-3, 40)); b = int(rng.integers(100000)) if rng.random() < 0.5 else b + 1
+        hdr = shape(i, max(a, 0), b)
+        n = base_len if rng.random() < 0.85 else int(rng.integers(1, 300))
+        bases = rng.choice(list("ACGT"), n)
+        if rng.random() < 0.2:
+            bases = np.char.lower(bases) if rng.random() < 0.5 else bases
+        qual = np.clip(rng.normal(30, 9, n).astype(int) + (rng.random(n) < 0.02) * 40, 0, 93)
+        nmask = rng.random(n) < 0.03
+        bases = np.where(nmask, "N", bases)
+        qual = np.where(nmask & (rng.random(n) < 0.7), 0, qual)                    # most Ns carry quality '!' ...
+        qual = np.where(~nmask & (rng.random(n) < 0.01), 0, qual)                  # ... and so do a few real bases
+        qs = "".join(chr(33 + int(q)) for q in qual)
+        if rng.random() < 0.04 and n > 2:
+            qs = qs[: int(rng.integers(1, n))]                                     # a quality line shorter than its bases
+        lines += ["@" + hdr, "".join(bases), "+" + (hdr if two_id else ""), qs]
+    return ("\n".join(lines) + "\n").encode()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_small_structurally_hostile_inputs(ctx, seed):
+    """Random small inputs through the default kernels: one block (== the reference run) and ragged blocks, every
+    stream against the oracle, and back."""
+    rng = np.random.default_rng(1000 + seed)
+    for rep in range(5):
+        nrec = int(rng.integers(1, 400))
+        fq = _fuzz_fastq(rng, nrec)
+        level = int(rng.integers(1, 5))
+        want = O.compress(fq, level)
+        if want is None or not want.streams:
+            continue
+        enc = ctx.encode_host(fq, level=level, block_reads=0)
+        assert_streams_equal(enc, want.streams, ctxmsg="fuzz seed %d rep %d one block" % (seed, rep))
+        assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == O.decompress(want.image)
+        br = int(rng.integers(1, max(2, nrec // 2 + 1)))
+        enc = ctx.encode_host(fq, level=level, block_reads=br)
+        for b, chunk in enumerate(util.split_records(fq, br)):
+            wantb = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            assert_streams_equal(enc, wantb, block=b, ctxmsg="fuzz seed %d rep %d block %d of %d" % (seed, rep, b, br))
+        back = ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096)
+        assert back == b"".join(O.decompress(O.compress(c, level).image) for c in util.split_records(fq, br))
+
+
+@pytest.mark.parametrize("kernel", (1, 2, 3, 4))
+def test_fuzz_other_kernel_variants(ctx, kernel):
+    """The same hostile inputs through the kernel variants kept for A/B runs: they must write the default kernels' bytes."""
+    rng = np.random.default_rng(77)
+    for rep in range(3):
+        nrec = int(rng.integers(20, 300))
+        fq = _fuzz_fastq(rng, nrec)
+        br = int(rng.integers(5, 60))
+        for prior_step in (0, 1):
+            ref = ctx.encode_host(fq, level=3, block_reads=br, prior_step=prior_step)
+            enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=prior_step, kernel=kernel)
+            assert bytes(enc.data) == bytes(ref.data) and enc.prior == ref.prior, "kernel %d rep %d prior %d" % (kernel, rep, prior_step)
+            assert [list(b.size) for b in enc.blocks] == [list(b.size) for b in ref.blocks]
