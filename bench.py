@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--reads", type=int, default=0, help="records per GPU (default: 10M x 150 bp, the BASELINE config; 60k for --kind 1 long reads)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "1024")))
+    ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "0")),
+                    help="records per block (default: 1024, which is also what the library's automatic choice gives for 150 bp reads; "
+                         "automatic for --kind 1 long reads)")
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")
     ap.add_argument("--kind", type=int, default=0, help="0 = 150 bp-style Illumina reads, 1 = 10-50 kb long reads (BASELINE config 5), 2 = 4-level binned qualities, "
                     "3 = bases sampled from a 10 Mbp genome (coverage = reads x length / 1e7)")
@@ -58,7 +60,18 @@ def parse():
         args.reads = 60_000 if args.kind == 1 else 10_000_000
     if args.kind == 1:
         args.cpu_sample_reads = min(args.cpu_sample_reads, 6_000)      # long reads: ~60 kB per record
+    if args.block_reads <= 0:
+        args.block_reads = capi.BLOCK_AUTO if args.kind == 1 else 1024
     return args
+
+
+def workload_name(args):
+    what = "full qlts+gens+recs" if args.workload == "full" else "qlts-only kernel"
+    if args.kind == 1:
+        return "synthetic %d long reads (10-50 kb, log-uniform) per GPU, %s, -l %d" % (args.reads, what, args.level)
+    flavour = {0: "Illumina reads", 2: "Illumina reads with 4-level binned qualities", 3: "reads sampled from a 10 Mbp genome"}.get(args.kind, "reads")
+    n = "%dM" % (args.reads // 1_000_000) if args.reads >= 1_000_000 and args.reads % 1_000_000 == 0 else str(args.reads)
+    return "synthetic %s x %d bp %s per GPU, %s, -l %d" % (n, args.read_len, flavour, what, args.level)
 
 
 def cpu_baseline(args, seed):
@@ -206,11 +219,9 @@ def main():
     out = {"metric": "MB/s FASTQ compressed", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-           "config": {"workload": ("synthetic %dM x %d bp Illumina reads per GPU, %s, -l %d" %
-                                   (args.reads // 1_000_000, args.read_len,
-                                    "full qlts+gens+recs" if args.workload == "full" else "qlts-only kernel", args.level))
-                      if args.reads >= 1_000_000 else "synthetic %d x %d bp reads" % (args.reads, args.read_len),
-                      "level": args.level, "block_reads": args.block_reads, "prior_step": args.prior_step, "blocks_per_gpu": int(res.n_blocks),
+           "config": {"workload": workload_name(args),
+                      "level": args.level, "block_reads": int(ctx.index(res.n_blocks)[0].n_records) if args.block_reads == capi.BLOCK_AUTO else args.block_reads,
+                      "prior_step": args.prior_step, "blocks_per_gpu": int(res.n_blocks),
                       "raw_bytes_per_gpu": nbytes, "parallelism": "blocks sharded x%d, RCCL gather" % world if world > 1 else "1 GPU"},
            "ratio": round(all_in / all_out, 4),
            "phase_ms": {"frame": round(phase[capi.T_FRAME], 3), "qlt": round(phase[capi.T_QLT], 3), "gen": round(phase[capi.T_GEN], 3),

@@ -65,7 +65,8 @@ typedef struct sfq_ctx sfq_ctx;
 typedef struct sfq_params {
     int32_t  level;        /* 1..4 : conf.level (config.cpp:260-263, clamped like config.cpp:232-237) */
     uint32_t block_reads;  /* records per independent block; 0 = a single block, i.e. streams that are
-                              byte-identical to the reference's own (format 6)                        */
+                              byte-identical to the reference's own (format 6); SFQ_BLOCK_AUTO = about 376 KiB of
+                              text per block (1024 records of 150 bp, a handful of long reads)            */
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks);
@@ -82,6 +83,7 @@ typedef struct sfq_params {
     uint32_t reserved[1];
 } sfq_params;
 #define SFQ_PRIOR_AUTO 0xFFFFFFFFu
+#define SFQ_BLOCK_AUTO 0xFFFFFFFFu
 
 /* One entry per block: what a decoder needs besides the stream bytes (the "block index").
  * The per-block stream bytes are the reference's streams for a FASTQ consisting of that block alone,

@@ -12,6 +12,7 @@ STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.
 M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
 PRIOR_AUTO = 0xFFFFFFFF
+BLOCK_AUTO = 0xFFFFFFFF
 
 EXPORTS = [
     "sfq_stream_name", "sfq_ctx_create", "sfq_ctx_destroy", "sfq_last_error", "sfq_ctx_set_table_budget",

@@ -323,6 +323,12 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
     launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, (u32*)ctx->status.p, st);
 
+    // SFQ_BLOCK_AUTO: blocks of about 376 KiB of text (1024 records of 150 bp; ~6 records of 60 kb): the unit of
+    // parallelism is the block, and a fixed record count would leave long-read inputs with a handful of huge blocks
+    if (p.block_reads == SFQ_BLOCK_AUTO) {
+        const u64 r = std::max<u64>(1, (376ull << 10) / std::max<u64>(1, nbytes / nrec));
+        p.block_reads = (u32)std::min<u64>(r >= 64 ? (r & ~63ull) : r, 4096);
+    }
     const u32 block_reads = p.block_reads ? p.block_reads : (u32)std::min<u64>(nrec, 0xFFFFFFFFu);
     const u64 nblocks64 = (nrec + block_reads - 1) / block_reads;
     if (nblocks64 > (1u << 24)) return fail(ctx, SFQ_E_ARG, "too many blocks (%llu)", (unsigned long long)nblocks64);

@@ -58,7 +58,8 @@ static void usage() {
            "-O               : silently overwrite existing files\n"
            "-l level         : compression level 1 to 4 (default is 3 ) \n"
            "-1, -2, -3, -4   : alias for -l 1, -l 2, etc \n"
-           "-B reads         : records per independent GPU block (default 1024; 0 = single block, reference-compatible file)\n"
+           "-B reads         : records per independent GPU block (default: about 376 KiB of text, i.e. 1024 reads of 150 bp;\n"
+           "                   0 = single block, reference-compatible file)\n"
            "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 2048)\n"
            "-g device        : HIP device index (default 0)\n"
            "-T percent       : share of the device memory this process may use for model tables (several processes on one GPU)\n"
@@ -76,7 +77,7 @@ static int level_gen_bits(int level) { switch (level) { case 1: return 18; case 
 
 struct Opts {
     int level = 3, device = 0;
-    long block_reads = 1024;
+    long block_reads = -1;                                             // -1 = automatic (about 376 KiB of text per block)
     bool overwrite = false, quiet = false;
     uint64_t slab_bytes = 2048ull << 20;
     int table_pct = 0;                                                 // -T: share of the device memory for model tables (0 = the library's default)
@@ -143,7 +144,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     }
     const bool legacy = o.block_reads == 0;
     sfq_params p; memset(&p, 0, sizeof p);
-    p.level = o.level; p.block_reads = (uint32_t)o.block_reads;
+    p.level = o.level; p.block_reads = o.block_reads < 0 ? SFQ_BLOCK_AUTO : (uint32_t)o.block_reads;
     p.prior_step = legacy ? 0 : SFQ_PRIOR_AUTO;                        // warm start needs the block format
 
     std::vector<uint8_t> streams[SFQ_NSTREAMS], first_all, prior_all;
@@ -226,7 +227,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         a.set("num_records", (long long)total_records);
         if (!o.quiet && b.extra_hi) a.set("qlt.extra.hi", b.extra_hi);
     } else {
-        a.set("blk.reads", o.block_reads);
+        a.set("blk.reads", (long long)blocks_all[0].n_records);            // of the first segment (each segment carries its own in the index)
         a.set("blk.count", (long long)blocks_all.size());
         a.set("num_records", (long long)total_records);
         if (segs.size() > 1) a.set("seg.count", (long long)segs.size());
@@ -374,7 +375,6 @@ int main(int argc, char** argv) {
         }
     }
     o.level = clamp_level(o.level);                                    // clamp at parse time (the reference records the clamped value only)
-    if (o.block_reads < 0) o.block_reads = 0;
 
     if (g_batch) {
         sfq_ctx* ctx = nullptr;

@@ -130,7 +130,7 @@ def main(argv=None):
     ap.add_argument("fastq")
     ap.add_argument("sfq")
     ap.add_argument("-l", "--level", type=int, default=3)
-    ap.add_argument("-B", "--block_reads", type=int, default=1024)
+    ap.add_argument("-B", "--block_reads", type=int, default=-1, help="records per block (default: automatic, about 376 KiB of text)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL when every rank has its own GPU, else gloo)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +151,8 @@ def main(argv=None):
     ctx = capi.Context(dev, table_budget=budget)
     part = dict(streams=[b""] * capi.NSTREAMS, blocks=[], first=b"", prior=b"", raw=len(text), records=0)
     if text:
-        enc = ctx.encode_host(text, level=args.level, block_reads=args.block_reads, prior_step=capi.PRIOR_AUTO)
+        enc = ctx.encode_host(text, level=args.level, block_reads=capi.BLOCK_AUTO if args.block_reads < 0 else args.block_reads,
+                              prior_step=capi.PRIOR_AUTO)
         part.update(streams=[enc.stream(s) for s in capi.STREAM_NAMES], blocks=list(enc.blocks), first=enc.first_hdrs,
                     prior=enc.prior, records=int(enc.res.n_records))
     if world > 1:
@@ -177,7 +178,8 @@ def main(argv=None):
     else:
         parts = [part]
     if rank == 0:
-        info, streams = assemble(parts, args.level, args.block_reads, args.fastq)
+        first = [p for p in parts if p["records"]]
+        info, streams = assemble(parts, args.level, int(first[0]["blocks"][0].n_records) if first else 0, args.fastq)
         write_archive(args.sfq, info, streams)
         raw = sum(p["raw"] for p in parts)
         print("%s: %d bytes -> %s: %d bytes of streams, %d segment(s)" % (args.fastq, raw, args.sfq, sum(len(s[1]) for s in streams),

@@ -17,7 +17,7 @@ overlaps one worker's file I/O with the other's kernels.
       -g, --gpus LIST         HIP device indices to use, default: all visible
       -e, --exec PATH         slimfastq-amd executable (default: slimfastq_amd/bin/slimfastq-amd)
       -l, --level N           compression level 1..4 (default 3)
-      -B, --block_reads N     records per block (default 1024)
+      -B, --block_reads N     records per block (default: automatic, about 376 KiB of text per block)
       -O, --overwrite         replace existing targets (default: skip them, like the reference script)
       -v, --verbose
 """
@@ -120,7 +120,7 @@ def main(argv=None):
     ap.add_argument("-g", "--gpus", default="")
     ap.add_argument("-e", "--exec", dest="exe", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "slimfastq-amd"))
     ap.add_argument("-l", "--level", type=int, default=3)
-    ap.add_argument("-B", "--block_reads", type=int, default=1024)
+    ap.add_argument("-B", "--block_reads", type=int, default=-1)
     ap.add_argument("-O", "--overwrite", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
     args = ap.parse_args(argv)
@@ -152,7 +152,8 @@ def main(argv=None):
         jobs.put((src, dst))
     gpus = [int(g) for g in args.gpus.split(",") if g.strip() != ""] or visible_gpus()
     nworkers = max(1, min(args.count or len(gpus), jobs.qsize()))
-    cmd = [args.exe, "-b", "-l", str(args.level), "-B", str(args.block_reads)] + (["-d"] if args.decompress else []) + (["-O"] if args.overwrite else [])
+    cmd = [args.exe, "-b", "-l", str(args.level)] + (["-B", str(args.block_reads)] if args.block_reads >= 0 else []) + \
+          (["-d"] if args.decompress else []) + (["-O"] if args.overwrite else [])
     per_gpu = (nworkers + len(gpus) - 1) // len(gpus)
     if per_gpu > 1:                                  # workers sharing a GPU share its memory: model tables take most of it
         cmd += ["-T", str(max(5, 60 // per_gpu))]

@@ -522,3 +522,16 @@ def test_fuzz_other_kernel_variants(ctx, kernel):
             enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=prior_step, kernel=kernel)
             assert bytes(enc.data) == bytes(ref.data) and enc.prior == ref.prior, "kernel %d rep %d prior %d" % (kernel, rep, prior_step)
             assert [list(b.size) for b in enc.blocks] == [list(b.size) for b in ref.blocks]
+
+
+def test_automatic_block_size_follows_the_text(ctx):
+    """SFQ_BLOCK_AUTO sizes blocks by bytes of text (about 376 KiB): 1024 records of 150 bp, a handful of long reads --
+    a fixed record count would leave a long-read file with a few huge blocks and the chip idle."""
+    fq = capi.synth_fastq(5000, 150, seed=4)
+    enc = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO)
+    assert enc.blocks[0].n_records == 1024 and len(enc.blocks) == 5
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    lr = capi.synth_fastq(300, 150, seed=4, kind=1)                   # 10-50 kb reads
+    enc = ctx.encode_host(lr, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO)
+    assert 2 <= enc.blocks[0].n_records <= 16 and len(enc.blocks) >= 300 // 16
+    assert ctx.decode_host(enc, level=3, out_cap=len(lr) + 4096) == lr
