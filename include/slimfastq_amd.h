@@ -79,6 +79,7 @@ typedef struct sfq_params {
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);
                               N > 0 = warm start: quality rows start from a prior counted over every N-th record
+                              (its first 4096 quality symbols)
                               (SFQ_PRIOR_AUTO picks N from the input size)                                      */
     uint32_t reserved[1];
 } sfq_params;

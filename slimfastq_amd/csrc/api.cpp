@@ -362,11 +362,16 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     u32 prior_step = p.block_reads ? p.prior_step : 0;
     // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
-    if (prior_step == SFQ_PRIOR_AUTO) prior_step = (u32)std::min<u64>(std::max<u64>(1, (nbytes / 2) / 60000000ull), 0x7FFFFFFFull);
+    // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
+    //  the longest walk)
+    if (prior_step == SFQ_PRIOR_AUTO) {
+        const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
+        prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 60000000ull), 0x7FFFFFFFull);
+    }
     if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
-        launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, (u32*)ctx->hist.p, st);
+        launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
         h_rows66.resize((size_t)q_rows * 66);

@@ -91,6 +91,7 @@ void launch_gather_first_hdrs(const BlockDesc* blocks, u32 nblocks, const u8* fq
 
 // quality prior (prior.hip)
 void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
-                     int level, u32* hist, hipStream_t st);
+                     int level, u32 cap /* symbols counted per sampled record */, u32* hist, hipStream_t st);
+#define PRIOR_SYMBOLS 4096u
 void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);
 void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);

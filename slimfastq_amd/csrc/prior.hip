@@ -3,7 +3,8 @@
 // The reference keeps ONE adaptive state per file, so cutting a file into independent blocks costs it
 // its learning again in every block (+25 % on the quality stream at 1024-record blocks).  Format 7 lets
 // every block start from a shared PRIOR instead of from all-zero rows:
-//   1. histogram: count (context, symbol) over a sample of the records       -- parallel, atomics
+//   1. histogram: count (context, symbol) over a sample of the records (the first PRIOR_SYMBOLS of each: the
+//                 prior is transmitted, so any deterministic sample will do)      -- parallel, atomics
 //   2. rows     : per context, symbols ordered by count and frequencies scaled -- one wave per context
 // The prior is stored once in the archive ("qlt.pri"); encoder and decoder build identical tables from
 // it, and a block's first touch of a row copies the prior row instead of starting from zero.  With it a
@@ -35,7 +36,7 @@ __device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 ke
 template <u32 THREADS, u32 READS_PER_LANE>
 __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq, u64 nbytes, const u64* __restrict__ line_off,
                                                  const BlockDesc* __restrict__ blocks, u32 block_reads,
-                                                 u64 nrec, u32 step, int level, u32* __restrict__ hist) {
+                                                 u64 nrec, u32 step, int level, u32 cap, u32* __restrict__ hist) {
     __shared__ u32 keys[HIST_SLOTS];
     __shared__ u32 cnts[HIST_SLOTS];
     for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
         if (r >= nrec) break;
         const u32 solid = blocks[r / block_reads].solid;
         const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
-        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u32 nfull = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u32 n = nfull < cap ? nfull : cap;             // the head of a long record stands for the rest
         // read the line as aligned dwords, four at a time: one memory latency per 16 symbols
         const u64 a0 = q0 & ~3ull;
         const u32 skip = (u32)(q0 - a0);
@@ -81,15 +83,15 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
     for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) if (cnts[i]) atomicAdd(&hist[keys[i]], cnts[i]);
 }
 void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
-                     int level, u32* hist, hipStream_t st) {
+                     int level, u32 cap, u32* hist, hipStream_t st) {
     const u64 nsamp = (nrec + step - 1) / step;
     // long records (one lane walks a whole record): few records per workgroup, so that many workgroups share the work
     if (nbytes / (nrec ? nrec : 1) > 4000) {
         const u64 per_wg = 64;
-        hipLaunchKernelGGL((k_qlt_hist<64, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(64), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
+        hipLaunchKernelGGL((k_qlt_hist<64, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(64), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     } else {
         const u64 per_wg = 256ull * 4;
-        hipLaunchKernelGGL((k_qlt_hist<256, 4>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, hist);
+        hipLaunchKernelGGL((k_qlt_hist<256, 4>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     }
 }
 

@@ -9,6 +9,7 @@ from slimfastq_amd import capi
 
 pytestmark = pytest.mark.gpu
 LEVEL_BITS = {1: 18, 2: 22, 3: 24, 4: 26}
+PRIOR_SYMBOLS = 4096      # the prior counts the first 4096 quality symbols of every sampled record (kernels.h)
 KERNELS = (0, 1, 2, 3, 4)  # 0 = default kernels, 1 = lane-per-block, 2 = wave-per-row quality, 3 = split model / lane-per-block coder,
                            # 4 = one block per wave in the quality kernel
 
@@ -233,7 +234,7 @@ def test_warm_start_prior_matches_oracle_rule(ctx, level, kernel):
     enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel, prior_step=step)
     starts, lens = util.line_table(fq)
     qoff, qlen = starts[3::4], lens[3::4]
-    counts = O.qlt_histogram(fq, qoff, qlen, level, 0, step)
+    counts = O.qlt_histogram(fq, qoff, np.minimum(qlen, PRIOR_SYMBOLS), level, 0, step)
     rows = O.qlt_prior_rows(counts)
     got_rows = util.unpack_prior(enc.prior, 4096 if level == 1 else 65536)
     assert np.array_equal(got_rows, rows)
@@ -253,15 +254,15 @@ def test_warm_start_prior_matches_oracle_rule(ctx, level, kernel):
 
 
 def test_warm_start_with_escapes_and_real_samples(ctx):
-    for name in ("tst1", "fast5.to", "badqlt", "edge_hiq"):
-        fq = util.golden_fastq(name)
+    for name in ("tst1", "fast5.to", "badqlt", "edge_hiq", "synthetic long reads"):
+        fq = capi.synth_fastq(40, 150, seed=8, kind=1) if name.startswith("synthetic") else util.golden_fastq(name)
         nrec = fq.count(b"\n") // 4
         br = max(2, nrec // 9)
         enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=1)
         starts, lens = util.line_table(fq)
         solid = enc.blocks[0].solid
         qoff, qlen = starts[3::4] + solid, lens[3::4] - solid
-        rows = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, qlen, 3, 0, 1))
+        rows = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, np.minimum(qlen, PRIOR_SYMBOLS), 3, 0, 1))
         want, _ = O.qlt_encode_blocks(fq, qoff, qlen, 3, br, rows)
         assert enc.stream("qlt") == want, name
         assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq, name
@@ -292,7 +293,7 @@ def test_warm_start_prior_with_heavily_scaled_counts(ctx):
     fq = capi.synth_fastq(40000, 150, seed=77)
     enc = ctx.encode_host(fq, level=3, block_reads=2500, prior_step=1)
     starts, lens = util.line_table(fq)
-    rows = O.qlt_prior_rows(O.qlt_histogram(fq, starts[3::4], lens[3::4], 3, 0, 1))
+    rows = O.qlt_prior_rows(O.qlt_histogram(fq, starts[3::4], np.minimum(lens[3::4], PRIOR_SYMBOLS), 3, 0, 1))
     assert int(((rows[:, :64] & 0xffff) == 0).sum()) > 0 and int(rows[:, 64].max()) > 30000
     assert np.array_equal(util.unpack_prior(enc.prior, 65536), rows)
     want, _ = O.qlt_encode_blocks(fq, starts[3::4], lens[3::4], 3, 2500, rows)
