@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SFQ_ABI_VERSION 1
+#define SFQ_ABI_VERSION 2
 
 /* status codes */
 #define SFQ_OK              0
@@ -69,20 +69,25 @@ typedef struct sfq_params {
                               text per block (1024 records of 150 bp, a handful of long reads)            */
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
-    uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (slow, for cross-checks);
-                              2 = wave-per-row quality kernel (the earlier default, kept for A/B runs);
-                              3 = split form: the model kernels park their (cum, freq, tot) triples and a second
-                              kernel runs the range coder one block per lane (measured slower, DESIGN.md section 4;
-                              falls back to 0 by itself when a block's triples do not fit their scratch);
-                              4 = one block per wave in the quality kernel (the earlier default)                */
+    uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (the reference loop on one lane:
+                              slow, the cross-check of the default kernels)                                       */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);
                               N > 0 = warm start: quality rows start from a prior counted over every N-th record
                               (its first 4096 quality symbols)
-                              (SFQ_PRIOR_AUTO picks N from the input size)                                      */
-    uint32_t reserved[1];
+                              (SFQ_PRIOR_AUTO picks N from the input size; frozen tables always have a prior)       */
+    uint32_t tables;       /* block mode only: SFQ_TABLES_ADAPTIVE (0) = every block runs the reference's adaptive rows
+                              (Log64Ranger / Base2Ranger updated per symbol), a wavefront per block;
+                              SFQ_TABLES_FROZEN (1) = the rows are built by counting passes and frozen while a chain
+                              is coded -- qualities from the transmitted prior, bases from the counts of the earlier
+                              generations of the same call -- one chain per LANE               */
+    uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic                                    */
+    uint32_t lds_rows;     /* frozen tables: quality rows staged in LDS per workgroup (0 = 255, SFQ_LDS_ROWS_NONE = none) */
 } sfq_params;
+#define SFQ_TABLES_ADAPTIVE 0u
+#define SFQ_TABLES_FROZEN   1u
+#define SFQ_LDS_ROWS_NONE  0xFFFFFFFFu
 #define SFQ_PRIOR_AUTO 0xFFFFFFFFu
 #define SFQ_BLOCK_AUTO 0xFFFFFFFFu
 
@@ -113,6 +118,8 @@ typedef struct sfq_result {
     uint64_t stream_offset[SFQ_NSTREAMS];  /* per stream: where its block-concatenation starts in d_out */
     uint64_t total_bytes;                  /* bytes used in d_out                                  */
     uint64_t first_hdr_bytes;              /* size of the first-header blob (see sfq_get_first_headers) */
+    uint32_t n_chains;                     /* frozen tables: chains per chain-coded stream (else 0)   */
+    uint32_t reserved;
     double   kernel_ms[8];                 /* device time of the last call, by phase (see SFQ_T_*) */
 } sfq_result;
 
@@ -164,6 +171,11 @@ int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
 int64_t sfq_get_qlt_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
 /* Install the prior the next sfq_decode_blocks call must start its quality rows from (n = 0: cold). */
 int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n);
+/* Frozen tables: the chain index of the LAST encode call (the "chn.idx" stream: records per chain, flags, and the size
+ * of every chain's qlt and gen stream); returns its size, copies it if cap allows; 0 = the call used adaptive tables.
+ * A decoder installs it before sfq_decode_blocks (n = 0: the archive has none, i.e. adaptive tables). */
+int64_t sfq_get_chain_index(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
+int sfq_set_chain_index(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n);
 
 /* ---- decompress ----------------------------------------------------------------------------
  * Replaces UsrLoad::decode()'s loop (usrs.cpp:555-571: rec.load / qlt.load / gen.load / save).

@@ -13,19 +13,22 @@ M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
 PRIOR_AUTO = 0xFFFFFFFF
 BLOCK_AUTO = 0xFFFFFFFF
+TABLES_ADAPTIVE, TABLES_FROZEN = 0, 1
+LDS_ROWS_NONE = 0xFFFFFFFF
 
 EXPORTS = [
     "sfq_stream_name", "sfq_ctx_create", "sfq_ctx_destroy", "sfq_last_error", "sfq_ctx_set_table_budget",
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
-    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory",
+    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index",
 ]
 
 
 class Params(C.Structure):
     _fields_ = [("level", C.c_int32), ("block_reads", C.c_uint32), ("gen_bits", C.c_int32), ("models", C.c_uint32),
-                ("kernel", C.c_uint32), ("version", C.c_uint32), ("prior_step", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("kernel", C.c_uint32), ("version", C.c_uint32), ("prior_step", C.c_uint32), ("tables", C.c_uint32),
+                ("chain_reads", C.c_uint32), ("lds_rows", C.c_uint32)]
 
 
 class BlockInfo(C.Structure):
@@ -38,7 +41,8 @@ class BlockInfo(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_blocks", C.c_uint32), ("abi_version", C.c_uint32),
                 ("stream_bytes", C.c_uint64 * NSTREAMS), ("stream_offset", C.c_uint64 * NSTREAMS),
-                ("total_bytes", C.c_uint64), ("first_hdr_bytes", C.c_uint64), ("kernel_ms", C.c_double * 8)]
+                ("total_bytes", C.c_uint64), ("first_hdr_bytes", C.c_uint64), ("n_chains", C.c_uint32), ("reserved", C.c_uint32),
+                ("kernel_ms", C.c_double * 8)]
 
 
 class SfqError(RuntimeError):
@@ -102,6 +106,9 @@ def lib():
         L.sfq_get_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_qlt_prior.restype = C.c_int64
         L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
+        L.sfq_get_chain_index.argtypes = [vp, u8p, u64]
+        L.sfq_get_chain_index.restype = C.c_int64
+        L.sfq_set_chain_index.argtypes = [vp, u8p, u64]
         L.sfq_synth_fastq.argtypes = [u64, u64, C.c_uint32, u64, C.c_int, u8p, u64]
         L.sfq_synth_fastq.restype = C.c_int64
         L.sfq_archive_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(u64)]
@@ -127,8 +134,8 @@ def synth_fastq(n_reads, read_len=150, seed=1, kind=0, first_read=0) -> bytes:
 class Encoded:
     """Host copy of one sfq_encode_blocks result."""
 
-    def __init__(self, res, blocks, first_hdrs, data, prior=b""):
-        self.res, self.blocks, self.first_hdrs, self.data, self.prior = res, blocks, first_hdrs, data, prior
+    def __init__(self, res, blocks, first_hdrs, data, prior=b"", chains=b""):
+        self.res, self.blocks, self.first_hdrs, self.data, self.prior, self.chains = res, blocks, first_hdrs, data, prior, chains
 
     def stream(self, s, block=None) -> bytes:
         """Bytes of stream s (an id or a name): the whole concatenation, or one block's part."""
@@ -148,7 +155,7 @@ class Encoded:
     @property
     def archive_bytes(self):
         """Everything a decoder needs: streams + first headers + quality prior + ~the block index."""
-        return int(self.res.total_bytes) + len(self.first_hdrs) + len(self.prior) + 14 * len(self.blocks)
+        return int(self.res.total_bytes) + len(self.first_hdrs) + len(self.prior) + len(self.chains) + 14 * len(self.blocks)
 
 
 class Context:
@@ -199,9 +206,18 @@ class Context:
         lib().sfq_get_qlt_prior(self._h, buf, n)
         return buf.raw[:n]
 
-    def encode_host(self, fastq: bytes, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, prior_step=0) -> Encoded:
+    def chains(self) -> bytes:
+        n = lib().sfq_get_chain_index(self._h, None, 0)
+        if n <= 0:
+            return b""
+        buf = C.create_string_buffer(n)
+        lib().sfq_get_chain_index(self._h, buf, n)
+        return buf.raw[:n]
+
+    def encode_host(self, fastq: bytes, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, prior_step=0, tables=0,
+                    chain_reads=0, lds_rows=0) -> Encoded:
         L = lib()
-        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step)
+        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step, tables, chain_reads, lds_rows)
         res = Result()
         cap = L.sfq_encode_bound(len(fastq))
         out = np.empty(cap, np.uint8)
@@ -209,23 +225,25 @@ class Context:
         self._check(L.sfq_encode_blocks_host(self._h, src.ctypes.data_as(C.c_void_p), len(fastq), C.byref(p),
                                              out.ctypes.data_as(C.c_void_p), cap, C.byref(res)))
         blocks = self.index(res.n_blocks)
-        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy(), self.prior())
+        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy(), self.prior(), self.chains())
 
     def encode_device(self, d_ptr, nbytes, d_out, out_cap, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, qlt_only=False,
-                      prior_step=0):
+                      prior_step=0, tables=0, chain_reads=0, lds_rows=0):
         """Device-pointer entry point (ints from torch .data_ptr()). Returns the Result struct."""
         L = lib()
-        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step)
+        p = Params(level, block_reads, gen_bits, models, kernel, 0, prior_step, tables, chain_reads, lds_rows)
         res = Result()
         f = L.sfq_encode_qlt_blocks if qlt_only else L.sfq_encode_blocks
         self._check(f(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p), C.c_void_p(d_out), out_cap, C.byref(res)))
         return res
 
-    def decode_device(self, blocks, first_hdrs: bytes, d_streams, stream_offset, d_out, out_cap, prior=b"", level=3, version=0):
+    def decode_device(self, blocks, first_hdrs: bytes, d_streams, stream_offset, d_out, out_cap, prior=b"", level=3, version=0,
+                      chains=b"", lds_rows=0):
         """Device-pointer decode (ints from torch .data_ptr()): returns (bytes written, Result)."""
         L = lib()
         self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
-        p = Params(level, 0, 0, 0, 0, version)
+        self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
+        p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, lds_rows)
         res = Result()
         n = C.c_uint64()
         fb = np.frombuffer(first_hdrs if len(first_hdrs) else b"\0", np.uint8)
@@ -237,18 +255,21 @@ class Context:
     def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()
-        prior = b""
+        prior = chains = b""
         if isinstance(enc_or_parts, Encoded):
-            blocks, first, data, prior = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data, enc_or_parts.prior
+            blocks, first, data, prior, chains = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data, enc_or_parts.prior, enc_or_parts.chains
             soff = (C.c_uint64 * NSTREAMS)(*list(enc_or_parts.res.stream_offset))
         else:
             blocks, first, data, so = enc_or_parts[:4]
             if len(enc_or_parts) > 4:
                 prior = enc_or_parts[4]
+            if len(enc_or_parts) > 5:
+                chains = enc_or_parts[5]
             soff = (C.c_uint64 * NSTREAMS)(*so)
         self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
+        self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
-        p = Params(level, 0, 0, 0, 0, version)
+        p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, 0)
         res = Result()
         if out_cap is None:
             out_cap = 64 * len(data) + (1 << 20)

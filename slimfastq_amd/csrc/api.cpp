@@ -47,8 +47,9 @@ struct sfq_ctx {
     DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
-    // parked triples of the split kernels
-    DevBuf trip_q, trip_g, ntrip;
+    // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
+    DevBuf qw, qmap, qrows, qtot, qesc, csz, coff, gcnt, grows, glog, gcost;
+    std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
@@ -92,9 +93,8 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     u64 fit = ctx->table_budget / per;
     if (fit == 0) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B too small for one block slot (%llu B)",
                               (unsigned long long)ctx->table_budget, (unsigned long long)per);
-    u32 cap = 12288;
-    if (const char* e = getenv("SFQ_MAX_SLOTS")) cap = (u32)std::max(8, atoi(e));      // experiment hook
-    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), cap);      // the chip holds 8192 waves; the multi-chain base kernel takes 2 slots per wave
+    const u32 cap = 12288;                                              // the chip holds 8192 waves; the two-block kernels take 2 slots per wave
+    u32 slots = (u32)std::min<u64>(std::min<u64>(want, fit), cap);
     Tables& t = ctx->tab;
     // Row tables are epoch-tagged and epochs only grow, so stale rows of any earlier geometry can never
     // match: slot storage needs no clearing, and a header array is zeroed only when it is (re)allocated.
@@ -211,6 +211,117 @@ int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
     return SFQ_OK;
 }
 
+// ---- frozen tables: host-side pieces -------------------------------------------------------------------------
+// Dense quality rows: contexts that have a prior row get ids 1.., hottest first (the first q_hot ids are staged in
+// LDS); id 0 is the uniform row of contexts the sample never saw.  The numbering is internal to a call.
+int build_qmap(sfq_ctx* ctx, const std::vector<u32>& weight, u32 q_rows, u32* nrows_out, hipStream_t st) {
+    std::vector<u32> order;
+    for (u32 c = 0; c < q_rows; c++) if (weight[c]) order.push_back(c);
+    if (order.size() > 65535) return fail(ctx, SFQ_E_UNSUPPORTED, "quality prior has %zu rows (more than 65535)", order.size());
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return weight[x] > weight[y]; });
+    std::vector<u16> map(q_rows, 0);
+    for (size_t i = 0; i < order.size(); i++) map[order[i]] = (u16)(i + 1);
+    int rc;
+    const u32 nrows = (u32)order.size() + 1;
+    if ((rc = reserve(ctx, ctx->qmap, (size_t)q_rows * 2))) return rc;
+    if ((rc = reserve(ctx, ctx->qrows, (size_t)nrows * 64 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->qtot, (size_t)nrows * 8))) return rc;
+    HIPC(hipMemcpyAsync(ctx->qmap.p, map.data(), (size_t)q_rows * 2, hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));                      // `map` is a local
+    *nrows_out = nrows;
+    return SFQ_OK;
+}
+// the escape row (qualities >= 63, qlts.cpp:80-86): all 256 values equally likely
+int build_qesc(sfq_ctx* ctx, hipStream_t st) {
+    int rc;
+    if ((rc = reserve(ctx, ctx->qesc, 256 * 4))) return rc;
+    u32 row[256];
+    for (u32 i = 0; i < 256; i++) row[i] = i | (1u << 16);
+    HIPC(hipMemcpyAsync(ctx->qesc.p, row, sizeof row, hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return SFQ_OK;
+}
+u32 recip_host(u32 tot) { return tot <= 1 ? 0xFFFFFFFFu : (u32)((1ull << 32) / tot); }
+// floor(1024 * log2(x)) for x in 1..1023, by integer arithmetic alone (squaring a 1.31 fixed-point mantissa)
+void log2_table(u16* t) {
+    t[0] = 0;
+    for (u32 x = 1; x < 1024; x++) {
+        u32 e = 31 - (u32)__builtin_clz(x);
+        u64 m = (u64)x << (31 - e);                       // mantissa in [2^31, 2^32)
+        u32 frac = 0;
+        for (int i = 0; i < 10; i++) {
+            m = (m * m) >> 31;                            // in [2^31, 2^33)
+            frac <<= 1;
+            if (m >> 32) { frac |= 1; m >>= 1; }
+        }
+        t[x] = (u16)(e * 1024 + frac);
+    }
+}
+// generations of the base model: blocks [bound[g], bound[g + 1]); the first is 1/64 of the blocks, each next one as long as
+// all before it (GEN_GROW_NUM / GEN_GROW_DEN of them)
+#define GEN_GROW_NUM 3
+#define GEN_GROW_DEN 2
+u32 gen_bounds(u32 nblocks, u32* bound) {
+    u32 n = 0; bound[0] = 0;
+    u64 b = std::max<u32>(1, (nblocks + 63) / 64);
+    while (b < nblocks && n + 2 < GEN_MAX_GENERATIONS) { bound[++n] = (u32)b; b = std::max<u64>(b + 1, b * GEN_GROW_NUM / GEN_GROW_DEN); }
+    bound[++n] = nblocks;
+    return n;                                              // number of generations
+}
+int default_chain_reads(u64 nrec, u64 nbytes) {
+    // chains are the unit of parallelism (64 per wavefront): aim at ~128 k of them, at least 16 KiB of text each
+    const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
+    u64 cr = std::max<u64>(1, nrec / 131072);
+    cr = std::max<u64>(cr, (16384 + per_rec - 1) / per_rec);
+    return (int)std::min<u64>(cr, 4096);
+}
+// Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
+// of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
+// Leaves ca.g_* describing which rows every generation codes with.
+int gen_tables_encode(sfq_ctx* ctx, ChainArgs& ca, u32 nblocks, u32 g_bits, hipStream_t st, u32* gen_on) {
+    *gen_on = 0;
+    ca.g_ngen = 0;
+    u32 bound[GEN_MAX_GENERATIONS + 1];
+    const u32 ngen = gen_bounds(nblocks, bound);
+    if (ngen < 3) return SFQ_OK;                                   // too few blocks to learn from
+    const u64 nctx = 1ull << g_bits;
+    int rc;
+    if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;
+    if ((rc = reserve(ctx, ctx->grows, (size_t)nctx * 4 * ngen))) return rc;
+    if ((rc = reserve(ctx, ctx->gcost, 64))) return rc;
+    if (!ctx->glog.p) {
+        if ((rc = reserve(ctx, ctx->glog, 1024 * 2))) return rc;
+        u16 t[1024]; log2_table(t);
+        HIPC(hipMemcpyAsync(ctx->glog.p, t, sizeof t, hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    HIPC(hipMemsetAsync(ctx->gcnt.p, 0, (size_t)nctx * 16, st));
+    HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
+    const u64 br = ca.block_reads;
+    auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };          // an upper bound (the last block may be short): lanes past the end idle
+    u32* rows = (u32*)ctx->grows.p;
+    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
+    launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
+    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
+    u64 h[2] = {0, 0};
+    // bases of generation 1: counted on the device as cost[1]?  cheaper: the host knows the text span; use the cost of the
+    // initial row instead -- 2 bits per base = 2048 units -- by letting the kernel report the base count
+    HIPC(hipMemcpyAsync(h, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    const u64 cost = h[0], nbases = h[1];
+    if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // no gain: every chain codes with the initial row
+    *gen_on = 1;
+    ca.g_ngen = ngen;
+    for (u32 g = 0; g <= ngen; g++) ca.g_bound[g] = bound[g];
+    ca.g_rows[0] = nullptr; ca.g_rows[1] = nullptr;                             // generations 0 and 1: the initial row
+    for (u32 g = 2; g < ngen; g++) {
+        launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * g, nctx, GEN_STEP, st);         // counts of generations < g
+        ca.g_rows[g] = rows + nctx * g;
+        if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
+    }
+    return SFQ_OK;
+}
+
 float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 }  // namespace
@@ -232,18 +343,9 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     if (hipSetDevice(hip_device) != hipSuccess) return SFQ_E_HIP;
     sfq_ctx* ctx = new sfq_ctx();
     ctx->dev = hip_device;
-    // queue priorities of the four model streams (quality, bases, headers, framing): experiment hook SFQ_PRIO="q,g,r,u",
-    // each -1 (high), 0, 1 (low)
-    int prio[4] = { 0, 0, 0, 0 };
-    if (const char* e = getenv("SFQ_PRIO")) sscanf(e, "%d,%d,%d,%d", &prio[0], &prio[1], &prio[2], &prio[3]);
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    auto mk = [&](hipStream_t* s, int pr) {
-        const int v = pr < 0 ? greatest : pr > 0 ? least : (least + greatest) / 2;
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, v);
-    };
-    if (mk(&ctx->st, prio[0]) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
-    for (int i = 0; i < 3; i++) if (mk(&ctx->st_aux[i], prio[i + 1]) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    // one stream per model (quality, bases, headers, framing); stream priorities were measured to change nothing
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    for (int i = 0; i < 3; i++) if (hipStreamCreateWithFlags(&ctx->st_aux[i], hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
@@ -264,7 +366,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->trip_q, &ctx->trip_g, &ctx->ntrip };
+        &ctx->qw, &ctx->qmap, &ctx->qrows, &ctx->qtot, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -287,8 +389,7 @@ uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
 // -------------------------------------------------------------------------------------------------
 // compress
 // -------------------------------------------------------------------------------------------------
-#define RETRY_FUSED 1   // encode_core: a block's triples did not fit their scratch region; repeat with the fused kernels
-static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
                        sfq_result* res, u32 force_models) {
     if (!ctx || !d_fastq || !pp || !d_out || !res) return fail(ctx, SFQ_E_ARG, "null argument");
     if (nbytes == 0) return fail(ctx, SFQ_E_FORMAT, "empty input");
@@ -296,6 +397,7 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
+    if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
     memset(res, 0, sizeof *res);
     res->abi_version = SFQ_ABI_VERSION;
     hipStream_t st = ctx->st;
@@ -335,9 +437,11 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     const u32 nblocks = (u32)nblocks64;
     // base-model context bits: the level's in single-block mode (reference parity); otherwise capped so a
     // block's table is not much larger than the block (a block cannot fill more contexts than it has bases)
+    const bool frozen = p.tables == SFQ_TABLES_FROZEN && p.block_reads != 0 && p.kernel == 0;
     int g_bits = p.gen_bits ? p.gen_bits : level_gen_bits(p.level);
     if (!p.gen_bits && p.block_reads) {
-        const double bases = (double)block_reads * ((double)nbytes / (double)nrec) * 0.5;
+        // (frozen tables: one table for the whole call, so the cap follows the call's bases, not the block's)
+        const double bases = (frozen ? (double)nrec : (double)block_reads) * ((double)nbytes / (double)nrec) * 0.5;
         int cap = 12;
         while (cap < 26 && (double)(1u << cap) < bases) cap += 2;
         g_bits = std::min(g_bits, cap);
@@ -358,8 +462,10 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // warm start (format 7 only): count a sample, build the prior rows, keep a host copy for "qlt.pri"
     ctx->prior_on = false;
     ctx->prior_blob.clear();
+    ctx->chain_blob.clear();
     std::vector<u32> h_rows66;
     u32 prior_step = p.block_reads ? p.prior_step : 0;
+    if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
     // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
     // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
@@ -379,31 +485,57 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
+    // frozen tables: chain geometry, dense quality rows
+    ChainArgs ca;
+    memset(&ca, 0, sizeof ca);
+    u32 nchains = 0;
+    if (frozen) {
+        const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
+        ca.geo.chain_reads = std::min(cr, block_reads);
+        ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
+        const u32 last_nrec = (u32)(nrec - (u64)(nblocks - 1) * block_reads);
+        const u64 nc = (u64)(nblocks - 1) * ca.geo.cpb + (last_nrec + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
+        if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
+        nchains = ca.geo.nchains = (u32)nc;
+        ca.nbytes = nbytes; ca.block_reads = block_reads;
+        if ((rc = reserve(ctx, ctx->csz, (size_t)nchains * 2 * 4))) return rc;
+        if (models & SFQ_M_QLT) {
+            if ((rc = reserve(ctx, ctx->qw, (size_t)q_rows * 4))) return rc;
+            launch_row_weights((const u32*)ctx->hist.p, q_rows, (u32*)ctx->qw.p, st);
+            std::vector<u32> w(q_rows);
+            HIPC(hipMemcpyAsync(w.data(), ctx->qw.p, (size_t)q_rows * 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            u32 nrows = 0;
+            if ((rc = build_qmap(ctx, w, q_rows, &nrows, st))) return rc;
+            if ((rc = build_qesc(ctx, st))) return rc;
+            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (const u16*)ctx->qmap.p, (u32*)ctx->qrows.p, (uint2*)ctx->qtot.p, st);
+            ca.qmap = (const u16*)ctx->qmap.p; ca.qrows = (const u32*)ctx->qrows.p; ca.qtot = (const uint2*)ctx->qtot.p;
+            ca.q_hot = std::min<u32>(nrows, p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : (p.lds_rows ? p.lds_rows : 255u));
+            if (ca.q_hot > 255) ca.q_hot = 255;
+            ca.qesc = (const u32*)ctx->qesc.p; ca.qesc_tot = make_uint2(256u, recip_host(256u));
+            HIPC(hipEventRecord(ctx->ev[1], st));
+        }
+    }
     u32 slots = 0;
-    const u32 KR = 8;                                                  // the multi-chain kernels take table slots in groups of up to 8
+    const u32 KR = 2;                                                  // the default kernels take table slots in pairs (two blocks per wave)
     const u32 nblocks_r = (nblocks + KR - 1) / KR * KR;
-    if ((rc = ensure_tables(ctx, nblocks_r, q_rows, (u32)g_bits, models, &slots))) return rc;
-    if (slots >= KR) slots &= ~(KR - 1);
+    if ((rc = ensure_tables(ctx, nblocks_r, q_rows, (u32)g_bits, frozen ? (models & ~(SFQ_M_QLT | SFQ_M_GEN)) : models, &slots))) return rc;
+    if (p.kernel == 0) {
+        if (slots < KR) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B holds %u block slot(s); the kernels need %u", (unsigned long long)ctx->table_budget, slots, KR);
+        slots &= ~(KR - 1);
+    }
     if ((rc = advance_epoch(ctx, nblocks))) return rc;
     ModelArgs a;
     fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
     a.fq = d_fastq;
-    const bool split = p.kernel == 3;
-    if (split) {
-        // 8 bytes per quality triple, 4 per base triple, at most one of each per two text bytes (dev_common.h trip_base)
-        if (models & SFQ_M_QLT) { if ((rc = reserve(ctx, ctx->trip_q, ((size_t)nbytes / 2 + 8) * 8))) return rc; a.trip_q = (u64*)ctx->trip_q.p; }
-        if (models & SFQ_M_GEN) { if ((rc = reserve(ctx, ctx->trip_g, ((size_t)nbytes / 2 + 8) * 4))) return rc; a.trip_g = (u32*)ctx->trip_g.p; }
-        if ((rc = reserve(ctx, ctx->ntrip, (size_t)nblocks * 8))) return rc;
-        a.ntrip_q = (u32*)ctx->ntrip.p; a.ntrip_g = a.ntrip_q + nblocks;
-    }
     // The four models are independent chains over the same text: each runs on its own HIP stream, forked
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
-    u32 order[4] = { SFQ_M_QLT, SFQ_M_GEN, SFQ_M_REC, SFQ_M_USR };
-    if (const char* e = getenv("SFQ_ORDER")) {         // experiment hook: launch order of the model kernels, e.g. "rgq"
-        for (int i = 0; i < 3 && e[i]; i++) order[i] = e[i] == 'q' ? SFQ_M_QLT : e[i] == 'g' ? SFQ_M_GEN : SFQ_M_REC;
-    }
+    // (frozen tables: the base model's generation tables need one host decision in the middle, so bases go last)
+    const u32 order[4] = { SFQ_M_QLT, frozen ? SFQ_M_REC : SFQ_M_GEN, SFQ_M_USR, frozen ? SFQ_M_GEN : SFQ_M_REC };
+    const int tslot[4] = { SFQ_T_QLT, frozen ? SFQ_T_REC : SFQ_T_GEN, SFQ_T_USR, frozen ? SFQ_T_GEN : SFQ_T_REC };
+    u32 gen_on = 0;
     hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
-    // Default kernels are persistent: one workgroup per table slot, blocks handed out through ticket counters.
+    // Default kernels are persistent: one workgroup per pair of table slots, blocks handed out through ticket counters.
     // The lane-per-block reference kernels (kernel = 1, and usr) run in batches of `slots` blocks.
     if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
     HIPC(hipMemsetAsync(ctx->tickets.p, 0, 64, st));
@@ -422,25 +554,22 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 // would run one after the other.  When all three models run, the two-block quality and base kernels
                 // keep to a third of the wave slots each (2 table slots per wave) and the header kernel's workgroups
                 // fill whatever is free: the three overlap from the start (measured: 225 -> 207 ms at 10 M reads).
-                if (p.kernel == 0 && (models & (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC)) == (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC) &&
-                    (order[m] == SFQ_M_QLT || order[m] == SFQ_M_GEN) && slots >= KR)
-                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * (order[m] == SFQ_M_GEN ? (u32)gen_chains() : 2u)) & ~(KR - 1)));
-                {   // experiment hook: waves (table slots) per model kernel
-                    static const char* const names[3] = { "SFQ_GRID_Q", "SFQ_GRID_G", "SFQ_GRID_R" };
-                    const char* e = m < 3 ? getenv(names[m]) : nullptr;
-                    if (e && atoi(e) >= (int)KR) a.nbatch = std::min<u32>(a.nbatch, (u32)atoi(e) & ~(KR - 1));
-                }
+                if ((models & (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC)) == (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC) &&
+                    (order[m] == SFQ_M_QLT || order[m] == SFQ_M_GEN))
+                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * KR) & ~(KR - 1)));
+                if (frozen) a.nbatch = std::min(slots, nblocks_r);          // the chain kernels are short: nobody keeps to a share
                 switch (order[m]) {
                 case SFQ_M_QLT:
-                    if (split) { launch_qlt_model_s(a, tickets + 0, mst[m]); launch_rc_lanes(a, true, mst[m]); }
-                    else if (p.kernel == 2) launch_qlt_encode_w(a, tickets + 0, mst[m]);
-                    else if (p.kernel == 4 || slots < KR) launch_qlt_encode_s(a, tickets + 0, mst[m]);
+                    if (frozen) { ca.m = a; ca.csz = (u32*)ctx->csz.p; launch_qlt_encode_c(ca, mst[m]); }
                     else launch_qlt_encode_k(a, tickets + 0, mst[m]);
                     break;
                 case SFQ_M_GEN:
-                    if (split) { launch_gen_model_w(a, tickets + 1, mst[m]); launch_rc_lanes(a, false, mst[m]); }
-                    else if (p.kernel == 2 || slots < KR) launch_gen_encode_w(a, tickets + 1, mst[m]);
-                    else launch_gen_encode_k(a, tickets + 1, mst[m]);
+                    if (frozen) {
+                        ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
+                        if ((rc = gen_tables_encode(ctx, ca, nblocks, (u32)g_bits, mst[m], &gen_on))) return rc;
+                        launch_gen_encode_c(ca, mst[m]);
+                        launch_gen_exc_w(a, tickets + 1, mst[m]);
+                    } else launch_gen_encode_k(a, tickets + 1, mst[m]);
                     break;
                 case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
                 }
@@ -468,6 +597,12 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // ---- pack ----------------------------------------------------------------------------------
     if ((rc = reserve(ctx, ctx->blk_stream_off, (size_t)nblocks * SFQ_NSTREAMS * 8))) return rc;
     if ((rc = reserve(ctx, ctx->stream_total, 2 * SFQ_NSTREAMS * 8))) return rc;
+    u32 chain_streams = 0;                             // streams packed chain by chain
+    if (frozen) {
+        ca.m = a;
+        if (models & SFQ_M_QLT) { launch_chain_block_sizes(ca, SFQ_S_QLT, (const u32*)ctx->csz.p, st); chain_streams |= 1u << SFQ_S_QLT; }
+        if (models & SFQ_M_GEN) { launch_chain_block_sizes(ca, SFQ_S_GEN, (const u32*)ctx->csz.p + nchains, st); chain_streams |= 1u << SFQ_S_GEN; }
+    }
     launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, st);
     // first headers -> blob
     if ((rc = reserve(ctx, ctx->lens, (size_t)nblocks * 4))) return rc;
@@ -490,13 +625,23 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // per-block status first: an overflowed block has a meaningless size
     int worst = 0;
     for (u32 b = 0; b < nblocks; b++) if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
-    if (worst == (int)ST_TRIP_OVERFLOW) return RETRY_FUSED;
     if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
                            -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" : "see status codes");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
     HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
     launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
-                   (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+                   (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st);
+    std::vector<u32> h_csz;
+    if (frozen) {
+        if (chain_streams & (1u << SFQ_S_QLT))
+            launch_compact_chains(ca, SFQ_S_QLT, 1, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        if (chain_streams & (1u << SFQ_S_GEN))
+            launch_compact_chains(ca, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        h_csz.assign((size_t)nchains * 2, 0);
+        if (!(chain_streams & (1u << SFQ_S_QLT))) HIPC(hipMemsetAsync(ctx->csz.p, 0, (size_t)nchains * 4, st));
+        if (!(chain_streams & (1u << SFQ_S_GEN))) HIPC(hipMemsetAsync((u32*)ctx->csz.p + nchains, 0, (size_t)nchains * 4, st));
+        HIPC(hipMemcpyAsync(h_csz.data(), ctx->csz.p, (size_t)nchains * 2 * 4, hipMemcpyDeviceToHost, st));
+    }
     HIPC(hipEventRecord(ctx->ev[11], st));
     ctx->first_hdrs.resize((size_t)hboff[nblocks]);
     if (hboff[nblocks] > blob_cap) return fail(ctx, SFQ_E_OVERFLOW, "first-header blob overflow");
@@ -505,6 +650,13 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
 
     if (ctx->prior_on) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
     ctx->prior_on = false;
+    ctx->chain_blob.clear();
+    if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
+        std::vector<u8>& o = ctx->chain_blob;
+        put_v(o, ca.geo.chain_reads); put_v(o, gen_on); put_v(o, nchains);
+        for (u32 c = 0; c < 2 * nchains; c++) put_v(o, h_csz[c]);
+    }
+    res->n_chains = nchains;
     ctx->index.resize(nblocks);
     for (u32 b = 0; b < nblocks; b++) {
         sfq_block_info& bi = ctx->index[b];
@@ -518,25 +670,10 @@ static int encode_core(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     res->n_records = nrec; res->n_blocks = nblocks; res->first_hdr_bytes = hboff[nblocks];
     res->kernel_ms[SFQ_T_FRAME] = ev_ms(ctx->ev[0], ctx->ev[1]);
-    res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);     // the models overlap: these do not add up
-    res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[4], ctx->ev[5]);
-    res->kernel_ms[SFQ_T_REC] = ev_ms(ctx->ev[6], ctx->ev[7]);
-    res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[8], ctx->ev[9]);
+    for (int m = 0; m < 4; m++) res->kernel_ms[tslot[m]] = ev_ms(ctx->ev[2 + 2 * m], ctx->ev[3 + 2 * m]);     // the models overlap: these do not add up
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
     return SFQ_OK;
-}
-
-static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
-                       sfq_result* res, u32 force_models) {
-    int rc = encode_core(ctx, d_fastq, nbytes, pp, d_out, out_cap, res, force_models);
-    if (rc == RETRY_FUSED) {            // e.g. Phred+64 qualities: most symbols are escapes with two triples each
-        sfq_params p = *pp;
-        p.kernel = 0;
-        rc = encode_core(ctx, d_fastq, nbytes, &p, d_out, out_cap, res, force_models);
-        if (rc == RETRY_FUSED) rc = fail(ctx, SFQ_E_HIP, "internal: fused kernels reported a triple overflow");
-    }
-    return rc;
 }
 
 int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
@@ -587,6 +724,16 @@ int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
     ctx->prior_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
+int64_t sfq_get_chain_index(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
+    if (!ctx) return SFQ_E_ARG;
+    if (h_blob && cap >= ctx->chain_blob.size() && !ctx->chain_blob.empty()) memcpy(h_blob, ctx->chain_blob.data(), ctx->chain_blob.size());
+    return (int64_t)ctx->chain_blob.size();
+}
+int sfq_set_chain_index(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
+    if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    ctx->chain_blob.assign(h_blob, h_blob + n);
+    return SFQ_OK;
+}
 
 // -------------------------------------------------------------------------------------------------
 // decompress
@@ -630,6 +777,45 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         for (int s = 0; s < SFQ_NSTREAMS; s++) { d.size[s] = bi.size[s]; bso[(size_t)b * SFQ_NSTREAMS + s] = run[s]; run[s] += bi.size[s]; }
         nrec += bi.n_records;
     }
+    // frozen tables: the chain index ("chn.idx")
+    const bool frozen = !ctx->chain_blob.empty();
+    u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0;
+    if (frozen) {
+        const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
+        size_t cp = 0; u64 v = 0;
+        if (!get_v(cb, cn, cp, v) || v == 0 || v > 0xFFFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        chain_reads = (u32)v;
+        if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        gen_on = (u32)v & 1u;
+        if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
+        cpb = (block_reads + chain_reads - 1) / chain_reads;
+        const u32 last_nrec = h_blocks[nblocks - 1].n_records;
+        const u64 want = (u64)(nblocks - 1) * cpb + (last_nrec + chain_reads - 1) / chain_reads;
+        if (v != want || want > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu chains, the blocks have %llu", (unsigned long long)v, (unsigned long long)want);
+        nchains = (u32)want;
+        std::vector<u32> h_csz((size_t)nchains * 2);
+        std::vector<u64> h_coff((size_t)nchains * 2);
+        for (int k = 0; k < 2; k++) {
+            const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
+            u64 at = stream_offset[sid];
+            for (u32 b = 0; b < nblocks; b++) {
+                u64 sum = 0;
+                for (u32 j = 0; j < cpb && (u64)b * cpb + j < nchains; j++) {
+                    const size_t c = (size_t)k * nchains + (size_t)b * cpb + j;
+                    if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+                    h_csz[c] = (u32)v; h_coff[c] = at; at += v; sum += v;
+                }
+                if (sum != h_blocks[b].size[sid]) return fail(ctx, SFQ_E_CORRUPT, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid));
+            }
+        }
+        if ((rc = reserve(ctx, ctx->csz, h_csz.size() * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->coff, h_coff.size() * 8))) return rc;
+        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz.data(), h_csz.size() * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff.data(), h_coff.size() * 8, hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));            // locals
+        if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
+    }
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     if ((rc = reserve(ctx, ctx->blk_stream_off, bso.size() * 8))) return rc;
     if ((rc = reserve(ctx, ctx->d_first, (size_t)first_hdr_bytes + 16))) return rc;
@@ -639,7 +825,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
 
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);
     u32 slots = 0;
-    if ((rc = ensure_tables(ctx, nblocks, q_rows, (u32)g_bits, SFQ_M_ALL, &slots))) return rc;
+    if ((rc = ensure_tables(ctx, nblocks, q_rows, (u32)g_bits, frozen ? (SFQ_M_REC | SFQ_M_USR) : SFQ_M_ALL, &slots))) return rc;
     if ((rc = advance_epoch(ctx, nblocks))) return rc;
 
     if ((rc = reserve(ctx, ctx->slen, (size_t)nrec * 4))) return rc;
@@ -655,8 +841,9 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
 
     ctx->prior_on = false;
+    std::vector<u32> prior_rows;
     if (!ctx->prior_blob.empty()) {
-        std::vector<u32> rows;
+        std::vector<u32>& rows = prior_rows;
         if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
@@ -695,6 +882,52 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
     HIPC(hipStreamWaitEvent(ctx->st_aux[1], ctx->ev[2], 0));
     hipStream_t st_rec = ctx->st_aux[0], st_gen = ctx->st_aux[1];
+    if (frozen) {
+        // quality: dense frozen rows from the prior, one chain per lane
+        ChainArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
+        {
+            std::vector<u32> w(q_rows, 0);
+            for (u32 c = 0; c < q_rows; c++) if (prior_rows[(size_t)c * 66 + 65]) w[c] = std::max<u32>(1, prior_rows[(size_t)c * 66 + 64]);
+            u32 nrows = 0;
+            if ((rc = build_qmap(ctx, w, q_rows, &nrows, st))) return rc;
+            if ((rc = build_qesc(ctx, st))) return rc;
+            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (const u16*)ctx->qmap.p, (u32*)ctx->qrows.p, (uint2*)ctx->qtot.p, st);
+            ca.qmap = (const u16*)ctx->qmap.p; ca.qrows = (const u32*)ctx->qrows.p; ca.qtot = (const uint2*)ctx->qtot.p;
+            ca.q_hot = std::min<u32>(nrows, p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : (p.lds_rows ? p.lds_rows : 255u));
+            if (ca.q_hot > 255) ca.q_hot = 255;
+            ca.qesc = (const u32*)ctx->qesc.p; ca.qesc_tot = make_uint2(256u, recip_host(256u));
+        }
+        ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
+        launch_qlt_decode_c(ca, da, st);
+        HIPC(hipEventRecord(ctx->ev[3], st));
+        HIPC(hipEventRecord(ctx->ev[7], st_gen));
+        // bases: generation by generation -- a generation's rows come from the counts of everything decoded before it
+        ca.csz = (u32*)ctx->csz.p + nchains; ca.coff = (const u64*)ctx->coff.p + nchains;
+        ca.st_buf = da.seq_stage; ca.st_bytes = tot_s; ca.st_off = da.soff; ca.st_len = da.slen;
+        u32 bound[GEN_MAX_GENERATIONS + 1];
+        const u32 ngen = gen_bounds(nblocks, bound);
+        if (!gen_on || ngen < 3) launch_gen_decode_c(ca, da, 0, nblocks, st_gen);
+        else {
+            const u64 nctx = 1ull << g_bits;
+            if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;
+            if ((rc = reserve(ctx, ctx->grows, (size_t)nctx * 4 * 2))) return rc;
+            HIPC(hipMemsetAsync(ctx->gcnt.p, 0, (size_t)nctx * 16, st_gen));
+            ca.g_ngen = ngen;
+            for (u32 g = 0; g <= ngen; g++) ca.g_bound[g] = bound[g];
+            u32* rows = (u32*)ctx->grows.p;
+            const u64 br = block_reads;
+            for (u32 g = 0; g < ngen; g++) {
+                // rows of generation g (two buffers in turn: a generation's rows are dead once it is decoded)
+                if (g >= 2) { launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * (g & 1), nctx, GEN_STEP, st_gen); ca.g_rows[g] = rows + nctx * (g & 1); }
+                else ca.g_rows[g] = nullptr;
+                launch_gen_decode_c(ca, da, bound[g], bound[g + 1], st_gen);
+                if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
+            }
+        }
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_l(da, st_gen); }
+    } else {
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
     HIPC(hipEventRecord(ctx->ev[3], st));
     HIPC(hipEventRecord(ctx->ev[7], st_gen));
@@ -702,6 +935,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st_gen);
         launch_gen_decode_l(da, st_gen);
+    }
     }
     HIPC(hipEventRecord(ctx->ev[4], st_gen));
     HIPC(hipStreamWaitEvent(st, ctx->ev[4], 0));

@@ -1,0 +1,484 @@
+// chains.hip -- lane-per-chain kernels with frozen tables (dev_chain.h): quality and base streams of block format 7.
+//
+//   k_qlt_frozen_rows   prior rows (prior.hip, exchange form) -> dense direct-indexed rows {cum | freq << 16}[64]
+//   k_qlt_encode_c      QltSave::save_1/2/3's symbol walk (qlts.cpp:74-136), one chain per lane, rows frozen
+//   k_qlt_decode_c      QltLoad::load_1/2/3 (qlts.cpp:163-234), likewise
+//   k_gen_count / k_gen_rows / k_gen_encode_c / k_gen_decode_c   bases: see the section below
+//   k_chain_block_sizes / k_compact_chains   a block's chain streams packed back to back
+//
+// A workgroup stages the hottest quality rows (and the totals of all rows) in LDS once and serves its chains'
+// lookups from there; colder rows come from L2.  Text is read 16 aligned bytes per lane at a time.
+#include "kernels.h"
+#include "dev_chain.h"
+
+#define LAST_QLT 63u
+#define QROW_BYTES 256u                 // 64 entries x 4 bytes
+#define B2_INIT 0x03030303u             // Base2Ranger row of a fresh table (base2_ranger.hpp:68-71)
+
+// ---- frozen quality rows -------------------------------------------------------------------------------------
+// rows66: per context 64 slots (freq | sym << 16), total, iend (prior.hip k_prior_rows).  The frozen row of a context
+// lists all 64 symbols in symbol order: g[s] = (f[s] >> t) + 1 with the smallest t that brings sum(g) <= 65535;
+// entry s = cum(g[0..s)) | g[s] << 16.  Contexts the sample never saw share the uniform row (dense id 0).
+__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, const u16* __restrict__ qmap,
+                                                        u32* __restrict__ qrows, uint2* __restrict__ qtot) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    u32 id = qmap[ctx];
+    const bool uniform_row = ctx == 0 && blockIdx.x == 0 && (threadIdx.x >> 6) == 0;   // wave 0 also writes the uniform row
+    if (uniform_row) { qrows[lane] = lane | (1u << 16); if (lane == 0) qtot[0] = make_uint2(64u, fz_recip(64u)); }
+    if (id == 0) return;
+    const u32* r = rows66 + (size_t)ctx * 66;
+    const u32 slot = r[lane], iend = r[65];
+    // slot order -> symbol order: lane j sends its frequency to lane sym(j)
+    const u32 sym = slot >> 16, fslot = lane < iend ? (slot & 0xffffu) : 0u;
+    u32 f = (u32)__builtin_amdgcn_ds_permute((int)((lane < iend ? sym : lane) * 4), (int)fslot);
+    // lanes >= iend sent 0 to themselves; but a lane < iend may also have been targeted by a lane >= iend (same index):
+    // symbols >= iend hold no slot, so only lanes >= iend receive from lanes >= iend -- no clash
+    u32 t = 0, g, tot;
+    for (;;) {
+        g = (f >> t) + 1;
+        tot = g;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tot += (u32)__shfl_xor((int)tot, d, 64);
+        if (tot <= FZ_MAX_TOT) break;
+        t++;
+    }
+    u32 incl = g;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
+    qrows[(size_t)id * 64 + lane] = (incl - g) | (g << 16);
+    if (lane == 0) qtot[id] = make_uint2(tot, fz_recip(tot));
+}
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, const u16* qmap, u32* qrows, uint2* qtot, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qmap, qrows, qtot);
+}
+// row weight = the sample's symbol count of the context (0 = no row); the host ranks contexts by it
+__global__ __launch_bounds__(256) void k_row_weights(const u32* __restrict__ hist, u32 q_rows, u32* __restrict__ w) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    u32 c = hist[(size_t)ctx * 64 + lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
+    if (lane == 0) w[ctx] = c;
+}
+void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st) {
+    hipLaunchKernelGGL(k_row_weights, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, w);
+}
+
+// ---- chain geometry ---------------------------------------------------------------------------------------------
+struct ChainPos { u32 b; u64 r0; u32 nrec; };
+__device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
+    ChainPos p;
+    p.b = c / a.geo.cpb;
+    const u32 j = c - p.b * a.geo.cpb;
+    const BlockDesc* d = &a.m.blocks[p.b];
+    const u32 k0 = j * a.geo.chain_reads;
+    p.nrec = k0 < d->nrec ? (d->nrec - k0 < a.geo.chain_reads ? d->nrec - k0 : a.geo.chain_reads) : 0u;
+    p.r0 = d->rec0 + k0;
+    return p;
+}
+// a chain's output region inside its block's region of the scratch arena: proportional to the text before it
+__device__ __forceinline__ u8* chain_region(const ChainArgs& a, const ChainPos& p, int stream, u32 num, u32 den, u32& cap) {
+    const BlockDesc* d = &a.m.blocks[p.b];
+    const u64 t0 = a.m.line_off[4 * d->rec0], tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
+    const u64 lo = ((tc - t0) * num / den + 3) & ~3ull, hi = ((te - t0) * num / den) & ~3ull;
+    cap = hi > lo ? (u32)(hi - lo) : 0u;
+    return a.m.arena + d->out_off[stream] + lo;
+}
+
+// 16 text bytes of a lane: aligned loads, nothing read outside [fq, fq_end)
+__device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {          // at is 16-byte aligned relative to address 0
+    const u8* p = fq + at;
+    if ((((uintptr_t)p) & 15) == 0 && at + 16 <= nbytes) return *reinterpret_cast<const uint4*>(p);
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 i = 0; i < 16; i++) if (at + i < nbytes) w[i >> 2] |= (u32)p[i] << ((i & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// =========================================================================================================
+// quality encode: one chain per lane
+// =========================================================================================================
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
+    extern __shared__ u32 lds[];                              // [hot rows][64] entries, then [nrows] totals (uint2)
+    const u32 hot = a.q_hot;                                  // dense ids 0 .. hot-1 live in LDS
+    u32* const lrows = lds;
+    for (u32 i = threadIdx.x; i < hot * 64; i += THREADS) lrows[i] = a.qrows[i];
+    __syncthreads();
+    const u32 c = blockIdx.x * THREADS + threadIdx.x;
+    const bool live = c < a.geo.nchains;
+    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
+    if (live) cp = chain_pos(a, c);
+    const BlockDesc* d = &a.m.blocks[cp.b];
+    LaneEnc rc; u32 cap = 0;
+    u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 1, 1, cap) : nullptr;
+    rc.init(outp, cap);
+    const u32 solid = live ? d->solid : 0;
+    const int level = a.m.level;
+    const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
+    const u8* fq = a.m.fq; const u64 nbytes = a.nbytes;
+    // the address bits that make a 16-byte piece: pieces are aligned in MEMORY, positions are offsets into fq
+    const u32 mis = (u32)((uintptr_t)fq & 15);
+    u32 k = 0;                        // records taken
+    u64 pos = 0, end = 0;             // current quality line [pos, end) as offsets into fq
+    u32 last = 0, p1 = 0, p2 = 0, delta = 5;
+    u32 extra = 0;
+    for (;;) {
+        // next line with symbols
+        while (pos >= end && k < cp.nrec) {
+            const u64 r = cp.r0 + k; k++;
+            const u64 q0 = a.m.line_off[4 * r + 3] + solid, q1e = a.m.line_off[4 * r + 4] - 1;
+            if (q1e > q0) { pos = q0; end = q1e; last = 0; p1 = p2 = 0; delta = 5; }
+        }
+        const bool act = pos < end;
+        if (!__any(act)) break;
+        // one aligned 16-byte piece of the line
+        const u64 piece = act ? ((pos + mis) & ~15ull) - mis : 0;        // offset of the piece (may be "negative" only when mis > pos: handled by load16's guard through wrap -> at + i < nbytes fails)
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (act) {
+            if ((i64)piece >= 0) w = load16(fq, nbytes, piece);
+            else { u32 t[4] = {0, 0, 0, 0}; for (u32 i = 0; i < 16; i++) { const i64 at = (i64)piece + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)fq[at] << ((i & 3) * 8); } w = make_uint4(t[0], t[1], t[2], t[3]); }
+        }
+        const u32 j0 = act ? (u32)(pos - piece) : 16u;                     // first byte of the piece that is ours
+        const u32 j1 = act ? (u32)((end - piece) < 16 ? (end - piece) : 16) : 0u;   // one past the last
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            if (j >= j0 && j < j1) {
+                const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
+                const u32 b = (((word >> ((j & 3) * 8)) & 0xffu) - '!') & 0xffu;
+                const u32 sym = b < LAST_QLT ? b : LAST_QLT;
+                const u32 id = a.qmap[last];
+                const u32 e = id < hot ? lrows[id * 64 + sym] : a.qrows[(size_t)id * 64 + sym];
+                const uint2 tt = a.qtot[id];
+                rc.encode(FZ_CUM(e), FZ_FREQ(e), tt.x, tt.y);
+                if (b >= LAST_QLT) {                                       // escape: the raw value through the frozen escape row (qlts.cpp:80-86)
+                    const u32 ee = a.qesc[b];
+                    rc.encode(FZ_CUM(ee), FZ_FREQ(ee), a.qesc_tot.x, a.qesc_tot.y);
+                    extra++;
+                }
+                if (level <= 2) last = (b | (last << 6)) & mask12;         // qlts.hpp:52-57
+                else {                                                    // qlts.hpp:62-74
+                    if (p1 > b) delta += p1 - b;
+                    const u32 d3 = delta >> 3;
+                    last = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                    p2 = p1; p1 = b;
+                }
+            }
+        }
+        if (act) pos = piece + j1;
+    }
+    if (live) {
+        const u32 size = rc.finish();
+        a.csz[c] = size;
+        if (extra) atomicAdd(&a.m.blocks[cp.b].extra_hi, extra);
+        if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));
+        else if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
+    }
+}
+void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
+    constexpr int T = 256;
+    const u32 grid = (a.geo.nchains + T - 1) / T;
+    hipLaunchKernelGGL(k_qlt_encode_c<T>, dim3(grid), dim3(T), a.q_hot * QROW_BYTES, st, a);
+}
+
+// =========================================================================================================
+// quality decode: one chain per lane; the symbol is found by a binary search over the row's cumulative entries
+// =========================================================================================================
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArgs da) {
+    extern __shared__ u32 lds[];
+    const u32 hot = a.q_hot;
+    u32* const lrows = lds;
+    for (u32 i = threadIdx.x; i < hot * 64; i += THREADS) lrows[i] = a.qrows[i];
+    __syncthreads();
+    const u32 c = blockIdx.x * THREADS + threadIdx.x;
+    if (c >= a.geo.nchains) return;
+    const ChainPos cp = chain_pos(a, c);
+    LaneDec rc; rc.init(da.streams + a.coff[c], a.csz[c]);
+    const int level = a.m.level;
+    const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
+    for (u32 k = 0; k < cp.nrec; k++) {
+        const u64 r = cp.r0 + k;
+        const u32 n = da.qlen[r];
+        u8* p = da.qual_stage + da.qoff[r];
+        u32 last = 0, p1 = 0, p2 = 0, delta = 5;
+        for (u32 i = 0; i < n; i++) {
+            const u32 id = a.qmap[last];
+            const uint2 tt = a.qtot[id];
+            const u32 prob = rc.get_freq(tt.x, tt.y);
+            const u32* row = id < hot ? lrows + id * 64 : a.qrows + (size_t)id * 64;
+            // largest s with cum[s] <= prob (cum is increasing: every g >= 1)
+            u32 s = 0;
+#pragma unroll
+            for (u32 step = 32; step > 0; step >>= 1) { const u32 t = s + step; if (FZ_CUM(row[t]) <= prob) s = t; }
+            const u32 e = row[s];
+            if (prob >= tt.x) rc.err = 1;
+            rc.decode(FZ_CUM(e), FZ_FREQ(e));
+            u32 b = s;
+            if (s == LAST_QLT) {                                            // qlts.cpp:168-171
+                const u32 pe = rc.get_freq(a.qesc_tot.x, a.qesc_tot.y);
+                u32 x = 0;
+#pragma unroll
+                for (u32 step = 128; step > 0; step >>= 1) { const u32 t = x + step; if (FZ_CUM(a.qesc[t]) <= pe) x = t; }
+                const u32 ee = a.qesc[x];
+                if (pe >= a.qesc_tot.x) rc.err = 1;
+                rc.decode(FZ_CUM(ee), FZ_FREQ(ee));
+                b = x;
+            }
+            p[i] = (u8)('!' + b);
+            if (level <= 2) last = (b | (last << 6)) & mask12;
+            else {
+                if (p1 > b) delta += p1 - b;
+                const u32 d3 = delta >> 3;
+                last = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                p2 = p1; p1 = b;
+            }
+        }
+    }
+    if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
+}
+void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st) {
+    constexpr int T = 256;
+    const u32 grid = (a.geo.nchains + T - 1) / T;
+    hipLaunchKernelGGL(k_qlt_decode_c<T>, dim3(grid), dim3(T), a.q_hot * QROW_BYTES, st, a, da);
+}
+
+// =========================================================================================================
+// packing: a block's chain streams back to back
+// =========================================================================================================
+// blocks[b].size[stream] = sum of its chains' sizes
+__global__ __launch_bounds__(256) void k_chain_block_sizes(ChainArgs a, int stream, const u32* csz) {
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.m.nblocks) return;
+    u32 sum = 0;
+    const u32 c0 = b * a.geo.cpb;
+    for (u32 j = 0; j < a.geo.cpb && c0 + j < a.geo.nchains; j++) sum += csz[c0 + j];
+    a.m.blocks[b].size[stream] = sum;
+}
+void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st) {
+    hipLaunchKernelGGL(k_chain_block_sizes, dim3((a.m.nblocks + 255) / 256), dim3(256), 0, st, a, stream, csz);
+}
+// one wave per chain: region -> its place in the packed stream
+__global__ __launch_bounds__(256) void k_compact_chains(ChainArgs a, int stream, u32 num, u32 den, const u32* csz,
+                                                        const u64* blk_stream_off, const u64* stream_base, u8* out) {
+    const u32 c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= a.geo.nchains) return;
+    const ChainPos cp = chain_pos(a, c);
+    const u32 n = csz[c];
+    if (!n) return;
+    u32 before = 0;
+    for (u32 cc = cp.b * a.geo.cpb + lane; cc < c; cc += 64) before += csz[cc];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += (u32)__shfl_xor((int)before, d, 64);
+    u32 cap;
+    const u8* src = chain_region(a, cp, stream, num, den, cap);
+    u8* dst = out + stream_base[stream] + blk_stream_off[(u64)cp.b * SFQ_NSTREAMS + stream] + before;
+    for (u32 i = lane; i < n; i += 64) dst[i] = src[i];
+}
+void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
+                           const u64* stream_base, u8* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact_chains, dim3((a.geo.nchains + 3) / 4), dim3(256), 0, st, a, stream, num, den, csz, blk_stream_off, stream_base, out);
+}
+
+// =========================================================================================================
+// bases
+//
+// The reference's base model is ONE file-wide table of Base2Ranger rows (gens.cpp:36-44, base2_ranger.hpp) that
+// learns the genome as coverage accumulates; independent blocks cannot (1.17x the reference's bytes on
+// genome-sampled reads).  Format 7 cuts the call's blocks into GENERATIONS (the first 1/64 of the blocks, then
+// growing geometrically): a chain of generation g codes with the rows built from the exact counts of every base of
+// generations < g, frozen while the generation is coded; a decoder rebuilds the same rows from what it has already
+// decoded.  Counting is integer atomics (commutative: the counts do not depend on scheduling); a row is
+// f[i] = 3 + GEN_STEP * n[i], halved the reference's way -- (f >> 1) | (f & 1), base2_ranger.hpp:48-53 -- until every
+// f[i] <= 255.  Generations 0 and 1 code with the initial row (3, 3, 3, 3); whether the tables are used at all
+// is decided once, from the cost generation 1 would have had under the rows of generation 0 (api.cpp).
+// N / quality-0 exceptions (gens.cpp:91-136) do not touch the model (an N is coded as 'A'): a wave per block
+// scans for them and codes the reference's gen.Ns / gen.Nn side streams.
+// =========================================================================================================
+__device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0..3, N-like -> 4, illegal -> 0x10
+    const u32 l = c | 0x20u;
+    u32 n = 0x10u;
+    n = (l == 'a' || c == '0') ? 0u : n;
+    n = (l == 'c' || c == '1') ? 1u : n;
+    n = (l == 'g' || c == '2') ? 2u : n;
+    n = (l == 't' || c == '3') ? 3u : n;
+    n = (l == 'n' || c == '.') ? 4u : n;
+    return n;
+}
+// per-lane walk over the base lines of records [r0, r0 + nrec): f(code 0..3, context before the base).  The bases are
+// read from the FASTQ text (encode: line_off) or from the decoder's staged bases (decode: st_off / st_len per record)
+template <typename F>
+__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, F&& f) {
+    const bool staged = a.st_off != nullptr;
+    const u8* fq = staged ? a.st_buf : a.m.fq; const u64 nbytes = staged ? a.st_bytes : a.nbytes;
+    const u32 mis = (u32)((uintptr_t)fq & 15);
+    u32 k = 0; u64 pos = 0, end = 0; u32 last = 0;
+    for (;;) {
+        while (pos >= end && k < nrec) {
+            const u64 r = r0 + k; k++;
+            u64 g0, g1;
+            if (staged) { g0 = a.st_off[r]; g1 = g0 + a.st_len[r]; }
+            else { g0 = a.m.line_off[4 * r + 1] + solid; g1 = a.m.line_off[4 * r + 2] - 1; }
+            if (g1 > g0) { pos = g0; end = g1; last = 0x007616c7u; }               // gens.cpp:139
+        }
+        const bool act = pos < end;
+        if (!__any(act)) break;
+        const u64 piece = act ? ((pos + mis) & ~15ull) - mis : 0;
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (act) {
+            if ((i64)piece >= 0) w = load16(fq, nbytes, piece);
+            else { u32 t[4] = {0, 0, 0, 0}; for (u32 i = 0; i < 16; i++) { const i64 at = (i64)piece + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)fq[at] << ((i & 3) * 8); } w = make_uint4(t[0], t[1], t[2], t[3]); }
+        }
+        const u32 j0 = act ? (u32)(pos - piece) : 16u;
+        const u32 j1 = act ? (u32)((end - piece) < 16 ? (end - piece) : 16) : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            if (j >= j0 && j < j1) {
+                const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
+                const u32 code = gen_code_of((word >> ((j & 3) * 8)) & 0xffu) & 3u;       // N is coded as 0 (gens.cpp:116-136)
+                f(code, last & mask);
+                last = (last << 2) | code;
+            }
+        }
+        if (act) pos = piece + j1;
+    }
+}
+
+// counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
+// cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
+__global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32* __restrict__ cnt, const u32* __restrict__ rows,
+                                                  const u16* __restrict__ log2fp, u64* cost) {
+    const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
+    u32 mybases = 0;
+    const u64 r = first + (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool live = r < endr;
+    u32 solid = 0, mask = 0;
+    if (live) {
+        // the block of record r: blocks are uniform (block_reads records) except the last
+        const u32 b = (u32)(r / a.block_reads);
+        solid = a.m.blocks[b].solid; mask = (1u << a.m.blocks[b].gen_bits) - 1u;
+    }
+    u64 mycost = 0;
+    walk_bases(a, r, live ? 1u : 0u, solid, mask, [&](u32 code, u32 ctx) {
+        atomicAdd(&cnt[((size_t)ctx << 2) | code], 1u);
+        if (rows) {
+            mybases++;
+            const u32 v = rows[ctx];
+            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+            mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
+        }
+    });
+    if (rows) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mycost += __shfl_xor(mycost, d, 64);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mybases += (u32)__shfl_xor((int)mybases, d, 64);
+        if ((threadIdx.x & 63) == 0 && mybases) {
+            atomicAdd((unsigned long long*)cost, (unsigned long long)mycost);
+            atomicAdd((unsigned long long*)cost + 1, (unsigned long long)mybases);
+        }
+    }
+}
+void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
+    if (!nrec_range) return;
+    hipLaunchKernelGGL(k_gen_count, dim3((u32)((nrec_range + 255) / 256)), dim3(256), 0, st, a, b0, b1, cnt, rows, log2fp, cost);
+}
+// rows from counts
+__global__ __launch_bounds__(256) void k_gen_rows(const u32* __restrict__ cnt, u32* __restrict__ rows, u64 nctx, u32 step) {
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nctx) return;
+    const uint4 n = *reinterpret_cast<const uint4*>(cnt + c * 4);
+    u64 f0 = 3 + (u64)step * n.x, f1 = 3 + (u64)step * n.y, f2 = 3 + (u64)step * n.z, f3 = 3 + (u64)step * n.w;
+    while ((f0 | f1 | f2 | f3) > 255) {                     // any of them > 255 (all are < 2^35)
+        f0 = (f0 >> 1) | (f0 & 1); f1 = (f1 >> 1) | (f1 & 1); f2 = (f2 >> 1) | (f2 & 1); f3 = (f3 >> 1) | (f3 & 1);
+    }
+    rows[c] = (u32)f0 | (u32)f1 << 8 | (u32)f2 << 16 | (u32)f3 << 24;
+}
+void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_rows, dim3((u32)((nctx + 255) / 256)), dim3(256), 0, st, cnt, rows, nctx, step);
+}
+
+// the rows a chain of block b codes with: null = the initial row
+__device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
+    if (!a.g_ngen) return nullptr;
+    u32 g = 0;
+    while (g + 1 < a.g_ngen && b >= a.g_bound[g + 1]) g++;            // generation g covers blocks [g_bound[g], g_bound[g + 1])
+    return a.g_rows[g];
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
+    __shared__ u32 rcp[1024];                                 // reciprocals of the row totals (<= 1020)
+    for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
+    __syncthreads();
+    const u32 c = blockIdx.x * THREADS + threadIdx.x;
+    const bool live = c < a.geo.nchains;
+    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
+    if (live) cp = chain_pos(a, c);
+    const BlockDesc* d = &a.m.blocks[cp.b];
+    LaneEnc rc; u32 cap = 0;
+    u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
+    rc.init(outp, cap);
+    const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
+    walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u, [&](u32 code, u32 ctx) {
+        const u32 v = rows ? rows[ctx] : B2_INIT;
+        const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+        const u32 tot = (f0 + f1) + (f2 + f3);
+        const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
+        rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                        // base2_ranger.hpp:74-84 without the update
+    });
+    if (live) {
+        a.csz[c] = rc.finish();
+        if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));
+        else if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
+    }
+}
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
+    constexpr int T = 256;
+    hipLaunchKernelGGL(k_gen_encode_c<T>, dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
+}
+
+// decode the chains of blocks [b0, b1): GenLoad::load_x (gens.cpp:215-249) without the N rules (k_gen_exc_decode)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArgs da, u32 b0, u32 b1) {
+    __shared__ u32 rcp[1024];
+    for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
+    __syncthreads();
+    const u32 c = b0 * a.geo.cpb + blockIdx.x * THREADS + threadIdx.x;
+    if (c >= a.geo.nchains || c >= b1 * a.geo.cpb) return;
+    const ChainPos cp = chain_pos(a, c);
+    const BlockDesc* d = &a.m.blocks[cp.b];
+    LaneDec rc; rc.init(da.streams + a.coff[c], a.csz[c]);
+    const u32* rows = gen_rows_of(a, cp.b);
+    const u32 alphabet = d->solid ? 0x33323130u /* "0123" */ : 0x54474341u /* "ACGT" */;    // gens.cpp:173-178
+    const u32 mask = (1u << d->gen_bits) - 1u;
+    for (u32 k = 0; k < cp.nrec; k++) {
+        const u64 r = cp.r0 + k;
+        const u32 llen = da.slen[r];
+        u8* g = da.seq_stage + da.soff[r];
+        u32 last = 0x007616c7u;
+        for (u32 i = 0; i < llen; i++) {
+            const u32 v = rows ? rows[last & mask] : B2_INIT;
+            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+            const u32 tot = (f0 + f1) + (f2 + f3);
+            const u32 prob = rc.get_freq(tot, rcp[tot]);
+            u32 b, cum, f;                                                              // base2_ranger.hpp:86-104
+            if (f0 > prob)                { b = 0; cum = 0;            f = f0; }
+            else if (f0 + f1 > prob)      { b = 1; cum = f0;           f = f1; }
+            else if (f0 + f1 + f2 > prob) { b = 2; cum = f0 + f1;      f = f2; }
+            else                          { b = 3; cum = f0 + f1 + f2; f = f3; if (prob >= tot) rc.err = 1; }
+            rc.decode(cum, f);
+            g[i] = (u8)((alphabet >> (8 * b)) & 0xff);
+            last = (last << 2) | b;
+        }
+    }
+    if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
+}
+void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st) {
+    constexpr int T = 256;
+    const u32 n = (b1 - b0) * a.geo.cpb;
+    if (!n) return;
+    hipLaunchKernelGGL(k_gen_decode_c<T>, dim3((n + T - 1) / T), dim3(T), 0, st, a, da, b0, b1);
+}

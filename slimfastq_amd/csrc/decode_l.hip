@@ -13,11 +13,7 @@
 
 // Active lanes per decode wavefront.  A wave waits for the slowest of its lanes' table reads, and the chains are
 // few (one per block): fewer lanes per wave = more waves, each waiting on fewer reads.
-#include <cstdlib>
-static u32 decode_lanes() {
-    static const u32 n = [] { const char* e = getenv("SFQ_DECODE_LANES"); const int v = e ? atoi(e) : 16; return (u32)(v == 8 || v == 16 || v == 32 || v == 64 ? v : 16); }();
-    return n;
-}
+static u32 decode_lanes() { return 16; }      // measured: 64 -> 16 lanes per wave = -18 % decode time
 
 struct DSlot {
     u32 b, epoch;
@@ -407,7 +403,41 @@ void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st) {
     const u32 L = decode_lanes();
     hipLaunchKernelGGL(k_rec_decode_l, dim3((a.m.nbatch + L - 1) / L), dim3(L), 0, st, a);
 }
-void launch_gen_fixup(const DecodeArgs&, u64, hipStream_t) {}
+
+// ---- frozen-table mode: the N rules applied to bases that chains.hip has staged (gens.cpp:200-213) -------------
+// gen.Ns lists the N positions whose quality is not '!' (-> the N byte), gen.Nn the real bases under quality '!'
+// (-> bit 7, which k_assemble reads as "keep this base"); both as gaps over the block's 1-based base index.
+__global__ __launch_bounds__(64) void k_gen_exc_decode_l(DecodeArgs a) {
+    DSlot sl;
+    if (!dslot_init(a.m, sl)) return;
+    BlockDesc* d = &a.m.blocks[sl.b];
+    XfDec x_ns, x_nn;
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NS); x_ns.init(s.p, s.n, XF_GEN_NS); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NN); x_nn.init(s.p, s.n, XF_GEN_NN); }
+    const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
+    u8* const g = a.seq_stage + a.soff[d->rec0];
+    const u64 nb = a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
+    u32 bad = 0;
+    for (u64 at = x_ns.get(sl.pw); at; ) {                                                  // gens.cpp:187
+        if (at > nb) { bad = 1; break; }
+        g[at - 1] = (u8)n_byte;
+        const u64 gap = x_ns.get(sl.pw);
+        if (!gap) break;
+        at += gap;
+    }
+    for (u64 at = x_nn.get(sl.pw); at; ) {                                                  // gens.cpp:188
+        if (at > nb) { bad = 1; break; }
+        g[at - 1] |= 0x80u;
+        const u64 gap = x_nn.get(sl.pw);
+        if (!gap) break;
+        at += gap;
+    }
+    if (bad | x_ns.rc.err | x_nn.rc.err) dset_status(d, SFQ_E_CORRUPT);
+}
+void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st) {
+    const u32 L = decode_lanes();
+    hipLaunchKernelGGL(k_gen_exc_decode_l, dim3((a.m.nbatch + L - 1) / L), dim3(L), 0, st, a);
+}
 
 // ---- UsrLoad::save (usrs.cpp:512-535): '@'hdr \n [pf]bases \n '+'[hdr] \n [pf]quals \n --------------------
 __global__ __launch_bounds__(256) void k_record_sizes(DecodeArgs a, u64 nrec, u32* rsize) {

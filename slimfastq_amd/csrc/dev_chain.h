@@ -1,0 +1,108 @@
+// dev_chain.h -- lane-per-chain coding with frozen tables (block format 7, sfq_params.tables = SFQ_TABLES_FROZEN).
+//
+// The adaptive kernels (models_w.hip / models_k.hip) spend a whole wavefront on one or two serial chains and
+// read-modify-write a private table row per symbol.  Here the learning is taken out of the per-symbol loop:
+// the frequency tables are built by counting passes (a transmitted sample for qualities and headers, the
+// earlier "generations" of the same file for bases), frozen while a chain is coded, and shared read-only by
+// every chain.  With nothing private but the range coder's state, ONE LANE carries a chain: 64 independent
+// chains per wavefront, no cross-lane work, table lookups from LDS / L2.  The arithmetic per symbol is still
+// RCoder::Encode / GetFreq / Decode (coder.hpp:66-102) on (cum, freq, tot) triples in the rangers' form
+// (freq + 1 over total + NSYM); only WHEN the counts are taken differs.  oracle/sfq_oracle.c restates the rule.
+//
+// Chain stream framing (ours, not the reference's): RCoder's first four output bytes are always zero
+// (low < 2^32 until four renormalisations have happened) and are not stored; the flush writes the five
+// significant bytes of the smallest multiple of 2^24 that is >= low (it lies inside [low, low + range));
+// trailing zero bytes are dropped -- a decoder reads zeros past the end, as FilerLoad::get does (filer.hpp:94-97).
+#pragma once
+#include "dev_coder.h"
+
+// frozen row entry: cum | freq << 16 (both < 65536); per row {tot, floor(2^32 / tot)}
+#define FZ_CUM(e)  ((e) & 0xFFFFu)
+#define FZ_FREQ(e) ((e) >> 16)
+#define FZ_MAX_TOT 65535u
+
+__device__ __forceinline__ u32 fz_recip(u32 tot) {      // floor(2^32 / tot) for tot >= 2; tot == 1 keeps 2^32 - 1
+    const u32 m0 = 0xFFFFFFFFu / tot;
+    return (tot != 1 && (0xFFFFFFFFu - m0 * tot) == tot - 1) ? m0 + 1 : m0;
+}
+
+struct LaneEnc {
+    u64 low; u32 range;
+    u32 n;          // bytes produced so far, the four elided ones included
+    u32 last_nz;    // n after the last non-zero byte
+    u32 acc;        // bytes of the dword being filled
+    u8* out; u32 cap;
+    u32 err;
+    __device__ __forceinline__ void init(u8* p, u32 c) { low = 0; range = 0xFFFFFFFFu; n = 0; last_nz = 0; acc = 0; out = p; cap = c; err = 0; }
+    __device__ __forceinline__ void put(u32 byte) {
+        if (n >= 4) {
+            const u32 at = n - 4;
+            acc |= byte << ((at & 3u) * 8u);
+            if ((at & 3u) == 3u) { if (at < cap) *reinterpret_cast<u32*>(out + (at & ~3u)) = acc; acc = 0; }
+        } else if (byte) err = 1;                            // cannot happen: low < 2^56 for the first four bytes
+        n++;
+        if (byte) last_nz = n;
+    }
+    // coder.hpp:66-81 with the divide as a multiply-high by recip = floor(2^32 / tot) plus one exact fix-up
+    __device__ __forceinline__ void encode(u32 cum, u32 freq, u32 tot, u32 recip) {
+        u32 r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        low += (u64)cum * r;                                 // cum * r < range: no 32-bit wrap (coder.hpp:69)
+        range = r * freq;
+        int guard = 0;
+        while (range < RC_TOP) {
+            if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
+            put((u32)(low >> 56));
+            range <<= 8; low <<= 8;
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }    // the reference would spin; every chain must drain
+        }
+    }
+    // flush; returns the stream's size
+    __device__ __forceinline__ u32 finish() {
+        u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;
+        for (int i = 0; i < 5; i++) { put((u32)(v >> 56)); v <<= 8; }
+        const u32 size = last_nz > 4 ? last_nz - 4 : 0;
+        const u32 wrote = n - 4, pend = wrote & 3u;          // bytes still in acc
+        for (u32 i = 0; i < pend; i++) { const u32 at = wrote - pend + i; if (at < cap && at < size) out[at] = (u8)(acc >> (8 * i)); }
+        if (size > cap) err |= 2;
+        return size;
+    }
+};
+
+struct LaneDec {
+    u64 low, code; u32 range;
+    const u8* p; u32 pos, n;
+    u32 err;
+    __device__ __forceinline__ u32 get() { const u32 b = pos < n ? p[pos] : 0u; pos++; return b; }
+    __device__ __forceinline__ void init(const u8* ptr, u32 len) {
+        p = ptr; pos = 0; n = len; low = 0; range = 0xFFFFFFFFu; err = 0;
+        code = 0;
+        for (int i = 0; i < 4; i++) code = (code << 8) | get();          // the four elided zero bytes, then four real ones
+    }
+    // coder.hpp:83-86
+    __device__ __forceinline__ u32 get_freq(u32 tot, u32 recip) {
+        u32 r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        if (r == 0) { err = 1; r = 1; }
+        range = r;
+        if (code >> 32) { err = 1; return 0; }
+        return (u32)code / r;
+    }
+    // coder.hpp:88-102
+    __device__ __forceinline__ void decode(u32 cum, u32 freq) {
+        const u32 temp = cum * range;
+        low += temp; code -= temp;
+        range *= freq;
+        int guard = 0;
+        while (range < RC_TOP) {
+            if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
+            code = (code << 8) | get();
+            range <<= 8; low <<= 8;
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+};
+
+// Chain geometry: a block of block_reads records is cut into chains of chain_reads records; chain c of the call is
+// chain c % cpb of block c / cpb (cpb = chains per block).  Every stream that is coded in chains (qlt, gen) has one
+// range-coder stream per chain; a block's bytes of that stream are its chains' streams back to back (kernels.h ChainArgs).

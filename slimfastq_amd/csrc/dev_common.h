@@ -68,26 +68,3 @@ struct BlockDesc {
     u32 out_cap[SFQ_NSTREAMS];
     u32 hdr_bytes;      // sum of header lengths in the block
 };
-
-// ---- parked triples (split kernels: models write, coder_l.hip codes) --------------------------------------
-// Block b's triples start at entry trip_base(b) of the call's triple buffers: half the block's text offset
-// (a block has at most one quality triple and one base triple per two text bytes; an escape symbol's second
-// triple eats into the slack the header / newline bytes leave).  A block that would not fit reports
-// ST_TRIP_OVERFLOW and the host repeats the call with the fused kernels.
-#define TRIP_Q_PACK_LO(cum, freq)      ((cum) | ((freq) << 20))
-#define TRIP_Q_PACK_HI(freq, tot)      (((freq) >> 12) | ((tot) << 8))
-#define TRIP_Q_CUM(lo, hi)             ((lo) & 0xFFFFFu)
-#define TRIP_Q_FREQ(lo, hi)            (((lo) >> 20) | (((hi) & 0xFFu) << 12))
-#define TRIP_Q_TOT(lo, hi)             ((hi) >> 8)
-#define TRIP_G_PACK(cum, freq, tot)    ((cum) | ((freq) << 11) | ((tot) << 21))
-#define TRIP_G_CUM(w)                  ((w) & 0x7FFu)
-#define TRIP_G_FREQ(w)                 (((w) >> 11) & 0x3FFu)
-#define TRIP_G_TOT(w)                  ((w) >> 21)
-#define ST_TRIP_OVERFLOW 0x1000u       // BlockDesc::status value, above every (u32)(-SFQ_E_*)
-#if defined(__HIPCC__)
-__device__ __forceinline__ u64 trip_base(const u64* line_off, u64 rec0) { return (line_off[4 * rec0] / 2 + 3) & ~3ull; }
-__device__ __forceinline__ u32 trip_cap(const u64* line_off, u64 rec0, u32 nrec) {
-    const u64 tb = trip_base(line_off, rec0), te = line_off[4 * (rec0 + nrec)] / 2;
-    return te > tb ? (u32)(te - tb) : 0u;
-}
-#endif

@@ -276,10 +276,10 @@ void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream
 }
 // grid = (nblocks, SFQ_NSTREAMS); stream_base[s] = offset of stream s in out
 __global__ __launch_bounds__(256) void k_compact(const BlockDesc* blocks, const u8* arena, const u64* blk_stream_off,
-                                                 const u64* stream_base, u8* out) {
+                                                 const u64* stream_base, u8* out, u32 skip_streams) {
     const u32 b = blockIdx.x, s = blockIdx.y;
     const u32 n = blocks[b].size[s];
-    if (!n) return;
+    if (!n || ((skip_streams >> s) & 1)) return;
     const u8* src = arena + blocks[b].out_off[s];
     u8* dst = out + stream_base[s] + blk_stream_off[(u64)b * SFQ_NSTREAMS + s];
     // src is 16-byte aligned; dst is not.  Copy dwords where dst allows, bytes at the edges.
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void k_compact(const BlockDesc* blocks, const 
     for (u32 i = head + nd * 4 + threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
-                    const u64* stream_base, u8* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(nblocks, SFQ_NSTREAMS), dim3(256), 0, st, blocks, arena, blk_stream_off, stream_base, out);
+                    const u64* stream_base, u8* out, u32 skip_streams, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact, dim3(nblocks, SFQ_NSTREAMS), dim3(256), 0, st, blocks, arena, blk_stream_off, stream_base, out, skip_streams);
 }
 
 // ---- first headers ("rec.first", recs.cpp:68-75): one per block, gathered into a blob -----------------

@@ -20,8 +20,6 @@ struct ModelArgs {
     // quality warm start (prior.hip); all null = cold rows, the reference's behaviour
     const u32* prior_w; const u32* prior_wovf;   // wave layout [q_rows][64] + overflow [q_rows][4]
     const u32* prior_ls; const RowHdr* prior_lh; // lane-per-block layout
-    // parked triples of the split kernels (dev_common.h TRIP_*): entries per block at trip_base(); counts per block
-    u64* trip_q; u32* trip_g; u32* ntrip_q; u32* ntrip_g;
 };
 
 // Decode-side extras.
@@ -42,6 +40,41 @@ struct DecodeArgs {
     u32  version;                           // archive format version (recs.cpp:400: < 5 takes load_pre5)
 };
 
+// ---- lane-per-chain kernels with frozen tables (chains.hip, dev_chain.h) ----------------------------------------
+struct ChainGeoArgs { u32 chain_reads, cpb, nchains; };     // chain c = chain c % cpb of block c / cpb
+#define GEN_MAX_GENERATIONS 40
+struct ChainArgs {
+    ModelArgs m;
+    ChainGeoArgs geo;
+    u64 nbytes;                 // size of the FASTQ text (encode)
+    u32 block_reads;            // records per block (uniform; the last block may be short)
+    u32* csz;                   // [nchains] sizes of the stream being coded (encode: written; decode: read)
+    const u64* coff;            // decode: [nchains] absolute offsets of the chains' streams
+    // quality: dense frozen rows
+    const u16* qmap;            // [q_rows] context -> dense row id (0 = the uniform row)
+    const u32* qrows;           // [nrows][64] cum | freq << 16, in symbol order
+    const uint2* qtot;          // [nrows] {tot, floor(2^32 / tot)}
+    u32 q_hot;                  // rows 0 .. q_hot-1 are staged in LDS
+    const u32* qesc; uint2 qesc_tot;   // escape row (256 entries), qlts.cpp:80-86
+    // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
+    const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
+    // bases: generation tables
+    u32 g_ngen;                 // 0 = every chain codes with the initial row
+    u32 g_bound[GEN_MAX_GENERATIONS + 1];      // generation g = blocks [g_bound[g], g_bound[g + 1])
+    const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
+};
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, const u16* qmap, u32* qrows, uint2* qtot, hipStream_t st);
+void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
+void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
+void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
+void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
+void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       // gen.Ns / gen.Nn side streams, a wave per block (models_k.hip)
+void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st);
+void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
+                           const u64* stream_base, u8* out, hipStream_t st);
+#define GEN_STEP 3u             // a counted base adds GEN_STEP to its row entry (chains.hip)
+
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
 void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
@@ -60,30 +93,24 @@ void launch_rec_encode_l(const ModelArgs& a, hipStream_t st);
 void launch_usr_encode_l(const ModelArgs& a, hipStream_t st);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
 
-// models, wave-per-block throughput kernels
-// (persistent: grid = a.nbatch table slots; blocks 0..a.nblocks-1 are handed out through *ticket, which must be 0)
-void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
-void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st);
-void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);   // 2 blocks per wave; a.nbatch even
-void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st);
+// models, wave-per-block throughput kernels (persistent: one workgroup per pair of table slots -- a.nbatch is even --
+// blocks 0..a.nblocks-1 are handed out through *ticket, which must be 0)
+void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);
-int  gen_chains();                                                            // blocks per wave of that kernel (2)   // K blocks per wave (SFQ_GEN_CHAINS = 2/4/8); a.nbatch a multiple of 8
 void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);
-// split form (default): the model kernels park (cum, freq, tot) triples, launch_rc_lanes codes them, one block per lane
-void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st);
-void launch_gen_model_w(const ModelArgs& a, u32* ticket, hipStream_t st);
-void launch_rc_lanes(const ModelArgs& a, bool quality, hipStream_t st);
 
+void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
+void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
+void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st);
-void launch_gen_fixup(const DecodeArgs& a, u64 nrec, hipStream_t st);
 
 // packing
 void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, hipStream_t st);
 void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
-                    const u64* stream_base, u8* out, hipStream_t st);
+                    const u64* stream_base, u8* out, u32 skip_streams /* bit s: stream s is packed by launch_compact_chains */, hipStream_t st);
 void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st);
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st);
 void launch_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens, hipStream_t st);

@@ -23,427 +23,6 @@
 
 #define LAST_QLT 63u
 
-// ---- the wave's output window: lane k holds byte k of the current 64-byte window ------------------------
-struct WaveOut {
-    u8* p;
-    u32 pos, cap;      // uniform
-    u32 win;           // per lane
-    __device__ __forceinline__ void init(u8* ptr, u32 c) { p = ptr; pos = 0; cap = c; win = 0; }
-    __device__ __forceinline__ void put(u32 byte, u32 lane) {     // byte uniform
-        win = wl(win, byte, pos & 63);
-        pos++;
-        if ((pos & 63) == 0) {
-            const u32 at = pos - 64 + lane;
-            if (at < cap) p[at] = (u8)win;
-        }
-    }
-    __device__ __forceinline__ void flush(u32 lane) {
-        const u32 pend = pos & 63;
-        const u32 at = pos - pend + lane;
-        if (lane < pend && at < cap) p[at] = (u8)win;
-    }
-};
-
-// ---- stage 3: scalar range coder over the parked triples -------------------------------------------------
-struct WaveCoder {
-    u64 low;        // uniform
-    u32 range;      // uniform
-    u32 err;
-    __device__ __forceinline__ void init() { low = 0; range = 0xFFFFFFFFu; err = 0; }
-
-    // encode triples [0, nt) held one per lane in (tcum, tfreq, ttot)
-    __device__ __forceinline__ void run(u32 tcum, u32 tfreq, u32 ttot, u32 nt, WaveOut& out, u32 lane) {
-        // 3a. reciprocals for all triples at once: m = floor((2^32-1) / tot)  (tot >= 4 always)
-        const u32 minv = 0xFFFFFFFFu / (lane < nt ? ttot : 1u);
-        // 3b. the serial chain, on uniform values (unrolling it x4 was measured: no gain)
-#pragma nounroll
-        for (u32 k = 0; k < nt; k++) {
-            const u32 cum = rl(tcum, k), freq = rl(tfreq, k), tot = rl(ttot, k), m = rl(minv, k);
-            // r = range / tot, exactly: the multiply-high estimate is never above and at most 2 below
-            u32 r = __umulhi(range, m);
-            u32 rem = range - r * tot;
-            while (rem >= tot) { r++; rem -= tot; }
-            low += (u64)(u32)(cum * r);                                  // coder.hpp:69
-            range = r * freq;                                            // coder.hpp:70
-            int guard = 0;
-#pragma nounroll
-            while (range < RC_TOP) {                                     // coder.hpp:74-80
-                if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
-                out.put((u32)(low >> 56), lane);
-                range <<= 8;
-                low <<= 8;
-                if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
-            }
-        }
-    }
-    // The same chain on the VECTOR unit (every lane computes the identical values).  The scalar form above is
-    // pure SALU, and the chip issues one instruction per type per SIMD slot: with the quality kernel's coder on
-    // the scalar pipe and the base kernel's on the vector pipe, the two kernels' waves interleave on a SIMD
-    // instead of queueing for the same pipe.
-    __device__ __forceinline__ void run_v(u32 tcum, u32 tfreq, u32 ttot, u32 nt, WaveOut& out, u32 lane) {
-        // exact reciprocals m = floor(2^32 / tot): the multiply-high estimate is then at most 1 below
-        const u32 td = lane < nt ? ttot : 1u;
-        const u32 m0 = 0xFFFFFFFFu / td;
-        const u32 minv = m0 + ((0xFFFFFFFFu - m0 * td) == td - 1 ? 1u : 0u);
-        u32 vr, vlo, vhi;                                      // range / low, laundered into VGPRs
-        asm volatile("v_mov_b32 %0, %1" : "=v"(vr) : "s"(range));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"((u32)low));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"((u32)(low >> 32)));
-#pragma nounroll
-        for (u32 k = 0; k < nt; k++) {
-            const u32 cum = rl(tcum, k), freq = rl(tfreq, k), tot = rl(ttot, k), m = rl(minv, k);
-            u32 r = __umulhi(vr, m);
-            const u32 rem = vr - r * tot;
-            r += rem >= tot ? 1u : 0u;
-            u64 lo64 = (((u64)vhi << 32) | vlo) + (u64)cum * r;          // cum * r < range: no truncation (coder.hpp:69)
-            vr = r * freq;                                               // coder.hpp:70
-            if (rl(vr, 0) < RC_TOP) {                                    // coder.hpp:74-80
-                int guard = 0;
-#pragma nounroll
-                do {
-                    if ((lo64 ^ (lo64 + vr)) >> 56) vr = (((u32)lo64 | (RC_TOP - 1)) - (u32)lo64);
-                    out.put(rl((u32)(lo64 >> 56), 0), lane);
-                    vr <<= 8;
-                    lo64 <<= 8;
-                    if (++guard > 12) { err = 1; vr = 0xFFFFFFFFu; break; }
-                } while (rl(vr, 0) < RC_TOP);
-            }
-            vlo = (u32)lo64; vhi = (u32)(lo64 >> 32);
-        }
-        range = rl(vr, 0);
-        low = ((u64)rl(vhi, 0) << 32) | rl(vlo, 0);
-    }
-    __device__ __forceinline__ void done(WaveOut& out, u32 lane) {       // coder.hpp:52-61
-        for (int i = 0; i < 8; i++) { out.put((u32)(low >> 56), lane); low <<= 8; }
-    }
-};
-
-// ---- stage 2: a Log64Ranger row spread over the wave ------------------------------------------------------
-// HBM layout of a row (this kernel's own; tables are scratch, not part of any format): 64 dwords = one
-// 256-byte coalesced load.  Dwords 0..2 are {total, iend | count << 16, epoch tag}, dwords 4..63 are slots
-// 0..59 (freq | sym << 16).  Slots 60..63 -- reached only when a context has seen 61+ distinct values --
-// live in a 16-byte overflow row.  Lane L therefore holds slot sid = (L + 60) & 63.
-struct WaveRow {
-    u32* rows;                 // [q_rows][64]
-    u32* ovf;                  // [q_rows][4]
-    u32 epoch;                 // tagged (EPOCH_W)
-    u32 cur;                   // row held in registers (0xFFFFFFFF = none) -- uniform
-    u32 v;                     // per lane: freq | sym << 16 of slot sid
-    u32 total, iend, count;    // uniform
-    u64 dirty;                 // lanes whose slot changed since the row was loaded
-    u32 nxt, vn;               // one-row-ahead prefetch: row id and its 64 dwords (in flight)
-    const u32* prior; const u32* prior_ovf;   // shared warm-start rows (null = cold)
-    __device__ __forceinline__ void init(u32* r, u32* o, u32 e) {
-        rows = r; ovf = o; epoch = e; prior = nullptr; prior_ovf = nullptr; cur = 0xFFFFFFFFu; nxt = 0xFFFFFFFFu; v = vn = 0; total = iend = count = 0; dirty = 0;
-    }
-    __device__ __forceinline__ void writeback(u32 lane) {
-        if (cur == 0xFFFFFFFFu) return;
-        const u32 hv = lane == 0 ? total : lane == 1 ? (iend | (count << 16)) : lane == 2 ? epoch : 0u;
-        const bool mine = (dirty >> lane) & 1;
-        if (lane < 3 || (lane >= 4 && mine)) rows[(size_t)cur * 64 + lane] = lane < 4 ? hv : v;
-        if (iend > 60 && lane < 4 && mine) ovf[(size_t)cur * 4 + lane] = v;
-    }
-    // issue the load of the row the NEXT symbol needs (it differs from the one being updated, so no
-    // store to it is pending; a later reload of the current row is ordered after its write-back)
-    __device__ __forceinline__ void prefetch(u32 ctx, u32 lane) {
-        if (ctx == cur || ctx == nxt) return;
-        nxt = ctx;
-        vn = rows[(size_t)ctx * 64 + lane];
-    }
-    __device__ __forceinline__ void select(u32 ctx, u32 lane) {
-        if (ctx == cur) return;
-        writeback(lane);
-        u32 raw;
-        if (ctx == nxt) raw = vn; else raw = rows[(size_t)ctx * 64 + lane];
-        nxt = 0xFFFFFFFFu;
-        cur = ctx;
-        const u32 h1 = rl(raw, 1);
-        const bool live = rl(raw, 2) == epoch;            // a stale tag = the all-zero row of a fresh table
-        total = live ? rl(raw, 0) : 0u;
-        iend  = live ? (h1 & 0xffffu) : 0u;
-        count = live ? (h1 >> 16) : 0u;
-        v = raw;
-        dirty = 0;
-        if (!live && prior) {                              // first touch in this block: start from the shared prior row
-            v = prior[(size_t)ctx * 64 + lane];
-            total = rl(v, 0);
-            iend = rl(v, 1) & 0xffffu;
-            if (iend > 60) { if (lane < 4) v = prior_ovf[(size_t)ctx * 4 + lane]; }
-            dirty = __ballot(((lane + 60) & 63) < iend);   // the private copy holds nothing yet: write every live slot back
-        } else if (iend > 60) { if (lane < 4) v = ovf[(size_t)ctx * 4 + lane]; }
-    }
-    // Log64Ranger::put minus the Encode call (log64_ranger.hpp:98-112); sym < 64, uniform
-    __device__ __forceinline__ void model(u32 sym, u32 lane, u32& cum, u32& freq, u32& tot) {
-        const u32 sid = (lane + 60) & 63;
-        if (iend <= sym) {                                            // :103-105
-            const bool fresh = sid >= iend && sid <= sym;
-            if (fresh) v = sid << 16;
-            dirty |= __ballot(fresh);
-            iend = sym + 1;
-        }
-        const u64 hit = __ballot(sid < iend && (v >> 16) == sym);
-        const u32 hl = (u32)__ffsll((long long)hit) - 1u;             // :107 (syms[0..iend) is a permutation: exactly one hit)
-        const u32 i = (hl + 60) & 63;
-        u32 f = rl(v, hl) & 0xffffu;
-        u32 sumf = 0;
-        if (i != 0) sumf = rl(wave_incl_scan(sid < i ? (v & 0xffffu) : 0u), 63);
-        cum = sumf + i; freq = f + 1; tot = total + L64_NSYM;         // :109
-        // update_freq (log64_ranger.hpp:69-87)
-        if (f > (u32)((1 << 16) - 64 - 6)) {
-            if (i == 0 && f + 20u > total) return;
-            const bool act = sid < iend;
-            if (act) v = (v & 0xffff0000u) | ((v & 0xffffu) >> 1);    // normalize :51-54
-            total = rl(wave_incl_scan(act ? (v & 0xffffu) : 0u), 63);
-            dirty |= __ballot(act);
-            f >>= 1;
-        }
-        f += 6; total += 6;
-        if (lane == hl) v = (v & 0xffff0000u) | f;
-        dirty |= 1ull << hl;
-        if (i != 0) {
-            count = (count + 1) & 0xffu;
-            if ((count & 0xfu) == 0) {
-                const u32 pl = (hl + 63) & 63;                        // lane of slot i-1
-                const u32 pv = rl(v, pl), nv = rl(v, hl);
-                if (f > (pv & 0xffffu)) { v = wl(v, nv, pl); v = wl(v, pv, hl); dirty |= 1ull << pl; }   // down_level :56-67
-            }
-        }
-    }
-};
-
-// =========================================================================================================
-// quality encode: QltSave::save_1/2/3 (qlts.cpp:74-136) for every record of the block
-// =========================================================================================================
-__device__ __forceinline__ void k_qlt_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
-    const u32 epoch = EPOCH_W(a.epoch_base + b + 1);
-    BlockDesc* d = &a.blocks[b];
-    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
-    WaveCoder rc; rc.init();
-    WaveRow row; row.init(a.q_slots + (size_t)t * a.q_rows * L64_NSYM, reinterpret_cast<u32*>(a.q_hdr + (size_t)t * a.q_rows), epoch);
-    row.prior = a.prior_w; row.prior_ovf = a.prior_wovf;
-    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
-    const u32 solid = d->solid;
-    const int level = a.level;
-    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-    u32 tcum = 0, tfreq = 0, ttot = 1, nt = 0;      // parked triples
-    u32 extra_hi = 0, perr = 0, touched = 0;
-
-    for (u32 k = 0; k < nrec; k++) {
-        const u64 r = rec0 + k;
-        const u64 q0 = a.line_off[4 * r + 3] + solid;
-        const u64 q1e = a.line_off[4 * r + 4] - 1;
-        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
-        const u8* p = a.fq + q0;
-        u32 p1 = 0, p2 = 0, p3 = 0, carry_d = 0;       // the three previous symbols and the running delta - 5
-        for (u32 base = 0; base < n; base += 64) {
-            const u32 m = n - base < 64 ? n - base : 64;
-            // ---- stage 1: symbols and contexts, across lanes ----
-            const u32 bv = lane < m ? (u32)(u8)(p[base + lane] - '!') : 0u;
-            const u32 v1 = wave_shr1(bv, p1);           // symbol k-1
-            const u32 v2 = wave_shr1(v1, p2);           // symbol k-2
-            const u32 v3 = wave_shr1(v2, p3);           // symbol k-3
-            u32 ctxv;
-            if (level == 1)      ctxv = (v1 | ((v2 & 63u) << 6)) & 0xFFFu;                                  // qlts.hpp:52-54 unrolled
-            else if (level == 2) ctxv = (v1 | (((v2 | ((v3 & 15u) << 6)) & 0x3FFu) << 6)) & 0xFFFFu;       // qlts.hpp:55-57 unrolled
-            else {                                                                                         // qlts.hpp:62-74
-                // delta after symbol j = 5 + sum_{i<=j} max(0, sym[i-1] - sym[i]); symbol k's context uses delta after k-1
-                const u32 drop = (lane < m && v1 > bv) ? v1 - bv : 0u;
-                const u32 inc = wave_incl_scan(drop);
-                const u32 dprev = 5u + carry_d + inc - drop;
-                const u32 d3 = dprev >> 3;
-                ctxv = (v1 | ((v2 < v3 ? v3 : v2) << 6) | ((u32)(v2 == v3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
-                if (base == 0 && lane == 0) ctxv = 0;   // qlts.cpp:109: last = 0 for the first symbol
-                carry_d += rl(inc, 63);
-            }
-            p3 = m >= 3 ? rl(bv, m - 3) : (m == 2 ? p1 : p2);
-            p2 = m >= 2 ? rl(bv, m - 2) : p1;
-            p1 = rl(bv, m - 1);
-            // every row this window will touch is known now: pull both of its 128-byte lines towards L2 so the
-            // serial loop below pays a cache hit, not an HBM miss, per context switch
-            if (lane < m) {
-                const u32* rp = row.rows + (size_t)ctxv * 64;
-                touched += rp[0] + rp[32];
-            }
-            // ---- stage 2: adaptive rows, one symbol at a time ----
-            for (u32 j = 0; j < m; j++) {
-                const u32 ctx = rl(ctxv, j), sym = rl(bv, j);
-                row.select(ctx, lane);
-                if (j + 1 < m) row.prefetch(rl(ctxv, j + 1), lane);
-                u32 cum, freq, tot;
-                row.model(sym < LAST_QLT ? sym : LAST_QLT, lane, cum, freq, tot);     // qlts.cpp:79-86
-                { const bool me = lane == nt; tcum = me ? cum : tcum; tfreq = me ? freq : tfreq; ttot = me ? tot : ttot; nt++; }
-                if (sym >= LAST_QLT) {                   // escape: the raw value through the PowerRanger row
-                    Triple e; e.cum = 0; e.freq = 1; e.tot = 1;
-                    if (lane == 0) e = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, pw.epoch, sym, perr);
-                    const u32 ec = rfl(e.cum), ef = rfl(e.freq), et = rfl(e.tot);
-                    { const bool me = lane == nt; tcum = me ? ec : tcum; tfreq = me ? ef : tfreq; ttot = me ? et : ttot; nt++; }
-                    extra_hi++;
-                }
-                if (nt >= 62) { rc.run(tcum, tfreq, ttot, nt, out, lane); nt = 0; }    // ---- stage 3 ----
-            }
-        }
-    }
-    row.writeback(lane);
-    rc.run(tcum, tfreq, ttot, nt, out, lane);
-    rc.done(out, lane);
-    out.flush(lane);
-    if (touched == 0x9e3779b9u && lane == 77) d->extra_hi = touched;   // never true (lane < 64): keeps the touch loads alive
-    if (lane == 0) {
-        d->extra_hi = extra_hi;
-        d->size[SFQ_S_QLT] = out.pos;
-        if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-        if (rc.err | rfl(perr)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-    }
-}
-__global__ __launch_bounds__(64) void k_qlt_encode_w(ModelArgs a, u32* ticket) {
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_w_block(a, blockIdx.x, b, threadIdx.x);
-}
-void launch_qlt_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_encode_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
-
-// =========================================================================================================
-// base encode: GenSave::save_x + normalize_gen (gens.cpp:91-159) for every record of the block
-//
-// Bases are the one model whose symbols can be modelled across lanes: the context of base k is a hash
-// of the previous 9..13 bases only (gens.cpp:138-148), so 64 consecutive bases gather their 4-byte
-// Base2Ranger rows at once, each lane computes its own (cum, freq, tot) and row update, and the rows are
-// scattered back.  Two bases of one 64-window that share a context would have to chain through the same
-// row; a bitonic sort of (context, lane) keys detects that exactly, and such a window falls back to 64
-// serial steps.  The range coder then consumes the 64 triples (stage 3 above).
-// =========================================================================================================
-template <bool SPLIT>
-__device__ __forceinline__ void k_gen_encode_w_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
-    const u32 epoch = EPOCH_L(a.epoch_base + b + 1);
-    BlockDesc* d = &a.blocks[b];
-    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_GEN], d->out_cap[SFQ_S_GEN]);
-    WaveCoder rc; rc.init();
-    u32* const trip = SPLIT ? a.trip_g + trip_base(a.line_off, d->rec0) : nullptr;
-    const u32 tcap = SPLIT ? trip_cap(a.line_off, d->rec0, d->nrec) : 0u;
-    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
-    XfEnc x_ns, x_nn;                                  // side-stream coders: lane 0 only
-    x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
-    x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
-    u32* tab = a.g_tab + ((size_t)t << a.g_bits);
-    const u32 solid = d->solid;
-    const u32 mask = (1u << d->gen_bits) - 1u;
-    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-    u64 genofs = 0, ns_index = 0, nn_index = 0;        // g_genofs_count, m_last.{Ns,Nn}_index (block-relative)
-    u32 n_byte = 0; int bad = 0;
-
-    for (u32 k = 0; k < nrec; k++) {
-        const u64 r = rec0 + k;
-        const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1;
-        const u64 q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
-        const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
-        const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
-        u32 carry = 0x007616c7u;                                                      // gens.cpp:139
-        for (u32 base = 0; base < llen; base += 64) {
-            const u32 m = llen - base < 64 ? llen - base : 64;
-            const u32 idx = base + lane;
-            const bool in = lane < m;
-            const u32 gch = in ? gp[idx] : 'A';
-            const u32 qch = (in && idx < qlen) ? qp[idx] : 40u;                       // gens.cpp:153
-            const u32 n = gencode_w(gch);                                             // normalize_gen gens.cpp:116-136
-            const bool bad_n = in && n == 4, bad_q = in && qch == '!';
-            if (__ballot(in && n > 4)) bad = SFQ_E_GENCHAR;
-            const u32 code = n & 3u;                                                  // N is coded as 0 (A)
-            const u64 mN = __ballot(bad_n), mQ = __ballot(bad_q);
-            u64 mx = mN | mQ;
-            while (mx) {                                                              // bad_q_or_bad_n gens.cpp:91-114, in order
-                const u32 bit = (u32)__ffsll((long long)mx) - 1u;
-                mx &= mx - 1;
-                const u64 pos = genofs + bit + 1;
-                const bool is_n = (mN >> bit) & 1, is_q = (mQ >> bit) & 1;
-                if (!is_n) {
-                    if (lane == 0) x_nn.put(pw, pos - nn_index);
-                    nn_index = pos;
-                } else {
-                    const u32 ch = rl(gch, bit);
-                    if (!n_byte) n_byte = ch;
-                    if (ch != n_byte) bad = SFQ_E_GENCHAR;
-                    if (!is_q) { if (lane == 0) x_ns.put(pw, pos - ns_index); ns_index = pos; }
-                }
-            }
-            genofs += m;
-            // contexts: a 32-bit shift register of 2-bit codes; lane k sees the codes of lanes < k, then the carry
-            u32 w = wave_shr1(code, 0u);                            // code[k-1]
-            w |= wave_shr1(w, 0u) << 2;                             // 2 symbols
-            w |= shfl_up0(w, 2, lane) << 4;                         // 4
-            w |= shfl_up0(w, 4, lane) << 8;                         // 8
-            w |= shfl_up0(w, 8, lane) << 16;                        // 16
-            const u32 ctx = ((lane < 16 ? carry << (2 * lane) : 0u) | w) & mask;
-            carry = (rl(w, 63) << 2) | rl(code, 63);                // only meaningful (and only used) after a full window
-            // rows
-            u32 row = in ? tab[ctx] : 0u;
-            const u32 key = in ? ((ctx << 6) | lane) : (0x80000000u | (lane << 6) | lane);
-            const u32 sk = bitonic_sort64(key, lane);
-            const u32 skp = (u32)__shfl_up((int)sk, 1, 64);
-            const bool dup = lane > 0 && (sk >> 6) == (skp >> 6);
-            u32 cum = 0, freq = 1, tot = 1;
-            if (!__ballot(dup)) {
-                const u32 nrow = b2_model(row, code, cum, freq, tot);
-                if (in) tab[ctx] = nrow;
-            } else {
-                for (u32 j = 0; j < m; j++) {                       // same-context bases in one window: chain them in order
-                    const u32 c = rl(ctx, j), s = rl(code, j);
-                    u32 cj, fj, tj;
-                    const u32 nrow = b2_model(tab[c], s, cj, fj, tj);
-                    if (lane == 0) tab[c] = nrow;
-                    if (lane == j) { cum = cj; freq = fj; tot = tj; }
-                }
-            }
-            if constexpr (SPLIT) {                                 // genofs already counts this window
-                const u64 at = genofs - m + lane;
-                if (in && at < tcap) trip[at] = TRIP_G_PACK(cum, freq, tot);
-            } else rc.run_v(cum, freq, tot, m, out, lane);
-        }
-    }
-    if constexpr (!SPLIT) { rc.done(out, lane); out.flush(lane); }
-    if (lane == 0) {
-        d->n_byte = n_byte;
-        if constexpr (SPLIT) {
-            a.ntrip_g[b] = genofs <= tcap ? (u32)genofs : 0u;
-            if (genofs > tcap) atomicMax(&d->status, ST_TRIP_OVERFLOW);
-        } else {
-            d->size[SFQ_S_GEN] = out.pos;
-            if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-            if (rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-        }
-        d->size[SFQ_S_GEN_NS] = x_ns.finish(pw);
-        d->size[SFQ_S_GEN_NN] = x_nn.finish(pw);
-        if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-        if (x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-        if (bad) atomicMax(&d->status, (u32)(-bad));
-    }
-}
-__global__ __launch_bounds__(64, 8) void k_gen_encode_w(ModelArgs a, u32* ticket) {
-    const u32 lane = threadIdx.x;
-    u32* const tab = a.g_tab + ((size_t)blockIdx.x << a.g_bits);
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
-        // Base2Ranger rows start at 3,3,3,3 (base2_ranger.hpp:68-71): the slot's table is re-initialised per block
-        const u32 n4 = 1u << (a.g_bits - 2);
-#pragma unroll 4
-        for (u32 i = lane; i < n4; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(B2_INIT, B2_INIT, B2_INIT, B2_INIT);
-        k_gen_encode_w_block<false>(a, blockIdx.x, b, lane);
-    }
-}
-void launch_gen_encode_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_encode_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
-__global__ __launch_bounds__(64, 8) void k_gen_model_w(ModelArgs a, u32* ticket) {
-    const u32 lane = threadIdx.x;
-    u32* const tab = a.g_tab + ((size_t)blockIdx.x << a.g_bits);
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
-        const u32 n4 = 1u << (a.g_bits - 2);
-#pragma unroll 4
-        for (u32 i = lane; i < n4; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(B2_INIT, B2_INIT, B2_INIT, B2_INIT);
-        k_gen_encode_w_block<true>(a, blockIdx.x, b, lane);
-    }
-}
-void launch_gen_model_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_model_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
 
 // =========================================================================================================
 // header encode: RecSave::save (recs.cpp:277-372) for every record of the block
@@ -978,161 +557,6 @@ __device__ __forceinline__ void l64_model_run_lane(u32* row, u32* ovf, u32 epoch
     }
 }
 
-// SPLIT: stage 3 is not run here; the triples are parked for coder_l.hip (launch_rc_lanes)
-template <bool SPLIT>
-__device__ __forceinline__ void k_qlt_encode_s_block(const ModelArgs& a, const u32 t, const u32 b, const u32 lane) {
-    const u32 epoch = EPOCH_L(a.epoch_base + b + 1), epoch_w = EPOCH_W(a.epoch_base + b + 1);
-    BlockDesc* d = &a.blocks[b];
-    WaveOut out; out.init(a.arena + d->out_off[SFQ_S_QLT], d->out_cap[SFQ_S_QLT]);
-    WaveCoder rc; rc.init();
-    u64* const trip = SPLIT ? a.trip_q + trip_base(a.line_off, d->rec0) : nullptr;
-    const u32 tcap = SPLIT ? trip_cap(a.line_off, d->rec0, d->nrec) : 0u;
-    u32 ntr = 0;                                       // triples parked so far (uniform)
-    u32* const qs = a.q_slots + (size_t)t * a.q_rows * L64_NSYM;                    // rows in the wave layout
-    u32* const qo = reinterpret_cast<u32*>(a.q_hdr + (size_t)t * a.q_rows);          // their overflow slots
-    PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = epoch;
-    const u32 solid = d->solid;
-    const int level = a.level;
-    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-    u32 extra_hi = 0, perr = 0;
-    __shared__ uint4 strip[64];                        // triples of the window in sorted order
-
-    for (u32 k = 0; k < nrec; k++) {
-        const u64 r = rec0 + k;
-        const u64 q0 = a.line_off[4 * r + 3] + solid;
-        const u64 q1e = a.line_off[4 * r + 4] - 1;
-        const u32 n = q1e > q0 ? (u32)(q1e - q0) : 0;
-        const u8* p = a.fq + q0;
-        u32 p1 = 0, p2 = 0, p3 = 0, carry_d = 0;
-        for (u32 base = 0; base < n; base += 64) {
-            const u32 m = n - base < 64 ? n - base : 64;
-            // ---- stage 1: symbols and contexts, across lanes (as in k_qlt_encode_w) ----
-            const u32 bv = lane < m ? (u32)(u8)(p[base + lane] - '!') : 0u;
-            const u32 v1 = wave_shr1(bv, p1);
-            const u32 v2 = wave_shr1(v1, p2);
-            const u32 v3 = wave_shr1(v2, p3);
-            u32 ctxv;
-            if (level == 1)      ctxv = (v1 | ((v2 & 63u) << 6)) & 0xFFFu;
-            else if (level == 2) ctxv = (v1 | (((v2 | ((v3 & 15u) << 6)) & 0x3FFu) << 6)) & 0xFFFFu;
-            else {
-                const u32 drop = (lane < m && v1 > bv) ? v1 - bv : 0u;
-                const u32 inc = wave_incl_scan(drop);
-                const u32 dprev = 5u + carry_d + inc - drop;
-                const u32 d3 = dprev >> 3;
-                ctxv = (v1 | ((v2 < v3 ? v3 : v2) << 6) | ((u32)(v2 == v3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
-                if (base == 0 && lane == 0) ctxv = 0;
-                carry_d += rl(inc, 63);
-            }
-            p3 = m >= 3 ? rl(bv, m - 3) : (m == 2 ? p1 : p2);
-            p2 = m >= 2 ? rl(bv, m - 2) : p1;
-            p1 = rl(bv, m - 1);
-            u32 tcum = 0, tfreq = 1, ttot = 1;
-            const u64 esc = __ballot(lane < m && bv >= LAST_QLT);
-            if (!esc) {
-                // ---- stage 2: rank every symbol inside its context, then one round per rank ----
-                const u32 key = lane < m ? ((ctxv << 6) | lane) : (0x80000000u | (lane << 6) | lane);
-                const u32 sk = bitonic_sort64(key, lane);                 // sorted lane: (context, original position)
-                const u32 sctx = sk >> 6, spos = sk & 63u;
-                const bool valid = !(sk >> 31);
-                const u32 ssym = (u32)__builtin_amdgcn_ds_bpermute((int)(spos * 4), (int)bv);
-                // symbols of one context are contiguous and in position order; consecutive equal symbols form a RUN.
-                // A context's runs are applied one per round, each by the lane of its first symbol.
-                const u32 prevctx = wave_shr1(sctx, 0xFFFFFFFFu), prevsym = wave_shr1(ssym, 0xFFFFFFFFu);
-                const bool ctx_head = sctx != prevctx;
-                const bool run_head = ctx_head || ssym != prevsym;
-                const u32 cstart = wave_incl_scan_max(ctx_head ? lane : 0u);          // first sorted lane of this context
-                const u32 nheads = wave_incl_scan(run_head ? 1u : 0u);
-                const u32 runidx = nheads - (u32)__builtin_amdgcn_ds_bpermute((int)(cstart * 4), (int)nheads);
-                const u64 heads = __ballot(run_head);
-                const u64 above = lane >= 63 ? 0ull : (heads >> (lane + 1));
-                const u32 runlen = above ? (u32)__ffsll((long long)above) : 64u - lane;   // distance to the next run head
-                u32* const row = qs + (size_t)(sctx & 0xFFFFu) * L64_NSYM;
-                u32* const ovf = qo + (size_t)(sctx & 0xFFFFu) * 4;
-                const u32* const prow = a.prior_w ? a.prior_w + (size_t)(sctx & 0xFFFFu) * L64_NSYM : nullptr;
-                const u32* const povf = a.prior_wovf + (size_t)(sctx & 0xFFFFu) * 4;
-                __syncthreads();                                          // one wave per workgroup: LDS ordering across lanes
-                for (u32 round = 0; ; round++) {
-                    const bool mine = valid && run_head && runidx == round;
-                    if (!__ballot(mine)) break;
-                    if (mine) l64_model_run_lane(row, ovf, epoch_w, prow, povf, ssym, runlen, &strip[lane], perr);
-                }
-                __syncthreads();
-                const uint4 tr = valid ? strip[lane] : make_uint4(0u, 1u, 1u, 0u);
-                const u32 scum = tr.x, sfreq = tr.y, stot = tr.z;
-                // back to position order
-                if constexpr (SPLIT) {
-                    const u32 plo = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)TRIP_Q_PACK_LO(scum, sfreq));
-                    const u32 phi = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)TRIP_Q_PACK_HI(sfreq, stot));
-                    if (lane < m && ntr + lane < tcap) trip[ntr + lane] = ((u64)phi << 32) | plo;
-                    ntr += m;
-                } else {
-                    tcum  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)scum);
-                    tfreq = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)sfreq);
-                    ttot  = (u32)__builtin_amdgcn_ds_permute((int)(spos * 4), (int)stot);
-                    rc.run(tcum, tfreq, ttot, m, out, lane);              // ---- stage 3 ----
-                }
-            } else {
-                // a window holding escape symbols (quality >= 63: qlts.cpp:80-86) is walked in order on lane 0;
-                // each symbol contributes one triple, an escape a second one from the PowerRanger row
-                for (u32 j = 0; j < m; j++) {
-                    const u32 ctx = rl(ctxv, j), sym = rl(bv, j);
-                    Triple t1; t1.cum = 0; t1.freq = 1; t1.tot = 1;
-                    Triple t2 = t1;
-                    if (lane == 0) {
-                        t1 = l64_model_lane(qs + (size_t)ctx * L64_NSYM, qo + (size_t)ctx * 4, epoch_w,
-                                            a.prior_w ? a.prior_w + (size_t)ctx * L64_NSYM : nullptr, a.prior_wovf + (size_t)ctx * 4,
-                                            sym < LAST_QLT ? sym : LAST_QLT, perr);
-                        if (sym >= LAST_QLT) t2 = Power::model(pw.slots + (size_t)PR_EXQ_ROW * PW_NSYM, pw.hdr + PR_EXQ_ROW, epoch, sym, perr);
-                    }
-                    const u32 c1 = rfl(t1.cum), f1 = rfl(t1.freq), o1 = rfl(t1.tot);
-                    const u32 c2 = rfl(t2.cum), f2 = rfl(t2.freq), o2 = rfl(t2.tot);
-                    const u32 cnt = sym >= LAST_QLT ? 2u : 1u;
-                    if constexpr (SPLIT) {
-                        if (lane == 0 && ntr + cnt <= tcap) {
-                            trip[ntr] = ((u64)TRIP_Q_PACK_HI(f1, o1) << 32) | TRIP_Q_PACK_LO(c1, f1);
-                            if (cnt == 2) trip[ntr + 1] = ((u64)TRIP_Q_PACK_HI(f2, o2) << 32) | TRIP_Q_PACK_LO(c2, f2);
-                        }
-                        ntr += cnt;
-                    } else {
-                        tcum = lane == 0 ? c1 : c2; tfreq = lane == 0 ? f1 : f2; ttot = lane == 0 ? o1 : o2;
-                        rc.run(tcum, tfreq, ttot, cnt, out, lane);
-                    }
-                    if (sym >= LAST_QLT) extra_hi++;
-                }
-            }
-        }
-    }
-    const u64 anyerr = __ballot(perr != 0);
-    if constexpr (SPLIT) {
-        if (lane == 0) {
-            d->extra_hi = extra_hi;
-            a.ntrip_q[b] = ntr <= tcap ? ntr : 0u;
-            if (ntr > tcap) atomicMax(&d->status, ST_TRIP_OVERFLOW);
-            if (anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-        }
-    } else {
-        rc.done(out, lane);
-        out.flush(lane);
-        if (lane == 0) {
-            d->extra_hi = extra_hi;
-            d->size[SFQ_S_QLT] = out.pos;
-            if (out.pos > out.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-            if (rc.err || anyerr) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-        }
-    }
-}
-__global__ __launch_bounds__(64, 8) void k_qlt_encode_s(ModelArgs a, u32* ticket) {
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block<false>(a, blockIdx.x, b, threadIdx.x);
-}
-void launch_qlt_encode_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_encode_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
-__global__ __launch_bounds__(64, 8) void k_qlt_model_s(ModelArgs a, u32* ticket) {
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) k_qlt_encode_s_block<true>(a, blockIdx.x, b, threadIdx.x);
-}
-void launch_qlt_model_s(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_model_s, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
 
 // =========================================================================================================
 // quality encode, two blocks per wave  (default quality kernel)
