@@ -1,6 +1,6 @@
 """frozen-table mode: device-resident encode -> decode round trip with timings (python scratch/frozen_rt.py <reads> [kind] [block_reads] [chain_reads])"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slimfastq_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qw, qmap, qrows, qtot, qesc, csz, coff, gcnt, grows, glog, gcost;
+    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
@@ -212,36 +212,16 @@ int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
 }
 
 // ---- frozen tables: host-side pieces -------------------------------------------------------------------------
-// Dense quality rows: contexts that have a prior row get ids 1.., hottest first (the first q_hot ids are staged in
-// LDS); id 0 is the uniform row of contexts the sample never saw.  The numbering is internal to a call.
-int build_qmap(sfq_ctx* ctx, const std::vector<u32>& weight, u32 q_rows, u32* nrows_out, hipStream_t st) {
-    std::vector<u32> order;
-    for (u32 c = 0; c < q_rows; c++) if (weight[c]) order.push_back(c);
-    if (order.size() > 65535) return fail(ctx, SFQ_E_UNSUPPORTED, "quality prior has %zu rows (more than 65535)", order.size());
-    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return weight[x] > weight[y]; });
-    std::vector<u16> map(q_rows, 0);
-    for (size_t i = 0; i < order.size(); i++) map[order[i]] = (u16)(i + 1);
-    int rc;
-    const u32 nrows = (u32)order.size() + 1;
-    if ((rc = reserve(ctx, ctx->qmap, (size_t)q_rows * 2))) return rc;
-    if ((rc = reserve(ctx, ctx->qrows, (size_t)nrows * 64 * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->qtot, (size_t)nrows * 8))) return rc;
-    HIPC(hipMemcpyAsync(ctx->qmap.p, map.data(), (size_t)q_rows * 2, hipMemcpyHostToDevice, st));
-    HIPC(hipStreamSynchronize(st));                      // `map` is a local
-    *nrows_out = nrows;
-    return SFQ_OK;
-}
 // the escape row (qualities >= 63, qlts.cpp:80-86): all 256 values equally likely
 int build_qesc(sfq_ctx* ctx, hipStream_t st) {
     int rc;
     if ((rc = reserve(ctx, ctx->qesc, 256 * 4))) return rc;
     u32 row[256];
-    for (u32 i = 0; i < 256; i++) row[i] = i | (1u << 16);
+    for (u32 i = 0; i < 256; i++) row[i] = (i << 8) | (256u << 16);          // cum | freq << 16, total 2^16
     HIPC(hipMemcpyAsync(ctx->qesc.p, row, sizeof row, hipMemcpyHostToDevice, st));
     HIPC(hipStreamSynchronize(st));
     return SFQ_OK;
 }
-u32 recip_host(u32 tot) { return tot <= 1 ? 0xFFFFFFFFu : (u32)((1ull << 32) / tot); }
 // floor(1024 * log2(x)) for x in 1..1023, by integer arithmetic alone (squaring a 1.31 fixed-point mantissa)
 void log2_table(u16* t) {
     t[0] = 0;
@@ -259,8 +239,8 @@ void log2_table(u16* t) {
 }
 // generations of the base model: blocks [bound[g], bound[g + 1]); the first is 1/64 of the blocks, each next one as long as
 // all before it (GEN_GROW_NUM / GEN_GROW_DEN of them)
-#define GEN_GROW_NUM 3
-#define GEN_GROW_DEN 2
+#define GEN_GROW_NUM 2
+#define GEN_GROW_DEN 1
 u32 gen_bounds(u32 nblocks, u32* bound) {
     u32 n = 0; bound[0] = 0;
     u64 b = std::max<u32>(1, (nblocks + 63) / 64);
@@ -366,7 +346,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->qw, &ctx->qmap, &ctx->qrows, &ctx->qtot, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -500,19 +480,11 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         ca.nbytes = nbytes; ca.block_reads = block_reads;
         if ((rc = reserve(ctx, ctx->csz, (size_t)nchains * 2 * 4))) return rc;
         if (models & SFQ_M_QLT) {
-            if ((rc = reserve(ctx, ctx->qw, (size_t)q_rows * 4))) return rc;
-            launch_row_weights((const u32*)ctx->hist.p, q_rows, (u32*)ctx->qw.p, st);
-            std::vector<u32> w(q_rows);
-            HIPC(hipMemcpyAsync(w.data(), ctx->qw.p, (size_t)q_rows * 4, hipMemcpyDeviceToHost, st));
-            HIPC(hipStreamSynchronize(st));
-            u32 nrows = 0;
-            if ((rc = build_qmap(ctx, w, q_rows, &nrows, st))) return rc;
+            if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
             if ((rc = build_qesc(ctx, st))) return rc;
-            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (const u16*)ctx->qmap.p, (u32*)ctx->qrows.p, (uint2*)ctx->qtot.p, st);
-            ca.qmap = (const u16*)ctx->qmap.p; ca.qrows = (const u32*)ctx->qrows.p; ca.qtot = (const uint2*)ctx->qtot.p;
-            ca.q_hot = std::min<u32>(nrows, p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : (p.lds_rows ? p.lds_rows : 255u));
-            if (ca.q_hot > 255) ca.q_hot = 255;
-            ca.qesc = (const u32*)ctx->qesc.p; ca.qesc_tot = make_uint2(256u, recip_host(256u));
+            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, st);
+            ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
+            ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
             HIPC(hipEventRecord(ctx->ev[1], st));
         }
     }
@@ -583,7 +555,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         launch_gen_encode_l(a, mst[m]);
                         break;
                     case SFQ_M_REC: launch_rec_encode_l(a, mst[m]); break;
-                    case SFQ_M_USR: launch_usr_encode_l(a, mst[m]); break;
+                    case SFQ_M_USR: if (p.kernel == 1) launch_usr_encode_l(a, mst[m]); else launch_usr_encode_w(a, mst[m]); break;
                     }
                 }
             }
@@ -887,18 +859,11 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         ChainArgs ca;
         memset(&ca, 0, sizeof ca);
         ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
-        {
-            std::vector<u32> w(q_rows, 0);
-            for (u32 c = 0; c < q_rows; c++) if (prior_rows[(size_t)c * 66 + 65]) w[c] = std::max<u32>(1, prior_rows[(size_t)c * 66 + 64]);
-            u32 nrows = 0;
-            if ((rc = build_qmap(ctx, w, q_rows, &nrows, st))) return rc;
-            if ((rc = build_qesc(ctx, st))) return rc;
-            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (const u16*)ctx->qmap.p, (u32*)ctx->qrows.p, (uint2*)ctx->qtot.p, st);
-            ca.qmap = (const u16*)ctx->qmap.p; ca.qrows = (const u32*)ctx->qrows.p; ca.qtot = (const uint2*)ctx->qtot.p;
-            ca.q_hot = std::min<u32>(nrows, p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : (p.lds_rows ? p.lds_rows : 255u));
-            if (ca.q_hot > 255) ca.q_hot = 255;
-            ca.qesc = (const u32*)ctx->qesc.p; ca.qesc_tot = make_uint2(256u, recip_host(256u));
-        }
+        if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
+        if ((rc = build_qesc(ctx, st))) return rc;
+        launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, st);
+        ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
+        ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));

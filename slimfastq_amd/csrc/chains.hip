@@ -16,55 +16,43 @@
 #define B2_INIT 0x03030303u             // Base2Ranger row of a fresh table (base2_ranger.hpp:68-71)
 
 // ---- frozen quality rows -------------------------------------------------------------------------------------
-// rows66: per context 64 slots (freq | sym << 16), total, iend (prior.hip k_prior_rows).  The frozen row of a context
-// lists all 64 symbols in symbol order: g[s] = (f[s] >> t) + 1 with the smallest t that brings sum(g) <= 65535;
-// entry s = cum(g[0..s)) | g[s] << 16.  Contexts the sample never saw share the uniform row (dense id 0).
-__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, const u16* __restrict__ qmap,
-                                                        u32* __restrict__ qrows, uint2* __restrict__ qtot) {
+// rows66: per context 64 slots (freq | sym << 16), total, iend (prior.hip k_prior_rows; the decoder unpacks "qlt.pri" into
+// the same form).  A frozen row lists all 64 symbols in symbol order with the Log64Ranger's weights -- freq + 1 over
+// total + 64 (log64_ranger.hpp:109) -- rescaled to a total of exactly 2^16, so that RCoder::Encode's range / tot
+// (coder.hpp:68) is a shift:  x[s] = f[s] + 1,  g[s] = max(1, floor(x[s] * 65536 / sum x)),  and the difference
+// 65536 - sum g goes to the largest g (the first of them).  Entry s = cum(g[0..s)) | g[s] << 16  (g <= 65473).
+// A context the sample never saw has the uniform row (g = 1024).  Rows are indexed by the context itself: q_rows x 256 B,
+// of which a file touches a few thousand rows (L2-resident).
+__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
-    u32 id = qmap[ctx];
-    const bool uniform_row = ctx == 0 && blockIdx.x == 0 && (threadIdx.x >> 6) == 0;   // wave 0 also writes the uniform row
-    if (uniform_row) { qrows[lane] = lane | (1u << 16); if (lane == 0) qtot[0] = make_uint2(64u, fz_recip(64u)); }
-    if (id == 0) return;
     const u32* r = rows66 + (size_t)ctx * 66;
     const u32 slot = r[lane], iend = r[65];
-    // slot order -> symbol order: lane j sends its frequency to lane sym(j)
+    if (iend == 0) { qrows[(size_t)ctx * 64 + lane] = (lane << 10) | (1024u << 16); return; }
+    // slot order -> symbol order: lane j sends its frequency to lane sym(j) (lanes >= iend hold no slot: they send 0 to themselves)
     const u32 sym = slot >> 16, fslot = lane < iend ? (slot & 0xffffu) : 0u;
-    u32 f = (u32)__builtin_amdgcn_ds_permute((int)((lane < iend ? sym : lane) * 4), (int)fslot);
-    // lanes >= iend sent 0 to themselves; but a lane < iend may also have been targeted by a lane >= iend (same index):
-    // symbols >= iend hold no slot, so only lanes >= iend receive from lanes >= iend -- no clash
-    u32 t = 0, g, tot;
-    for (;;) {
-        g = (f >> t) + 1;
-        tot = g;
+    const u32 f = (u32)__builtin_amdgcn_ds_permute((int)((lane < iend ? sym : lane) * 4), (int)fslot);
+    const u32 x = f + 1;
+    u32 S = x;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) tot += (u32)__shfl_xor((int)tot, d, 64);
-        if (tot <= FZ_MAX_TOT) break;
-        t++;
+    for (int d = 32; d > 0; d >>= 1) S += (u32)__shfl_xor((int)S, d, 64);
+    u32 g = (x << 16) / S;                                  // x <= 65536: no overflow
+    g = g ? g : 1u;
+    u32 sum = g, best = (g << 6) | (63u - lane);             // largest g, lowest symbol first
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sum += (u32)__shfl_xor((int)sum, d, 64);
+        const u32 o = (u32)__shfl_xor((int)best, d, 64); best = o > best ? o : best;
     }
+    if (lane == 63u - (best & 63u)) g += 65536u - sum;
     u32 incl = g;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
-    qrows[(size_t)id * 64 + lane] = (incl - g) | (g << 16);
-    if (lane == 0) qtot[id] = make_uint2(tot, fz_recip(tot));
+    qrows[(size_t)ctx * 64 + lane] = (incl - g) | (g << 16);
 }
-void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, const u16* qmap, u32* qrows, uint2* qtot, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qmap, qrows, qtot);
-}
-// row weight = the sample's symbol count of the context (0 = no row); the host ranks contexts by it
-__global__ __launch_bounds__(256) void k_row_weights(const u32* __restrict__ hist, u32 q_rows, u32* __restrict__ w) {
-    const u32 lane = threadIdx.x & 63;
-    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ctx >= q_rows) return;
-    u32 c = hist[(size_t)ctx * 64 + lane];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
-    if (lane == 0) w[ctx] = c;
-}
-void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st) {
-    hipLaunchKernelGGL(k_row_weights, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, w);
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows);
 }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
@@ -102,11 +90,6 @@ __device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {     
 // =========================================================================================================
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
-    extern __shared__ u32 lds[];                              // [hot rows][64] entries, then [nrows] totals (uint2)
-    const u32 hot = a.q_hot;                                  // dense ids 0 .. hot-1 live in LDS
-    u32* const lrows = lds;
-    for (u32 i = threadIdx.x; i < hot * 64; i += THREADS) lrows[i] = a.qrows[i];
-    __syncthreads();
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < a.geo.nchains;
     ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
@@ -149,13 +132,11 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
                 const u32 b = (((word >> ((j & 3) * 8)) & 0xffu) - '!') & 0xffu;
                 const u32 sym = b < LAST_QLT ? b : LAST_QLT;
-                const u32 id = a.qmap[last];
-                const u32 e = id < hot ? lrows[id * 64 + sym] : a.qrows[(size_t)id * 64 + sym];
-                const uint2 tt = a.qtot[id];
-                rc.encode(FZ_CUM(e), FZ_FREQ(e), tt.x, tt.y);
+                const u32 e = a.qrows[(size_t)last * 64 + sym];
+                rc.encode16(FZ_CUM(e), FZ_FREQ(e));
                 if (b >= LAST_QLT) {                                       // escape: the raw value through the frozen escape row (qlts.cpp:80-86)
                     const u32 ee = a.qesc[b];
-                    rc.encode(FZ_CUM(ee), FZ_FREQ(ee), a.qesc_tot.x, a.qesc_tot.y);
+                    rc.encode16(FZ_CUM(ee), FZ_FREQ(ee));
                     extra++;
                 }
                 if (level <= 2) last = (b | (last << 6)) & mask12;         // qlts.hpp:52-57
@@ -180,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
     constexpr int T = 256;
     const u32 grid = (a.geo.nchains + T - 1) / T;
-    hipLaunchKernelGGL(k_qlt_encode_c<T>, dim3(grid), dim3(T), a.q_hot * QROW_BYTES, st, a);
+    hipLaunchKernelGGL(k_qlt_encode_c<T>, dim3(grid), dim3(T), 0, st, a);
 }
 
 // =========================================================================================================
@@ -188,11 +169,6 @@ void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
 // =========================================================================================================
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArgs da) {
-    extern __shared__ u32 lds[];
-    const u32 hot = a.q_hot;
-    u32* const lrows = lds;
-    for (u32 i = threadIdx.x; i < hot * 64; i += THREADS) lrows[i] = a.qrows[i];
-    __syncthreads();
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.geo.nchains) return;
     const ChainPos cp = chain_pos(a, c);
@@ -205,25 +181,21 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
         u8* p = da.qual_stage + da.qoff[r];
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {
-            const u32 id = a.qmap[last];
-            const uint2 tt = a.qtot[id];
-            const u32 prob = rc.get_freq(tt.x, tt.y);
-            const u32* row = id < hot ? lrows + id * 64 : a.qrows + (size_t)id * 64;
+            const u32 prob = rc.get_freq16();
+            const u32* row = a.qrows + (size_t)last * 64;
             // largest s with cum[s] <= prob (cum is increasing: every g >= 1)
             u32 s = 0;
 #pragma unroll
             for (u32 step = 32; step > 0; step >>= 1) { const u32 t = s + step; if (FZ_CUM(row[t]) <= prob) s = t; }
             const u32 e = row[s];
-            if (prob >= tt.x) rc.err = 1;
             rc.decode(FZ_CUM(e), FZ_FREQ(e));
             u32 b = s;
             if (s == LAST_QLT) {                                            // qlts.cpp:168-171
-                const u32 pe = rc.get_freq(a.qesc_tot.x, a.qesc_tot.y);
+                const u32 pe = rc.get_freq16();
                 u32 x = 0;
 #pragma unroll
                 for (u32 step = 128; step > 0; step >>= 1) { const u32 t = x + step; if (FZ_CUM(a.qesc[t]) <= pe) x = t; }
                 const u32 ee = a.qesc[x];
-                if (pe >= a.qesc_tot.x) rc.err = 1;
                 rc.decode(FZ_CUM(ee), FZ_FREQ(ee));
                 b = x;
             }
@@ -242,7 +214,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st) {
     constexpr int T = 256;
     const u32 grid = (a.geo.nchains + T - 1) / T;
-    hipLaunchKernelGGL(k_qlt_decode_c<T>, dim3(grid), dim3(T), a.q_hot * QROW_BYTES, st, a, da);
+    hipLaunchKernelGGL(k_qlt_decode_c<T>, dim3(grid), dim3(T), 0, st, a, da);
 }
 
 // =========================================================================================================

@@ -16,7 +16,7 @@
 #pragma once
 #include "dev_coder.h"
 
-// frozen row entry: cum | freq << 16 (both < 65536); per row {tot, floor(2^32 / tot)}
+// frozen row entry: cum | freq << 16 (both < 65536); the total of a row is 2^16
 #define FZ_CUM(e)  ((e) & 0xFFFFu)
 #define FZ_FREQ(e) ((e) >> 16)
 #define FZ_MAX_TOT 65535u
@@ -57,6 +57,19 @@ struct LaneEnc {
             if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }    // the reference would spin; every chain must drain
         }
     }
+    // the same with tot = 2^16: range / tot is a shift
+    __device__ __forceinline__ void encode16(u32 cum, u32 freq) {
+        const u32 r = range >> 16;
+        low += (u64)cum * r;
+        range = r * freq;
+        int guard = 0;
+        while (range < RC_TOP) {
+            if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
+            put((u32)(low >> 56));
+            range <<= 8; low <<= 8;
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
     // flush; returns the stream's size
     __device__ __forceinline__ u32 finish() {
         u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;
@@ -87,6 +100,14 @@ struct LaneDec {
         range = r;
         if (code >> 32) { err = 1; return 0; }
         return (u32)code / r;
+    }
+    __device__ __forceinline__ u32 get_freq16() {                     // tot = 2^16
+        const u32 r = range >> 16;
+        range = r;
+        if (code >> 32) { err = 1; return 0; }
+        const u32 q = (u32)code / r;
+        if (q > 0xFFFFu) { err = 1; return 0xFFFFu; }
+        return q;
     }
     // coder.hpp:88-102
     __device__ __forceinline__ void decode(u32 cum, u32 freq) {

@@ -50,12 +50,10 @@ struct ChainArgs {
     u32 block_reads;            // records per block (uniform; the last block may be short)
     u32* csz;                   // [nchains] sizes of the stream being coded (encode: written; decode: read)
     const u64* coff;            // decode: [nchains] absolute offsets of the chains' streams
-    // quality: dense frozen rows
-    const u16* qmap;            // [q_rows] context -> dense row id (0 = the uniform row)
-    const u32* qrows;           // [nrows][64] cum | freq << 16, in symbol order
-    const uint2* qtot;          // [nrows] {tot, floor(2^32 / tot)}
-    u32 q_hot;                  // rows 0 .. q_hot-1 are staged in LDS
-    const u32* qesc; uint2 qesc_tot;   // escape row (256 entries), qlts.cpp:80-86
+    // quality: frozen rows, total 2^16 each
+    const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
+    u32 q_hot;                  // rows staged in LDS per workgroup
+    const u32* qesc;            // escape row (256 entries), qlts.cpp:80-86
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
     // bases: generation tables
@@ -63,8 +61,7 @@ struct ChainArgs {
     u32 g_bound[GEN_MAX_GENERATIONS + 1];      // generation g = blocks [g_bound[g], g_bound[g + 1])
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
 };
-void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, const u16* qmap, u32* qrows, uint2* qtot, hipStream_t st);
-void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
@@ -73,7 +70,7 @@ void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       //
 void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);
-#define GEN_STEP 3u             // a counted base adds GEN_STEP to its row entry (chains.hip)
+#define GEN_STEP 4u             // a counted base adds GEN_STEP to its row entry (chains.hip)
 
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
@@ -98,6 +95,7 @@ void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st);
 void launch_qlt_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st);
 void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow, hipStream_t st);
+void launch_usr_encode_w(const ModelArgs& a, hipStream_t st);      // framing exceptions, a wave per block; blocks [batch0, batch0 + nbatch), slot = workgroup
 
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);

@@ -247,3 +247,62 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
 void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
 }
+
+// =========================================================================================================
+// framing exceptions, a wave per block: UsrSave::get_record's bookkeeping (usrs.cpp:322-375) + update (126-160).
+// A record is an exception when its line length differs from the previous record's (usr.x), its quality length from
+// its own base length (usr.x.q), or its SOLiD prefix characters from the previous record's (usr.pfg / usr.pfq): all
+// neighbour comparisons, so 64 records are tested at once and only the (rare) hits are coded, on lane 0.
+// (k_usr_encode_l walks the records one by one on a single lane: 1024 dependent memory round trips per block.)
+// =========================================================================================================
+__global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    for (u32 b = a.batch0 + t; b < a.batch0 + a.nbatch; b += gridDim.x) {
+        BlockDesc* d = &a.blocks[b];
+        PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
+        XfEnc x_llen, x_qlen, x_sgen, x_sqlt;
+        x_llen.init(a.arena + d->out_off[SFQ_S_USR_X],   d->out_cap[SFQ_S_USR_X],   XF_USR_X);
+        x_qlen.init(a.arena + d->out_off[SFQ_S_USR_XQ],  d->out_cap[SFQ_S_USR_XQ],  XF_USR_XQ);
+        x_sgen.init(a.arena + d->out_off[SFQ_S_USR_PFG], d->out_cap[SFQ_S_USR_PFG], XF_USR_PFG);
+        x_sqlt.init(a.arena + d->out_off[SFQ_S_USR_PFQ], d->out_cap[SFQ_S_USR_PFQ], XF_USR_PFQ);
+        const u32 solid = d->solid;
+        u32 c_llen = d->llen, c_pfg = 0, c_pfq = 0;            // the running values carried from window to window
+        u64 i_llen = 0, i_qlen = 0, i_sgen = 0, i_sqlt = 0;
+        for (u32 k0 = 0; k0 < d->nrec; k0 += 64) {
+            const u32 m = d->nrec - k0 < 64 ? d->nrec - k0 : 64;
+            const bool in = lane < m;
+            const u64 r = d->rec0 + k0 + (in ? lane : 0);
+            const u64 g0 = a.line_off[4 * r + 1], g1 = a.line_off[4 * r + 2] - 1;
+            const u64 q0 = a.line_off[4 * r + 3], q1 = a.line_off[4 * r + 4] - 1;
+            const u32 sl_len = (u32)(g1 - g0) - solid;
+            const u32 ql = (q1 - q0) >= solid ? (u32)(q1 - q0) - solid : 0;
+            const u32 cg = solid ? (u32)a.fq[g0] : 0u, cq = solid ? (u32)a.fq[q0] : 0u;
+            const u32 p_len = wave_shr1(sl_len, c_llen), p_cg = wave_shr1(cg, c_pfg), p_cq = wave_shr1(cq, c_pfq);
+            const u64 mL = __ballot(in && sl_len != p_len), mQ = __ballot(in && ql != sl_len);
+            const u64 mG = __ballot(in && solid && cg != p_cg), mS = __ballot(in && solid && cq != p_cq);
+            u64 mx = mL | mQ | mG | mS;
+            while (mx) {
+                const u32 bit = (u32)__ffsll((long long)mx) - 1u;
+                mx &= mx - 1;
+                const u64 rcnt = (u64)k0 + bit + 1;
+                if ((mG >> bit) & 1) { const u32 c = rl(cg, bit); if (lane == 0) { x_sgen.put(pw, rcnt - i_sgen); x_sgen.put_chr(pw, c); } i_sgen = rcnt; }   // usrs.cpp:323-327
+                if ((mL >> bit) & 1) { const u32 v = rl(sl_len, bit); if (lane == 0) { x_llen.put(pw, rcnt - i_llen); x_llen.put(pw, (u16)v); } i_llen = rcnt; }   // usrs.cpp:342-343
+                if ((mS >> bit) & 1) { const u32 c = rl(cq, bit); if (lane == 0) { x_sqlt.put(pw, rcnt - i_sqlt); x_sqlt.put_chr(pw, c); } i_sqlt = rcnt; }   // usrs.cpp:356-360
+                if ((mQ >> bit) & 1) { const u32 v = rl(ql, bit); if (lane == 0) { x_qlen.put(pw, rcnt - i_qlen); x_qlen.put(pw, (u16)v); } i_qlen = rcnt; }     // usrs.cpp:371-372
+            }
+            c_llen = rl(sl_len, m - 1); c_pfg = rl(cg, m - 1); c_pfq = rl(cq, m - 1);
+        }
+        if (lane == 0) {
+            d->size[SFQ_S_USR_X]   = x_llen.finish(pw);
+            d->size[SFQ_S_USR_XQ]  = x_qlen.finish(pw);
+            d->size[SFQ_S_USR_PFG] = x_sgen.finish(pw);
+            d->size[SFQ_S_USR_PFQ] = x_sqlt.finish(pw);
+            if (x_llen.sink.pos > x_llen.sink.cap || x_qlen.sink.pos > x_qlen.sink.cap ||
+                x_sgen.sink.pos > x_sgen.sink.cap || x_sqlt.sink.pos > x_sqlt.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+        }
+    }
+}
+void launch_usr_encode_w(const ModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_usr_encode_w, dim3(a.nbatch), dim3(64), 0, st, a);
+}
