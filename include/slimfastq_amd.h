@@ -171,6 +171,10 @@ int sfq_get_first_headers(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
 int64_t sfq_get_qlt_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
 /* Install the prior the next sfq_decode_blocks call must start its quality rows from (n = 0: cold). */
 int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n);
+/* Frozen tables: the header prior of the LAST encode call (the "rec.pri" stream: scaled symbol counts of the header
+ * model's rows); same conventions.  0 = the call coded its headers with adaptive rows. */
+int64_t sfq_get_rec_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap);
+int sfq_set_rec_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n);
 /* Frozen tables: the chain index of the LAST encode call (the "chn.idx" stream: records per chain, flags, and the size
  * of every chain's qlt and gen stream); returns its size, copies it if cap allows; 0 = the call used adaptive tables.
  * A decoder installs it before sfq_decode_blocks (n = 0: the archive has none, i.e. adaptive tables). */

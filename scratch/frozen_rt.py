@@ -22,15 +22,15 @@ for tables in (1, 0):
     ms = list(res.kernel_ms)
     print("tables=%d encode %.1f ms (%.1f GB/s) ratio %.4f chains %d  phases frame %.1f qlt %.1f gen %.1f rec %.1f usr %.1f pack %.1f total %.1f" % (
         tables, dt * 1e3, nbytes / dt / 1e9, nbytes / res.total_bytes, res.n_chains, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]), flush=True)
-    print("   stream bytes", dict(zip(capi.STREAM_NAMES, list(res.stream_bytes))), "prior", len(ctx.prior()), "chains idx", len(ctx.chains()))
+    print("   stream bytes", dict(zip(capi.STREAM_NAMES, list(res.stream_bytes))), "prior", len(ctx.prior()), "chains idx", len(ctx.chains()), "rec prior", len(ctx.rec_prior()))
     if models:
         continue
-    blocks = ctx.index(res.n_blocks); first = ctx.first_headers(res.first_hdr_bytes); prior = ctx.prior(); chains = ctx.chains()
+    blocks = ctx.index(res.n_blocks); first = ctx.first_headers(res.first_hdr_bytes); prior = ctx.prior(); chains = ctx.chains(); rpri = ctx.rec_prior()
     packed = d_out[:res.total_bytes].clone()
     d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        got, r2 = ctx.decode_device(blocks, first, packed.data_ptr(), list(res.stream_offset), d_back.data_ptr(), d_back.numel(), prior=prior, level=3, chains=chains)
+        got, r2 = ctx.decode_device(blocks, first, packed.data_ptr(), list(res.stream_offset), d_back.data_ptr(), d_back.numel(), prior=prior, level=3, chains=chains, rec_prior=rpri)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     same = bool(got == nbytes and torch.equal(d_back[:nbytes], d_in))
     ms = list(r2.kernel_ms)

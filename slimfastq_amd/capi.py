@@ -21,7 +21,7 @@ EXPORTS = [
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
-    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index",
+    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index", "sfq_get_rec_prior", "sfq_set_rec_prior",
 ]
 
 
@@ -106,6 +106,9 @@ def lib():
         L.sfq_get_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_qlt_prior.restype = C.c_int64
         L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
+        L.sfq_get_rec_prior.argtypes = [vp, u8p, u64]
+        L.sfq_get_rec_prior.restype = C.c_int64
+        L.sfq_set_rec_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_chain_index.argtypes = [vp, u8p, u64]
         L.sfq_get_chain_index.restype = C.c_int64
         L.sfq_set_chain_index.argtypes = [vp, u8p, u64]
@@ -134,8 +137,9 @@ def synth_fastq(n_reads, read_len=150, seed=1, kind=0, first_read=0) -> bytes:
 class Encoded:
     """Host copy of one sfq_encode_blocks result."""
 
-    def __init__(self, res, blocks, first_hdrs, data, prior=b"", chains=b""):
+    def __init__(self, res, blocks, first_hdrs, data, prior=b"", chains=b"", rec_prior=b""):
         self.res, self.blocks, self.first_hdrs, self.data, self.prior, self.chains = res, blocks, first_hdrs, data, prior, chains
+        self.rec_prior = rec_prior
 
     def stream(self, s, block=None) -> bytes:
         """Bytes of stream s (an id or a name): the whole concatenation, or one block's part."""
@@ -155,7 +159,7 @@ class Encoded:
     @property
     def archive_bytes(self):
         """Everything a decoder needs: streams + first headers + quality prior + ~the block index."""
-        return int(self.res.total_bytes) + len(self.first_hdrs) + len(self.prior) + len(self.chains) + 14 * len(self.blocks)
+        return int(self.res.total_bytes) + len(self.first_hdrs) + len(self.prior) + len(self.chains) + len(self.rec_prior) + 14 * len(self.blocks)
 
 
 class Context:
@@ -206,6 +210,14 @@ class Context:
         lib().sfq_get_qlt_prior(self._h, buf, n)
         return buf.raw[:n]
 
+    def rec_prior(self) -> bytes:
+        n = lib().sfq_get_rec_prior(self._h, None, 0)
+        if n <= 0:
+            return b""
+        buf = C.create_string_buffer(n)
+        lib().sfq_get_rec_prior(self._h, buf, n)
+        return buf.raw[:n]
+
     def chains(self) -> bytes:
         n = lib().sfq_get_chain_index(self._h, None, 0)
         if n <= 0:
@@ -225,7 +237,7 @@ class Context:
         self._check(L.sfq_encode_blocks_host(self._h, src.ctypes.data_as(C.c_void_p), len(fastq), C.byref(p),
                                              out.ctypes.data_as(C.c_void_p), cap, C.byref(res)))
         blocks = self.index(res.n_blocks)
-        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy(), self.prior(), self.chains())
+        return Encoded(res, blocks, self.first_headers(res.first_hdr_bytes), out[:res.total_bytes].copy(), self.prior(), self.chains(), self.rec_prior())
 
     def encode_device(self, d_ptr, nbytes, d_out, out_cap, level=3, block_reads=0, gen_bits=0, models=0, kernel=0, qlt_only=False,
                       prior_step=0, tables=0, chain_reads=0, lds_rows=0):
@@ -238,11 +250,12 @@ class Context:
         return res
 
     def decode_device(self, blocks, first_hdrs: bytes, d_streams, stream_offset, d_out, out_cap, prior=b"", level=3, version=0,
-                      chains=b"", lds_rows=0):
+                      chains=b"", lds_rows=0, rec_prior=b""):
         """Device-pointer decode (ints from torch .data_ptr()): returns (bytes written, Result)."""
         L = lib()
         self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
         self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
+        self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
         p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, lds_rows)
         res = Result()
         n = C.c_uint64()
@@ -255,9 +268,10 @@ class Context:
     def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()
-        prior = chains = b""
+        prior = chains = rec_prior = b""
         if isinstance(enc_or_parts, Encoded):
             blocks, first, data, prior, chains = enc_or_parts.blocks, enc_or_parts.first_hdrs, enc_or_parts.data, enc_or_parts.prior, enc_or_parts.chains
+            rec_prior = enc_or_parts.rec_prior
             soff = (C.c_uint64 * NSTREAMS)(*list(enc_or_parts.res.stream_offset))
         else:
             blocks, first, data, so = enc_or_parts[:4]
@@ -265,9 +279,12 @@ class Context:
                 prior = enc_or_parts[4]
             if len(enc_or_parts) > 5:
                 chains = enc_or_parts[5]
+            if len(enc_or_parts) > 6:
+                rec_prior = enc_or_parts[6]
             soff = (C.c_uint64 * NSTREAMS)(*so)
         self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
         self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
+        self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
         p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, 0)
         res = Result()

@@ -48,8 +48,9 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost;
+    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
+    std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
@@ -212,6 +213,63 @@ int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
 }
 
 // ---- frozen tables: host-side pieces -------------------------------------------------------------------------
+// ---- "rec.pri": the header prior.  Counts -> scaled frequencies f = (14 * count) >> s with the smallest s that brings
+// the row's largest to <= 32000 (the PowerRanger adds 14 per hit, power_ranger.hpp:37-41); the blob lists, per non-empty row,
+// varint(row - previous row + 1), varint(entries), entries x { byte value, varint(f) }, then a 0.
+std::vector<u8> pack_rec_prior(const std::vector<u32>& cnt, std::vector<u32>& f) {
+    std::vector<u8> o;
+    f.assign((size_t)PR_REC_ROWS * 256, 0);
+    put_v(o, PR_REC_ROWS);
+    u32 prev = 0;
+    for (u32 r = 0; r < PR_REC_ROWS; r++) {
+        const u32* c = cnt.data() + (size_t)r * 256;
+        u64 mx = 0; u32 nnz = 0;
+        for (u32 s = 0; s < 256; s++) mx = std::max<u64>(mx, c[s]);
+        if (!mx) continue;
+        u32 sh = 0;
+        while (((mx * 14) >> sh) > 32000) sh++;
+        u32* fr = f.data() + (size_t)r * 256;
+        for (u32 s = 0; s < 256; s++) { fr[s] = (u32)(((u64)c[s] * 14) >> sh); nnz += fr[s] != 0; }
+        if (!nnz) continue;
+        put_v(o, r - prev + 1); prev = r;
+        put_v(o, nnz);
+        for (u32 s = 0; s < 256; s++) if (fr[s]) { o.push_back((u8)s); put_v(o, fr[s]); }
+    }
+    put_v(o, 0);
+    return o;
+}
+bool unpack_rec_prior(const u8* b, size_t n, std::vector<u32>& f) {
+    size_t p = 0; u64 v;
+    if (!get_v(b, n, p, v) || v != PR_REC_ROWS) return false;
+    f.assign((size_t)PR_REC_ROWS * 256, 0);
+    u64 r = 0; bool first = true;
+    for (;;) {
+        if (!get_v(b, n, p, v)) return false;
+        if (v == 0) break;
+        r = first ? v - 1 : r + v - 1; first = false;
+        if (r >= PR_REC_ROWS) return false;
+        u64 nnz;
+        if (!get_v(b, n, p, nnz) || nnz == 0 || nnz > 256) return false;
+        int last = -1;
+        for (u64 j = 0; j < nnz; j++) {
+            if (p >= n) return false;
+            const int sym = b[p++];
+            if (sym <= last || !get_v(b, n, p, v) || v == 0 || v > 32000) return false;
+            last = sym; f[(size_t)r * 256 + sym] = (u32)v;
+        }
+    }
+    return true;
+}
+int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
+    int rc;
+    if ((rc = reserve(ctx, ctx->hfreq, f.size() * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rrows, f.size() * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rcoarse, (size_t)PR_REC_ROWS * 16 * 4))) return rc;
+    HIPC(hipMemcpyAsync(ctx->hfreq.p, f.data(), f.size() * 4, hipMemcpyHostToDevice, st));
+    launch_rec_frozen_rows((const u32*)ctx->hfreq.p, PR_REC_ROWS, (u32*)ctx->rrows.p, (u32*)ctx->rcoarse.p, st);
+    HIPC(hipStreamSynchronize(st));            // `f` may be a local
+    return SFQ_OK;
+}
 // the escape row (qualities >= 63, qlts.cpp:80-86): all 256 values equally likely
 int build_qesc(sfq_ctx* ctx, hipStream_t st) {
     int rc;
@@ -346,7 +404,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -443,6 +501,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ctx->prior_on = false;
     ctx->prior_blob.clear();
     ctx->chain_blob.clear();
+    ctx->rec_prior_blob.clear();
     std::vector<u32> h_rows66;
     u32 prior_step = p.block_reads ? p.prior_step : 0;
     if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
@@ -543,7 +602,24 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         launch_gen_exc_w(a, tickets + 1, mst[m]);
                     } else launch_gen_encode_k(a, tickets + 1, mst[m]);
                     break;
-                case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
+                case SFQ_M_REC:
+                    if (frozen) {
+                        // header prior: the model run over short runs of records spread over the call, symbols counted
+                        if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
+                        HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, mst[m]));
+                        const u32 run = 18;
+                        const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
+                        const u64 stride = std::max<u64>(run, nrec / nruns);
+                        launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, mst[m]);
+                        std::vector<u32> hc((size_t)PR_REC_ROWS * 256), hf;
+                        HIPC(hipMemcpyAsync(hc.data(), ctx->hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, mst[m]));
+                        HIPC(hipStreamSynchronize(mst[m]));
+                        ctx->rec_prior_blob = pack_rec_prior(hc, hf);
+                        if ((rc = upload_rec_rows(ctx, hf, mst[m]))) return rc;
+                        ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
+                        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ca.m.batch0 = b0; ca.m.nbatch = std::min(slots, nblocks - b0); launch_rec_encode_c(ca, mst[m]); }
+                    } else launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]);
+                    break;
                 }
             } else {
                 for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
@@ -696,6 +772,16 @@ int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
     ctx->prior_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
+int64_t sfq_get_rec_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
+    if (!ctx) return SFQ_E_ARG;
+    if (h_blob && cap >= ctx->rec_prior_blob.size() && !ctx->rec_prior_blob.empty()) memcpy(h_blob, ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size());
+    return (int64_t)ctx->rec_prior_blob.size();
+}
+int sfq_set_rec_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
+    if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    ctx->rec_prior_blob.assign(h_blob, h_blob + n);
+    return SFQ_OK;
+}
 int64_t sfq_get_chain_index(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
     if (!ctx) return SFQ_E_ARG;
     if (h_blob && cap >= ctx->chain_blob.size() && !ctx->chain_blob.empty()) memcpy(h_blob, ctx->chain_blob.data(), ctx->chain_blob.size());
@@ -742,6 +828,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         if (b + 1 < nblocks && bi.n_records != block_reads) return fail(ctx, SFQ_E_ARG, "block %u: non-uniform block size", b);
         if (bi.n_records == 0 || (b + 1 == nblocks && bi.n_records > block_reads)) return fail(ctx, SFQ_E_ARG, "block %u: bad record count", b);
         if (bi.first_hdr_off + bi.first_hdr_len > first_hdr_bytes) return fail(ctx, SFQ_E_ARG, "block %u: first header outside the blob", b);
+        if (bi.first_hdr_len > SFQ_MAX_ID_LLEN) return fail(ctx, SFQ_E_CORRUPT, "block %u: first header of %u bytes (limit %u, usrs.hpp:34)", b, bi.first_hdr_len, (u32)SFQ_MAX_ID_LLEN);
         if (bi.gen_bits < 2 || bi.gen_bits > 26) return fail(ctx, SFQ_E_ARG, "block %u: gen_bits %u", b, bi.gen_bits);
         d.rec0 = nrec; d.nrec = bi.n_records; d.llen = bi.llen; d.solid = bi.solid; d.two_id = bi.two_id;
         d.gen_bits = bi.gen_bits; d.n_byte = bi.n_byte; d.first_hdr_off = bi.first_hdr_off; d.first_hdr_len = bi.first_hdr_len;
@@ -906,6 +993,12 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     HIPC(hipStreamWaitEvent(st, ctx->ev[4], 0));
 
     // 3. headers; the staging size comes from the index when known, else grows on overflow
+    const bool frozen_rec = frozen && !ctx->rec_prior_blob.empty();
+    if (frozen_rec) {
+        std::vector<u32> hf;
+        if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
+        if ((rc = upload_rec_rows(ctx, hf, ctx->st_aux[0]))) return rc;
+    }
     std::vector<u64> hso((size_t)nblocks + 1);
     std::vector<u32> hsc(nblocks);
     if ((rc = reserve(ctx, ctx->hso, ((size_t)nblocks + 1) * 8))) return rc;
@@ -927,6 +1020,11 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
         if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; ctx->epoch_base += nblocks; da.m.epoch_base = ctx->epoch_base; }
+        if (frozen_rec) {
+            ChainArgs cr; memset(&cr, 0, sizeof cr);
+            cr.rrows = (const u32*)ctx->rrows.p; cr.rcoarse = (const u32*)ctx->rcoarse.p;
+            for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_c(cr, da, 16, st_rec); }
+        } else
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
         HIPC(hipStreamSynchronize(st_rec));
         HIPC(hipStreamSynchronize(st));

@@ -454,3 +454,148 @@ void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b
     if (!n) return;
     hipLaunchKernelGGL(k_gen_decode_c<T>, dim3((n + T - 1) / T), dim3(T), 0, st, a, da, b0, b1);
 }
+
+// =========================================================================================================
+// headers
+//
+// RecSave::save / RecLoad::load (dev_rec_lane.h: the reference's field-by-field model, lane-serial) with the symbols
+// of the "rec" stream coded through FROZEN PowerRanger rows: a counting pass runs the same model over short runs of
+// records spread over the call, the counts travel once as the header prior ("rec.pri"), and every block's header chain
+// -- one per LANE -- codes with the rows built from it.  A row lists all 256 byte values with the ranger's weights
+// (freq + 1 over total + 256, power_ranger.hpp:100; freq = 14 per hit) rescaled to a total of exactly 2^16, like the
+// quality rows.  "rec.x" (a header whose shape changed: the whole line) stays on the block's adaptive XFile rows.
+// =========================================================================================================
+#include "dev_rec_lane.h"
+
+struct RecFrozenEnc {
+    static constexpr bool counting = false;
+    const u32* rows; LaneEnc rc;
+    __device__ __forceinline__ void record(u32) {}
+    __device__ __forceinline__ void put(u32 row, u32 sym) { const u32 e = rows[(size_t)row * 256 + sym]; rc.encode16(FZ_CUM(e), FZ_FREQ(e)); }
+    __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+};
+struct RecCountEnc {
+    static constexpr bool counting = true;
+    u32* cnt; bool on;
+    __device__ __forceinline__ void record(u32 k) { on = k >= 2; }       // record 0 is the run's "first header", record 1 warms the field types up
+    __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
+    __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+};
+// counting pass: lane i walks records [i * stride, i * stride + run)
+__global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt) {
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nruns) return;
+    const u64 r0 = (u64)i * stride;
+    if (r0 >= nrec) return;
+    const u32 n = (u32)(nrec - r0 < run ? nrec - r0 : run);
+    RecCountEnc cd; cd.cnt = cnt; cd.on = false;
+    XfEnc x_rec; x_rec.init(nullptr, 0, XF_REC_X);
+    PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
+    u32 hb; int bad;
+    rec_encode_lane(a, r0, n, cd, x_rec, none, hb, bad);
+}
+void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_count, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt);
+}
+// frozen rows from the prior's scaled frequencies f[row][256]: x = f + 1, g = max(1, floor(x * 65536 / sum x)), the
+// remainder to the largest g (the first of them); entry = cum | g << 16; coarse[row][16] = cum at every 16th symbol
+__global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__ f, u32 nrows, u32* __restrict__ rrows, u32* __restrict__ coarse) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const uint4 fv = *reinterpret_cast<const uint4*>(f + (size_t)row * 256 + lane * 4);
+    const u32 x[4] = { fv.x + 1, fv.y + 1, fv.z + 1, fv.w + 1 };
+    u32 S = x[0] + x[1] + x[2] + x[3];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) S += (u32)__shfl_xor((int)S, d, 64);
+    u32 g[4]; u32 sum = 0, best = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        g[j] = (u32)(((u64)x[j] << 16) / S); g[j] = g[j] ? g[j] : 1u;
+        sum += g[j];
+        const u32 key = (g[j] << 8) | (255u - (lane * 4 + j));
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sum += (u32)__shfl_xor((int)sum, d, 64);
+        const u32 o = (u32)__shfl_xor((int)best, d, 64); best = o > best ? o : best;
+    }
+    const u32 bsym = 255u - (best & 255u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (lane * 4 + j == bsym) g[j] += 65536u - sum;
+    const u32 mine = g[0] + g[1] + g[2] + g[3];
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
+    u32 cum = incl - mine;
+    if ((lane & 3) == 0) coarse[(size_t)row * 16 + (lane >> 2)] = cum;
+    uint4 e;
+    e.x = cum | (g[0] << 16); cum += g[0];
+    e.y = cum | (g[1] << 16); cum += g[1];
+    e.z = cum | (g[2] << 16); cum += g[2];
+    e.w = cum | (g[3] << 16);
+    *reinterpret_cast<uint4*>(rrows + (size_t)row * 256 + lane * 4) = e;
+}
+void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, coarse);
+}
+
+// header encode: one block per lane (blocks [batch0, batch0 + nbatch), table slot = lane index within the batch)
+__global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a) {
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.m.nbatch) return;
+    const u32 b = a.m.batch0 + t;
+    BlockDesc* d = &a.m.blocks[b];
+    PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
+    RecFrozenEnc cd; cd.rows = a.rrows; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
+    XfEnc x_rec; x_rec.init(a.m.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    u32 hdr_bytes = 0; int bad = 0;
+    rec_encode_lane(a.m, d->rec0, d->nrec, cd, x_rec, pw, hdr_bytes, bad);
+    d->hdr_bytes = hdr_bytes;
+    d->size[SFQ_S_REC] = cd.rc.finish();
+    d->size[SFQ_S_REC_X] = x_rec.finish(pw);
+    if ((cd.rc.err & 2) || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+    if ((cd.rc.err & 1) | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    if (bad) atomicMax(&d->status, (u32)(-bad));
+}
+void launch_rec_encode_c(const ChainArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_encode_c, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+}
+
+// header decode
+struct RecFrozenDec {
+    const u32* rows; const u32* coarse; LaneDec rc;
+    __device__ __forceinline__ u32 get(u32 row) {
+        const u32 prob = rc.get_freq16();
+        // the sixteenth of the row, then the symbol in it: largest s with cum[s] <= prob
+        const u32* cr = coarse + (size_t)row * 16;
+        u32 k = 0;
+#pragma unroll
+        for (u32 step = 8; step > 0; step >>= 1) { const u32 t = k + step; if (cr[t] <= prob) k = t; }
+        const u32* er = rows + (size_t)row * 256 + k * 16;
+        u32 s = 0;
+#pragma unroll
+        for (u32 step = 8; step > 0; step >>= 1) { const u32 t = s + step; if (FZ_CUM(er[t]) <= prob) s = t; }
+        const u32 e = er[s];
+        rc.decode(FZ_CUM(e), FZ_FREQ(e));
+        return k * 16 + s;
+    }
+    __device__ __forceinline__ u64 get_u(u32 row0) { return get_u_rows(*this, row0); }
+    __device__ __forceinline__ u32 err() const { return rc.err; }
+};
+__global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= da.m.nbatch) return;
+    const u32 b = da.m.batch0 + t;
+    BlockDesc* d = &da.m.blocks[b];
+    PwTab pw; pw.slots = da.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = da.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(da.m.epoch_base + b + 1);
+    RecFrozenDec cd; cd.rows = a.rrows; cd.coarse = a.rcoarse;
+    cd.rc.init(da.streams + da.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_REC], d->size[SFQ_S_REC]);
+    XfDec x_rec;
+    x_rec.init(da.streams + da.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_REC_X], d->size[SFQ_S_REC_X], XF_REC_X);
+    rec_decode_lane(da, d, b, cd, x_rec, pw);
+}
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_decode_c, dim3((da.m.nbatch + lanes - 1) / lanes), dim3(lanes), 0, st, a, da);
+}

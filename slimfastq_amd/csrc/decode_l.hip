@@ -8,6 +8,7 @@
 // assemble (which applies the one rule that ties bases to qualities: quality '!' means N, gens.cpp:206-208).
 #include "kernels.h"
 #include "dev_models.h"
+#include "dev_rec_lane.h"
 
 #define LAST_QLT 63u
 
@@ -225,179 +226,15 @@ void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st) {
 }
 
 // ---- RecLoad::load (recs.cpp:374-461) ----------------------------------------------------------------------
-enum {
-    ST_DGT = 0, ST_DLT = 1, ST_STR = 2, ST_HGT = 3, ST_HLT = 4, ST_HGT_Z = 5, ST_HLT_Z = 6,
-    ST_HGTC = 7, ST_HLTC = 8, ST_HGTC_Z = 9, ST_HLTC_Z = 10, ST_DGT_Z = 11, ST_DLT_Z = 12
-};
-struct DSpaceMap { u16 off[66]; u16 wln[66]; u8 str[66]; u32 len; };
-__device__ __forceinline__ bool d_isword(u32 c) { return (c - '0' < 10u) || ((c | 0x20) - 'a' < 26u); }
-__device__ bool d_map_space(const u8* p, u32 n, DSpaceMap& m) {       // recs.cpp:141-157
-    m.len = 0; m.off[0] = 0;
-    for (u32 i = 0; ; i++) {
-        u32 c = i < n ? p[i] : '\n';
-        if (!d_isword(c)) {
-            m.wln[m.len] = (u16)(i - m.off[m.len]);
-            m.str[m.len++] = (u8)c;
-            m.off[m.len] = (u16)(i + 1);
-            if (i >= n || c == 0) break;
-            if (m.len > 64) return false;
-        }
-    }
-    return m.len <= 64;
-}
-// sprintf("%lld" / "%llx" / "%llX") of a non-zero value (recs.cpp:453-456)
-__device__ u32 fmt_dec(u8* b, u64 val) {
-    u32 n = 0;
-    i64 sv = (i64)val;
-    u64 mag = sv < 0 ? (u64)0 - val : val;
-    if (sv < 0) b[n++] = '-';
-    u8 tmp[20]; u32 k = 0;
-    while (mag) { tmp[k++] = (u8)('0' + mag % 10); mag /= 10; }
-    while (k) b[n++] = tmp[--k];
-    return n;
-}
-__device__ u32 fmt_hex(u8* b, u64 val, bool upper) {
-    u32 n = 0; int sh = 60;
-    while (sh > 0 && ((val >> sh) & 0xf) == 0) sh -= 4;
-    for (; sh >= 0; sh -= 4) {
-        u32 d = (u32)(val >> sh) & 0xf;
-        b[n++] = (u8)(d < 10 ? '0' + d : (upper ? 'A' : 'a') + d - 10);
-    }
-    return n;
-}
-__device__ bool d_is_number(const u8* p, int len, i64& num) {          // recs.cpp:265-275
-    if (*p == '0') return false;
-    num = 0;
-    for (int i = 0; i < len; i++) {
-        if (p[i] - '0' < 10u) num = (num << 3) + (num << 1) + p[i] - '0';
-        else return false;
-    }
-    return true;
-}
-
 __global__ __launch_bounds__(64) void k_rec_decode_l(DecodeArgs a) {
     DSlot sl;
     if (!dslot_init(a.m, sl)) return;
     BlockDesc* d = &a.m.blocks[sl.b];
-    ByteSrc src = stream_src(a, d, sl.b, SFQ_S_REC);
-    RcDec rc; rc.init(src);
+    RecAdaptiveDec cd;
+    cd.pw = sl.pw; cd.src = stream_src(a, d, sl.b, SFQ_S_REC); cd.rc.init(cd.src);
     XfDec x_rec;
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_REC_X); x_rec.init(s.p, s.n, XF_REC_X); }
-    u64 index = x_rec.get(sl.pw);                                                           // recs.cpp:104
-    u8* const stage = a.hdr_stage + a.hdr_stage_off[sl.b];
-    const u64 cap = a.hdr_stage_cap[sl.b];
-    u64 pos = 0;            // write cursor in stage
-    DSpaceMap sm;
-    u8  ctype[2][66];
-    u64 cnumb[2][66];
-    u32 imap = 0;
-    int bad = 0;
-    const u8* prev = nullptr; u32 prev_n = 0;
-    for (u32 k = 0; k < d->nrec; k++) {
-        const u64 r = d->rec0 + k, rcnt = (u64)k + 1;
-        // worst case for one header: every field regenerated at its longest (MAX_ID_LLEN) -> bounded check
-        if (pos + SFQ_MAX_ID_LLEN + 2 > cap) { bad = SFQ_E_OVERFLOW; break; }
-        u8* buf = stage + pos;
-        u32 n = 0;
-        if (k == 0) {                                                                       // load_first_line recs.cpp:113-119
-            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
-            imap = 0;
-            n = d->first_hdr_len;
-            const u8* f = a.first_hdrs + d->first_hdr_off;
-            for (u32 i = 0; i < n; i++) buf[i] = f[i];
-        } else {
-            const u32 pmap = imap;
-            imap ^= 1;
-            if (index == rcnt) {                                                            // recs.cpp:386-393
-                u64 len = x_rec.get(sl.pw);
-                if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
-                for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)x_rec.get_chr(sl.pw);
-                n = (u32)len;
-                index += x_rec.get(sl.pw);
-                for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
-            } else {
-                if (!d_map_space(prev, prev_n, sm)) { bad = SFQ_E_CORRUPT; break; }
-                const u64 map = sl.pw.get_u(0 * 16 + 2, rc, src);
-                u8* b = buf;
-                for (u32 i = 0; i < sm.len; i++) {
-                    if ((u64)(b - buf) + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
-                    const u32 rr = (i + 1) * 16;
-                    if (a.version >= 5) {                                                   // recs.cpp:403-459
-                        if (!(map & (1ULL << i))) {
-                            const u8* pp = prev + sm.off[i];
-                            for (u32 j = 0; j < sm.wln[i]; j++) b[j] = pp[j];
-                            b += sm.wln[i];
-                            *b++ = sm.str[i];
-                            ctype[imap][i] = ctype[pmap][i];
-                            cnumb[imap][i] = cnumb[pmap][i];
-                            continue;
-                        }
-                        const u32 type = sl.pw.get(rr + 0, rc, src);
-                        if (type == ST_STR) {
-                            u64 len = sl.pw.get_u(rr + 2, rc, src);
-                            if (len > SFQ_MAX_ID_LLEN || (u64)(b - buf) + len + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
-                            for (u32 j = 0; j < (u32)len; j++) b[j] = (u8)sl.pw.get(rr + 1, rc, src);
-                            b += len;
-                            ctype[imap][i] = 0;
-                            *b++ = sm.str[i];
-                            continue;
-                        }
-                        const u64 pval = ctype[pmap][i] == 0 ? 0 : cnumb[pmap][i];
-                        const u64 gap = sl.pw.get_u(rr + 2, rc, src);
-                        if (type > ST_DLT_Z) { bad = SFQ_E_CORRUPT; break; }
-                        const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC ||
-                                          type == ST_HLTC_Z || type == ST_DLT_Z;
-                        const u64 val = less ? pval - gap : pval + gap;
-                        const bool deci = type < ST_STR || type >= ST_DGT_Z;
-                        const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z ||
-                                          type == ST_DGT_Z || type == ST_DLT_Z;
-                        const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
-                        ctype[imap][i] = deci ? 1 : 2;
-                        cnumb[imap][i] = val;
-                        if (val == 0) *b++ = '0';                                            // recs.cpp:453-454
-                        else {
-                            if (lead) *b++ = '0';
-                            b += deci ? fmt_dec(b, val) : fmt_hex(b, val, upper);
-                        }
-                        *b++ = sm.str[i];
-                    } else {                                                                // load_pre5 recs.cpp:463-510
-                        if (map & (1ULL << i)) {
-                            const u32 type = sl.pw.get(rr + 0, rc, src);
-                            if (type == ST_DGT || type == ST_DLT) {
-                                i64 pval = 0;
-                                d_is_number(prev + sm.off[i], sm.wln[i], pval);
-                                const i64 gap = (i64)sl.pw.get_u(rr + 2, rc, src);
-                                const i64 val = type == ST_DGT ? pval + gap : pval - gap;
-                                if (val == 0) *b++ = '0'; else b += fmt_dec(b, (u64)val);
-                            } else if (type == ST_STR) {
-                                u64 len = sl.pw.get_u(rr + 2, rc, src);
-                                if (len > SFQ_MAX_ID_LLEN || (u64)(b - buf) + len + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
-                                for (u32 j = 0; j < (u32)len; j++) b[j] = (u8)sl.pw.get(rr + 1, rc, src);
-                                b += len;
-                            } else { bad = SFQ_E_CORRUPT; break; }
-                        } else {
-                            const u8* pp = prev + sm.off[i];
-                            for (u32 j = 0; j < sm.wln[i]; j++) b[j] = pp[j];
-                            b += sm.wln[i];
-                        }
-                        *b++ = sm.str[i];
-                    }
-                }
-                if (bad) break;
-                n = (u32)(b - buf) - 1;                                                     // recs.cpp:460
-            }
-        }
-        buf[n] = '\n';
-        a.hlen[r] = n; a.hoff[r] = a.hdr_stage_off[sl.b] + pos;
-        prev = buf; prev_n = n;
-        pos += (u64)n + 1;
-        if (rc.err | x_rec.rc.err) { bad = SFQ_E_CORRUPT; break; }
-    }
-    if (bad) {
-        dset_status(d, bad);
-        // leave the remaining records empty so the assembly stays in bounds
-        for (u32 k = 0; k < d->nrec; k++) { const u64 r = d->rec0 + k; if (a.hoff[r] == ~0ULL) { a.hlen[r] = 0; a.hoff[r] = a.hdr_stage_off[sl.b]; } }
-    }
+    rec_decode_lane(a, d, sl.b, cd, x_rec, sl.pw);
 }
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st) {
     const u32 L = decode_lanes();

@@ -54,6 +54,9 @@ struct ChainArgs {
     const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
     u32 q_hot;                  // rows staged in LDS per workgroup
     const u32* qesc;            // escape row (256 entries), qlts.cpp:80-86
+    // headers: frozen PowerRanger rows, total 2^16 each
+    const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
+    const u32* rcoarse;         // [PR_REC_ROWS][16] cum at every 16th symbol (decode)
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
     // bases: generation tables
@@ -67,6 +70,9 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* c
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       // gen.Ns / gen.Nn side streams, a wave per block (models_k.hip)
+void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st);
+void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st);
+void launch_rec_encode_c(const ChainArgs& a, hipStream_t st);       // blocks [m.batch0, m.batch0 + m.nbatch), one per lane
 void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);
@@ -99,6 +105,7 @@ void launch_usr_encode_w(const ModelArgs& a, hipStream_t st);      // framing ex
 
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st);
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);

@@ -160,85 +160,20 @@ void launch_gen_encode_l(const ModelArgs& a, hipStream_t st) {
 // ===================================================================================================
 // header encode
 // ===================================================================================================
-#include "dev_rec.h"
+#include "dev_rec_lane.h"
 
 __global__ __launch_bounds__(64) void k_rec_encode_l(ModelArgs a) {
     Slot sl;
     if (!slot_init(a, sl)) return;
     BlockDesc* d = &a.blocks[sl.b];
-    ByteSink snk = { a.arena + d->out_off[SFQ_S_REC], 0, d->out_cap[SFQ_S_REC] };
-    RcEnc rc; rc.init();
+    RecAdaptiveEnc cd;
+    cd.pw = sl.pw; cd.snk.p = a.arena + d->out_off[SFQ_S_REC]; cd.snk.pos = 0; cd.snk.cap = d->out_cap[SFQ_S_REC]; cd.rc.init();
     XfEnc x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
-    SpaceMap sm[2];
-    u8  ctype[2][66];
-    u64 cnumb[2][66];
-    u32 imap = 0; int bad = 0;
-    u64 last_index = 0;                       // m_last.index recs.hpp:54
-    u32 hdr_bytes = 0;
-    const u8* prev = nullptr;
-    for (u32 k = 0; k < d->nrec; k++) {
-        const u64 r = d->rec0 + k;
-        const u64 record_count = (u64)k + 1;  // g_record_count, block-relative
-        const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
-        const u8* buf = a.fq + h0;
-        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
-        hdr_bytes += n;
-        if (k == 0) {                                                         // recs.cpp:279-287 (first line -> "rec.first")
-            imap = 0;
-            if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
-            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
-            prev = buf;
-            continue;
-        }
-        const u32 pmap = imap;
-        imap ^= 1;
-        if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
-        SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
-        bool shape = mi.len != mp.len;
-        if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
-        if (shape) {                                                          // recs.cpp:292-305
-            x_rec.put(sl.pw, record_count - last_index);
-            last_index = record_count;
-            x_rec.put_str(sl.pw, buf, n);
-            for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
-            prev = buf;
-            continue;
-        }
-        u64 map = 0;
-        for (u32 i = 0; i < mi.len; i++)
-            if (mi.wln[i] != mp.wln[i] || bytes_differ(buf + mi.off[i], prev + mp.off[i], mi.wln[i])) map |= 1ULL << i;
-        sl.pw.put_u(0 * 16 + 2, rc, snk, map);                               // put_num(0, map) recs.cpp:313
-        for (u32 i = 0; i < mi.len; i++) {
-            if (map & (1ULL << i)) {
-                const u8* bp = buf + mi.off[i];
-                u64 bnum;
-                u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
-                const u32 rr = (i + 1) * 16;
-                if (type == ST_STR) {                                         // recs.cpp:324-331
-                    sl.pw.put(rr + 0, rc, snk, type);
-                    sl.pw.put_u(rr + 2, rc, snk, mi.wln[i]);
-                    for (u32 j = 0; j < mi.wln[i]; j++) sl.pw.put(rr + 1, rc, snk, bp[j]);
-                    ctype[imap][i] = 0;
-                    continue;
-                }
-                u64 pnum = ctype[pmap][i] ? cnumb[pmap][i] : 0;                // recs.cpp:333-348
-                u64 gap;
-                ctype[imap][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
-                cnumb[imap][i] = bnum;
-                if (bnum < pnum) { gap = pnum - bnum; type++; }
-                else gap = bnum - pnum;
-                sl.pw.put(rr + 0, rc, snk, type);
-                sl.pw.put_u(rr + 2, rc, snk, gap);
-            } else {
-                ctype[imap][i] = ctype[pmap][i];
-                cnumb[imap][i] = cnumb[pmap][i];
-            }
-        }
-        prev = buf;
-    }
-    rc.done(snk);
+    u32 hdr_bytes = 0; int bad = 0;
+    rec_encode_lane(a, d->rec0, d->nrec, cd, x_rec, sl.pw, hdr_bytes, bad);
+    cd.rc.done(cd.snk);
     d->hdr_bytes = hdr_bytes;
-    finish_stream(d, SFQ_S_REC, snk, rc.err);
+    finish_stream(d, SFQ_S_REC, cd.snk, cd.rc.err);
     d->size[SFQ_S_REC_X] = x_rec.finish(sl.pw);
     if (x_rec.sink.pos > x_rec.sink.cap) set_status(d, SFQ_E_OVERFLOW);
     if (x_rec.rc.err) set_status(d, SFQ_E_CORRUPT);
