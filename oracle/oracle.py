@@ -309,3 +309,100 @@ def qlt_encode_blocks(buf: bytes, off, length, level=3, block_reads=1024, prior_
     if L.sfqo_qlt_encode_blocks(buf, po, pl, len(off), level, block_reads, pr, C.byref(out), C.byref(n), sizes.ctypes.data_as(C.c_void_p)) != 0:
         raise _err()
     return _take(out, n), sizes
+
+
+# ---- frozen tables (block format 7, sfq_params.tables = 1): this project's own mode, restated in sfq_oracle.c ----
+def _nchains(nrec, block_reads, chain_reads):
+    nb = (nrec + block_reads - 1) // block_reads
+    cpb = (block_reads + chain_reads - 1) // chain_reads
+    last = nrec - (nb - 1) * block_reads
+    return (nb - 1) * cpb + (last + chain_reads - 1) // chain_reads
+
+
+def qlt_frozen_rows(prior_rows):
+    """prior rows [q_rows, 66] -> frozen entries uint32 [q_rows, 64] (cum | freq << 16, total 2^16)."""
+    L = lib()
+    prior_rows = np.ascontiguousarray(prior_rows, np.uint32)
+    q_rows = prior_rows.shape[0]
+    out = np.zeros(q_rows * 64, np.uint32)
+    L.sfqo_qlt_frozen_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sfqo_qlt_frozen_rows(prior_rows.ctypes.data_as(C.c_void_p), q_rows, out.ctypes.data_as(C.c_void_p))
+    return out.reshape(q_rows, 64)
+
+
+def qlt_encode_chains(buf: bytes, off, length, level, block_reads, chain_reads, frozen_rows):
+    """-> (chain streams back to back, per-chain sizes, escapes)."""
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    frozen_rows = np.ascontiguousarray(frozen_rows, np.uint32)
+    sizes = np.zeros(_nchains(len(off), block_reads, chain_reads), np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); extra = C.c_uint32()
+    L.sfqo_qlt_encode_chains.restype = C.c_longlong
+    L.sfqo_qlt_encode_chains.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
+                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_uint32)]
+    got = L.sfqo_qlt_encode_chains(buf, po, pl, len(off), level, block_reads, chain_reads, frozen_rows.ctypes.data_as(C.c_void_p),
+                                   C.byref(out), C.byref(n), sizes.ctypes.data_as(C.c_void_p), C.byref(extra))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, extra.value
+
+
+def gen_encode_chains(buf: bytes, goff, glen, gen_bits, block_reads, chain_reads, step=4):
+    """-> (chain streams back to back, per-chain sizes, gen_on)."""
+    L = lib()
+    goff, po = _arr(goff, np.uint64); glen, pl = _arr(glen, np.uint32)
+    sizes = np.zeros(_nchains(len(goff), block_reads, chain_reads), np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); on = C.c_int()
+    L.sfqo_gen_encode_chains.restype = C.c_longlong
+    L.sfqo_gen_encode_chains.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_uint32,
+                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int)]
+    got = L.sfqo_gen_encode_chains(buf, po, pl, len(goff), gen_bits, block_reads, chain_reads, step, C.byref(out), C.byref(n),
+                                   sizes.ctypes.data_as(C.c_void_p), C.byref(on))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, on.value
+
+
+REC_ROWS = 66 * 16
+
+
+def rec_count(buf: bytes, off, length, stride, run, nruns):
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    counts = np.zeros(REC_ROWS * 256, np.uint32)
+    L.sfqo_rec_count.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    if L.sfqo_rec_count(buf, po, pl, len(off), stride, run, nruns, counts.ctypes.data_as(C.c_void_p)) != 0:
+        raise _err()
+    return counts
+
+
+def rec_prior_freqs(counts):
+    L = lib()
+    f = np.zeros(REC_ROWS * 256, np.uint32)
+    L.sfqo_rec_prior_freqs.argtypes = [C.c_void_p, C.c_void_p]
+    L.sfqo_rec_prior_freqs(counts.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+    return f
+
+
+def rec_frozen_rows(f):
+    L = lib()
+    f = np.ascontiguousarray(f, np.uint32)
+    rows = np.zeros(REC_ROWS * 256, np.uint32)
+    L.sfqo_rec_frozen_rows.argtypes = [C.c_void_p, C.c_void_p]
+    L.sfqo_rec_frozen_rows(f.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p))
+    return rows
+
+
+def rec_encode_blocks_frozen(buf: bytes, off, length, block_reads, frozen_rows):
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    frozen_rows = np.ascontiguousarray(frozen_rows, np.uint32)
+    nb = (len(off) + block_reads - 1) // block_reads
+    sizes = np.zeros(nb, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    L.sfqo_rec_encode_blocks_frozen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p]
+    if L.sfqo_rec_encode_blocks_frozen(buf, po, pl, len(off), block_reads, frozen_rows.ctypes.data_as(C.c_void_p), C.byref(out), C.byref(n),
+                                       sizes.ctypes.data_as(C.c_void_p)) != 0:
+        raise _err()
+    return _take(out, n), sizes

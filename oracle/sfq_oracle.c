@@ -787,6 +787,9 @@ typedef struct {
     xsave* x_file; xload* l_file;
     u64* xrec; size_t n_xrec, cap_xrec; int keep_lists;
     int comp_version;
+    /* frozen-table mode (this project's format 7, not reference behaviour): when set, the symbols of the "rec" stream
+       go to hook(arg, row, byte) instead of the adaptive PowerRanger rows; row = field * 16 + {0 type, 1 str, 2.. num} */
+    void (*hook)(void* arg, int row, u8 sym); void* hook_arg; int no_x;
 } recm;
 
 enum {  /* recs.cpp:159-190 */
@@ -845,6 +848,24 @@ static u8 numberwang(const u8* p, int len, u64* num, u8 pctype) {             /*
     }
     return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
 }
+static void rec_sym(recm* r, int field, int which, u8 sym) {                   /* which: 0 type, 1 str */
+    if (r->hook) r->hook(r->hook_arg, field * 16 + which, sym);
+    else pw_put(which ? &r->ranger[field].str : &r->ranger[field].type, &r->rc, sym);
+}
+static void rec_num(recm* r, int field, u64 num) {                             /* PowerRangerU::put_u's byte sequence */
+    if (!r->hook) { pwu_put(&r->ranger[field].num, &r->rc, num); return; }
+    const int row0 = field * 16 + 2;
+    if (num <= 0x7f) { r->hook(r->hook_arg, row0, (u8)num); return; }
+    if (num < 0x7ffe) { r->hook(r->hook_arg, row0, (u8)(0x80 | (num >> 8))); r->hook(r->hook_arg, row0 + 1, (u8)num); return; }
+    r->hook(r->hook_arg, row0, 0xff);
+    if (num < 1ULL << 32) {
+        r->hook(r->hook_arg, row0 + 1, 0xfe);
+        for (int shift = 0, i = 2; shift < 32; shift += 8, i++) r->hook(r->hook_arg, row0 + i, (u8)(num >> shift));
+        return;
+    }
+    r->hook(r->hook_arg, row0 + 1, 0xff);
+    for (int shift = 0, i = 6; shift < 64; shift += 8, i++) r->hook(r->hook_arg, row0 + i, (u8)(num >> shift));
+}
 /* RecSave::save recs.cpp:277-372.  `first_out` receives the first header (recs.cpp:68-75). */
 static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, const u8* prev_buf,
                      sfqo_archive* a, wr* info) {
@@ -870,9 +891,11 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
     if (g_failed) return;
     space_map *mi = &r->smap[imap], *mp = &r->smap[pmap];
     if (mi->len != mp->len || memcmp(mi->str, mp->str, (size_t)mi->len)) {
-        xs_put(r->x_file, record_count - r->index);
-        r->index = record_count;
-        xs_put_str(r->x_file, buf, (size_t)(end - buf));
+        if (!r->no_x) {
+            xs_put(r->x_file, record_count - r->index);
+            r->index = record_count;
+            xs_put_str(r->x_file, buf, (size_t)(end - buf));
+        }
         memset(r->ctype[imap], 0, sizeof r->ctype[imap]);
         if (r->keep_lists) push64(&r->xrec, &r->n_xrec, &r->cap_xrec, record_count);
         return;
@@ -881,16 +904,16 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
     for (int i = 0; i < mi->len; i++)
         if (mi->wln[i] != mp->wln[i] || memcmp(buf + mi->off[i], prev_buf + mp->off[i], (size_t)mi->wln[i]))
             map |= 1ULL << i;
-    pwu_put(&r->ranger[0].num, &r->rc, map);                                  /* put_num(0, map) */
+    rec_num(r, 0, map);                                                       /* put_num(0, map) */
     for (int i = 0; i < r->smap[0].len; i++) {
         if (map & (1ULL << i)) {
             const u8* b = buf + mi->off[i];
             u64 bnum;
             u8 type = numberwang(b, mi->wln[i], &bnum, r->ctype[pmap][i]);
             if (type == ST_STR) {
-                pw_put(&r->ranger[i + 1].type, &r->rc, type);
-                pwu_put(&r->ranger[i + 1].num, &r->rc, (u64)mi->wln[i]);       /* put_str recs.cpp:77-81 */
-                for (int j = 0; j < mi->wln[i]; j++) pw_put(&r->ranger[i + 1].str, &r->rc, b[j]);
+                rec_sym(r, i + 1, 0, type);
+                rec_num(r, i + 1, (u64)mi->wln[i]);                            /* put_str recs.cpp:77-81 */
+                for (int j = 0; j < mi->wln[i]; j++) rec_sym(r, i + 1, 1, b[j]);
                 r->ctype[imap][i] = 0;
                 continue;
             }
@@ -900,8 +923,8 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
             r->cnumb[imap][i] = bnum;
             if (bnum < pnum) { gap = pnum - bnum; type++; }
             else gap = bnum - pnum;
-            pw_put(&r->ranger[i + 1].type, &r->rc, type);
-            pwu_put(&r->ranger[i + 1].num, &r->rc, gap);
+            rec_sym(r, i + 1, 0, type);
+            rec_num(r, i + 1, gap);
         } else {
             r->ctype[imap][i] = r->ctype[pmap][i];
             r->cnumb[imap][i] = r->cnumb[pmap][i];
@@ -1514,6 +1537,285 @@ int sfqo_qlt_encode_blocks(const u8* base, const u64* off, const u32* len, size_
         wr_close(w);
     }
     free(q.ranger);
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : 0;
+}
+
+
+/* ================================================================================================
+ * Block format 7, FROZEN tables (sfq_params.tables = 1).  NOT reference behaviour: this project's own mode, restated
+ * here so that the GPU path has a CPU checker.  The learning is taken out of the per-symbol loop:
+ * rows are built by counting passes and frozen while a "chain" (a run of records with its own range coder) is coded.
+ * What stays the reference's: the context functions, the symbol alphabets, the header model, RCoder::Encode.
+ * ============================================================================================== */
+
+/* the chain's range coder: RCoder (coder.hpp) with the four always-zero leading bytes elided, a five-byte flush of
+   the smallest multiple of 2^24 >= low, trailing zero bytes dropped */
+typedef struct { u64 low; u32 range; u8* out; size_t n, cap, emitted; } chenc;
+static void ch_init(chenc* c) { c->low = 0; c->range = (u32)-1; c->out = NULL; c->n = c->cap = 0; c->emitted = 0; }
+static void ch_put(chenc* c, u8 b) {
+    if (c->emitted++ < 4) { if (b) fail("chain coder: a leading byte is not zero"); return; }
+    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 256; c->out = xrealloc(c->out, c->cap); }
+    c->out[c->n++] = b;
+}
+static void ch_renorm(chenc* c) {                                             /* coder.hpp:74-80 */
+    int guard = 0;
+    while (c->range < TOP) {
+        if ((c->low ^ (c->low + c->range)) & (0xffULL << 56)) c->range = (((u32)c->low | (u32)(TOP - 1)) - (u32)c->low);
+        ch_put(c, (u8)(c->low >> 56));
+        c->range <<= 8; c->low <<= 8;
+        if (++guard > 64) { fail("coder stuck"); return; }
+    }
+}
+static void ch_encode(chenc* c, u32 cum, u32 freq, u32 tot) {                 /* coder.hpp:66-73 */
+    c->range /= tot;
+    c->low += (u32)(cum * c->range);
+    c->range *= freq;
+    ch_renorm(c);
+}
+static size_t ch_finish(chenc* c) {
+    u64 v = (c->low + 0xFFFFFFull) & ~0xFFFFFFull;
+    for (int i = 0; i < 5; i++) { ch_put(c, (u8)(v >> 56)); v <<= 8; }
+    while (c->n && c->out[c->n - 1] == 0) c->n--;
+    return c->n;
+}
+
+/* rows with a total of exactly 2^16 from weights x[0..n): g = max(1, floor(x * 65536 / sum x)), the remainder to the
+   largest g (the first of them); entry = cum | g << 16 */
+static void frozen_row(const u32* x, int n, u32* out) {
+    u64 S = 0;
+    for (int i = 0; i < n; i++) S += x[i];
+    u32 g[256]; u64 sum = 0; int best = 0;
+    for (int i = 0; i < n; i++) { g[i] = (u32)(((u64)x[i] << 16) / S); if (!g[i]) g[i] = 1; sum += g[i]; if (g[i] > g[best]) best = i; }
+    g[best] = (u32)(g[best] + 65536 - sum);
+    u32 cum = 0;
+    for (int i = 0; i < n; i++) { out[i] = cum | (g[i] << 16); cum += g[i]; }
+}
+/* quality rows: prior rows (sfqo_qlt_prior_rows, 66 dwords per context) -> [q_rows][64] frozen entries in symbol order
+   with the Log64Ranger's weights freq + 1 (log64_ranger.hpp:109); an unseen context has the uniform row */
+int sfqo_qlt_frozen_rows(const u32* rows66, size_t q_rows, u32* out) {
+    for (size_t c = 0; c < q_rows; c++) {
+        const u32* r = rows66 + c * 66;
+        u32 x[64];
+        for (int s2 = 0; s2 < 64; s2++) x[s2] = 1;
+        for (u32 j = 0; j < r[65]; j++) x[r[j] >> 16] = (r[j] & 0xffff) + 1;
+        if (!r[65]) { for (int s2 = 0; s2 < 64; s2++) out[c * 64 + s2] = ((u32)s2 << 10) | (1024u << 16); }
+        else frozen_row(x, 64, out + c * 64);
+    }
+    return 0;
+}
+typedef struct { chenc* c; const u32* rows; u32 extra; } qfz;
+static void qfz_cb(void* arg, u32 ctx, u8 b) {
+    qfz* q = arg;
+    const u32 sym = b < LAST_QLT ? b : LAST_QLT;
+    const u32 e = q->rows[(size_t)ctx * 64 + sym];
+    ch_encode(q->c, e & 0xffff, e >> 16, 65536);
+    if (b >= LAST_QLT) { ch_encode(q->c, (u32)b << 8, 256, 65536); q->extra++; }     /* the escape row: all 256 values alike */
+}
+/* The chains of a call: blocks of block_reads records, each cut into chains of chain_reads records.  out = the chains'
+   streams back to back, sizes[c] = each chain's length (c counts through the blocks).  Returns the number of chains. */
+long long sfqo_qlt_encode_chains(const u8* base, const u64* off, const u32* len, size_t nrec, int level, size_t block_reads,
+                                 size_t chain_reads, const u32* frozen_rows, u8** out, size_t* out_len, u32* sizes, u32* extra_hi) {
+    g_failed = 0; g_err[0] = 0;
+    obuf o = { 0, 0, 0 };
+    size_t nc = 0; u32 extra = 0;
+    for (size_t b0 = 0; b0 < nrec; b0 += block_reads) {
+        const size_t b1 = b0 + block_reads < nrec ? b0 + block_reads : nrec;
+        for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
+            const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+            chenc c; ch_init(&c);
+            qfz q = { &c, frozen_rows, 0 };
+            for (size_t i = r0; i < r1 && !g_failed; i++) qlt_walk(base + off[i], len[i], level, qfz_cb, &q);
+            const size_t n = ch_finish(&c);
+            ob_write(&o, c.out, n);
+            if (sizes) sizes[nc] = (u32)n;
+            extra += q.extra;
+            free(c.out);
+        }
+    }
+    if (extra_hi) *extra_hi = extra;
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : (long long)nc;
+}
+
+/* ---- bases: generation tables ---- */
+/* floor(1024 * log2(x)), x in 1..1023, by integer arithmetic (squaring a 1.31 fixed-point mantissa ten times) */
+static u32 log2fp(u32 x) {
+    u32 e = 0; while ((x >> (e + 1)) != 0) e++;
+    u64 m = (u64)x << (31 - e);
+    u32 frac = 0;
+    for (int i = 0; i < 10; i++) { m = (m * m) >> 31; frac <<= 1; if (m >> 32) { frac |= 1; m >>= 1; } }
+    return e * 1024 + frac;
+}
+static u32 gen_row(const u32* n, u32 step) {          /* f = 3 + step * n, halved the reference's way while any exceeds 255 */
+    u64 f[4];
+    for (int i = 0; i < 4; i++) f[i] = 3 + (u64)step * n[i];
+    while ((f[0] | f[1] | f[2] | f[3]) > 255) for (int i = 0; i < 4; i++) f[i] = (f[i] >> 1) | (f[i] & 1);
+    return (u32)(f[0] | f[1] << 8 | f[2] << 16 | f[3] << 24);
+}
+static size_t gen_bounds(size_t nblocks, size_t* bound) {   /* generation g = blocks [bound[g], bound[g + 1]) */
+    size_t n = 0; bound[0] = 0;
+    size_t b = (nblocks + 63) / 64; if (!b) b = 1;
+    while (b < nblocks && n + 2 < 40) { bound[++n] = b; b = b * 2 > b + 1 ? b * 2 : b + 1; }
+    bound[++n] = nblocks;
+    return n;
+}
+/* walk the bases of records [r0, r1): cb(ctx, code) per base; N is coded as 0, the context restarts per record */
+static void gen_walk(const u8* base, const u64* goff, const u32* glen, size_t r0, size_t r1, u32 mask,
+                     void (*cb)(void*, u32, int), void* arg) {
+    for (size_t i = r0; i < r1; i++) {
+        u32 last = 0x007616c7u;                                                 /* gens.cpp:139 */
+        for (u32 k = 0; k < glen[i]; k++) {
+            int code = gencode_of(base[goff[i] + k]) & 3;
+            if (gencode_of(base[goff[i] + k]) > 4) code = 0;
+            cb(arg, last & mask, code);
+            last = (last << 2) | (u32)code;
+        }
+    }
+}
+typedef struct { u32* cnt; const u32* rows; u64 cost, nbases; } gcount;
+static void gcount_cb(void* arg, u32 ctx, int code) {
+    gcount* g = arg;
+    g->cnt[(size_t)ctx * 4 + code]++;
+    if (g->rows) {
+        const u32 v = g->rows[ctx];
+        const u32 tot = (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24);
+        g->cost += log2fp(tot) - log2fp((v >> (8 * code)) & 0xff);
+        g->nbases++;
+    }
+}
+typedef struct { chenc* c; const u32* rows; } gfz;
+static void gfz_cb(void* arg, u32 ctx, int code) {
+    gfz* g = arg;
+    const u32 v = g->rows ? g->rows[ctx] : B2_INIT;
+    const u32 f[4] = { v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, v >> 24 };
+    u32 cum = 0; for (int i = 0; i < code; i++) cum += f[i];
+    ch_encode(g->c, cum, f[code], f[0] + f[1] + f[2] + f[3]);                   /* base2_ranger.hpp:74-84 without the update */
+}
+/* gen_on: 1 = the generation tables were used (decided from generation 1's cost under generation 0's rows) */
+long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
+                                 size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+    g_failed = 0; g_err[0] = 0;
+    const size_t nblocks = (nrec + block_reads - 1) / block_reads;
+    const size_t nctx = (size_t)1 << gen_bits; const u32 mask = (u32)nctx - 1;
+    size_t bound[48];
+    const size_t ngen = gen_bounds(nblocks, bound);
+    u32* cnt = xcalloc(nctx * 4, 4);
+    u32** rows = xcalloc(ngen + 1, sizeof(u32*));
+    int on = 0;
+#define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
+    if (ngen >= 3) {
+        gcount gc = { cnt, NULL, 0, 0 };
+        gen_walk(base, goff, glen, REC_OF(bound[0]), REC_OF(bound[1]), mask, gcount_cb, &gc);
+        u32* r1 = xmalloc(nctx * 4);
+        for (size_t c = 0; c < nctx; c++) r1[c] = gen_row(cnt + c * 4, step);
+        gc.rows = r1;
+        gen_walk(base, goff, glen, REC_OF(bound[1]), REC_OF(bound[2]), mask, gcount_cb, &gc);
+        free(r1);
+        on = gc.nbases && gc.cost * 100 < gc.nbases * 2048 * 99;
+        if (on) for (size_t g = 2; g < ngen; g++) {
+            rows[g] = xmalloc(nctx * 4);
+            for (size_t c = 0; c < nctx; c++) rows[g][c] = gen_row(cnt + c * 4, step);
+            if (g + 1 < ngen) { gcount g2 = { cnt, NULL, 0, 0 }; gen_walk(base, goff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), mask, gcount_cb, &g2); }
+        }
+    }
+    obuf o = { 0, 0, 0 };
+    size_t nc = 0;
+    for (size_t b = 0; b < nblocks; b++) {
+        size_t g = 0; while (g + 1 < ngen && b >= bound[g + 1]) g++;
+        const size_t b0 = REC_OF(b), b1 = REC_OF(b + 1);
+        for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
+            const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+            chenc c; ch_init(&c);
+            gfz gz = { &c, on ? rows[g] : NULL };
+            gen_walk(base, goff, glen, r0, r1, mask, gfz_cb, &gz);
+            const size_t n = ch_finish(&c);
+            ob_write(&o, c.out, n);
+            if (sizes) sizes[nc] = (u32)n;
+            free(c.out);
+        }
+    }
+#undef REC_OF
+    for (size_t g = 0; g <= ngen; g++) free(rows[g]);
+    free(rows); free(cnt);
+    if (gen_on) *gen_on = on;
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : (long long)nc;
+}
+
+/* ---- headers: frozen PowerRanger rows ---- */
+#define REC_ROWS (66 * 16)
+static void hcount_hook(void* arg, int row, u8 sym) { u32** a = arg; if (a[1]) a[0][(size_t)row * 256 + sym]++; }
+/* the counting pass: the header model over runs of `run` records starting every `stride` records; the first record of a
+   run is its "first header", the second warms the field types up, the rest are counted.  counts[REC_ROWS][256] */
+int sfqo_rec_count(const u8* base, const u64* off, const u32* len, size_t nrec, size_t stride, size_t run, size_t nruns, u32* counts) {
+    g_failed = 0; g_err[0] = 0;
+    for (size_t i = 0; i < nruns; i++) {
+        const size_t r0 = i * stride;
+        if (r0 >= nrec) break;
+        const size_t n = nrec - r0 < run ? nrec - r0 : run;
+        recm r; rec_alloc(&r);
+        void* arg[2] = { counts, NULL };
+        r.hook = hcount_hook; r.hook_arg = arg; r.no_x = 1;
+        const u8* prev = NULL;
+        for (size_t k = 0; k < n && !g_failed; k++) {
+            arg[1] = k >= 2 ? (void*)counts : NULL;
+            rec_save(&r, (u64)k + 1, base + off[r0 + k], base + off[r0 + k] + len[r0 + k], prev, NULL, NULL);
+            prev = base + off[r0 + k];
+        }
+        free(r.ranger);
+    }
+    return g_failed ? -1 : 0;
+}
+/* counts -> scaled frequencies f = (14 * count) >> s, the row's largest <= 32000 (what "rec.pri" carries) */
+int sfqo_rec_prior_freqs(const u32* counts, u32* f) {
+    for (int r = 0; r < REC_ROWS; r++) {
+        u64 mx = 0;
+        for (int s2 = 0; s2 < 256; s2++) if (counts[r * 256 + s2] > mx) mx = counts[r * 256 + s2];
+        int sh = 0;
+        while (((mx * 14) >> sh) > 32000) sh++;
+        for (int s2 = 0; s2 < 256; s2++) f[r * 256 + s2] = (u32)(((u64)counts[r * 256 + s2] * 14) >> sh);
+    }
+    return 0;
+}
+int sfqo_rec_frozen_rows(const u32* f, u32* rows) {
+    for (int r = 0; r < REC_ROWS; r++) {
+        u32 x[256];
+        for (int s2 = 0; s2 < 256; s2++) x[s2] = f[r * 256 + s2] + 1;           /* power_ranger.hpp:100 */
+        frozen_row(x, 256, rows + (size_t)r * 256);
+    }
+    return 0;
+}
+typedef struct { chenc* c; const u32* rows; } hfz;
+static void hfz_hook(void* arg, int row, u8 sym) {
+    hfz* h = arg;
+    const u32 e = h->rows[(size_t)row * 256 + sym];
+    ch_encode(h->c, e & 0xffff, e >> 16, 65536);
+}
+/* "rec" streams of consecutive blocks through frozen rows; the rec.x exceptions are NOT produced here (they stay the
+   reference's adaptive XFile stream per block: sfqo_rec_encode gives them) */
+int sfqo_rec_encode_blocks_frozen(const u8* base, const u64* off, const u32* len, size_t nrec, size_t block_reads,
+                                  const u32* frozen_rows, u8** out, size_t* out_len, u32* sizes) {
+    g_failed = 0; g_err[0] = 0;
+    obuf o = { 0, 0, 0 };
+    size_t nb = 0;
+    for (size_t b0 = 0; b0 < nrec; b0 += block_reads, nb++) {
+        const size_t b1 = b0 + block_reads < nrec ? b0 + block_reads : nrec;
+        chenc c; ch_init(&c);
+        hfz h = { &c, frozen_rows };
+        recm r; rec_alloc(&r);
+        r.hook = hfz_hook; r.hook_arg = &h; r.no_x = 1;
+        const u8* prev = NULL;
+        for (size_t i = b0; i < b1 && !g_failed; i++) {
+            rec_save(&r, (u64)(i - b0) + 1, base + off[i], base + off[i] + len[i], prev, NULL, NULL);
+            prev = base + off[i];
+        }
+        free(r.ranger);
+        const size_t n = ch_finish(&c);
+        ob_write(&o, c.out, n);
+        if (sizes) sizes[nb] = (u32)n;
+        free(c.out);
+    }
     *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
     return g_failed ? -1 : 0;
 }

@@ -95,6 +95,24 @@ int sfqo_rec_encode(const uint8_t* base, const uint64_t* off, const uint32_t* le
 int sfqo_xfile_encode_u(const uint64_t* vals, size_t n, uint8_t** out, size_t* out_len);
 int sfqo_xfile_decode_u(const uint8_t* stream, size_t n, uint64_t* vals, size_t nvals);
 
+/* ---- block format 7 extensions (this project's own, restated for the tests; see sfq_oracle.c) ----------------- */
+int sfqo_qlt_histogram(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, int level,
+                       size_t first, size_t step, uint32_t* counts);
+int sfqo_qlt_prior_rows(const uint32_t* counts, size_t q_rows, uint32_t* rows);
+int sfqo_qlt_encode_blocks(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, int level, size_t block_reads,
+                           const uint32_t* prior_rows, uint8_t** out, size_t* out_len, uint32_t* sizes);
+/* frozen tables */
+int sfqo_qlt_frozen_rows(const uint32_t* rows66, size_t q_rows, uint32_t* out);
+long long sfqo_qlt_encode_chains(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, int level, size_t block_reads,
+                                 size_t chain_reads, const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* extra_hi);
+long long sfqo_gen_encode_chains(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, size_t nrec, int gen_bits, size_t block_reads,
+                                 size_t chain_reads, uint32_t step, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+int sfqo_rec_count(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t stride, size_t run, size_t nruns, uint32_t* counts);
+int sfqo_rec_prior_freqs(const uint32_t* counts, uint32_t* f);
+int sfqo_rec_frozen_rows(const uint32_t* f, uint32_t* rows);
+int sfqo_rec_encode_blocks_frozen(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t block_reads,
+                                  const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes);
+
 void sfqo_free(void* p);
 
 #ifdef __cplusplus

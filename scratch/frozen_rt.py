@@ -13,7 +13,7 @@ d_in = torch.from_numpy(np.frombuffer(fq, np.uint8).copy()).cuda()
 ctx = capi.Context(0)
 cap = capi.lib().sfq_encode_bound(nbytes)
 d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-for tables in (1, 0):
+for tables in ((1, 0) if len(sys.argv) <= 6 else (1,)):
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO,
@@ -22,7 +22,9 @@ for tables in (1, 0):
     ms = list(res.kernel_ms)
     print("tables=%d encode %.1f ms (%.1f GB/s) ratio %.4f chains %d  phases frame %.1f qlt %.1f gen %.1f rec %.1f usr %.1f pack %.1f total %.1f" % (
         tables, dt * 1e3, nbytes / dt / 1e9, nbytes / res.total_bytes, res.n_chains, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]), flush=True)
-    print("   stream bytes", dict(zip(capi.STREAM_NAMES, list(res.stream_bytes))), "prior", len(ctx.prior()), "chains idx", len(ctx.chains()), "rec prior", len(ctx.rec_prior()))
+    print("   stream bytes", dict(zip(capi.STREAM_NAMES, list(res.stream_bytes))), "prior", len(ctx.prior()), "chains idx", len(ctx.chains()), "rec prior", len(ctx.rec_prior()), "first hdrs", res.first_hdr_bytes,
+          "archive ~", res.total_bytes + len(ctx.prior()) + len(ctx.chains()) + len(ctx.rec_prior()) + res.first_hdr_bytes + 14 * res.n_blocks,
+          "ratio(all) %.4f" % (nbytes / (res.total_bytes + len(ctx.prior()) + len(ctx.chains()) + len(ctx.rec_prior()) + res.first_hdr_bytes + 14 * res.n_blocks)))
     if models:
         continue
     blocks = ctx.index(res.n_blocks); first = ctx.first_headers(res.first_hdr_bytes); prior = ctx.prior(); chains = ctx.chains(); rpri = ctx.rec_prior()

@@ -48,7 +48,8 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse;
+    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap;
+    u32 r_hot = 0;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
     bool prior_on = false;                 // the device prior tables are valid for the running call
@@ -262,6 +263,20 @@ bool unpack_rec_prior(const u8* b, size_t n, std::vector<u32>& f) {
 }
 int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
     int rc;
+    {   // the rows worth staging in LDS: the ones the prior saw most
+        std::vector<std::pair<u64, u32>> w;
+        for (u32 r = 0; r < PR_REC_ROWS; r++) { u64 t = 0; for (u32 sx = 0; sx < 256; sx++) t += f[(size_t)r * 256 + sx]; if (t) w.push_back({ t, r }); }
+        std::stable_sort(w.begin(), w.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
+        u16 map[PR_REC_ROWS], hot[64];
+        for (u32 r = 0; r < PR_REC_ROWS; r++) map[r] = 0xFFFFu;
+        const u32 nh = (u32)std::min<size_t>(w.size(), 44);
+        for (u32 i = 0; i < nh; i++) { hot[i] = (u16)w[i].second; map[w[i].second] = (u16)i; }
+        if ((rc = reserve(ctx, ctx->rmap, sizeof map + sizeof hot))) return rc;
+        HIPC(hipMemcpyAsync(ctx->rmap.p, map, sizeof map, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync((u8*)ctx->rmap.p + sizeof map, hot, sizeof hot, hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));
+        ctx->r_hot = nh;
+    }
     if ((rc = reserve(ctx, ctx->hfreq, f.size() * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rrows, f.size() * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rcoarse, (size_t)PR_REC_ROWS * 16 * 4))) return rc;
@@ -404,7 +419,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -617,6 +632,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         ctx->rec_prior_blob = pack_rec_prior(hc, hf);
                         if ((rc = upload_rec_rows(ctx, hf, mst[m]))) return rc;
                         ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
+                        ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
                         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ca.m.batch0 = b0; ca.m.nbatch = std::min(slots, nblocks - b0); launch_rec_encode_c(ca, mst[m]); }
                     } else launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]);
                     break;

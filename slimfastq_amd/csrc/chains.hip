@@ -467,17 +467,36 @@ void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b
 // =========================================================================================================
 #include "dev_rec_lane.h"
 
+#define REC_HBUF 128u                    // bytes of LDS per staged header (two per lane: the current and the previous one)
+#define REC_LDS_ROWS 44u                 // frozen rows staged in LDS per wave (1 KiB each)
 struct RecFrozenEnc {
     static constexpr bool counting = false;
     const u32* rows; LaneEnc rc;
+    u8* lbuf;                            // this lane's two header buffers in LDS
+    const u16* lmap; const u32* lrows;   // LDS: row -> staged slot (0xFFFF = not staged), the staged rows
     __device__ __forceinline__ void record(u32) {}
-    __device__ __forceinline__ void put(u32 row, u32 sym) { const u32 e = rows[(size_t)row * 256 + sym]; rc.encode16(FZ_CUM(e), FZ_FREQ(e)); }
+    // headers are scanned byte by byte several times (tokens, field compare, number typing): a copy in LDS costs one
+    // round of loads instead of a memory round trip per byte.  (n + 1 bytes: the separator behind the text is read too.)
+    __device__ __forceinline__ const u8* stage(const u8* g, u32 n, u32 k) {
+        if (n + 1 > REC_HBUF) return g;
+        u8* dst = lbuf + (k & 1u) * REC_HBUF;
+        const u32 nw = (n + 4) / 4;                                     // covers bytes 0..n; the text goes on behind the header line
+#pragma unroll 8
+        for (u32 i = 0; i < nw; i++) reinterpret_cast<u32*>(dst)[i] = reinterpret_cast<const u32*>(g)[i];     // (global loads need no alignment on gfx9)
+        return dst;
+    }
+    __device__ __forceinline__ void put(u32 row, u32 sym) {
+        const u32 slot = lmap[row];
+        const u32 e = slot != 0xFFFFu ? lrows[slot * 256 + sym] : rows[(size_t)row * 256 + sym];
+        rc.encode16(FZ_CUM(e), FZ_FREQ(e));
+    }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
 struct RecCountEnc {
     static constexpr bool counting = true;
     u32* cnt; bool on;
     __device__ __forceinline__ void record(u32 k) { on = k >= 2; }       // record 0 is the run's "first header", record 1 warms the field types up
+    __device__ __forceinline__ const u8* stage(const u8* g, u32, u32) { return g; }
     __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
@@ -543,12 +562,19 @@ void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hi
 
 // header encode: one block per lane (blocks [batch0, batch0 + nbatch), table slot = lane index within the batch)
 __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a) {
+    __shared__ u32 lrows[REC_LDS_ROWS * 256];
+    __shared__ u16 lmap[PR_REC_ROWS];
+    __shared__ u32 ltext[64 * 2 * REC_HBUF / 4];
+    for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) lmap[i] = a.rmap[i];
+    for (u32 i = threadIdx.x; i < a.r_hot * 256; i += 64) lrows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
+    __syncthreads();
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= a.m.nbatch) return;
     const u32 b = a.m.batch0 + t;
     BlockDesc* d = &a.m.blocks[b];
     PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
     RecFrozenEnc cd; cd.rows = a.rrows; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
+    cd.lbuf = reinterpret_cast<u8*>(ltext) + threadIdx.x * 2 * REC_HBUF; cd.lmap = lmap; cd.lrows = lrows;
     XfEnc x_rec; x_rec.init(a.m.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
     u32 hdr_bytes = 0; int bad = 0;
     rec_encode_lane(a.m, d->rec0, d->nrec, cd, x_rec, pw, hdr_bytes, bad);

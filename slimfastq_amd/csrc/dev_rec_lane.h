@@ -23,8 +23,8 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 rec0, u3
         const u64 record_count = (u64)k + 1;  // g_record_count, block-relative
         cd.record(k);
         const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
-        const u8* buf = a.fq + h0;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        const u8* buf = cd.stage(a.fq + h0, n, k);       // the text itself, or the coder's faster copy of it
         hdr_bytes += n;
         if (k == 0) {                                                         // recs.cpp:279-287 (first line -> "rec.first")
             imap = 0;
@@ -119,6 +119,7 @@ struct RecAdaptiveEnc {
     static constexpr bool counting = false;
     PwTab pw; RcEnc rc; ByteSink snk;
     __device__ __forceinline__ void record(u32) {}
+    __device__ __forceinline__ const u8* stage(const u8* g, u32, u32) { return g; }
     __device__ __forceinline__ void put(u32 row, u32 sym) { pw.put(row, rc, snk, sym); }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { pw.put_u(row0, rc, snk, num); }
 };

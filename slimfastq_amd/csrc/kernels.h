@@ -57,6 +57,7 @@ struct ChainArgs {
     // headers: frozen PowerRanger rows, total 2^16 each
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
     const u32* rcoarse;         // [PR_REC_ROWS][16] cum at every 16th symbol (decode)
+    const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> slot (0xFFFF = none), slot -> row, how many
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
     // bases: generation tables

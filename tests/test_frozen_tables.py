@@ -1,0 +1,121 @@
+"""Block format 7 with FROZEN tables (sfq_params.tables = 1): one chain per lane, rows built by counting passes.
+Not reference behaviour -- the rule is restated in oracle/sfq_oracle.c and the GPU bytes must equal it chain by chain;
+the context functions, alphabets, header model and the range coder's arithmetic are the reference's (pinned elsewhere)."""
+import numpy as np
+import pytest
+
+from slimfastq_amd import capi
+from oracle import oracle as O
+import util
+
+pytestmark = pytest.mark.gpu
+PRIOR_SYMBOLS = 4096
+GEN_STEP = 4
+
+
+def rec_sample(nrec):
+    run = 18
+    nruns = min(8192, max(1, nrec // run))
+    return max(run, nrec // nruns), run, nruns
+
+
+def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
+    enc = ctx.encode_host(fq, level=level, block_reads=br, prior_step=step, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    starts, lens = util.line_table(fq)
+    nrec = len(starts) // 4
+    solid = enc.blocks[0].solid
+    got_cr, flags, qsz, gsz = util.unpack_chains(enc.chains)
+    assert got_cr == min(cr, br)
+    # qualities: prior -> frozen rows -> chains
+    qoff, qlen = starts[3::4] + solid, lens[3::4] - solid
+    rows66 = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, np.minimum(qlen, PRIOR_SYMBOLS), level, 0, step))
+    assert np.array_equal(util.unpack_prior(enc.prior, 4096 if level == 1 else 65536), rows66), what
+    want, sizes, extra = O.qlt_encode_chains(fq, qoff, qlen, level, br, got_cr, O.qlt_frozen_rows(rows66))
+    assert list(qsz) == list(sizes), what
+    assert enc.stream("qlt") == want, what
+    assert sum(b.extra_hi for b in enc.blocks) == extra
+    # bases: generation tables
+    goff, glen = starts[1::4] + solid, lens[1::4] - solid
+    want, sizes, on = O.gen_encode_chains(fq, goff, glen, enc.blocks[0].gen_bits, br, got_cr, GEN_STEP)
+    assert (flags & 1) == on, what
+    assert list(gsz) == list(sizes), what
+    assert enc.stream("gen") == want, what
+    # headers: counted sample -> "rec.pri" -> frozen rows -> one chain per block
+    hoff, hlen = starts[0::4] + 1, lens[0::4] - 1
+    stride, run, nruns = rec_sample(nrec)
+    f = O.rec_prior_freqs(O.rec_count(fq, hoff, hlen, stride, run, nruns))
+    assert np.array_equal(util.unpack_rec_prior(enc.rec_prior), f), what
+    want, sizes = O.rec_encode_blocks_frozen(fq, hoff, hlen, br, O.rec_frozen_rows(f))
+    assert [b.size[0] for b in enc.blocks] == list(sizes), what
+    assert enc.stream("rec") == want, what
+    # the side streams are the reference's own, block by block
+    chunks = util.split_records(fq, br)
+    for b in (0, len(chunks) - 1):
+        ref = O.compress(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
+        for name in ("gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"):
+            assert enc.stream(name, b) == ref.get(name, b""), (what, name, b)
+    return enc
+
+
+@pytest.mark.parametrize("level", (1, 2, 3, 4))
+def test_frozen_streams_equal_oracle_rule_synthetic(ctx, level):
+    fq = capi.synth_fastq(7000, 150, seed=70 + level)
+    enc = check_against_oracle(ctx, fq, level, br=500, cr=64, step=2)
+    assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+
+
+def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
+    """Reads sampled from a small genome: generation 1 is cheaper under generation 0's rows, the tables switch on, and the
+    base stream gets well below 2 bits per base; iid bases leave them off."""
+    fq = capi.synth_fastq(60000, 150, seed=5, kind=3)
+    # kind 3 samples a 10 Mbp genome: too thin at this size -- fold the reads onto a tiny genome by reusing few reads
+    lines = fq.split(b"\n")[:-1]
+    reads = [lines[i + 1] for i in range(0, len(lines), 4)][:300]
+    rng = np.random.default_rng(3)
+    out = []
+    for i in range(0, len(lines), 4):
+        src = reads[rng.integers(len(reads))]
+        k = int(rng.integers(0, 40))
+        seq = (src[k:] + src[:k])
+        out += [lines[i], seq, lines[i + 2], lines[i + 3]]
+    fq2 = b"\n".join(out) + b"\n"
+    enc = check_against_oracle(ctx, fq2, 3, br=128, cr=32, step=1, what="genome-like")
+    _, flags, _, gsz = util.unpack_chains(enc.chains)
+    assert flags & 1
+    assert int(gsz.sum()) * 8 < 1.2 * 60000 * 150
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq2) + 4096) == fq2
+    enc = ctx.encode_host(fq, level=3, block_reads=128, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=32)
+    assert not util.unpack_chains(enc.chains)[1] & 1
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
+@pytest.mark.parametrize("name", ("tst1", "tst3", "tst7", "solid", "tsta", "tstb", "tstc", "tstd", "badqlt", "badsprintf", "fast5.to",
+                                  "edge_hiq", "edge_n", "edge_len", "edge_hdr", "edge_lower", "edge_one", "small"))
+def test_frozen_golden_samples(ctx, name):
+    fq = util.golden_fastq(name)
+    nrec = fq.count(b"\n") // 4
+    br = max(2, nrec // 7)
+    lossy = "<decoded>" in util.golden_streams(name, 3)
+    want = util.golden_streams(name, 3)["<decoded>"] if lossy else fq
+    enc = check_against_oracle(ctx, fq, 3, br=br, cr=max(1, br // 3), step=1, what=name)
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == want, name
+
+
+def test_frozen_ragged_chains_and_long_reads(ctx):
+    fq = capi.synth_fastq(90, 150, seed=8, kind=1)           # 10-50 kb reads
+    for br, cr in ((7, 2), (1, 1), (90, 90), (16, 5)):
+        enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="long %d/%d" % (br, cr))
+        assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    fq = capi.synth_fastq(3001, 37, seed=9)
+    enc = check_against_oracle(ctx, fq, 3, br=1000, cr=33, step=1)
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
+def test_frozen_automatic_parameters_round_trip(ctx):
+    fq = capi.synth_fastq(40000, 150, seed=12)
+    enc = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+    assert enc.chains and enc.rec_prior and enc.prior
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    # the frozen rows code about as well as the adaptive ones
+    ada = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO)
+    assert enc.archive_bytes < 1.02 * ada.archive_bytes

@@ -89,3 +89,53 @@ def unpack_prior(blob: bytes, q_rows: int):
                 rows[c, j] = s << 16; j += 1
         rows[c, 64] = total; rows[c, 65] = iend
     return rows
+
+
+def _vints(blob: bytes):
+    p = 0
+    out = []
+    while p < len(blob):
+        v = sh = 0
+        while True:
+            c = blob[p]; p += 1
+            v |= (c & 0x7f) << sh; sh += 7
+            if not c & 0x80:
+                break
+        out.append(v)
+    return out
+
+
+def unpack_chains(blob: bytes):
+    """"chn.idx" -> (chain_reads, flags, qlt sizes, gen sizes); mirrors api.cpp."""
+    v = _vints(blob)
+    cr, flags, n = v[0], v[1], v[2]
+    assert len(v) == 3 + 2 * n
+    return cr, flags, np.array(v[3:3 + n], np.uint32), np.array(v[3 + n:], np.uint32)
+
+
+def unpack_rec_prior(blob: bytes):
+    """"rec.pri" -> uint32 [66 * 16 * 256] scaled frequencies; mirrors api.cpp pack_rec_prior."""
+    f = np.zeros(66 * 16 * 256, np.uint32)
+    p = 0
+
+    def vint():
+        nonlocal p
+        v = sh = 0
+        while True:
+            c = blob[p]; p += 1
+            v |= (c & 0x7f) << sh; sh += 7
+            if not c & 0x80:
+                return v
+    assert vint() == 66 * 16
+    r = 0; first = True
+    while True:
+        v = vint()
+        if v == 0:
+            break
+        r = v - 1 if first else r + v - 1
+        first = False
+        for _ in range(vint()):
+            sym = blob[p]; p += 1
+            f[r * 256 + sym] = vint()
+    assert p == len(blob)
+    return f
