@@ -89,14 +89,13 @@ def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
-@pytest.mark.parametrize("name", ("tst1", "tst3", "tst7", "solid", "tsta", "tstb", "tstc", "tstd", "badqlt", "badsprintf", "fast5.to",
-                                  "edge_hiq", "edge_n", "edge_len", "edge_hdr", "edge_lower", "edge_one", "small"))
+@pytest.mark.parametrize("name", util.golden_names())
 def test_frozen_golden_samples(ctx, name):
     fq = util.golden_fastq(name)
     nrec = fq.count(b"\n") // 4
     br = max(2, nrec // 7)
-    lossy = "<decoded>" in util.golden_streams(name, 3)
-    want = util.golden_streams(name, 3)["<decoded>"] if lossy else fq
+    # what the reference restores block by block (it is lossy on a few inputs: SURVEY H7)
+    want = b"".join(O.decompress(O.compress(c, 3).image) for c in util.split_records(fq, br))
     enc = check_against_oracle(ctx, fq, 3, br=br, cr=max(1, br // 3), step=1, what=name)
     assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == want, name
 
