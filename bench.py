@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--kind", type=int, default=0, help="0 = 150 bp-style Illumina reads, 1 = 10-50 kb long reads (BASELINE config 5), 2 = 4-level binned qualities, "
                     "3 = bases sampled from a 10 Mbp genome (coverage = reads x length / 1e7)")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--tables", type=int, default=1, help="1 = frozen tables, one chain per lane (the default of block format 7); "
+                    "0 = adaptive tables, a wavefront per block (the reference's per-symbol updates)")
+    ap.add_argument("--chain-reads", type=int, default=0)
+    ap.add_argument("--lds-rows", type=int, default=0)
+    ap.add_argument("--no-adaptive-leg", action="store_true", help="skip the secondary measurement with adaptive tables")
     ap.add_argument("--prior-step", type=int, default=-1, help="-1 = auto warm start (default), 0 = cold blocks, N = every N-th record")
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
@@ -67,6 +72,7 @@ def parse():
 
 def workload_name(args):
     what = "full qlts+gens+recs" if args.workload == "full" else "qlts-only kernel"
+    what += ", frozen tables (one chain per lane)" if args.tables else ", adaptive tables (a wavefront per block)"
     if args.kind == 1:
         return "synthetic %d long reads (10-50 kb, log-uniform) per GPU, %s, -l %d" % (args.reads, what, args.level)
     flavour = {0: "Illumina reads", 2: "Illumina reads with 4-level binned qualities", 3: "reads sampled from a 10 Mbp genome"}.get(args.kind, "reads")
@@ -141,9 +147,10 @@ def main():
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
 
-    def step():
+    def step(tables=args.tables):
         res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=args.level,
-                                block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step)
+                                block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
+                                tables=tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
         if world > 1:
             # the path's one exchange step: compressed streams to the writer rank, over RCCL/xGMI
             sdist.gather_bytes(d_out[:res.total_bytes], dst=0)
@@ -187,11 +194,8 @@ def main():
     nq = args.reads * args.read_len
     hdr_bytes = nbytes - args.reads * (2 * args.read_len + 6)
     alg = {capi.T_QLT: nq + sb[2], capi.T_GEN: nq + sb[1] + sb[3] + sb[4], capi.T_REC: hdr_bytes + sb[0] + sb[5]}
-    # The three model kernels overlap, so their launch durations are similar.  "Dominant" = the quality kernel: it
-    # issues the most instructions (4.4e10 of the 1.1e11 per launch: profiles/*_pmc_summary.txt), which is the
-    # resource the path is bound by, and its share of the chip is fixed from launch to end, so its duration is the
-    # stable one (the other two share what it leaves).  Without the quality model: the one with the most bytes.
-    dom = capi.T_QLT if phase[capi.T_QLT] > 0 else max(names, key=lambda k: alg[k])
+    # The model kernels overlap on the chip.  "Dominant" = the one whose phase lasts longest (HIP events on its own stream).
+    dom = max(names, key=lambda k: phase[k])
     achieved = alg[dom] / (phase[dom] * 1e-3) / 1e9 if phase[dom] > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": names[dom] + "_encode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
@@ -205,14 +209,11 @@ def main():
         latest = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))[-1]
         pmc = json.load(open(latest))
         c = pmc["config"]
-        if (args.reads, args.read_len, args.level, args.kind, args.block_reads, args.kernel, args.workload) == \
-           (c["reads"], c["read_len"], c["level"], c["kind"], c["block_reads"], c["kernel"], "full") and prior_step == capi.PRIOR_AUTO:
+        if (args.reads, args.read_len, args.level, args.kind, args.block_reads, args.kernel, args.workload, args.tables) == \
+           (c["reads"], c["read_len"], c["level"], c["kind"], c["block_reads"], c["kernel"], "full", c.get("tables", 0)) and prior_step == capi.PRIOR_AUTO:
             k = pmc["kernels"][names[dom] + "_encode"]
             roofline["traffic"] = k["fetch_bytes"] + k["write_bytes"]
             roofline["traffic_source"] = pmc["source"]
-            # the traffic is random 64-byte table sectors; scratch/randmem.hip measured what HBM sustains for that pattern
-            roofline["random_sector_peak_GBps"] = 3260.0
-            roofline["traffic_frac_of_random_sector_peak"] = round(roofline["traffic"] / (phase[dom] * 1e-3) / 1e9 / 3260.0, 4)
     except (OSError, KeyError, ValueError, IndexError):
         pass
 
@@ -222,6 +223,7 @@ def main():
            "config": {"workload": workload_name(args),
                       "level": args.level, "block_reads": int(ctx.index(res.n_blocks)[0].n_records) if args.block_reads == capi.BLOCK_AUTO else args.block_reads,
                       "prior_step": args.prior_step, "blocks_per_gpu": int(res.n_blocks),
+                      "tables": "frozen" if args.tables else "adaptive", "chains_per_gpu": int(res.n_chains),
                       "raw_bytes_per_gpu": nbytes, "parallelism": "blocks sharded x%d, RCCL gather" % world if world > 1 else "1 GPU"},
            "ratio": round(all_in / all_out, 4),
            "phase_ms": {"frame": round(phase[capi.T_FRAME], 3), "qlt": round(phase[capi.T_QLT], 3), "gen": round(phase[capi.T_GEN], 3),
@@ -233,24 +235,36 @@ def main():
         # outside the timed region, never part of `value`
         blocks = ctx.index(res.n_blocks)
         first = ctx.first_headers(res.first_hdr_bytes)
-        prior = ctx.prior()
+        prior, chains, rec_prior = ctx.prior(), ctx.chains(), ctx.rec_prior()
         packed = d_out[:res.total_bytes].clone()
         soff = list(res.stream_offset)
         d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
         times = []
         for _ in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            got, _r = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=args.level)
+            got, _r = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=args.level,
+                                        chains=chains, rec_prior=rec_prior)
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
         same = bool(got == nbytes and torch.equal(d_back[:nbytes], d_in))
         out["decode"] = {"value": round(nbytes / min(times) / 1e6, 2), "unit": "MB/s FASTQ restored", "ms": round(min(times) * 1e3, 3),
                          "round_trip_identical": same}
         del d_back, packed
+    if world == 1 and args.tables and args.workload == "full" and not args.models and not args.no_adaptive_leg:
+        # secondary: the same call with ADAPTIVE tables (every block runs the reference's per-symbol row updates, a wavefront per
+        # block) -- round 1's headline mode, kept beside the default so the two can be compared; never part of `value`
+        step(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            ra = step(0)
+        torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / 3
+        out["adaptive_tables"] = {"value": round(nbytes / ta / 1e6, 2), "unit": "MB/s", "ms_per_step": round(ta * 1e3, 3),
+                                  "ratio": round(nbytes / ra.total_bytes, 4)}
     if world == 1 and not args.no_cpu_baseline:
         cb, sample, ref_payload = cpu_baseline(args, seed)
         out["cpu_baseline"] = cb
         # ratio vs the reference on the same sample: ours in blocks vs the reference's single adaptive stream
-        enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step)
+        enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
+                              tables=args.tables, chain_reads=args.chain_reads)
         ours = enc.archive_bytes                                   # streams + first headers + prior + block index
         if args.workload == "full":
             out["ratio_vs_reference"] = {"sample_raw": len(sample), "reference_stream_bytes": int(ref_payload),

@@ -3,6 +3,8 @@
 //   -u fastq  -f file.sfq  -d  -O  -l N | -1..-4  -q  -s  -v  -h        (same meaning as the reference)
 //   -B reads  : records per independent block (default 1024; 0 = one block = a format-6 file the
 //               reference itself can decode)
+//   -A        : adaptive tables (every block runs the reference's per-symbol table updates) instead of the default
+//               frozen tables (rows built by counting passes, one chain per GPU lane)
 //   -g dev    : HIP device
 // All model / coder work happens in libslimfastq_amd.so on the GPU; this file parses arguments, reads and
 // writes files and fills the info page.
@@ -60,6 +62,9 @@ static void usage() {
            "-1, -2, -3, -4   : alias for -l 1, -l 2, etc \n"
            "-B reads         : records per independent GPU block (default: about 376 KiB of text, i.e. 1024 reads of 150 bp;\n"
            "                   0 = single block, reference-compatible file)\n"
+           "-A               : adaptive tables: every block updates its rows per symbol, as the reference does (slower);\n"
+           "                   default: frozen tables, built by counting passes, one coding chain per GPU lane\n"
+           "-C reads         : frozen tables: records per chain (default: automatic)\n"
            "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 2048)\n"
            "-g device        : HIP device index (default 0)\n"
            "-T percent       : share of the device memory this process may use for model tables (several processes on one GPU)\n"
@@ -81,11 +86,13 @@ struct Opts {
     bool overwrite = false, quiet = false;
     uint64_t slab_bytes = 2048ull << 20;
     int table_pct = 0;                                                 // -T: share of the device memory for model tables (0 = the library's default)
+    bool adaptive = false;                                             // -A
+    long chain_reads = 0;                                              // -C
 };
 
 // "seg.idx": an archive is a sequence of SEGMENTS, each the result of one library call (one slab of a large
 // input, or one rank of a multi-GPU job): its blocks, its share of every stream, its own quality prior.
-struct Segment { uint64_t nblocks, prior_bytes, raw_bytes; };
+struct Segment { uint64_t nblocks, prior_bytes, raw_bytes, chain_bytes, recpri_bytes; };
 static void put_v(std::vector<uint8_t>& o, uint64_t v) { while (v >= 0x80) { o.push_back((uint8_t)(v | 0x80)); v >>= 7; } o.push_back((uint8_t)v); }
 static bool get_v(const std::vector<uint8_t>& b, size_t& p, uint64_t& v) {
     v = 0;
@@ -146,8 +153,11 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     sfq_params p; memset(&p, 0, sizeof p);
     p.level = o.level; p.block_reads = o.block_reads < 0 ? SFQ_BLOCK_AUTO : (uint32_t)o.block_reads;
     p.prior_step = legacy ? 0 : SFQ_PRIOR_AUTO;                        // warm start needs the block format
+    const bool frozen = !legacy && !o.adaptive;
+    p.tables = frozen ? SFQ_TABLES_FROZEN : SFQ_TABLES_ADAPTIVE;
+    p.chain_reads = (uint32_t)std::max(0l, o.chain_reads);
 
-    std::vector<uint8_t> streams[SFQ_NSTREAMS], first_all, prior_all;
+    std::vector<uint8_t> streams[SFQ_NSTREAMS], first_all, prior_all, chain_all, recpri_all;
     std::vector<sfq_block_info> blocks_all;
     std::vector<Segment> segs;
     uint64_t total_in = 0, total_records = 0;
@@ -197,10 +207,14 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         first_all.resize(f0 + (size_t)res.first_hdr_bytes);
         for (int s = 0; s < SFQ_NSTREAMS; s++)
             streams[s].insert(streams[s].end(), out.p + res.stream_offset[s], out.p + res.stream_offset[s] + res.stream_bytes[s]);
-        Segment sg{res.n_blocks, 0, use};
+        Segment sg{res.n_blocks, 0, use, 0, 0};
         if (!legacy) {
             const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
             if (pn > 0) { const size_t q0 = prior_all.size(); prior_all.resize(q0 + (size_t)pn); sfq_get_qlt_prior(ctx, prior_all.data() + q0, (uint64_t)pn); sg.prior_bytes = (uint64_t)pn; }
+            const int64_t cn = sfq_get_chain_index(ctx, nullptr, 0);
+            if (cn > 0) { const size_t q0 = chain_all.size(); chain_all.resize(q0 + (size_t)cn); sfq_get_chain_index(ctx, chain_all.data() + q0, (uint64_t)cn); sg.chain_bytes = (uint64_t)cn; }
+            const int64_t rn = sfq_get_rec_prior(ctx, nullptr, 0);
+            if (rn > 0) { const size_t q0 = recpri_all.size(); recpri_all.resize(q0 + (size_t)rn); sfq_get_rec_prior(ctx, recpri_all.data() + q0, (uint64_t)rn); sg.recpri_bytes = (uint64_t)rn; }
         }
         segs.push_back(sg);
         total_in += use; total_records += res.n_records;
@@ -231,16 +245,22 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         a.set("blk.count", (long long)blocks_all.size());
         a.set("num_records", (long long)total_records);
         if (segs.size() > 1) a.set("seg.count", (long long)segs.size());
+        if (frozen) a.set("blk.tables", 1);                                // frozen tables: chn.idx / rec.pri per segment
     }
     for (int s = 0; s < SFQ_NSTREAMS; s++) if (!streams[s].empty()) a.add(sfq_stream_name(s), std::move(streams[s]));
     if (!legacy) {
         a.add("blk.idx", sfqc::pack_block_index(blocks_all));
         a.add("blk.hdr", first_all);
         if (!prior_all.empty()) a.add("qlt.pri", prior_all);
+        if (!chain_all.empty()) a.add("chn.idx", chain_all);
+        if (!recpri_all.empty()) a.add("rec.pri", recpri_all);
         if (segs.size() > 1) {
             std::vector<uint8_t> si;
             put_v(si, segs.size());
-            for (auto& g : segs) { put_v(si, g.nblocks); put_v(si, g.prior_bytes); put_v(si, g.raw_bytes); }
+            for (auto& g : segs) {
+                put_v(si, g.nblocks); put_v(si, g.prior_bytes); put_v(si, g.raw_bytes);
+                if (frozen) { put_v(si, g.chain_bytes); put_v(si, g.recpri_bytes); }
+            }
             a.add("seg.idx", si);
         }
     }
@@ -264,6 +284,10 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     std::vector<uint8_t> first;
     std::vector<Segment> segs;
     const std::vector<uint8_t>* pri = a.find("qlt.pri");
+    const std::vector<uint8_t>* chn = a.find("chn.idx");
+    const std::vector<uint8_t>* rpr = a.find("rec.pri");
+    const bool frozen = a.get_long("blk.tables", 0) == 1;
+    if (frozen && !chn) croak("archive says frozen tables but holds no chain index (chn.idx)");
     if (version >= kBlockVersion) {
         const std::vector<uint8_t>* idx = a.find("blk.idx");
         if (!idx || !sfqc::unpack_block_index(*idx, blocks)) croak("bad block index");
@@ -272,8 +296,13 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             size_t q = 0; uint64_t n = 0;
             if (!get_v(*si, q, n) || n == 0 || n > blocks.size()) croak("bad segment index");
             segs.resize((size_t)n);
-            for (auto& g : segs) if (!get_v(*si, q, g.nblocks) || !get_v(*si, q, g.prior_bytes) || !get_v(*si, q, g.raw_bytes)) croak("bad segment index");
-        } else segs.push_back(Segment{blocks.size(), pri ? pri->size() : 0, (uint64_t)a.get_long("orig.size", 0)});
+            for (auto& g : segs) {
+                g.chain_bytes = g.recpri_bytes = 0;
+                if (!get_v(*si, q, g.nblocks) || !get_v(*si, q, g.prior_bytes) || !get_v(*si, q, g.raw_bytes)) croak("bad segment index");
+                if (frozen && (!get_v(*si, q, g.chain_bytes) || !get_v(*si, q, g.recpri_bytes))) croak("bad segment index");
+            }
+        } else segs.push_back(Segment{blocks.size(), pri ? pri->size() : 0, (uint64_t)a.get_long("orig.size", 0), chn ? chn->size() : 0, rpr ? rpr->size() : 0});
+        if (blocks.empty()) croak("bad block index (no blocks)");
     } else {
         sfq_block_info b; memset(&b, 0, sizeof b);
         b.n_records = (uint32_t)a.get_long("num_records");
@@ -285,9 +314,13 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         std::string f = a.get("rec.first");
         first.assign(f.begin(), f.end());
         b.first_hdr_len = (uint32_t)first.size();
-        for (int s = 0; s < SFQ_NSTREAMS; s++) if (auto* v = a.find(sfq_stream_name(s))) b.size[s] = (uint32_t)v->size();
+        if (a.get_long("num_records") > 0xFFFFFFFFll) croak("archive too large for the single-block GPU path (more than 2^32 - 1 records)");
+        for (int s = 0; s < SFQ_NSTREAMS; s++) if (auto* v = a.find(sfq_stream_name(s))) {
+            if (v->size() > 0xFFFFFFFFull) croak("archive too large for the single-block GPU path (stream %s has %zu bytes)", sfq_stream_name(s), v->size());
+            b.size[s] = (uint32_t)v->size();
+        }
         blocks.push_back(b);
-        segs.push_back(Segment{1, 0, (uint64_t)a.get_long("orig.size", 0)});
+        segs.push_back(Segment{1, 0, (uint64_t)a.get_long("orig.size", 0), 0, 0});
     }
     FILE* of = stdout;
     if (!usr.empty()) {
@@ -304,12 +337,15 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     sfq_params p; memset(&p, 0, sizeof p);
     p.level = level; p.version = version >= kBlockVersion ? kInternalVersion : (uint32_t)version;
     // walk the segments: each one's blocks, its slice of every stream (streams are segment-major), its prior
-    size_t b0 = 0, pri_off = 0;
+    size_t b0 = 0, pri_off = 0, chn_off = 0, rpr_off = 0;
     uint64_t spos[SFQ_NSTREAMS] = {0};
     std::vector<uint8_t> data;
     Bytes out;
     for (const Segment& g : segs) {
-        if (b0 + g.nblocks > blocks.size() || (pri ? pri_off + g.prior_bytes > pri->size() : g.prior_bytes != 0)) croak("bad segment index");
+        if (g.nblocks == 0 || g.nblocks > blocks.size() - b0) croak("bad segment index");
+        if (pri ? g.prior_bytes > pri->size() - pri_off : g.prior_bytes != 0) croak("bad segment index");
+        if (chn ? g.chain_bytes > chn->size() - chn_off : g.chain_bytes != 0) croak("bad segment index");
+        if (rpr ? g.recpri_bytes > rpr->size() - rpr_off : g.recpri_bytes != 0) croak("bad segment index");
         std::vector<sfq_block_info> sb(blocks.begin() + (ptrdiff_t)b0, blocks.begin() + (ptrdiff_t)(b0 + g.nblocks));
         const uint64_t rec0 = sb[0].first_record, h0 = sb[0].first_hdr_off;
         uint64_t need[SFQ_NSTREAMS] = {0}, hbytes = 0;
@@ -327,6 +363,8 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         }
         if (g.prior_bytes) { if (sfq_set_qlt_prior(ctx, pri->data() + pri_off, g.prior_bytes)) croak("%s", sfq_last_error(ctx)); }
         else sfq_set_qlt_prior(ctx, nullptr, 0);
+        if (sfq_set_chain_index(ctx, g.chain_bytes ? chn->data() + chn_off : nullptr, g.chain_bytes)) croak("%s", sfq_last_error(ctx));
+        if (sfq_set_rec_prior(ctx, g.recpri_bytes ? rpr->data() + rpr_off : nullptr, g.recpri_bytes)) croak("%s", sfq_last_error(ctx));
         uint64_t cap = g.raw_bytes, got = 0;
         if (!cap) cap = data.size() * 8 + (1 << 20);
         sfq_result res;
@@ -343,7 +381,7 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         tick("sfq_decode_blocks_host");
         if (fwrite(out.p, 1, (size_t)got, of) != got) croak("USR: Error writing output");
         tick("write output");
-        b0 += g.nblocks; pri_off += g.prior_bytes;
+        b0 += g.nblocks; pri_off += g.prior_bytes; chn_off += g.chain_bytes; rpr_off += g.recpri_bytes;
     }
     if (of != stdout) fclose(of); else fflush(stdout);
 }
@@ -353,7 +391,7 @@ int main(int argc, char** argv) {
     Opts o;
     bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdOb1234u:f:l:B:g:S:T:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdObA1234u:f:l:B:g:S:T:C:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
@@ -368,6 +406,8 @@ int main(int argc, char** argv) {
         case 'g': o.device = atoi(optarg); break;
         case 'T': o.table_pct = std::min(90, std::max(1, atoi(optarg))); break;
         case 'b': g_batch = true; break;
+        case 'A': o.adaptive = true; break;
+        case 'C': o.chain_reads = strtol(optarg, 0, 0); break;
         case 'v': printf("Version %s\nInternal format version=%u (block format %u)\n", kUserVersion, kInternalVersion, kBlockVersion); exit(0);
         case 'h': usage();
         case 's': statistics = true; g_encode = false; break;
@@ -395,6 +435,9 @@ int main(int argc, char** argv) {
                 printf("ok\t%s\t%s\n", src.c_str(), dst.c_str());
             } catch (const JobError& e) {
                 printf("fail\t%s\t%s\n", src.c_str(), e.msg.c_str());
+                failed++;
+            } catch (const std::exception& e) {                        // e.g. bad_alloc on a hostile archive: the job fails, the worker lives
+                printf("fail\t%s\t%s\n", src.c_str(), e.what());
                 failed++;
             }
             fflush(stdout);

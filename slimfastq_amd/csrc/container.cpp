@@ -41,6 +41,7 @@ uint64_t Archive::payload_bytes() const {
 // ---- reading ------------------------------------------------------------------------------------------
 static bool read_chain(const uint8_t* img, size_t npages, const DirEnt& e, bool is_info, std::vector<uint8_t>& out, std::string& err) {
     out.clear();
+    if (e.size > (uint64_t)npages * PAGE) { err = "corrupt directory: a stream larger than the file"; return false; }   // untrusted 64-bit size
     out.reserve((size_t)e.size);
     uint64_t left = e.size;
     auto page = [&](uint32_t id) -> const uint8_t* { return id < npages ? img + (size_t)id * PAGE : nullptr; };
