@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap;
+    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
     u32 r_hot = 0;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
@@ -419,7 +419,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -545,7 +545,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     u32 nchains = 0;
     if (frozen) {
         const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
-        ca.geo.chain_reads = std::min(cr, block_reads);
+        ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
         ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
         const u32 last_nrec = (u32)(nrec - (u64)(nblocks - 1) * block_reads);
         const u64 nc = (u64)(nblocks - 1) * ca.geo.cpb + (last_nrec + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
@@ -633,7 +633,9 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         if ((rc = upload_rec_rows(ctx, hf, mst[m]))) return rc;
                         ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
                         ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
-                        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ca.m.batch0 = b0; ca.m.nbatch = std::min(slots, nblocks - b0); launch_rec_encode_c(ca, mst[m]); }
+                        if ((rc = reserve(ctx, ctx->rflags, (size_t)nblocks * 4))) return rc;
+                        HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nblocks * 4, mst[m]));
+                        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ca.m.batch0 = b0; ca.m.nbatch = std::min(slots, nblocks - b0); launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[m]); }
                     } else launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]);
                     break;
                 }

@@ -85,6 +85,58 @@ __device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {     
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// ---- a lane's text, piece by piece -----------------------------------------------------------------------------------
+// A chain's symbols are the LINE-th lines (1 = bases, 3 = qualities) of records [r0, r0 + nrec), minus a SOLiD prefix
+// character.  The lane takes them in 16-byte pieces that are aligned in memory; next() describes the coming piece from
+// the line bounds alone, so the caller can have the piece after the one it is working on in flight, and the bounds of
+// a line are themselves fetched a record ahead: no memory round trip sits on the lane's critical path.
+struct Piece { u64 at; u32 j0, j1; bool valid, newline; };      // bytes [j0, j1) of the 16 at offset `at` are the lane's; newline: they start a line
+struct LineWalk {
+    const u64* line_off; const u64* st_off; const u32* st_len;   // FASTQ text (line_off) or the decoder's staged lines (st_off / st_len)
+    const u8* buf; u64 nbytes; u32 mis;
+    u64 r0; u32 nrec, k, line, solid;
+    u64 pos, end, npos, nend;
+    bool fresh;
+    __device__ __forceinline__ void bounds(u32 kk, u64& b0, u64& b1) const {
+        const u64 r = r0 + kk;
+        if (st_off) { b0 = st_off[r]; b1 = b0 + st_len[r]; }
+        else { b0 = line_off[4 * r + line] + solid; b1 = line_off[4 * r + line + 1] - 1; }
+    }
+    __device__ __forceinline__ void init(const ChainArgs& a, u64 r0_, u32 nrec_, u32 line_, u32 solid_) {
+        line_off = a.m.line_off; st_off = a.st_off; st_len = a.st_len;
+        buf = st_off ? a.st_buf : a.m.fq; nbytes = st_off ? a.st_bytes : a.nbytes; mis = (u32)((uintptr_t)buf & 15);
+        r0 = r0_; nrec = nrec_; line = line_; solid = solid_; k = 0; pos = end = 0; npos = nend = 0; fresh = false;
+        if (nrec) bounds(0, npos, nend);
+    }
+    __device__ __forceinline__ Piece next() {
+        while (pos >= end && k < nrec) {
+            pos = npos; end = nend; k++; fresh = true;
+            if (k < nrec) bounds(k, npos, nend);                   // used a whole line later
+            if (end < pos) end = pos;
+        }
+        Piece p; p.valid = pos < end; p.newline = false; p.at = 0; p.j0 = 16; p.j1 = 0;
+        if (p.valid) {
+            p.at = ((pos + mis) & ~15ull) - mis;                   // aligned in memory; "negative" (wrapped) only in front of the buffer
+            p.j0 = (u32)(pos - p.at);
+            p.j1 = (u32)((end - p.at) < 16 ? (end - p.at) : 16);
+            p.newline = fresh; fresh = false;
+            pos = p.at + p.j1;
+        }
+        return p;
+    }
+    __device__ __forceinline__ uint4 fetch(const Piece& p) const {
+        if (!p.valid) return make_uint4(0, 0, 0, 0);
+        if ((i64)p.at >= 0) return load16(buf, nbytes, p.at);
+        u32 t[4] = {0, 0, 0, 0};
+        for (u32 i = 0; i < 16; i++) { const i64 at = (i64)p.at + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)buf[at] << ((i & 3) * 8); }
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    }
+};
+__device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j is a compile-time constant where this is used
+    const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
+    return (word >> ((j & 3) * 8)) & 0xffu;
+}
+
 // =========================================================================================================
 // quality encode: one chain per lane
 // =========================================================================================================
@@ -98,47 +150,26 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     LaneEnc rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 1, 1, cap) : nullptr;
     rc.init(outp, cap);
-    const u32 solid = live ? d->solid : 0;
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
-    const u8* fq = a.m.fq; const u64 nbytes = a.nbytes;
-    // the address bits that make a 16-byte piece: pieces are aligned in MEMORY, positions are offsets into fq
-    const u32 mis = (u32)((uintptr_t)fq & 15);
-    u32 k = 0;                        // records taken
-    u64 pos = 0, end = 0;             // current quality line [pos, end) as offsets into fq
+    LineWalk lw; lw.init(a, cp.r0, cp.nrec, 3, live ? d->solid : 0u);
     u32 last = 0, p1 = 0, p2 = 0, delta = 5;
     u32 extra = 0;
-    for (;;) {
-        // next line with symbols
-        while (pos >= end && k < cp.nrec) {
-            const u64 r = cp.r0 + k; k++;
-            const u64 q0 = a.m.line_off[4 * r + 3] + solid, q1e = a.m.line_off[4 * r + 4] - 1;
-            if (q1e > q0) { pos = q0; end = q1e; last = 0; p1 = p2 = 0; delta = 5; }
-        }
-        const bool act = pos < end;
-        if (!__any(act)) break;
-        // one aligned 16-byte piece of the line
-        const u64 piece = act ? ((pos + mis) & ~15ull) - mis : 0;        // offset of the piece (may be "negative" only when mis > pos: handled by load16's guard through wrap -> at + i < nbytes fails)
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (act) {
-            if ((i64)piece >= 0) w = load16(fq, nbytes, piece);
-            else { u32 t[4] = {0, 0, 0, 0}; for (u32 i = 0; i < 16; i++) { const i64 at = (i64)piece + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)fq[at] << ((i & 3) * 8); } w = make_uint4(t[0], t[1], t[2], t[3]); }
-        }
-        const u32 j0 = act ? (u32)(pos - piece) : 16u;                     // first byte of the piece that is ours
-        const u32 j1 = act ? (u32)((end - piece) < 16 ? (end - piece) : 16) : 0u;   // one past the last
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    while (__any(pc.valid)) {
+        const Piece pn = lw.next();                   // the next piece is in flight while this one is coded
+        const uint4 wn = lw.fetch(pn);
+        if (pc.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
+        // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once
+        u32 e[16];
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            if (j >= j0 && j < j1) {
-                const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
-                const u32 b = (((word >> ((j & 3) * 8)) & 0xffu) - '!') & 0xffu;
+            e[j] = 0;
+            if (j >= pc.j0 && j < pc.j1) {
+                const u32 b = (piece_byte(w, j) - '!') & 0xffu;
                 const u32 sym = b < LAST_QLT ? b : LAST_QLT;
-                const u32 e = a.qrows[(size_t)last * 64 + sym];
-                rc.encode16(FZ_CUM(e), FZ_FREQ(e));
-                if (b >= LAST_QLT) {                                       // escape: the raw value through the frozen escape row (qlts.cpp:80-86)
-                    const u32 ee = a.qesc[b];
-                    rc.encode16(FZ_CUM(ee), FZ_FREQ(ee));
-                    extra++;
-                }
+                e[j] = a.qrows[(size_t)last * 64 + sym];
                 if (level <= 2) last = (b | (last << 6)) & mask12;         // qlts.hpp:52-57
                 else {                                                    // qlts.hpp:62-74
                     if (p1 > b) delta += p1 - b;
@@ -148,7 +179,20 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 }
             }
         }
-        if (act) pos = piece + j1;
+        // (b) the serial part: the range coder
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            if (j >= pc.j0 && j < pc.j1) {
+                rc.encode16(FZ_CUM(e[j]), FZ_FREQ(e[j]));
+                const u32 b = (piece_byte(w, j) - '!') & 0xffu;
+                if (b >= LAST_QLT) {                                       // escape: the raw value through the frozen escape row (qlts.cpp:80-86)
+                    const u32 ee = a.qesc[b];
+                    rc.encode16(FZ_CUM(ee), FZ_FREQ(ee));
+                    extra++;
+                }
+            }
+        }
+        pc = pn; w = wn;
     }
     if (live) {
         const u32 size = rc.finish();
@@ -279,42 +323,29 @@ __device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0.
     n = (l == 'n' || c == '.') ? 4u : n;
     return n;
 }
-// per-lane walk over the base lines of records [r0, r0 + nrec): f(code 0..3, context before the base).  The bases are
-// read from the FASTQ text (encode: line_off) or from the decoder's staged bases (decode: st_off / st_len per record)
-template <typename F>
-__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, F&& f) {
-    const bool staged = a.st_off != nullptr;
-    const u8* fq = staged ? a.st_buf : a.m.fq; const u64 nbytes = staged ? a.st_bytes : a.nbytes;
-    const u32 mis = (u32)((uintptr_t)fq & 15);
-    u32 k = 0; u64 pos = 0, end = 0; u32 last = 0;
-    for (;;) {
-        while (pos >= end && k < nrec) {
-            const u64 r = r0 + k; k++;
-            u64 g0, g1;
-            if (staged) { g0 = a.st_off[r]; g1 = g0 + a.st_len[r]; }
-            else { g0 = a.m.line_off[4 * r + 1] + solid; g1 = a.m.line_off[4 * r + 2] - 1; }
-            if (g1 > g0) { pos = g0; end = g1; last = 0x007616c7u; }               // gens.cpp:139
-        }
-        const bool act = pos < end;
-        if (!__any(act)) break;
-        const u64 piece = act ? ((pos + mis) & ~15ull) - mis : 0;
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (act) {
-            if ((i64)piece >= 0) w = load16(fq, nbytes, piece);
-            else { u32 t[4] = {0, 0, 0, 0}; for (u32 i = 0; i < 16; i++) { const i64 at = (i64)piece + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)fq[at] << ((i & 3) * 8); } w = make_uint4(t[0], t[1], t[2], t[3]); }
-        }
-        const u32 j0 = act ? (u32)(pos - piece) : 16u;
-        const u32 j1 = act ? (u32)((end - piece) < 16 ? (end - piece) : 16) : 0u;
+// per-lane walk over the base lines of records [r0, r0 + nrec): look(ctx) for every base of a piece first (so that a
+// caller can start its table lookups together), then code(j, code) for each base in order.  The bases come from the FASTQ
+// text or from the decoder's staged bases (ChainArgs::st_*).  N is coded as 0 (gens.cpp:116-136).
+template <typename LOOK, typename CODE>
+__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, LOOK&& look, CODE&& code) {
+    LineWalk lw; lw.init(a, r0, nrec, 1, solid);
+    u32 last = 0;
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    while (__any(pc.valid)) {
+        const Piece pn = lw.next();
+        const uint4 wn = lw.fetch(pn);
+        if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            if (j >= j0 && j < j1) {
-                const u32 word = j < 4 ? w.x : j < 8 ? w.y : j < 12 ? w.z : w.w;
-                const u32 code = gen_code_of((word >> ((j & 3) * 8)) & 0xffu) & 3u;       // N is coded as 0 (gens.cpp:116-136)
-                f(code, last & mask);
-                last = (last << 2) | code;
+            if (j >= pc.j0 && j < pc.j1) {
+                look(j, last & mask);
+                last = (last << 2) | (gen_code_of(piece_byte(w, j)) & 3u);
             }
         }
-        if (act) pos = piece + j1;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) code(j, gen_code_of(piece_byte(w, j)) & 3u);
+        pc = pn; w = wn;
     }
 }
 
@@ -333,15 +364,18 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
         solid = a.m.blocks[b].solid; mask = (1u << a.m.blocks[b].gen_bits) - 1u;
     }
     u64 mycost = 0;
-    walk_bases(a, r, live ? 1u : 0u, solid, mask, [&](u32 code, u32 ctx) {
-        atomicAdd(&cnt[((size_t)ctx << 2) | code], 1u);
-        if (rows) {
-            mybases++;
-            const u32 v = rows[ctx];
-            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-            mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
-        }
-    });
+    u32 cx[16], rv[16];
+    walk_bases(a, r, live ? 1u : 0u, solid, mask,
+        [&](u32 j, u32 ctx) { cx[j] = ctx; rv[j] = rows ? rows[ctx] : 0u; },
+        [&](u32 j, u32 code) {
+            atomicAdd(&cnt[((size_t)cx[j] << 2) | code], 1u);
+            if (rows) {
+                mybases++;
+                const u32 v = rv[j];
+                const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+                mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
+            }
+        });
     if (rows) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mycost += __shfl_xor(mycost, d, 64);
@@ -394,13 +428,16 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
     rc.init(outp, cap);
     const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
-    walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u, [&](u32 code, u32 ctx) {
-        const u32 v = rows ? rows[ctx] : B2_INIT;
-        const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-        const u32 tot = (f0 + f1) + (f2 + f3);
-        const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
-        rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                        // base2_ranger.hpp:74-84 without the update
-    });
+    u32 rv[16];
+    walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u,
+        [&](u32 j, u32 ctx) { rv[j] = rows ? rows[ctx] : B2_INIT; },
+        [&](u32 j, u32 code) {
+            const u32 v = rv[j];
+            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+            const u32 tot = (f0 + f1) + (f2 + f3);
+            const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
+            rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                    // base2_ranger.hpp:74-84 without the update
+        });
     if (live) {
         a.csz[c] = rc.finish();
         if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));
@@ -560,17 +597,20 @@ void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hi
     hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, coarse);
 }
 
-// header encode: one block per lane (blocks [batch0, batch0 + nbatch), table slot = lane index within the batch)
-__global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a) {
+// header encode, general path: one block per lane (blocks [batch0, batch0 + nbatch), table slot = lane index within the
+// batch); only the blocks the fast kernel below has handed over (flags[b] != 0)
+__global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* flags) {
     __shared__ u32 lrows[REC_LDS_ROWS * 256];
     __shared__ u16 lmap[PR_REC_ROWS];
     __shared__ u32 ltext[64 * 2 * REC_HBUF / 4];
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    const u32 b = a.m.batch0 + t;
+    const bool mine = t < a.m.nbatch && flags[b] != 0;
+    if (!__any(mine)) return;
     for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) lmap[i] = a.rmap[i];
     for (u32 i = threadIdx.x; i < a.r_hot * 256; i += 64) lrows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
     __syncthreads();
-    const u32 t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= a.m.nbatch) return;
-    const u32 b = a.m.batch0 + t;
+    if (!mine) return;
     BlockDesc* d = &a.m.blocks[b];
     PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
     RecFrozenEnc cd; cd.rows = a.rrows; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
@@ -585,8 +625,180 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a) {
     if ((cd.rc.err & 1) | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
     if (bad) atomicMax(&d->status, (u32)(-bad));
 }
-void launch_rec_encode_c(const ChainArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_encode_c, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a);
+
+// header encode, fast path: the same model (recs.cpp:277-372) for blocks whose headers are at most RF_MAXLEN bytes and
+// RF_NF fields, with everything a lane touches per record in LDS, laid out [..][lane]: the header text (current and
+// previous), the field tables of both, the field types / values, and the hottest frozen rows.  The general path above
+// keeps those in per-lane scratch and reads the text through generic pointers: ~300 memory instructions per record,
+// which is what its time is made of.  A block with a longer header or more fields is handed over (flags[b] = 1).
+#define RF_MAXLEN 127u
+#define RF_NF 24u
+struct RecFastLds {
+    u8  text[2][RF_MAXLEN + 1][64];
+    u8  off[2][RF_NF][64], wln[2][RF_NF][64], sep[2][RF_NF][64];
+    u8  ctype[RF_NF][64];
+    u64 cnumb[RF_NF][64];
+    u32 rows[REC_LDS_ROWS * 256];
+    u16 map[PR_REC_ROWS];
+};
+// numberwang (recs.cpp:192-262) over text[buf][off ..][lane]
+__device__ __forceinline__ u32 nw_lds(const RecFastLds& L, u32 buf, u32 lane, u32 off, int len, u64& num, u32 pctype) {
+    int i = 0;
+    const bool has_z = L.text[buf][off][lane] == '0';
+    if (has_z) if (L.text[buf][off + (++i)][lane] == '0') return ST_STR;
+    u32 caps = 0;
+    num = 0;
+    while (pctype != 2) {
+        if (i >= len) return has_z ? ST_DGT_Z : ST_DGT;
+        const u32 c = L.text[buf][off + i][lane];
+        if (isdig(c)) {
+            const u64 tnum = (num << 3) + (num << 1) + c - '0';
+            i++;
+            if (tnum < num) return ST_STR;
+            num = tnum;
+            continue;
+        }
+        if ((c | 0x20) < 'a' || (c | 0x20) > 'f') return ST_STR;
+        caps = 1 + (c < 'a');
+        i = has_z;
+        num = 0;
+        break;
+    }
+    if (len > 16) return ST_STR;
+    for (; i < len; i++) {
+        const u32 c = L.text[buf][off + i][lane]; u32 nib;
+        if (isdig(c)) nib = c - '0';
+        else if (c >= 'a' && c <= 'f') { if (caps == 2) return ST_STR; caps = 1; nib = 10 + (c - 'a'); }
+        else if (c >= 'A' && c <= 'F') { if (caps == 1) return ST_STR; caps = 2; nib = 10 + (c - 'A'); }
+        else return ST_STR;
+        num = (num << 4) + nib;
+    }
+    return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
+}
+struct RecFastEnc {
+    const u32* rows; const RecFastLds* L; LaneEnc rc;
+    __device__ __forceinline__ void put(u32 row, u32 sym) {
+        const u32 slot = L->map[row];
+        const u32 e = slot != 0xFFFFu ? L->rows[slot * 256 + sym] : rows[(size_t)row * 256 + sym];
+        rc.encode16(FZ_CUM(e), FZ_FREQ(e));
+    }
+    __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+};
+__global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
+    __shared__ RecFastLds L;
+    const u32 lane = threadIdx.x;
+    for (u32 i = lane; i < PR_REC_ROWS; i += 64) L.map[i] = a.rmap[i];
+    for (u32 i = lane; i < a.r_hot * 256; i += 64) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
+    __syncthreads();
+    const u32 t = blockIdx.x * 64 + lane;
+    if (t >= a.m.nbatch) return;
+    const u32 b = a.m.batch0 + t;
+    BlockDesc* d = &a.m.blocks[b];
+    PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
+    RecFastEnc cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
+    XfEnc x_rec; x_rec.init(a.m.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    u32 cur = 0, nf_prev = 0, hdr_bytes = 0;
+    u64 last_index = 0;
+    bool slow = false;
+    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+    u64 nh0 = a.m.line_off[4 * rec0] + 1, nh1 = a.m.line_off[4 * rec0 + 1] - 1;     // the next record's header line, fetched a record ahead
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 record_count = (u64)k + 1;
+        const u64 h0 = nh0, h1 = nh1;
+        if (k + 1 < nrec) { const u64 r1 = rec0 + k + 1; nh0 = a.m.line_off[4 * r1] + 1; nh1 = a.m.line_off[4 * r1 + 1] - 1; }
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        if (n > RF_MAXLEN) { slow = true; break; }
+        hdr_bytes += n;
+        // the text into LDS, tokenised on the way (map_space, recs.cpp:141-157): a separator closes a field; the byte behind
+        // the text is the line's '\n', the last separator; a NUL ends the scan.  Eight dwords are fetched at a time, so a
+        // header costs a memory round trip or two, not one per dword.
+        const u32* g = reinterpret_cast<const u32*>(a.m.fq + h0);      // (global loads need no alignment on gfx9; the text goes on behind the line)
+        const u32 nw = (n + 4) / 4;
+        u32 nf = 0, start = 0; bool stop = false;
+        for (u32 i0 = 0; i0 < nw; i0 += 8) {
+            u32 wv[8];
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) wv[q] = i0 + q < nw ? g[i0 + q] : 0u;
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) {
+#pragma unroll
+                for (u32 j = 0; j < 4; j++) {
+                    const u32 pos = 4 * (i0 + q) + j, c = (wv[q] >> (8 * j)) & 0xffu;
+                    if (pos <= n) {
+                        L.text[cur][pos][lane] = (u8)c;
+                        if (!stop && !isword(c)) {
+                            if (nf < RF_NF) { L.off[cur][nf][lane] = (u8)start; L.wln[cur][nf][lane] = (u8)(pos - start); L.sep[cur][nf][lane] = (u8)c; }
+                            nf++; start = pos + 1;
+                            if (c == 0) stop = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (nf > RF_NF) { slow = true; break; }
+        const u32 prv = cur ^ 1u;
+        if (k == 0) {                                                         // recs.cpp:279-287: the first line goes to "rec.first"
+            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+            nf_prev = nf; cur = prv;
+            continue;
+        }
+        bool shape = nf != nf_prev;
+        for (u32 f = 0; !shape && f < nf; f++) shape = L.sep[cur][f][lane] != L.sep[prv][f][lane];
+        if (shape) {                                                          // recs.cpp:292-305
+            x_rec.put(pw, record_count - last_index);
+            last_index = record_count;
+            x_rec.put(pw, n);                                                 // put_str: the length, then the characters
+            for (u32 j = 0; j < n; j++) x_rec.put_chr(pw, L.text[cur][j][lane]);
+            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+            nf_prev = nf; cur = prv;
+            continue;
+        }
+        u64 map = 0;
+        for (u32 f = 0; f < nf; f++) {
+            const u32 wl = L.wln[cur][f][lane];
+            bool ch = wl != L.wln[prv][f][lane];
+            if (!ch) {
+                const u32 o = L.off[cur][f][lane], po = L.off[prv][f][lane];
+                for (u32 j = 0; j < wl; j++) if (L.text[cur][o + j][lane] != L.text[prv][po + j][lane]) { ch = true; break; }
+            }
+            if (ch) map |= 1ull << f;
+        }
+        cd.put_u(0 * 16 + 2, map);                                            // put_num(0, map) recs.cpp:313
+        for (u32 f = 0; f < nf; f++) {
+            if (!((map >> f) & 1)) continue;
+            const u32 o = L.off[cur][f][lane], wl = L.wln[cur][f][lane], pct = L.ctype[f][lane];
+            u64 bnum;
+            u32 type = nw_lds(L, cur, lane, o, (int)wl, bnum, pct);
+            const u32 rr = (f + 1) * 16;
+            if (type == ST_STR) {                                             // recs.cpp:324-331
+                cd.put(rr + 0, type);
+                cd.put_u(rr + 2, wl);
+                for (u32 j = 0; j < wl; j++) cd.put(rr + 1, L.text[cur][o + j][lane]);
+                L.ctype[f][lane] = 0;
+                continue;
+            }
+            const u64 pnum = pct ? L.cnumb[f][lane] : 0;                       // recs.cpp:333-348
+            u64 gap;
+            L.ctype[f][lane] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+            L.cnumb[f][lane] = bnum;
+            if (bnum < pnum) { gap = pnum - bnum; type++; }
+            else gap = bnum - pnum;
+            cd.put(rr + 0, type);
+            cd.put_u(rr + 2, gap);
+        }
+        nf_prev = nf; cur = prv;
+    }
+    if (slow) { flags[b] = 1; return; }                                       // the general kernel starts this block over
+    d->hdr_bytes = hdr_bytes;
+    d->size[SFQ_S_REC] = cd.rc.finish();
+    d->size[SFQ_S_REC_X] = x_rec.finish(pw);
+    if ((cd.rc.err & 2) || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+    if ((cd.rc.err & 1) | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+}
+// flags: one dword per block of the call, zeroed by the caller before the first batch
+void launch_rec_encode_c(const ChainArgs& a, u32* flags, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_encode_f, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a, flags);
+    hipLaunchKernelGGL(k_rec_encode_c, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a, (const u32*)flags);
 }
 
 // header decode

@@ -73,7 +73,7 @@ void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       // gen.Ns / gen.Nn side streams, a wave per block (models_k.hip)
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st);
-void launch_rec_encode_c(const ChainArgs& a, hipStream_t st);       // blocks [m.batch0, m.batch0 + m.nbatch), one per lane
+void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [nblocks], zeroed */, hipStream_t st);   // blocks [m.batch0, m.batch0 + m.nbatch), one per lane
 void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);
