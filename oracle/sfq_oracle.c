@@ -1549,8 +1549,8 @@ int sfqo_qlt_encode_blocks(const u8* base, const u64* off, const u32* len, size_
  * What stays the reference's: the context functions, the symbol alphabets, the header model, RCoder::Encode.
  * ============================================================================================== */
 
-/* the chain's range coder: RCoder (coder.hpp) with the four always-zero leading bytes elided, a five-byte flush of
-   the smallest multiple of 2^24 >= low, trailing zero bytes dropped */
+/* the chain's range coder: RCoder (coder.hpp) with the four always-zero leading bytes elided and a five-byte flush of
+   the smallest multiple of 2^24 >= low, less the flush's own trailing zero bytes */
 typedef struct { u64 low; u32 range; u8* out; size_t n, cap, emitted; } chenc;
 static void ch_init(chenc* c) { c->low = 0; c->range = (u32)-1; c->out = NULL; c->n = c->cap = 0; c->emitted = 0; }
 static void ch_put(chenc* c, u8 b) {
@@ -1576,7 +1576,7 @@ static void ch_encode(chenc* c, u32 cum, u32 freq, u32 tot) {                 /*
 static size_t ch_finish(chenc* c) {
     u64 v = (c->low + 0xFFFFFFull) & ~0xFFFFFFull;
     for (int i = 0; i < 5; i++) { ch_put(c, (u8)(v >> 56)); v <<= 8; }
-    while (c->n && c->out[c->n - 1] == 0) c->n--;
+    for (int i = 0; i < 5 && c->n && c->out[c->n - 1] == 0; i++) c->n--;     /* the flush's own trailing zeros (a decoder reads zeros past the end) */
     return c->n;
 }
 

@@ -336,15 +336,18 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
         const Piece pn = lw.next();
         const uint4 wn = lw.fetch(pn);
         if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
+        u32 codes = 0;                                             // 2 bits per base of the piece
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             if (j >= pc.j0 && j < pc.j1) {
+                const u32 cd = gen_code_of(piece_byte(w, j)) & 3u;
                 look(j, last & mask);
-                last = (last << 2) | (gen_code_of(piece_byte(w, j)) & 3u);
+                last = (last << 2) | cd;
+                codes |= cd << (2 * j);
             }
         }
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) code(j, gen_code_of(piece_byte(w, j)) & 3u);
+        for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) code(j, (codes >> (2 * j)) & 3u);
         pc = pn; w = wn;
     }
 }
@@ -428,16 +431,22 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
     rc.init(outp, cap);
     const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
-    u32 rv[16];
-    walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u,
-        [&](u32 j, u32 ctx) { rv[j] = rows ? rows[ctx] : B2_INIT; },
-        [&](u32 j, u32 code) {
-            const u32 v = rv[j];
-            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-            const u32 tot = (f0 + f1) + (f2 + f3);
-            const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
-            rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                    // base2_ranger.hpp:74-84 without the update
-        });
+    if (!__any(rows != nullptr)) {
+        // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
+        const u32 r12 = fz_recip(12u);
+        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, [&](u32, u32) {}, [&](u32, u32 code) { rc.encode(3u * code, 3u, 12u, r12); });
+    } else {
+        u32 rv[16];
+        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u,
+            [&](u32 j, u32 ctx) { rv[j] = rows ? rows[ctx] : B2_INIT; },
+            [&](u32 j, u32 code) {
+                const u32 v = rv[j];
+                const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+                const u32 tot = (f0 + f1) + (f2 + f3);
+                const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
+                rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                // base2_ranger.hpp:74-84 without the update
+            });
+    }
     if (live) {
         a.csz[c] = rc.finish();
         if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));

@@ -11,8 +11,8 @@
 //
 // Chain stream framing (ours, not the reference's): RCoder's first four output bytes are always zero
 // (low < 2^32 until four renormalisations have happened) and are not stored; the flush writes the five
-// significant bytes of the smallest multiple of 2^24 that is >= low (it lies inside [low, low + range));
-// trailing zero bytes are dropped -- a decoder reads zeros past the end, as FilerLoad::get does (filer.hpp:94-97).
+// significant bytes of the smallest multiple of 2^24 that is >= low (it lies inside [low, low + range)), less
+// those of the five that are trailing zeros -- a decoder reads zeros past the end, as FilerLoad::get does (filer.hpp:94-97).
 #pragma once
 #include "dev_coder.h"
 
@@ -29,26 +29,18 @@ __device__ __forceinline__ u32 fz_recip(u32 tot) {      // floor(2^32 / tot) for
 struct LaneEnc {
     u64 low; u32 range;
     u32 n;          // bytes produced so far, the four elided ones included
-    u32 last_nz;    // n after the last non-zero byte
-    u32 acc;        // bytes of the dword being filled
+    u32 acc;        // the last up-to-4 bytes, oldest in the low byte once four are in
     u8* out; u32 cap;
     u32 err;
-    __device__ __forceinline__ void init(u8* p, u32 c) { low = 0; range = 0xFFFFFFFFu; n = 0; last_nz = 0; acc = 0; out = p; cap = c; err = 0; }
+    __device__ __forceinline__ void init(u8* p, u32 c) { low = 0; range = 0xFFFFFFFFu; n = 0; acc = 0; out = p; cap = c; err = 0; }
+    // byte k of the coder lands at out[k - 4]: the first four bytes are always zero (low < 2^56 until four bytes have
+    // left) and are dropped with the first dword
     __device__ __forceinline__ void put(u32 byte) {
-        if (n >= 4) {
-            const u32 at = n - 4;
-            acc |= byte << ((at & 3u) * 8u);
-            if ((at & 3u) == 3u) { if (at < cap) *reinterpret_cast<u32*>(out + (at & ~3u)) = acc; acc = 0; }
-        } else if (byte) err = 1;                            // cannot happen: low < 2^56 for the first four bytes
+        acc = __builtin_amdgcn_alignbit(byte, acc, 8);             // (acc >> 8) | (byte << 24)
         n++;
-        if (byte) last_nz = n;
+        if ((n & 3u) == 0 && n > 4 && n - 4 <= cap) *reinterpret_cast<u32*>(out + n - 8) = acc;
     }
-    // coder.hpp:66-81 with the divide as a multiply-high by recip = floor(2^32 / tot) plus one exact fix-up
-    __device__ __forceinline__ void encode(u32 cum, u32 freq, u32 tot, u32 recip) {
-        u32 r = __umulhi(range, recip);
-        r += (range - r * tot) >= tot ? 1u : 0u;
-        low += (u64)cum * r;                                 // cum * r < range: no 32-bit wrap (coder.hpp:69)
-        range = r * freq;
+    __device__ __forceinline__ void renorm() {                              // coder.hpp:74-80
         int guard = 0;
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
@@ -57,28 +49,35 @@ struct LaneEnc {
             if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }    // the reference would spin; every chain must drain
         }
     }
+    // coder.hpp:66-73 with the divide as a multiply-high by recip = floor(2^32 / tot) plus one exact fix-up
+    __device__ __forceinline__ void encode(u32 cum, u32 freq, u32 tot, u32 recip) {
+        u32 r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        low += (u64)cum * r;                                 // cum * r < range: no 32-bit wrap (coder.hpp:69)
+        range = r * freq;
+        renorm();
+    }
     // the same with tot = 2^16: range / tot is a shift
     __device__ __forceinline__ void encode16(u32 cum, u32 freq) {
         const u32 r = range >> 16;
         low += (u64)cum * r;
         range = r * freq;
-        int guard = 0;
-        while (range < RC_TOP) {
-            if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
-            put((u32)(low >> 56));
-            range <<= 8; low <<= 8;
-            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
-        }
+        renorm();
     }
-    // flush; returns the stream's size
+    // flush; returns the stream's size (the flush's own trailing zero bytes are dropped)
     __device__ __forceinline__ u32 finish() {
-        u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;
-        for (int i = 0; i < 5; i++) { put((u32)(v >> 56)); v <<= 8; }
-        const u32 size = last_nz > 4 ? last_nz - 4 : 0;
-        const u32 wrote = n - 4, pend = wrote & 3u;          // bytes still in acc
-        for (u32 i = 0; i < pend; i++) { const u32 at = wrote - pend + i; if (at < cap && at < size) out[at] = (u8)(acc >> (8 * i)); }
-        if (size > cap) err |= 2;
-        return size;
+        const u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;
+        if (n < 4 && (v >> (32 + 8 * n))) err = 1;            // cannot happen: the elided bytes are zero (v < 2^(32 + 8 n))
+        const u32 top5_lo = (u32)(v >> 24);                  // flush bytes 1..4 (byte 0 = v >> 56)
+        u32 tz = 0;                                          // trailing zero bytes among the five
+        if (top5_lo == 0) tz = (v >> 56) ? 4u : 5u; else tz = ((u32)__builtin_ctz(top5_lo)) >> 3;
+        u64 t = v;
+        for (int i = 0; i < 5; i++) { put((u32)(t >> 56)); t <<= 8; }
+        const u32 stored = n - 4;                            // n >= 5
+        const u32 pend = stored & 3u;                        // bytes still in acc (its top `pend` bytes)
+        for (u32 i = 0; i < pend; i++) { const u32 at = stored - pend + i; if (at < cap) out[at] = (u8)(acc >> (8 * (4 - pend + i))); }
+        if (stored > cap) err |= 2;
+        return stored - (tz < stored ? tz : stored);
     }
 };
 

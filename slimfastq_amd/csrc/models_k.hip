@@ -185,70 +185,6 @@ void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st) {
 }
 
 // =========================================================================================================
-// N / quality-0 exceptions alone (frozen-table mode: the bases themselves are coded by chains.hip): a wave per block
-// scans 64 bases at a time and codes gen.Ns / gen.Nn exactly as gen_window does (bad_q_or_bad_n, gens.cpp:91-114)
-// =========================================================================================================
-__global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
-    const u32 lane = threadIdx.x, t = blockIdx.x;
-    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
-        BlockDesc* d = &a.blocks[b];
-        PwTab pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
-        XfEnc x_ns, x_nn;                                  // lane 0 codes
-        x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
-        x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
-        const u32 solid = d->solid;
-        const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-        u64 genofs = 0, ns_index = 0, nn_index = 0;
-        u32 n_byte = 0; int bad = 0;
-        for (u32 k = 0; k < nrec; k++) {
-            const u64 r = rec0 + k;
-            const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1;
-            const u64 q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
-            const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
-            const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
-            for (u32 base = 0; base < llen; base += 64) {
-                const u32 m = llen - base < 64 ? llen - base : 64;
-                const u32 idx = base + lane;
-                const bool in = lane < m;
-                const u32 gch = in ? gp[idx] : 'A';
-                const u32 qch = (in && idx < qlen) ? qp[idx] : 40u;                       // gens.cpp:153
-                const u32 n = gencode_w(gch);
-                if (__ballot(in && n > 4)) bad = SFQ_E_GENCHAR;
-                const u64 mN = __ballot(in && n == 4), mQ = __ballot(in && qch == '!');
-                u64 mx = mN | mQ;
-                while (mx) {
-                    const u32 bit = (u32)__ffsll((long long)mx) - 1u;
-                    mx &= mx - 1;
-                    const u64 pos = genofs + bit + 1;
-                    const bool is_n = (mN >> bit) & 1, is_q = (mQ >> bit) & 1;
-                    if (!is_n) {
-                        if (lane == 0) x_nn.put(pw, pos - nn_index);
-                        nn_index = pos;
-                    } else {
-                        const u32 ch = rl(gch, bit);
-                        if (!n_byte) n_byte = ch;
-                        if (ch != n_byte) bad = SFQ_E_GENCHAR;
-                        if (!is_q) { if (lane == 0) x_ns.put(pw, pos - ns_index); ns_index = pos; }
-                    }
-                }
-                genofs += m;
-            }
-        }
-        if (lane == 0) {
-            d->n_byte = n_byte;
-            d->size[SFQ_S_GEN_NS] = x_ns.finish(pw);
-            d->size[SFQ_S_GEN_NN] = x_nn.finish(pw);
-            if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-            if (x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
-            if (bad) atomicMax(&d->status, (u32)(-bad));
-        }
-    }
-}
-void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
-}
-
-// =========================================================================================================
 // framing exceptions, a wave per block: UsrSave::get_record's bookkeeping (usrs.cpp:322-375) + update (126-160).
 // A record is an exception when its line length differs from the previous record's (usr.x), its quality length from
 // its own base length (usr.x.q), or its SOLiD prefix characters from the previous record's (usr.pfg / usr.pfq): all

@@ -166,6 +166,85 @@ struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
     }
 };
 
+// =========================================================================================================
+// N / quality-0 exceptions alone (frozen-table mode: the bases themselves are coded by chains.hip): a wave per block
+// scans 64 bases at a time and codes gen.Ns / gen.Nn as models_k.hip gen_window does (bad_q_or_bad_n, gens.cpp:91-114),
+// each gap through the wave-cooperative PowerRanger rows (a gap is 1-2 symbols of a 256-slot row: on one lane the row
+// search is a walk of dependent HBM reads, ~100 us per gap)
+// =========================================================================================================
+__global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        BlockDesc* d = &a.blocks[b];
+        WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
+        XfEncW x_ns, x_nn;                                 // the whole wave codes a gap: lane = four slots of the PowerRanger row
+        x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
+        x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+        const u32 solid = d->solid;
+        const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+        u64 genofs = 0, ns_index = 0, nn_index = 0;
+        u32 n_byte = 0; int bad = 0;
+        // the next record's line bounds are fetched a record ahead; a record is taken 256 bases at a time (four loads
+        // per lane in flight), so a 150-base read costs one memory round trip, not three
+        u64 ng0 = a.line_off[4 * rec0 + 1], ng1 = a.line_off[4 * rec0 + 2], nq0 = a.line_off[4 * rec0 + 3], nq1 = a.line_off[4 * rec0 + 4];
+        for (u32 k = 0; k < nrec; k++) {
+            const u64 g0 = ng0 + solid, g1 = ng1 - 1, q0 = nq0 + solid, q1 = nq1 - 1;
+            if (k + 1 < nrec) { const u64 r1 = rec0 + k + 1; ng0 = a.line_off[4 * r1 + 1]; ng1 = a.line_off[4 * r1 + 2]; nq0 = a.line_off[4 * r1 + 3]; nq1 = a.line_off[4 * r1 + 4]; }
+            const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
+            const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
+            for (u32 base0 = 0; base0 < llen; base0 += 256) {
+                u32 gch[4], qch[4];
+#pragma unroll
+                for (u32 u = 0; u < 4; u++) {
+                    const u32 idx = base0 + 64 * u + lane;
+                    gch[u] = idx < llen ? gp[idx] : 'A';
+                    qch[u] = (idx < llen && idx < qlen) ? qp[idx] : 40u;                  // gens.cpp:153
+                }
+#pragma unroll
+                for (u32 u = 0; u < 4; u++) {
+                    const u32 base = base0 + 64 * u;
+                    if (base >= llen) break;
+                    const u32 m = llen - base < 64 ? llen - base : 64;
+                    const bool in = lane < m;
+                    const u32 n = gencode_w(gch[u]);
+                    if (__ballot(in && n > 4)) bad = SFQ_E_GENCHAR;
+                    const u64 mN = __ballot(in && n == 4), mQ = __ballot(in && qch[u] == '!');
+                    u64 mx = mN | mQ;
+                    while (mx) {
+                        const u32 bit = (u32)__ffsll((long long)mx) - 1u;
+                        mx &= mx - 1;
+                        const u64 pos = genofs + bit + 1;
+                        const bool is_n = (mN >> bit) & 1, is_q = (mQ >> bit) & 1;
+                        if (!is_n) {
+                            x_nn.put(pw, pos - nn_index, lane);
+                            nn_index = pos;
+                        } else {
+                            const u32 ch = rl(gch[u], bit);
+                            if (!n_byte) n_byte = ch;
+                            if (ch != n_byte) bad = SFQ_E_GENCHAR;
+                            if (!is_q) { x_ns.put(pw, pos - ns_index, lane); ns_index = pos; }
+                        }
+                    }
+                    genofs += m;
+                }
+            }
+        }
+        const u32 sz_ns = x_ns.finish(pw, lane), sz_nn = x_nn.finish(pw, lane);
+        if (lane == 0) {
+            d->n_byte = n_byte;
+            d->size[SFQ_S_GEN_NS] = sz_ns;
+            d->size[SFQ_S_GEN_NN] = sz_nn;
+            if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+            if (bad) atomicMax(&d->status, (u32)(-bad));
+        }
+    }
+}
+void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
+}
+
+
 // general path: any header length (tokenising and field state in per-lane scratch)
 __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const u32 t, const u32 b, BlockDesc* d, const u32 lane) {
     WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
