@@ -393,16 +393,19 @@ def rec_frozen_rows(f):
     return rows
 
 
-def rec_encode_blocks_frozen(buf: bytes, off, length, block_reads, frozen_rows):
+def rec_encode_chains_frozen(buf: bytes, off, length, block_reads, chain_reads, frozen_rows):
+    """-> (header chain streams back to back, per-chain sizes, per-chain header bytes)."""
     L = lib()
     off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
     frozen_rows = np.ascontiguousarray(frozen_rows, np.uint32)
-    nb = (len(off) + block_reads - 1) // block_reads
-    sizes = np.zeros(nb, np.uint32)
+    nc = _nchains(len(off), block_reads, chain_reads)
+    sizes = np.zeros(nc, np.uint32); hb = np.zeros(nc, np.uint32)
     out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
-    L.sfqo_rec_encode_blocks_frozen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
-                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p]
-    if L.sfqo_rec_encode_blocks_frozen(buf, po, pl, len(off), block_reads, frozen_rows.ctypes.data_as(C.c_void_p), C.byref(out), C.byref(n),
-                                       sizes.ctypes.data_as(C.c_void_p)) != 0:
+    L.sfqo_rec_encode_chains_frozen.restype = C.c_longlong
+    L.sfqo_rec_encode_chains_frozen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
+    got = L.sfqo_rec_encode_chains_frozen(buf, po, pl, len(off), block_reads, chain_reads, frozen_rows.ctypes.data_as(C.c_void_p),
+                                          C.byref(out), C.byref(n), sizes.ctypes.data_as(C.c_void_p), hb.ctypes.data_as(C.c_void_p))
+    if got != nc:
         raise _err()
-    return _take(out, n), sizes
+    return _take(out, n), sizes, hb

@@ -890,8 +890,13 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
     map_space(r, buf, imap);
     if (g_failed) return;
     space_map *mi = &r->smap[imap], *mp = &r->smap[pmap];
-    if (mi->len != mp->len || memcmp(mi->str, mp->str, (size_t)mi->len)) {
-        if (!r->no_x) {
+    const int shape = mi->len != mp->len || memcmp(mi->str, mp->str, (size_t)mi->len);
+    if (r->hook) r->hook(r->hook_arg, 65 * 16, (u8)(shape ? 1 : 0));          /* frozen mode: every record starts with a flag symbol */
+    if (shape) {
+        if (r->hook) {                                                        /* ... and a header whose shape changed is coded in the chain itself */
+            rec_num(r, 65, (u64)(end - buf));
+            for (const u8* q = buf; q < end; q++) r->hook(r->hook_arg, 65 * 16 + 1, *q);
+        } else {
             xs_put(r->x_file, record_count - r->index);
             r->index = record_count;
             xs_put_str(r->x_file, buf, (size_t)(end - buf));
@@ -1792,30 +1797,39 @@ static void hfz_hook(void* arg, int row, u8 sym) {
     const u32 e = h->rows[(size_t)row * 256 + sym];
     ch_encode(h->c, e & 0xffff, e >> 16, 65536);
 }
-/* "rec" streams of consecutive blocks through frozen rows; the rec.x exceptions are NOT produced here (they stay the
-   reference's adaptive XFile stream per block: sfqo_rec_encode gives them) */
-int sfqo_rec_encode_blocks_frozen(const u8* base, const u64* off, const u32* len, size_t nrec, size_t block_reads,
-                                  const u32* frozen_rows, u8** out, size_t* out_len, u32* sizes) {
+/* "rec" streams through frozen rows: a block's headers are cut into chains of chain_reads records; every chain starts
+   from the block's first header (the base, never coded) with cold field types.  out = the chains' streams back to back,
+   sizes[c] / hdr_bytes[c] per chain.  Returns the number of chains. */
+long long sfqo_rec_encode_chains_frozen(const u8* base, const u64* off, const u32* len, size_t nrec, size_t block_reads, size_t chain_reads,
+                                        const u32* frozen_rows, u8** out, size_t* out_len, u32* sizes, u32* hdr_bytes) {
     g_failed = 0; g_err[0] = 0;
     obuf o = { 0, 0, 0 };
-    size_t nb = 0;
-    for (size_t b0 = 0; b0 < nrec; b0 += block_reads, nb++) {
+    size_t nc = 0;
+    for (size_t b0 = 0; b0 < nrec; b0 += block_reads) {
         const size_t b1 = b0 + block_reads < nrec ? b0 + block_reads : nrec;
-        chenc c; ch_init(&c);
-        hfz h = { &c, frozen_rows };
-        recm r; rec_alloc(&r);
-        r.hook = hfz_hook; r.hook_arg = &h; r.no_x = 1;
-        const u8* prev = NULL;
-        for (size_t i = b0; i < b1 && !g_failed; i++) {
-            rec_save(&r, (u64)(i - b0) + 1, base + off[i], base + off[i] + len[i], prev, NULL, NULL);
-            prev = base + off[i];
+        for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
+            const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+            chenc c; ch_init(&c);
+            hfz h = { &c, frozen_rows };
+            recm r; rec_alloc(&r);
+            r.hook = hfz_hook; r.hook_arg = &h;
+            rec_save(&r, 1, base + off[b0], base + off[b0] + len[b0], NULL, NULL, NULL);      /* the base */
+            const u8* prev = base + off[b0];
+            u32 hb = 0;
+            for (size_t i = r0; i < r1 && !g_failed; i++) {
+                hb += len[i];
+                if (i == b0) continue;
+                rec_save(&r, (u64)(i - b0) + 1, base + off[i], base + off[i] + len[i], prev, NULL, NULL);
+                prev = base + off[i];
+            }
+            free(r.ranger);
+            const size_t n = ch_finish(&c);
+            ob_write(&o, c.out, n);
+            if (sizes) sizes[nc] = (u32)n;
+            if (hdr_bytes) hdr_bytes[nc] = hb;
+            free(c.out);
         }
-        free(r.ranger);
-        const size_t n = ch_finish(&c);
-        ob_write(&o, c.out, n);
-        if (sizes) sizes[nb] = (u32)n;
-        free(c.out);
     }
     *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
-    return g_failed ? -1 : 0;
+    return g_failed ? -1 : (long long)nc;
 }

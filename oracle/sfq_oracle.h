@@ -110,8 +110,8 @@ long long sfqo_gen_encode_chains(const uint8_t* base, const uint64_t* goff, cons
 int sfqo_rec_count(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t stride, size_t run, size_t nruns, uint32_t* counts);
 int sfqo_rec_prior_freqs(const uint32_t* counts, uint32_t* f);
 int sfqo_rec_frozen_rows(const uint32_t* f, uint32_t* rows);
-int sfqo_rec_encode_blocks_frozen(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t block_reads,
-                                  const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes);
+long long sfqo_rec_encode_chains_frozen(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t block_reads, size_t chain_reads,
+                                        const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* hdr_bytes);
 
 void sfqo_free(void* p);
 

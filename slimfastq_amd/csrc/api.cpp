@@ -542,7 +542,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     // frozen tables: chain geometry, dense quality rows
     ChainArgs ca;
     memset(&ca, 0, sizeof ca);
-    u32 nchains = 0;
+    u32 nchains = 0, nsub = 0;
     if (frozen) {
         const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
         ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
@@ -552,7 +552,16 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
         nchains = ca.geo.nchains = (u32)nc;
         ca.nbytes = nbytes; ca.block_reads = block_reads;
-        if ((rc = reserve(ctx, ctx->csz, (size_t)nchains * 2 * 4))) return rc;
+        // header chains: longer than the quality / base chains (each starts from the block's first header with cold field
+        // types, which costs it a few bytes)
+        {
+            const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(256u, ca.geo.chain_reads), block_reads), nrec);
+            ca.rgeo.chain_reads = rcr;
+            ca.rgeo.cpb = (block_reads + rcr - 1) / rcr;
+            nsub = ca.rgeo.nchains = (u32)((u64)(nblocks - 1) * ca.rgeo.cpb + (last_nrec + rcr - 1) / rcr);
+        }
+        if ((rc = reserve(ctx, ctx->csz, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4))) return rc;
+        HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
         if (models & SFQ_M_QLT) {
             if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
             if ((rc = build_qesc(ctx, st))) return rc;
@@ -633,9 +642,10 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         if ((rc = upload_rec_rows(ctx, hf, mst[m]))) return rc;
                         ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
                         ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
-                        if ((rc = reserve(ctx, ctx->rflags, (size_t)nblocks * 4))) return rc;
-                        HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nblocks * 4, mst[m]));
-                        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ca.m.batch0 = b0; ca.m.nbatch = std::min(slots, nblocks - b0); launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[m]); }
+                        if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
+                        HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[m]));
+                        ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
+                        launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[m]);
                     } else launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]);
                     break;
                 }
@@ -666,8 +676,12 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     u32 chain_streams = 0;                             // streams packed chain by chain
     if (frozen) {
         ca.m = a;
-        if (models & SFQ_M_QLT) { launch_chain_block_sizes(ca, SFQ_S_QLT, (const u32*)ctx->csz.p, st); chain_streams |= 1u << SFQ_S_QLT; }
-        if (models & SFQ_M_GEN) { launch_chain_block_sizes(ca, SFQ_S_GEN, (const u32*)ctx->csz.p + nchains, st); chain_streams |= 1u << SFQ_S_GEN; }
+        if (models & SFQ_M_QLT) { launch_chain_block_sizes(ca, ca.geo, SFQ_S_QLT, (const u32*)ctx->csz.p, nullptr, st); chain_streams |= 1u << SFQ_S_QLT; }
+        if (models & SFQ_M_GEN) { launch_chain_block_sizes(ca, ca.geo, SFQ_S_GEN, (const u32*)ctx->csz.p + nchains, nullptr, st); chain_streams |= 1u << SFQ_S_GEN; }
+        if (models & SFQ_M_REC) {
+            const u32* rs = (const u32*)ctx->csz.p + 2 * (size_t)nchains;
+            launch_chain_block_sizes(ca, ca.rgeo, SFQ_S_REC, rs, rs + nsub, st); chain_streams |= 1u << SFQ_S_REC;
+        }
     }
     launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, st);
     // first headers -> blob
@@ -700,13 +714,13 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     std::vector<u32> h_csz;
     if (frozen) {
         if (chain_streams & (1u << SFQ_S_QLT))
-            launch_compact_chains(ca, SFQ_S_QLT, 1, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+            launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 1, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         if (chain_streams & (1u << SFQ_S_GEN))
-            launch_compact_chains(ca, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        h_csz.assign((size_t)nchains * 2, 0);
-        if (!(chain_streams & (1u << SFQ_S_QLT))) HIPC(hipMemsetAsync(ctx->csz.p, 0, (size_t)nchains * 4, st));
-        if (!(chain_streams & (1u << SFQ_S_GEN))) HIPC(hipMemsetAsync((u32*)ctx->csz.p + nchains, 0, (size_t)nchains * 4, st));
-        HIPC(hipMemcpyAsync(h_csz.data(), ctx->csz.p, (size_t)nchains * 2 * 4, hipMemcpyDeviceToHost, st));
+            launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        if (chain_streams & (1u << SFQ_S_REC))
+            launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        h_csz.assign((size_t)nchains * 2 + (size_t)nsub * 2, 0);
+        HIPC(hipMemcpyAsync(h_csz.data(), ctx->csz.p, h_csz.size() * 4, hipMemcpyDeviceToHost, st));
     }
     HIPC(hipEventRecord(ctx->ev[11], st));
     ctx->first_hdrs.resize((size_t)hboff[nblocks]);
@@ -719,8 +733,13 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
         std::vector<u8>& o = ctx->chain_blob;
-        put_v(o, ca.geo.chain_reads); put_v(o, gen_on); put_v(o, nchains);
+        const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
+        put_v(o, ca.geo.chain_reads); put_v(o, gen_on | (rec_chains ? 2u : 0u)); put_v(o, nchains);
         for (u32 c = 0; c < 2 * nchains; c++) put_v(o, h_csz[c]);
+        if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
+            put_v(o, ca.rgeo.chain_reads); put_v(o, nsub);
+            for (u32 c = 0; c < 2 * nsub; c++) put_v(o, h_csz[(size_t)2 * nchains + c]);
+        }
     }
     res->n_chains = nchains;
     ctx->index.resize(nblocks);
@@ -856,14 +875,15 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     }
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
-    u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0;
+    u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
+    std::vector<u32> h_rsz, h_rhb;
     if (frozen) {
         const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
         size_t cp = 0; u64 v = 0;
         if (!get_v(cb, cn, cp, v) || v == 0 || v > 0xFFFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         chain_reads = (u32)v;
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
-        gen_on = (u32)v & 1u;
+        gen_on = (u32)v & 1u; rec_chains = ((u32)v >> 1) & 1u;
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
         cpb = (block_reads + chain_reads - 1) / chain_reads;
@@ -873,6 +893,23 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         nchains = (u32)want;
         std::vector<u32> h_csz((size_t)nchains * 2);
         std::vector<u64> h_coff((size_t)nchains * 2);
+        auto parse_rec_chains = [&]() -> bool {
+            if (!get_v(cb, cn, cp, v) || v == 0 || v > block_reads) return false;
+            rchain_reads = (u32)v;
+            rcpb = (block_reads + rchain_reads - 1) / rchain_reads;
+            const u64 wantr = (u64)(nblocks - 1) * rcpb + (h_blocks[nblocks - 1].n_records + rchain_reads - 1) / rchain_reads;
+            if (!get_v(cb, cn, cp, v) || v != wantr || wantr > 0x7FFFFFFFull) return false;
+            nsub = (u32)wantr;
+            h_rsz.resize(nsub); h_rhb.resize(nsub);
+            for (u32 c = 0; c < nsub; c++) { if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return false; h_rsz[c] = (u32)v; }
+            for (u32 c = 0; c < nsub; c++) { if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return false; h_rhb[c] = (u32)v; }
+            for (u32 b = 0; b < nblocks; b++) {
+                u64 sum = 0;
+                for (u32 j = 0; j < rcpb && (u64)b * rcpb + j < nsub; j++) sum += h_rsz[(size_t)b * rcpb + j];
+                if (sum != h_blocks[b].size[SFQ_S_REC]) return false;
+            }
+            return true;
+        };
         for (int k = 0; k < 2; k++) {
             const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
             u64 at = stream_offset[sid];
@@ -885,6 +922,11 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
                 }
                 if (sum != h_blocks[b].size[sid]) return fail(ctx, SFQ_E_CORRUPT, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid));
             }
+        }
+        if (rec_chains) {
+            if (!parse_rec_chains()) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
+            u64 at = stream_offset[SFQ_S_REC];
+            for (u32 c = 0; c < nsub; c++) { h_csz.push_back(h_rsz[c]); h_coff.push_back(at); at += h_rsz[c]; }
         }
         if ((rc = reserve(ctx, ctx->csz, h_csz.size() * 4))) return rc;
         if ((rc = reserve(ctx, ctx->coff, h_coff.size() * 8))) return rc;
@@ -1011,18 +1053,29 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     HIPC(hipStreamWaitEvent(st, ctx->ev[4], 0));
 
     // 3. headers; the staging size comes from the index when known, else grows on overflow
-    const bool frozen_rec = frozen && !ctx->rec_prior_blob.empty();
+    const bool frozen_rec = frozen && rec_chains != 0;
+    if (frozen_rec && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "header chains need the header prior (rec.pri)");
     if (frozen_rec) {
         std::vector<u32> hf;
         if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
         if ((rc = upload_rec_rows(ctx, hf, ctx->st_aux[0]))) return rc;
     }
-    std::vector<u64> hso((size_t)nblocks + 1);
-    std::vector<u32> hsc(nblocks);
-    if ((rc = reserve(ctx, ctx->hso, ((size_t)nblocks + 1) * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->hsc, (size_t)nblocks * 4))) return rc;
+    const u32 nstage = frozen_rec ? nsub : nblocks;            // staging slices: one per header chain / per block
+    std::vector<u64> hso((size_t)nstage + 1);
+    std::vector<u32> hsc(nstage);
+    if ((rc = reserve(ctx, ctx->hso, ((size_t)nstage + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->hsc, (size_t)nstage * 4))) return rc;
     for (int attempt = 0; ; attempt++) {
         u64 o = 0;
+        if (frozen_rec) {
+            for (u32 c = 0; c < nsub; c++) {
+                const u32 b = c / rcpb, j = c - b * rcpb;
+                const u32 nr = std::min<u32>(rchain_reads, h_blocks[b].n_records - std::min(h_blocks[b].n_records, j * rchain_reads));
+                u64 cap = (u64)h_rhb[c] + nr + SFQ_MAX_ID_LLEN + 64;
+                if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+                hso[c] = o; hsc[c] = (u32)cap; o += (cap + 15) & ~15ull;
+            }
+        } else
         for (u32 b = 0; b < nblocks; b++) {
             const sfq_block_info& bi = h_blocks[b];
             u64 cap = bi.hdr_bytes ? (u64)bi.hdr_bytes + bi.n_records + SFQ_MAX_ID_LLEN + 64
@@ -1030,18 +1083,20 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
             if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
             hso[b] = o; hsc[b] = (u32)cap; o += (cap + 15) & ~15ull;
         }
-        hso[nblocks] = o;
+        hso[nstage] = o;
         if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
-        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nblocks + 1) * 8, hipMemcpyHostToDevice, st_rec));
-        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nstage + 1) * 8, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nstage * 4, hipMemcpyHostToDevice, st_rec));
         HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
         HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
         if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; ctx->epoch_base += nblocks; da.m.epoch_base = ctx->epoch_base; }
         if (frozen_rec) {
             ChainArgs cr; memset(&cr, 0, sizeof cr);
-            cr.rrows = (const u32*)ctx->rrows.p; cr.rcoarse = (const u32*)ctx->rcoarse.p;
-            for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_c(cr, da, 16, st_rec); }
+            cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rcoarse = (const u32*)ctx->rcoarse.p;
+            cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
+            cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
+            launch_rec_decode_c(cr, da, 64, st_rec);
         } else
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
         HIPC(hipStreamSynchronize(st_rec));

@@ -265,27 +265,29 @@ void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t s
 // packing: a block's chain streams back to back
 // =========================================================================================================
 // blocks[b].size[stream] = sum of its chains' sizes
-__global__ __launch_bounds__(256) void k_chain_block_sizes(ChainArgs a, int stream, const u32* csz) {
+__global__ __launch_bounds__(256) void k_chain_block_sizes(ChainArgs a, ChainGeoArgs geo, int stream, const u32* csz, const u32* rhb) {
     const u32 b = blockIdx.x * 256 + threadIdx.x;
     if (b >= a.m.nblocks) return;
-    u32 sum = 0;
-    const u32 c0 = b * a.geo.cpb;
-    for (u32 j = 0; j < a.geo.cpb && c0 + j < a.geo.nchains; j++) sum += csz[c0 + j];
+    u32 sum = 0, hb = 0;
+    const u32 c0 = b * geo.cpb;
+    for (u32 j = 0; j < geo.cpb && c0 + j < geo.nchains; j++) { sum += csz[c0 + j]; if (rhb) hb += rhb[c0 + j]; }
     a.m.blocks[b].size[stream] = sum;
+    if (rhb) a.m.blocks[b].hdr_bytes = hb;
 }
-void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st) {
-    hipLaunchKernelGGL(k_chain_block_sizes, dim3((a.m.nblocks + 255) / 256), dim3(256), 0, st, a, stream, csz);
+void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb, hipStream_t st) {
+    hipLaunchKernelGGL(k_chain_block_sizes, dim3((a.m.nblocks + 255) / 256), dim3(256), 0, st, a, geo, stream, csz, rhb);
 }
 // one wave per chain: region -> its place in the packed stream
-__global__ __launch_bounds__(256) void k_compact_chains(ChainArgs a, int stream, u32 num, u32 den, const u32* csz,
+__global__ __launch_bounds__(256) void k_compact_chains(ChainArgs a, ChainGeoArgs geo, int stream, u32 num, u32 den, const u32* csz,
                                                         const u64* blk_stream_off, const u64* stream_base, u8* out) {
     const u32 c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= a.geo.nchains) return;
+    if (c >= geo.nchains) return;
+    a.geo = geo;                                           // chain_pos / chain_region read the geometry from `a`
     const ChainPos cp = chain_pos(a, c);
     const u32 n = csz[c];
     if (!n) return;
     u32 before = 0;
-    for (u32 cc = cp.b * a.geo.cpb + lane; cc < c; cc += 64) before += csz[cc];
+    for (u32 cc = cp.b * geo.cpb + lane; cc < c; cc += 64) before += csz[cc];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) before += (u32)__shfl_xor((int)before, d, 64);
     u32 cap;
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(256) void k_compact_chains(ChainArgs a, int stream,
     u8* dst = out + stream_base[stream] + blk_stream_off[(u64)cp.b * SFQ_NSTREAMS + stream] + before;
     for (u32 i = lane; i < n; i += 64) dst[i] = src[i];
 }
-void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
+void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact_chains, dim3((a.geo.nchains + 3) / 4), dim3(256), 0, st, a, stream, num, den, csz, blk_stream_off, stream_base, out);
+    hipLaunchKernelGGL(k_compact_chains, dim3((geo.nchains + 3) / 4), dim3(256), 0, st, a, geo, stream, num, den, csz, blk_stream_off, stream_base, out);
 }
 
 // =========================================================================================================
@@ -506,17 +508,39 @@ void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b
 //
 // RecSave::save / RecLoad::load (dev_rec_lane.h: the reference's field-by-field model, lane-serial) with the symbols
 // of the "rec" stream coded through FROZEN PowerRanger rows: a counting pass runs the same model over short runs of
-// records spread over the call, the counts travel once as the header prior ("rec.pri"), and every block's header chain
+// records spread over the call, the counts travel once as the header prior ("rec.pri"), and every header chain
 // -- one per LANE -- codes with the rows built from it.  A row lists all 256 byte values with the ranger's weights
 // (freq + 1 over total + 256, power_ranger.hpp:100; freq = 14 per hit) rescaled to a total of exactly 2^16, like the
-// quality rows.  "rec.x" (a header whose shape changed: the whole line) stays on the block's adaptive XFile rows.
+// quality rows.  A block's headers are cut into chains of rgeo.chain_reads records; every chain starts from the
+// block's first header (the base, stored once as "rec.first") with cold field types, so the chains of a block are
+// independent.  A header whose shape changed is coded inside its chain (flag symbol + the whole line): no "rec.x".
 // =========================================================================================================
 #include "dev_rec_lane.h"
+
+struct RecChainPos { u32 b; u64 r0; u32 nrec; };
+__device__ __forceinline__ RecChainPos rec_chain_pos(const ChainArgs& a, u32 c) {
+    RecChainPos p;
+    p.b = c / a.rgeo.cpb;
+    const u32 j = c - p.b * a.rgeo.cpb;
+    const BlockDesc* d = &a.m.blocks[p.b];
+    const u32 k0 = j * a.rgeo.chain_reads;
+    p.nrec = k0 < d->nrec ? (d->nrec - k0 < a.rgeo.chain_reads ? d->nrec - k0 : a.rgeo.chain_reads) : 0u;
+    p.r0 = d->rec0 + k0;
+    return p;
+}
+// a header chain's output region inside its block's "rec" region (1.5 bytes per byte of text, frame.hip k_block_prepare)
+__device__ __forceinline__ u8* rec_chain_region(const ChainArgs& a, const RecChainPos& p, u32& cap) {
+    const BlockDesc* d = &a.m.blocks[p.b];
+    const u64 t0 = a.m.line_off[4 * d->rec0], tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
+    const u64 lo = ((tc - t0) * 3 / 2 + 3) & ~3ull, hi = ((te - t0) * 3 / 2) & ~3ull;
+    cap = hi > lo ? (u32)(hi - lo) : 0u;
+    return a.m.arena + d->out_off[SFQ_S_REC] + lo;
+}
 
 #define REC_HBUF 128u                    // bytes of LDS per staged header (two per lane: the current and the previous one)
 #define REC_LDS_ROWS 44u                 // frozen rows staged in LDS per wave (1 KiB each)
 struct RecFrozenEnc {
-    static constexpr bool counting = false;
+    static constexpr bool inband = true;
     const u32* rows; LaneEnc rc;
     u8* lbuf;                            // this lane's two header buffers in LDS
     const u16* lmap; const u32* lrows;   // LDS: row -> staged slot (0xFFFF = not staged), the staged rows
@@ -539,14 +563,14 @@ struct RecFrozenEnc {
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
 struct RecCountEnc {
-    static constexpr bool counting = true;
+    static constexpr bool inband = true;
     u32* cnt; bool on;
-    __device__ __forceinline__ void record(u32 k) { on = k >= 2; }       // record 0 is the run's "first header", record 1 warms the field types up
+    __device__ __forceinline__ void record(u32 k) { on = k >= 1; }       // the run's first coded record only warms the field types up
     __device__ __forceinline__ const u8* stage(const u8* g, u32, u32) { return g; }
     __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
-// counting pass: lane i walks records [i * stride, i * stride + run)
+// counting pass: lane i walks records [i * stride, i * stride + run): the first is the run's base
 __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt) {
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nruns) return;
@@ -557,7 +581,7 @@ __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 str
     XfEnc x_rec; x_rec.init(nullptr, 0, XF_REC_X);
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     u32 hb; int bad;
-    rec_encode_lane(a, r0, n, cd, x_rec, none, hb, bad);
+    rec_encode_lane(a, r0, r0, n, cd, x_rec, none, hb, bad);
 }
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_count, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt);
@@ -606,40 +630,40 @@ void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hi
     hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, coarse);
 }
 
-// header encode, general path: one block per lane (blocks [batch0, batch0 + nbatch), table slot = lane index within the
-// batch); only the blocks the fast kernel below has handed over (flags[b] != 0)
+// header encode, general path: one chain per lane; only the chains the fast kernel below has handed over (flags[c] != 0)
 __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* flags) {
     __shared__ u32 lrows[REC_LDS_ROWS * 256];
     __shared__ u16 lmap[PR_REC_ROWS];
     __shared__ u32 ltext[64 * 2 * REC_HBUF / 4];
-    const u32 t = blockIdx.x * 64 + threadIdx.x;
-    const u32 b = a.m.batch0 + t;
-    const bool mine = t < a.m.nbatch && flags[b] != 0;
+    const u32 c = blockIdx.x * 64 + threadIdx.x;
+    const bool mine = c < a.rgeo.nchains && flags[c] != 0;
     if (!__any(mine)) return;
     for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) lmap[i] = a.rmap[i];
     for (u32 i = threadIdx.x; i < a.r_hot * 256; i += 64) lrows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
     __syncthreads();
     if (!mine) return;
-    BlockDesc* d = &a.m.blocks[b];
-    PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
-    RecFrozenEnc cd; cd.rows = a.rrows; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
+    const RecChainPos cp = rec_chain_pos(a, c);
+    BlockDesc* d = &a.m.blocks[cp.b];
+    u32 cap = 0;
+    u8* outp = rec_chain_region(a, cp, cap);
+    RecFrozenEnc cd; cd.rows = a.rrows; cd.rc.init(outp, cap);
     cd.lbuf = reinterpret_cast<u8*>(ltext) + threadIdx.x * 2 * REC_HBUF; cd.lmap = lmap; cd.lrows = lrows;
-    XfEnc x_rec; x_rec.init(a.m.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    XfEnc x_rec; x_rec.init(nullptr, 0, XF_REC_X);
+    PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     u32 hdr_bytes = 0; int bad = 0;
-    rec_encode_lane(a.m, d->rec0, d->nrec, cd, x_rec, pw, hdr_bytes, bad);
-    d->hdr_bytes = hdr_bytes;
-    d->size[SFQ_S_REC] = cd.rc.finish();
-    d->size[SFQ_S_REC_X] = x_rec.finish(pw);
-    if ((cd.rc.err & 2) || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-    if ((cd.rc.err & 1) | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    rec_encode_lane(a.m, d->rec0, cp.r0, cp.nrec, cd, x_rec, none, hdr_bytes, bad);
+    a.rhb[c] = hdr_bytes;
+    a.csz[c] = cd.rc.finish();
+    if (cd.rc.err & 2) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+    if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
     if (bad) atomicMax(&d->status, (u32)(-bad));
 }
 
-// header encode, fast path: the same model (recs.cpp:277-372) for blocks whose headers are at most RF_MAXLEN bytes and
+// header encode, fast path: the same model (recs.cpp:277-372) for chains whose headers are at most RF_MAXLEN bytes and
 // RF_NF fields, with everything a lane touches per record in LDS, laid out [..][lane]: the header text (current and
 // previous), the field tables of both, the field types / values, and the hottest frozen rows.  The general path above
 // keeps those in per-lane scratch and reads the text through generic pointers: ~300 memory instructions per record,
-// which is what its time is made of.  A block with a longer header or more fields is handed over (flags[b] = 1).
+// which is what its time is made of.  A chain with a longer header or more fields is handed over (flags[c] = 1).
 #define RF_MAXLEN 127u
 #define RF_NF 24u
 struct RecFastLds {
@@ -693,71 +717,81 @@ struct RecFastEnc {
     }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
+// a header line into LDS, tokenised on the way (map_space, recs.cpp:141-157): a separator closes a field; the byte behind
+// the text is the line's '\n', the last separator; a NUL ends the scan.  Eight dwords are fetched at a time, so a header
+// costs a memory round trip or two, not one per dword.  Returns the number of fields (more than RF_NF: not all recorded).
+__device__ __forceinline__ u32 rf_stage(RecFastLds& L, u32 buf, u32 lane, const u8* text, u32 n) {
+    const u32* g = reinterpret_cast<const u32*>(text);             // (global loads need no alignment on gfx9; the text goes on behind the line)
+    const u32 nw = (n + 4) / 4;
+    u32 nf = 0, start = 0; bool stop = false;
+    for (u32 i0 = 0; i0 < nw; i0 += 8) {
+        u32 wv[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) wv[q] = i0 + q < nw ? g[i0 + q] : 0u;
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) {
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) {
+                const u32 pos = 4 * (i0 + q) + j, c = (wv[q] >> (8 * j)) & 0xffu;
+                if (pos <= n) {
+                    L.text[buf][pos][lane] = (u8)c;
+                    if (!stop && !isword(c)) {
+                        if (nf < RF_NF) { L.off[buf][nf][lane] = (u8)start; L.wln[buf][nf][lane] = (u8)(pos - start); L.sep[buf][nf][lane] = (u8)c; }
+                        nf++; start = pos + 1;
+                        if (c == 0) stop = true;
+                    }
+                }
+            }
+        }
+    }
+    return nf;
+}
 __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
     __shared__ RecFastLds L;
     const u32 lane = threadIdx.x;
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) L.map[i] = a.rmap[i];
     for (u32 i = lane; i < a.r_hot * 256; i += 64) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
     __syncthreads();
-    const u32 t = blockIdx.x * 64 + lane;
-    if (t >= a.m.nbatch) return;
-    const u32 b = a.m.batch0 + t;
-    BlockDesc* d = &a.m.blocks[b];
-    PwTab pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
-    RecFastEnc cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(a.m.arena + d->out_off[SFQ_S_REC], d->out_cap[SFQ_S_REC]);
-    XfEnc x_rec; x_rec.init(a.m.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
+    const u32 c = blockIdx.x * 64 + lane;
+    if (c >= a.rgeo.nchains) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    BlockDesc* d = &a.m.blocks[cp.b];
+    u32 cap = 0;
+    u8* outp = rec_chain_region(a, cp, cap);
+    RecFastEnc cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(outp, cap);
     u32 cur = 0, nf_prev = 0, hdr_bytes = 0;
-    u64 last_index = 0;
     bool slow = false;
-    const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-    u64 nh0 = a.m.line_off[4 * rec0] + 1, nh1 = a.m.line_off[4 * rec0 + 1] - 1;     // the next record's header line, fetched a record ahead
-    for (u32 k = 0; k < nrec; k++) {
-        const u64 record_count = (u64)k + 1;
-        const u64 h0 = nh0, h1 = nh1;
-        if (k + 1 < nrec) { const u64 r1 = rec0 + k + 1; nh0 = a.m.line_off[4 * r1] + 1; nh1 = a.m.line_off[4 * r1 + 1] - 1; }
+    const u64 base_rec = d->rec0;
+    {                                                                         // recs.cpp:279-287: the base, the block's first header
+        const u64 h0 = a.m.line_off[4 * base_rec] + 1, h1 = a.m.line_off[4 * base_rec + 1] - 1;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
-        if (n > RF_MAXLEN) { slow = true; break; }
-        hdr_bytes += n;
-        // the text into LDS, tokenised on the way (map_space, recs.cpp:141-157): a separator closes a field; the byte behind
-        // the text is the line's '\n', the last separator; a NUL ends the scan.  Eight dwords are fetched at a time, so a
-        // header costs a memory round trip or two, not one per dword.
-        const u32* g = reinterpret_cast<const u32*>(a.m.fq + h0);      // (global loads need no alignment on gfx9; the text goes on behind the line)
-        const u32 nw = (n + 4) / 4;
-        u32 nf = 0, start = 0; bool stop = false;
-        for (u32 i0 = 0; i0 < nw; i0 += 8) {
-            u32 wv[8];
-#pragma unroll
-            for (u32 q = 0; q < 8; q++) wv[q] = i0 + q < nw ? g[i0 + q] : 0u;
-#pragma unroll
-            for (u32 q = 0; q < 8; q++) {
-#pragma unroll
-                for (u32 j = 0; j < 4; j++) {
-                    const u32 pos = 4 * (i0 + q) + j, c = (wv[q] >> (8 * j)) & 0xffu;
-                    if (pos <= n) {
-                        L.text[cur][pos][lane] = (u8)c;
-                        if (!stop && !isword(c)) {
-                            if (nf < RF_NF) { L.off[cur][nf][lane] = (u8)start; L.wln[cur][nf][lane] = (u8)(pos - start); L.sep[cur][nf][lane] = (u8)c; }
-                            nf++; start = pos + 1;
-                            if (c == 0) stop = true;
-                        }
-                    }
-                }
-            }
+        if (n > RF_MAXLEN) slow = true;
+        else {
+            nf_prev = rf_stage(L, cur, lane, a.m.fq + h0, n);
+            if (nf_prev > RF_NF) slow = true;
+            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+            cur ^= 1u;
         }
+    }
+    u64 nh0 = 0, nh1 = 0;                                                     // the next record's header line, fetched a record ahead
+    if (cp.nrec) { nh0 = a.m.line_off[4 * cp.r0] + 1; nh1 = a.m.line_off[4 * cp.r0 + 1] - 1; }
+    for (u32 k = 0; k < cp.nrec && !slow; k++) {
+        const u64 r = cp.r0 + k;
+        const u64 h0 = nh0, h1 = nh1;
+        if (k + 1 < cp.nrec) { nh0 = a.m.line_off[4 * (r + 1)] + 1; nh1 = a.m.line_off[4 * (r + 1) + 1] - 1; }
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        hdr_bytes += n;
+        if (r == base_rec) continue;                                          // the base itself
+        if (n > RF_MAXLEN) { slow = true; break; }
+        const u32 nf = rf_stage(L, cur, lane, a.m.fq + h0, n);
         if (nf > RF_NF) { slow = true; break; }
         const u32 prv = cur ^ 1u;
-        if (k == 0) {                                                         // recs.cpp:279-287: the first line goes to "rec.first"
-            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
-            nf_prev = nf; cur = prv;
-            continue;
-        }
         bool shape = nf != nf_prev;
         for (u32 f = 0; !shape && f < nf; f++) shape = L.sep[cur][f][lane] != L.sep[prv][f][lane];
-        if (shape) {                                                          // recs.cpp:292-305
-            x_rec.put(pw, record_count - last_index);
-            last_index = record_count;
-            x_rec.put(pw, n);                                                 // put_str: the length, then the characters
-            for (u32 j = 0; j < n; j++) x_rec.put_chr(pw, L.text[cur][j][lane]);
+        cd.put(REC_FLAG_ROW, shape ? 1u : 0u);
+        if (shape) {                                                          // recs.cpp:292-305, in the chain itself
+            cd.put_u(REC_FLAG_ROW + 2, n);
+            for (u32 j = 0; j < n; j++) cd.put(REC_FLAG_ROW + 1, L.text[cur][j][lane]);
             for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
             nf_prev = nf; cur = prv;
             continue;
@@ -797,21 +831,21 @@ __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
         }
         nf_prev = nf; cur = prv;
     }
-    if (slow) { flags[b] = 1; return; }                                       // the general kernel starts this block over
-    d->hdr_bytes = hdr_bytes;
-    d->size[SFQ_S_REC] = cd.rc.finish();
-    d->size[SFQ_S_REC_X] = x_rec.finish(pw);
-    if ((cd.rc.err & 2) || x_rec.sink.pos > x_rec.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-    if ((cd.rc.err & 1) | x_rec.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    if (slow) { flags[c] = 1; return; }                                       // the general kernel starts this chain over
+    a.rhb[c] = hdr_bytes;
+    a.csz[c] = cd.rc.finish();
+    if (cd.rc.err & 2) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+    if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
-// flags: one dword per block of the call, zeroed by the caller before the first batch
+// flags: one dword per header chain, zeroed by the caller
 void launch_rec_encode_c(const ChainArgs& a, u32* flags, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_encode_f, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a, flags);
-    hipLaunchKernelGGL(k_rec_encode_c, dim3((a.m.nbatch + 63) / 64), dim3(64), 0, st, a, (const u32*)flags);
+    hipLaunchKernelGGL(k_rec_encode_f, dim3((a.rgeo.nchains + 63) / 64), dim3(64), 0, st, a, flags);
+    hipLaunchKernelGGL(k_rec_encode_c, dim3((a.rgeo.nchains + 63) / 64), dim3(64), 0, st, a, (const u32*)flags);
 }
 
-// header decode
+// header decode: one chain per lane.  DecodeArgs::hdr_stage_off / hdr_stage_cap are per CHAIN here.
 struct RecFrozenDec {
+    static constexpr bool inband = true;
     const u32* rows; const u32* coarse; LaneDec rc;
     __device__ __forceinline__ u32 get(u32 row) {
         const u32 prob = rc.get_freq16();
@@ -832,17 +866,16 @@ struct RecFrozenDec {
     __device__ __forceinline__ u32 err() const { return rc.err; }
 };
 __global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= da.m.nbatch) return;
-    const u32 b = da.m.batch0 + t;
-    BlockDesc* d = &da.m.blocks[b];
-    PwTab pw; pw.slots = da.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = da.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(da.m.epoch_base + b + 1);
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.rgeo.nchains) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    BlockDesc* d = &da.m.blocks[cp.b];
     RecFrozenDec cd; cd.rows = a.rrows; cd.coarse = a.rcoarse;
-    cd.rc.init(da.streams + da.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_REC], d->size[SFQ_S_REC]);
-    XfDec x_rec;
-    x_rec.init(da.streams + da.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_REC_X], d->size[SFQ_S_REC_X], XF_REC_X);
-    rec_decode_lane(da, d, b, cd, x_rec, pw);
+    cd.rc.init(da.streams + a.coff[c], a.csz[c]);
+    XfDec x_rec; x_rec.init(nullptr, 0, XF_REC_X);
+    PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
+    rec_decode_lane(da, d, cp.r0, cp.nrec, c, cd, x_rec, none);
 }
 void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_decode_c, dim3((da.m.nbatch + lanes - 1) / lanes), dim3(lanes), 0, st, a, da);
+    hipLaunchKernelGGL(k_rec_decode_c, dim3((a.rgeo.nchains + lanes - 1) / lanes), dim3(lanes), 0, st, a, da);
 }

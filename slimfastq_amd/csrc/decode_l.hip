@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_rec_decode_l(DecodeArgs a) {
     cd.pw = sl.pw; cd.src = stream_src(a, d, sl.b, SFQ_S_REC); cd.rc.init(cd.src);
     XfDec x_rec;
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_REC_X); x_rec.init(s.p, s.n, XF_REC_X); }
-    rec_decode_lane(a, d, sl.b, cd, x_rec, sl.pw);
+    rec_decode_lane(a, d, d->rec0, d->nrec, sl.b, cd, x_rec, sl.pw);
 }
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st) {
     const u32 L = decode_lanes();

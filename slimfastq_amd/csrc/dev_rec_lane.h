@@ -6,41 +6,54 @@
 #include "dev_models.h"
 #include "dev_rec.h"
 
-// RecSave::save (recs.cpp:277-372) for the records of one block, by one lane.  C codes the symbols of the "rec"
-// stream: put(row, byte) / put_u(row0, number) on PowerRanger row numbers (dev_common.h: field i uses rows
-// (i + 1) * 16 + {0 type, 1 str, 2.. num}).  The "rec.x" exceptions go through the block's adaptive XFile rows.
+// RecSave::save (recs.cpp:277-372) for records [rec0, rec0 + nrec) of a block whose first record is base_rec, by one
+// lane.  The block's first header is the BASE: never coded (it travels as "rec.first", recs.cpp:68-75), it is what the
+// first coded record is compared with.  The reference's case is rec0 == base_rec (a block = one chain); the frozen-table
+// mode cuts a block's headers into several chains that all start from the block's base (chains.hip).
+// C codes the symbols of the "rec" stream: put(row, byte) / put_u(row0, number) on PowerRanger row numbers
+// (dev_common.h: field i uses rows (i + 1) * 16 + {0 type, 1 str, 2.. num}).  A header whose shape changed goes whole
+// to the block's adaptive "rec.x" XFile -- or, for a coder with C::inband, into the chain itself: every record starts
+// with a flag symbol (row REC_FLAG_ROW: 0 = fields follow, 1 = the length and the characters of the whole line follow).
+#define REC_FLAG_ROW (65 * 16)        /* the rows of field 65: no header has that many fields (map_space stops at 64) */
 template <typename C>
-__device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 rec0, u32 nrec, C& cd, XfEnc& x_rec, const PwTab& xpw, u32& hdr_bytes_out, int& bad_out) {
+__device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec, u64 rec0, u32 nrec, C& cd, XfEnc& x_rec, const PwTab& xpw,
+                                                u32& hdr_bytes_out, int& bad_out) {
     SpaceMap sm[2];
     u8  ctype[2][66];
     u64 cnumb[2][66];
     u32 imap = 0; int bad = 0;
     u64 last_index = 0;                       // m_last.index recs.hpp:54
-    u32 hdr_bytes = 0;
+    u32 hdr_bytes = 0, step = 0, coded = 0;
     const u8* prev = nullptr;
-    for (u32 k = 0; k < nrec; k++) {
+    {                                                                         // recs.cpp:279-287: the base
+        const u64 h0 = a.line_off[4 * base_rec] + 1, h1 = a.line_off[4 * base_rec + 1] - 1;
+        const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
+        const u8* buf = cd.stage(a.fq + h0, n, step++);
+        if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
+        for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+        prev = buf;
+    }
+    for (u32 k = 0; k < nrec && !bad; k++) {
         const u64 r = rec0 + k;
-        const u64 record_count = (u64)k + 1;  // g_record_count, block-relative
-        cd.record(k);
+        const u64 record_count = r - base_rec + 1;   // g_record_count, block-relative
         const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
-        const u8* buf = cd.stage(a.fq + h0, n, k);       // the text itself, or the coder's faster copy of it
         hdr_bytes += n;
-        if (k == 0) {                                                         // recs.cpp:279-287 (first line -> "rec.first")
-            imap = 0;
-            if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
-            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
-            prev = buf;
-            continue;
-        }
+        if (r == base_rec) continue;                                          // the base itself
+        cd.record(coded++);
+        const u8* buf = cd.stage(a.fq + h0, n, step++);  // the text itself, or the coder's faster copy of it
         const u32 pmap = imap;
         imap ^= 1;
         if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
         SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
         bool shape = mi.len != mp.len;
         if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
+        if constexpr (C::inband) cd.put(REC_FLAG_ROW, shape ? 1u : 0u);
         if (shape) {                                                          // recs.cpp:292-305
-            if constexpr (!C::counting) {
+            if constexpr (C::inband) {
+                cd.put_u(REC_FLAG_ROW + 2, n);
+                for (u32 j = 0; j < n; j++) cd.put(REC_FLAG_ROW + 1, buf[j]);
+            } else {
                 x_rec.put(xpw, record_count - last_index);
                 last_index = record_count;
                 x_rec.put_str(xpw, buf, n);
@@ -116,7 +129,7 @@ __device__ __forceinline__ u64 get_u_rows(C& cd, u32 row0) {
 }
 // the adaptive coder: the block's own PowerRanger rows (the reference's behaviour)
 struct RecAdaptiveEnc {
-    static constexpr bool counting = false;
+    static constexpr bool inband = false;
     PwTab pw; RcEnc rc; ByteSink snk;
     __device__ __forceinline__ void record(u32) {}
     __device__ __forceinline__ const u8* stage(const u8* g, u32, u32) { return g; }
@@ -173,8 +186,9 @@ __device__ bool d_is_number(const u8* p, int len, i64& num) {          // recs.c
 }
 
 template <typename C>
-__device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* d, u32 blk, C& cd, XfDec& x_rec, const PwTab& xpw) {
-    u64 index = x_rec.get(xpw);                                                             // recs.cpp:104
+__device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* d, u64 rec0, u32 nrec, u32 blk, C& cd, XfDec& x_rec, const PwTab& xpw) {
+    u64 index = 0;
+    if constexpr (!C::inband) index = x_rec.get(xpw);                                       // recs.cpp:104
     u8* const stage = a.hdr_stage + a.hdr_stage_off[blk];
     const u64 cap = a.hdr_stage_cap[blk];
     u64 pos = 0;            // write cursor in stage
@@ -183,24 +197,31 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
     u64 cnumb[2][66];
     u32 imap = 0;
     int bad = 0;
-    const u8* prev = nullptr; u32 prev_n = 0;
-    for (u32 k = 0; k < d->nrec; k++) {
-        const u64 r = d->rec0 + k, rcnt = (u64)k + 1;
+    // the base: the block's first header (load_first_line recs.cpp:113-119); records [rec0, rec0 + nrec) of the block follow it
+    const u8* prev = a.first_hdrs + d->first_hdr_off; u32 prev_n = d->first_hdr_len;
+    for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+    if (prev_n > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; nrec = 0; }                        // (also refused by sfq_decode_blocks)
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = rec0 + k, rcnt = r - d->rec0 + 1;
         // worst case for one header: every field regenerated at its longest (MAX_ID_LLEN) -> bounded check
         if (pos + SFQ_MAX_ID_LLEN + 2 > cap) { bad = SFQ_E_OVERFLOW; break; }
         u8* buf = stage + pos;
         u32 n = 0;
-        if (k == 0) {                                                                       // load_first_line recs.cpp:113-119
-            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
-            imap = 0;
-            n = d->first_hdr_len;
-            if (n > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }                         // (also refused by sfq_decode_blocks)
-            const u8* f = a.first_hdrs + d->first_hdr_off;
-            for (u32 i = 0; i < n; i++) buf[i] = f[i];
+        if (r == d->rec0) {                                                                 // the base itself
+            n = prev_n;
+            for (u32 i = 0; i < n; i++) buf[i] = prev[i];
         } else {
             const u32 pmap = imap;
             imap ^= 1;
-            if (index == rcnt) {                                                            // recs.cpp:386-393
+            bool whole = false;
+            if constexpr (C::inband) whole = cd.get(REC_FLAG_ROW) != 0; else whole = index == rcnt;
+            if (whole && C::inband) {
+                u64 len = cd.get_u(REC_FLAG_ROW + 2);
+                if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
+                for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)cd.get(REC_FLAG_ROW + 1);
+                n = (u32)len;
+                for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            } else if (whole) {                                                             // recs.cpp:386-393
                 u64 len = x_rec.get(xpw);
                 if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
                 for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)x_rec.get_chr(xpw);
@@ -290,10 +311,11 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
     if (bad) {
         atomicMax(&d->status, (u32)(-bad));
         // leave the remaining records empty so the assembly stays in bounds
-        for (u32 k = 0; k < d->nrec; k++) { const u64 r = d->rec0 + k; if (a.hoff[r] == ~0ULL) { a.hlen[r] = 0; a.hoff[r] = a.hdr_stage_off[blk]; } }
+        for (u32 k = 0; k < nrec; k++) { const u64 r = rec0 + k; if (a.hoff[r] == ~0ULL) { a.hlen[r] = 0; a.hoff[r] = a.hdr_stage_off[blk]; } }
     }
 }
 struct RecAdaptiveDec {
+    static constexpr bool inband = false;
     PwTab pw; RcDec rc; ByteSrc src;
     __device__ __forceinline__ u32 get(u32 row) { return pw.get(row, rc, src); }
     __device__ __forceinline__ u64 get_u(u32 row0) { return pw.get_u(row0, rc, src); }

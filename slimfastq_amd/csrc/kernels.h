@@ -45,7 +45,9 @@ struct ChainGeoArgs { u32 chain_reads, cpb, nchains; };     // chain c = chain c
 #define GEN_MAX_GENERATIONS 40
 struct ChainArgs {
     ModelArgs m;
-    ChainGeoArgs geo;
+    ChainGeoArgs geo;           // chains of the quality and base streams
+    ChainGeoArgs rgeo;          // chains of the header stream (longer: each starts from the block's first header)
+    u32* rhb;                   // [rgeo.nchains] header bytes of each header chain (encode: written)
     u64 nbytes;                 // size of the FASTQ text (encode)
     u32 block_reads;            // records per block (uniform; the last block may be short)
     u32* csz;                   // [nchains] sizes of the stream being coded (encode: written; decode: read)
@@ -73,9 +75,9 @@ void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       // gen.Ns / gen.Nn side streams, a wave per block (models_k.hip)
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st);
-void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [nblocks], zeroed */, hipStream_t st);   // blocks [m.batch0, m.batch0 + m.nbatch), one per lane
-void launch_chain_block_sizes(const ChainArgs& a, int stream, const u32* csz, hipStream_t st);
-void launch_compact_chains(const ChainArgs& a, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
+void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, hipStream_t st);   // one header chain per lane; a.csz / a.rhb per chain
+void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb /* or null */, hipStream_t st);
+void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);
 #define GEN_STEP 4u             // a counted base adds GEN_STEP to its row entry (chains.hip)
 

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_rec_encode_l(ModelArgs a) {
     cd.pw = sl.pw; cd.snk.p = a.arena + d->out_off[SFQ_S_REC]; cd.snk.pos = 0; cd.snk.cap = d->out_cap[SFQ_S_REC]; cd.rc.init();
     XfEnc x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
     u32 hdr_bytes = 0; int bad = 0;
-    rec_encode_lane(a, d->rec0, d->nrec, cd, x_rec, sl.pw, hdr_bytes, bad);
+    rec_encode_lane(a, d->rec0, d->rec0, d->nrec, cd, x_rec, sl.pw, hdr_bytes, bad);
     cd.rc.done(cd.snk);
     d->hdr_bytes = hdr_bytes;
     finish_stream(d, SFQ_S_REC, cd.snk, cd.rc.err);

@@ -24,7 +24,8 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     starts, lens = util.line_table(fq)
     nrec = len(starts) // 4
     solid = enc.blocks[0].solid
-    got_cr, flags, qsz, gsz = util.unpack_chains(enc.chains)
+    ci = util.unpack_chains(enc.chains)
+    got_cr, flags, qsz, gsz = ci["chain_reads"], ci["flags"], ci["qlt"], ci["gen"]
     assert got_cr == min(cr, br)
     # qualities: prior -> frozen rows -> chains
     qoff, qlen = starts[3::4] + solid, lens[3::4] - solid
@@ -45,15 +46,19 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     stride, run, nruns = rec_sample(nrec)
     f = O.rec_prior_freqs(O.rec_count(fq, hoff, hlen, stride, run, nruns))
     assert np.array_equal(util.unpack_rec_prior(enc.rec_prior), f), what
-    want, sizes = O.rec_encode_blocks_frozen(fq, hoff, hlen, br, O.rec_frozen_rows(f))
-    assert [b.size[0] for b in enc.blocks] == list(sizes), what
+    assert flags & 2
+    rcr = ci["rec_chain_reads"]
+    assert rcr == min(max(256, got_cr), br, nrec)
+    want, sizes, hb = O.rec_encode_chains_frozen(fq, hoff, hlen, br, rcr, O.rec_frozen_rows(f))
+    assert list(ci["rec"]) == list(sizes) and list(ci["rec_hdr_bytes"]) == list(hb), what
     assert enc.stream("rec") == want, what
     # the side streams are the reference's own, block by block
     chunks = util.split_records(fq, br)
     for b in (0, len(chunks) - 1):
         ref = O.compress(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
-        for name in ("gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"):
+        for name in ("gen.Ns", "gen.Nn", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"):
             assert enc.stream(name, b) == ref.get(name, b""), (what, name, b)
+        assert enc.stream("rec.x", b) == b""             # a header whose shape changed is coded inside its chain
     return enc
 
 
@@ -80,12 +85,12 @@ def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
         out += [lines[i], seq, lines[i + 2], lines[i + 3]]
     fq2 = b"\n".join(out) + b"\n"
     enc = check_against_oracle(ctx, fq2, 3, br=128, cr=32, step=1, what="genome-like")
-    _, flags, _, gsz = util.unpack_chains(enc.chains)
-    assert flags & 1
-    assert int(gsz.sum()) * 8 < 1.2 * 60000 * 150
+    ci = util.unpack_chains(enc.chains)
+    assert ci["flags"] & 1
+    assert int(ci["gen"].sum()) * 8 < 1.2 * 60000 * 150
     assert ctx.decode_host(enc, level=3, out_cap=len(fq2) + 4096) == fq2
     enc = ctx.encode_host(fq, level=3, block_reads=128, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=32)
-    assert not util.unpack_chains(enc.chains)[1] & 1
+    assert not util.unpack_chains(enc.chains)["flags"] & 1
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 

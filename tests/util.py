@@ -106,11 +106,17 @@ def _vints(blob: bytes):
 
 
 def unpack_chains(blob: bytes):
-    """"chn.idx" -> (chain_reads, flags, qlt sizes, gen sizes); mirrors api.cpp."""
+    """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp."""
     v = _vints(blob)
     cr, flags, n = v[0], v[1], v[2]
-    assert len(v) == 3 + 2 * n
-    return cr, flags, np.array(v[3:3 + n], np.uint32), np.array(v[3 + n:], np.uint32)
+    out = {"chain_reads": cr, "flags": flags, "qlt": np.array(v[3:3 + n], np.uint32), "gen": np.array(v[3 + n:3 + 2 * n], np.uint32)}
+    p = 3 + 2 * n
+    if flags & 2:
+        rcr, m = v[p], v[p + 1]; p += 2
+        out.update(rec_chain_reads=rcr, rec=np.array(v[p:p + m], np.uint32), rec_hdr_bytes=np.array(v[p + m:p + 2 * m], np.uint32))
+        p += 2 * m
+    assert p == len(v)
+    return out
 
 
 def unpack_rec_prior(blob: bytes):
