@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
+    DevBuf qrows, qcoarse, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
     u32 r_hot = 0;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
@@ -269,7 +269,7 @@ int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
         std::stable_sort(w.begin(), w.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
         u16 map[PR_REC_ROWS], hot[64];
         for (u32 r = 0; r < PR_REC_ROWS; r++) map[r] = 0xFFFFu;
-        const u32 nh = (u32)std::min<size_t>(w.size(), 44);
+        const u32 nh = (u32)std::min<size_t>(w.size(), 16);       // REC_LDS_ROWS (chains.hip)
         for (u32 i = 0; i < nh; i++) { hot[i] = (u16)w[i].second; map[w[i].second] = (u16)i; }
         if ((rc = reserve(ctx, ctx->rmap, sizeof map + sizeof hot))) return rc;
         HIPC(hipMemcpyAsync(ctx->rmap.p, map, sizeof map, hipMemcpyHostToDevice, st));
@@ -419,7 +419,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -565,7 +565,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         if (models & SFQ_M_QLT) {
             if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
             if ((rc = build_qesc(ctx, st))) return rc;
-            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, st);
+            launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, nullptr, st);
             ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
             ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
             HIPC(hipEventRecord(ctx->ev[1], st));
@@ -1008,8 +1008,9 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
         if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
         if ((rc = build_qesc(ctx, st))) return rc;
-        launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, st);
-        ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
+        if ((rc = reserve(ctx, ctx->qcoarse, (size_t)q_rows * 8 * 4))) return rc;
+        launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u32*)ctx->qcoarse.p, st);
+        ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qcoarse = (const u32*)ctx->qcoarse.p;
         ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);

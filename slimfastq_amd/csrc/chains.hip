@@ -23,13 +23,18 @@
 // 65536 - sum g goes to the largest g (the first of them).  Entry s = cum(g[0..s)) | g[s] << 16  (g <= 65473).
 // A context the sample never saw has the uniform row (g = 1024).  Rows are indexed by the context itself: q_rows x 256 B,
 // of which a file touches a few thousand rows (L2-resident).
-__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows) {
+// qcoarse (decode only, may be null): [q_rows][8] the cum of every 8th symbol, so that a decoder finds a symbol in two steps
+__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows, u32* __restrict__ qcoarse) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
     const u32* r = rows66 + (size_t)ctx * 66;
     const u32 slot = r[lane], iend = r[65];
-    if (iend == 0) { qrows[(size_t)ctx * 64 + lane] = (lane << 10) | (1024u << 16); return; }
+    if (iend == 0) {
+        qrows[(size_t)ctx * 64 + lane] = (lane << 10) | (1024u << 16);
+        if (qcoarse && (lane & 7) == 0) qcoarse[(size_t)ctx * 8 + (lane >> 3)] = lane << 10;
+        return;
+    }
     // slot order -> symbol order: lane j sends its frequency to lane sym(j) (lanes >= iend hold no slot: they send 0 to themselves)
     const u32 sym = slot >> 16, fslot = lane < iend ? (slot & 0xffffu) : 0u;
     const u32 f = (u32)__builtin_amdgcn_ds_permute((int)((lane < iend ? sym : lane) * 4), (int)fslot);
@@ -50,9 +55,10 @@ __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
     qrows[(size_t)ctx * 64 + lane] = (incl - g) | (g << 16);
+    if (qcoarse && (lane & 7) == 0) qcoarse[(size_t)ctx * 8 + (lane >> 3)] = incl - g;
 }
-void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows);
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qcoarse);
 }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
@@ -226,12 +232,17 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {
             const u32 prob = rc.get_freq16();
-            const u32* row = a.qrows + (size_t)last * 64;
-            // largest s with cum[s] <= prob (cum is increasing: every g >= 1)
-            u32 s = 0;
-#pragma unroll
-            for (u32 step = 32; step > 0; step >>= 1) { const u32 t = s + step; if (FZ_CUM(row[t]) <= prob) s = t; }
-            const u32 e = row[s];
+            // largest s with cum[s] <= prob (cum is increasing: every g >= 1): the eighth of the row from the coarse
+            // entries, then the symbol among its eight -- two dependent fetches of 32 bytes each
+            const uint4* cq = reinterpret_cast<const uint4*>(a.qcoarse + (size_t)last * 8);
+            const uint4 c0 = cq[0], c1 = cq[1];
+            const u32 k8 = (c0.y <= prob) + (c0.z <= prob) + (c0.w <= prob) + (c1.x <= prob) + (c1.y <= prob) + (c1.z <= prob) + (c1.w <= prob);
+            const uint4* eq = reinterpret_cast<const uint4*>(a.qrows + (size_t)last * 64 + k8 * 8);
+            const uint4 e0 = eq[0], e1 = eq[1];
+            const u32 i8 = (FZ_CUM(e0.y) <= prob) + (FZ_CUM(e0.z) <= prob) + (FZ_CUM(e0.w) <= prob) + (FZ_CUM(e1.x) <= prob) +
+                           (FZ_CUM(e1.y) <= prob) + (FZ_CUM(e1.z) <= prob) + (FZ_CUM(e1.w) <= prob);
+            const u32 s = k8 * 8 + i8;
+            const u32 e = i8 == 0 ? e0.x : i8 == 1 ? e0.y : i8 == 2 ? e0.z : i8 == 3 ? e0.w : i8 == 4 ? e1.x : i8 == 5 ? e1.y : i8 == 6 ? e1.z : e1.w;
             rc.decode(FZ_CUM(e), FZ_FREQ(e));
             u32 b = s;
             if (s == LAST_QLT) {                                            // qlts.cpp:168-171
@@ -538,7 +549,7 @@ __device__ __forceinline__ u8* rec_chain_region(const ChainArgs& a, const RecCha
 }
 
 #define REC_HBUF 128u                    // bytes of LDS per staged header (two per lane: the current and the previous one)
-#define REC_LDS_ROWS 44u                 // frozen rows staged in LDS per wave (1 KiB each)
+#define REC_LDS_ROWS 16u                 // frozen rows staged in LDS per wave (1 KiB each): a handful of rows take nearly all symbols
 struct RecFrozenEnc {
     static constexpr bool inband = true;
     const u32* rows; LaneEnc rc;
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* fla
 // keeps those in per-lane scratch and reads the text through generic pointers: ~300 memory instructions per record,
 // which is what its time is made of.  A chain with a longer header or more fields is handed over (flags[c] = 1).
 #define RF_MAXLEN 127u
-#define RF_NF 24u
+#define RF_NF 16u                        // (the whole LDS image is ~50 KiB: three waves per CU)
 struct RecFastLds {
     u8  text[2][RF_MAXLEN + 1][64];
     u8  off[2][RF_NF][64], wln[2][RF_NF][64], sep[2][RF_NF][64];
