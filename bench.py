@@ -148,8 +148,19 @@ def main():
     torch.cuda.synchronize()
 
     def step(tables=args.tables):
+        ps = prior_step
+        if world > 1 and prior_step == capi.PRIOR_AUTO:
+            # one prior for the whole job: rank 0 builds it from its shard, broadcasts it (a few hundred KB),
+            # every rank codes from it -- so a record block's bytes do not depend on how many GPUs shared the file
+            from slimfastq_amd.dist_compress import bcast_bytes
+            pri = rp = b""
+            if rank == 0:
+                pri, rp = ctx.build_priors(d_in.data_ptr(), nbytes, level=args.level, block_reads=args.block_reads, tables=tables)
+            pri = bcast_bytes(pri, 0, d_in.device); rp = bcast_bytes(rp, 0, d_in.device)
+            ctx.set_priors(pri, rp)
+            ps = capi.PRIOR_GIVEN
         res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=args.level,
-                                block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
+                                block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=ps,
                                 tables=tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
         if world > 1:
             # the path's one exchange step: compressed streams to the writer rank, over RCCL/xGMI

@@ -83,12 +83,14 @@ typedef struct sfq_params {
                               is coded -- qualities from the transmitted prior, bases from the counts of the earlier
                               generations of the same call -- one chain per LANE               */
     uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic                                    */
-    uint32_t lds_rows;     /* frozen tables: quality rows staged in LDS per workgroup (0 = 255, SFQ_LDS_ROWS_NONE = none) */
+    uint32_t lds_rows;     /* frozen tables, encode: the N most used quality rows are staged in LDS by every workgroup
+                              (0 or SFQ_LDS_ROWS_NONE = none: measured no faster than the L2-resident table) */
 } sfq_params;
 #define SFQ_TABLES_ADAPTIVE 0u
 #define SFQ_TABLES_FROZEN   1u
 #define SFQ_LDS_ROWS_NONE  0xFFFFFFFFu
-#define SFQ_PRIOR_AUTO 0xFFFFFFFFu
+#define SFQ_PRIOR_AUTO  0xFFFFFFFFu
+#define SFQ_PRIOR_GIVEN 0xFFFFFFFEu  /* prior_step: the priors installed with sfq_set_qlt_prior / sfq_set_rec_prior */
 #define SFQ_BLOCK_AUTO 0xFFFFFFFFu
 
 /* One entry per block: what a decoder needs besides the stream bytes (the "block index").
@@ -158,6 +160,10 @@ int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, con
 /* BASELINE.json config C2: the quality model alone == QltSave::save over all records (qlts.hpp:82-90). */
 int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
                           uint8_t* d_out, uint64_t out_cap, sfq_result* result);
+/* The priors of a text without coding it: afterwards sfq_get_qlt_prior (and, with frozen tables, sfq_get_rec_prior) hold what
+ * an sfq_encode_blocks call with the same parameters would have built.  For several contexts / GPUs that compress parts
+ * of one file from ONE prior: build it once, install it everywhere (sfq_set_*_prior), encode with prior_step = SFQ_PRIOR_GIVEN. */
+int sfq_build_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params);
 /* Same with host buffers (stages through the context's device memory; PCIe-inclusive). */
 int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
                            uint8_t* h_out, uint64_t out_cap, sfq_result* result);

@@ -7,6 +7,7 @@ kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 br = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 cr = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 models = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+lds = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 fq = capi.synth_fastq(n, 150, seed=1, kind=kind)
 nbytes = len(fq)
 d_in = torch.from_numpy(np.frombuffer(fq, np.uint8).copy()).cuda()
@@ -17,7 +18,7 @@ for tables in ((1, 0) if len(sys.argv) <= 6 else (1,)):
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO,
-                                tables=tables, chain_reads=cr, models=models)
+                                tables=tables, chain_reads=cr, models=models, lds_rows=lds)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ms = list(res.kernel_ms)
     print("tables=%d encode %.1f ms (%.1f GB/s) ratio %.4f chains %d  phases frame %.1f qlt %.1f gen %.1f rec %.1f usr %.1f pack %.1f total %.1f" % (

@@ -12,6 +12,7 @@ STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.
 M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
 PRIOR_AUTO = 0xFFFFFFFF
+PRIOR_GIVEN = 0xFFFFFFFE
 BLOCK_AUTO = 0xFFFFFFFF
 TABLES_ADAPTIVE, TABLES_FROZEN = 0, 1
 LDS_ROWS_NONE = 0xFFFFFFFF
@@ -21,7 +22,7 @@ EXPORTS = [
     "sfq_ctx_stream", "sfq_ctx_synchronize", "sfq_encode_bound", "sfq_encode_blocks", "sfq_encode_qlt_blocks",
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
-    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index", "sfq_get_rec_prior", "sfq_set_rec_prior",
+    "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index", "sfq_get_rec_prior", "sfq_set_rec_prior", "sfq_build_priors",
 ]
 
 
@@ -106,6 +107,7 @@ def lib():
         L.sfq_get_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_qlt_prior.restype = C.c_int64
         L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
+        L.sfq_build_priors.argtypes = [vp, u8p, u64, C.POINTER(Params)]
         L.sfq_get_rec_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_rec_prior.restype = C.c_int64
         L.sfq_set_rec_prior.argtypes = [vp, u8p, u64]
@@ -217,6 +219,17 @@ class Context:
         buf = C.create_string_buffer(n)
         lib().sfq_get_rec_prior(self._h, buf, n)
         return buf.raw[:n]
+
+    def build_priors(self, d_ptr, nbytes, level=3, block_reads=BLOCK_AUTO, prior_step=PRIOR_AUTO, tables=1):
+        """Priors of a device-resident text (quality prior, header prior); install elsewhere with set_priors()."""
+        p = Params(level, block_reads, 0, 0, 0, 0, prior_step, tables, 0, 0)
+        self._check(lib().sfq_build_priors(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p)))
+        return self.prior(), self.rec_prior()
+
+    def set_priors(self, prior: bytes, rec_prior: bytes = b""):
+        L = lib()
+        self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
+        self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
 
     def chains(self) -> bytes:
         n = lib().sfq_get_chain_index(self._h, None, 0)

@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qcoarse, qesc, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
+    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
     u32 r_hot = 0;
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
@@ -328,6 +328,28 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
     cr = std::max<u64>(cr, (16384 + per_rec - 1) / per_rec);
     return (int)std::min<u64>(cr, 4096);
 }
+// The header prior of an encode with frozen tables: counted over this call's text -- the header model run over short runs
+// of records spread over the call -- or the installed one (SFQ_PRIOR_GIVEN); leaves the frozen rows on the device.
+int rec_prior_for_encode(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipStream_t st) {
+    int rc;
+    std::vector<u32> hf;
+    if (given) {
+        if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
+    } else {
+        if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
+        HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, st));
+        const u32 run = 18;
+        const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
+        const u64 stride = std::max<u64>(run, nrec / nruns);
+        launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, st);
+        std::vector<u32> hc((size_t)PR_REC_ROWS * 256);
+        HIPC(hipMemcpyAsync(hc.data(), ctx->hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        ctx->rec_prior_blob = pack_rec_prior(hc, hf);
+    }
+    return upload_rec_rows(ctx, hf, st);
+}
+
 // Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
 // of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
 // Leaves ca.g_* describing which rows every generation codes with.
@@ -419,7 +441,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
     for (DevBuf* b : all) release(*b);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
@@ -442,9 +464,10 @@ uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
 // -------------------------------------------------------------------------------------------------
 // compress
 // -------------------------------------------------------------------------------------------------
+// priors_only: stop once the call's priors ("qlt.pri", and "rec.pri" with frozen tables) are built (sfq_build_priors)
 static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
-                       sfq_result* res, u32 force_models) {
-    if (!ctx || !d_fastq || !pp || !d_out || !res) return fail(ctx, SFQ_E_ARG, "null argument");
+                       sfq_result* res, u32 force_models, bool priors_only = false) {
+    if (!ctx || !d_fastq || !pp || (!d_out && !priors_only) || !res) return fail(ctx, SFQ_E_ARG, "null argument");
     if (nbytes == 0) return fail(ctx, SFQ_E_FORMAT, "empty input");
     HIPC(hipSetDevice(ctx->dev));
     sfq_params p = *pp;
@@ -514,11 +537,15 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);       // qlts.hpp:36-40
     // warm start (format 7 only): count a sample, build the prior rows, keep a host copy for "qlt.pri"
     ctx->prior_on = false;
-    ctx->prior_blob.clear();
-    ctx->chain_blob.clear();
-    ctx->rec_prior_blob.clear();
-    std::vector<u32> h_rows66;
     u32 prior_step = p.block_reads ? p.prior_step : 0;
+    // SFQ_PRIOR_GIVEN: the priors installed with sfq_set_qlt_prior / sfq_set_rec_prior (e.g. built once for a file that
+    // several GPUs share, sfq_build_priors) instead of priors counted over this call's text
+    const bool given = prior_step == SFQ_PRIOR_GIVEN;
+    if (given && ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no quality prior installed (sfq_set_qlt_prior)");
+    if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
+    if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
+    ctx->chain_blob.clear();
+    std::vector<u32> h_rows66;
     if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
     // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
@@ -528,7 +555,17 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
         prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 60000000ull), 0x7FFFFFFFull);
     }
-    if (prior_step && (models & SFQ_M_QLT)) {
+    if (given && (models & SFQ_M_QLT)) {
+        std::vector<u32> rows;
+        if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
+        if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
+        HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
+        HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
+        HIPC(hipStreamSynchronize(st));            // `rows` is a local
+        HIPC(hipEventRecord(ctx->ev[1], st));
+        ctx->prior_on = true;
+    } else if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
         launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
@@ -567,7 +604,30 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             if ((rc = build_qesc(ctx, st))) return rc;
             launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, nullptr, st);
             ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
-            ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
+            ca.q_hot = 0;
+            const u32 want_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : std::min<u32>(p.lds_rows, 240u);
+            if (want_hot) {
+                // LDS staging (measured, DESIGN.md section 5: off by default): the contexts the sample saw most
+                if ((rc = reserve(ctx, ctx->qw, (size_t)q_rows * 4 + 8192))) return rc;
+                launch_row_weights((const u32*)ctx->hist.p, q_rows, (u32*)ctx->qw.p, st);
+                std::vector<u32> w(q_rows);
+                HIPC(hipMemcpyAsync(w.data(), ctx->qw.p, (size_t)q_rows * 4, hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                std::vector<u32> order;
+                for (u32 c = 0; c < q_rows; c++) if (w[c]) order.push_back(c);
+                std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return w[x] > w[y]; });
+                std::vector<u32> tab(1024, 0xFFFFFFFFu); std::vector<u16> hot;
+                for (u32 c : order) {
+                    if (hot.size() >= want_hot) break;
+                    const u32 hsl = (c * 0x9E3Bu >> 4) & 1023u;                  // chains.hip qh_hash
+                    if (tab[hsl] != 0xFFFFFFFFu) continue;                       // direct-mapped: the hotter context keeps the slot
+                    tab[hsl] = c | ((u32)hot.size() << 16); hot.push_back((u16)c);
+                }
+                HIPC(hipMemcpyAsync((u8*)ctx->qw.p, tab.data(), 4096, hipMemcpyHostToDevice, st));
+                if (!hot.empty()) HIPC(hipMemcpyAsync((u8*)ctx->qw.p + 4096, hot.data(), hot.size() * 2, hipMemcpyHostToDevice, st));
+                HIPC(hipStreamSynchronize(st));
+                ca.q_hot = (u32)hot.size(); ca.qh_tab = (const u32*)ctx->qw.p; ca.qh_ctx = (const u16*)((u8*)ctx->qw.p + 4096);
+            }
             HIPC(hipEventRecord(ctx->ev[1], st));
         }
     }
@@ -583,6 +643,14 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ModelArgs a;
     fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
     a.fq = d_fastq;
+    if (priors_only) {
+        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_for_encode(ctx, a, nrec, given, st))) return rc; }
+        HIPC(hipStreamSynchronize(st));
+        if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
+        ctx->prior_on = false;
+        res->n_records = nrec; res->n_blocks = nblocks;
+        return SFQ_OK;
+    }
     // The four models are independent chains over the same text: each runs on its own HIP stream, forked
     // from / joined to the context's stream with events, so their kernels overlap on the chip.
     // (frozen tables: the base model's generation tables need one host decision in the middle, so bases go last)
@@ -623,23 +691,15 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                         ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
                         if ((rc = gen_tables_encode(ctx, ca, nblocks, (u32)g_bits, mst[m], &gen_on))) return rc;
                         launch_gen_encode_c(ca, mst[m]);
-                        launch_gen_exc_w(a, tickets + 1, mst[m]);
+                        // the N / quality-0 exceptions are independent of the chains: on the framing stream, beside them
+                        launch_gen_exc_w(a, tickets + 1, mst[2]);
+                        HIPC(hipEventRecord(ctx->ev[12], mst[2]));
+                        HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
                     } else launch_gen_encode_k(a, tickets + 1, mst[m]);
                     break;
                 case SFQ_M_REC:
                     if (frozen) {
-                        // header prior: the model run over short runs of records spread over the call, symbols counted
-                        if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
-                        HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, mst[m]));
-                        const u32 run = 18;
-                        const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
-                        const u64 stride = std::max<u64>(run, nrec / nruns);
-                        launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, mst[m]);
-                        std::vector<u32> hc((size_t)PR_REC_ROWS * 256), hf;
-                        HIPC(hipMemcpyAsync(hc.data(), ctx->hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, mst[m]));
-                        HIPC(hipStreamSynchronize(mst[m]));
-                        ctx->rec_prior_blob = pack_rec_prior(hc, hf);
-                        if ((rc = upload_rec_rows(ctx, hf, mst[m]))) return rc;
+                        if ((rc = rec_prior_for_encode(ctx, a, nrec, given, mst[m]))) return rc;
                         ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
                         ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
                         if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
@@ -728,7 +788,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
 
-    if (ctx->prior_on) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
+    if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
     ctx->prior_on = false;
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
@@ -768,6 +828,10 @@ int sfq_encode_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, con
 int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params,
                           uint8_t* d_out, uint64_t out_cap, sfq_result* result) {
     return encode_impl(ctx, d_fastq, nbytes, params, d_out, out_cap, result, SFQ_M_QLT);
+}
+int sfq_build_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params) {
+    sfq_result res;
+    return encode_impl(ctx, d_fastq, nbytes, params, nullptr, 0, &res, 0, true);
 }
 int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
                            uint8_t* h_out, uint64_t out_cap, sfq_result* result) {
@@ -1011,7 +1075,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         if ((rc = reserve(ctx, ctx->qcoarse, (size_t)q_rows * 8 * 4))) return rc;
         launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u32*)ctx->qcoarse.p, st);
         ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qcoarse = (const u32*)ctx->qcoarse.p;
-        ca.q_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows;
+        ca.q_hot = 0;
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));

@@ -61,6 +61,20 @@ void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoa
     hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qcoarse);
 }
 
+// the sample's symbol count of every context: the host picks the rows worth staging in LDS from it
+__global__ __launch_bounds__(256) void k_row_weights(const u32* __restrict__ hist, u32 q_rows, u32* __restrict__ w) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    u32 c = hist[(size_t)ctx * 64 + lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
+    if (lane == 0) w[ctx] = c;
+}
+void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st) {
+    hipLaunchKernelGGL(k_row_weights, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, w);
+}
+
 // ---- chain geometry ---------------------------------------------------------------------------------------------
 struct ChainPos { u32 b; u64 r0; u32 nrec; };
 __device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
@@ -146,8 +160,21 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 // =========================================================================================================
 // quality encode: one chain per lane
 // =========================================================================================================
-template <int THREADS>
+// LDS staging of the hottest rows (BASELINE north_star: "ranger probability tables are staged in LDS"): the workgroup
+// copies the q_hot most used rows into LDS once; a symbol's context is looked up in a direct-mapped LDS table
+// (QH_SLOTS entries: context | slot << 16), a hit reads the row entry from LDS, a miss from the L2-resident table.
+#define QH_SLOTS 1024u
+#define QH_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ u32 qh_hash(u32 ctx) { return (ctx * 0x9E3Bu >> 4) & (QH_SLOTS - 1); }
+template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
+    extern __shared__ u32 lds[];                              // [QH_SLOTS] the context table, then [q_hot][64] row entries
+    u32* const ltab = lds; u32* const lrows = lds + QH_SLOTS;
+    if constexpr (LDS) {
+        for (u32 i = threadIdx.x; i < QH_SLOTS; i += THREADS) ltab[i] = a.qh_tab[i];
+        for (u32 i = threadIdx.x; i < a.q_hot * 64; i += THREADS) lrows[i] = a.qrows[(size_t)a.qh_ctx[i >> 6] * 64 + (i & 63)];
+        __syncthreads();
+    }
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < a.geo.nchains;
     ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
@@ -175,7 +202,10 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
             if (j >= pc.j0 && j < pc.j1) {
                 const u32 b = (piece_byte(w, j) - '!') & 0xffu;
                 const u32 sym = b < LAST_QLT ? b : LAST_QLT;
-                e[j] = a.qrows[(size_t)last * 64 + sym];
+                if constexpr (LDS) {
+                    const u32 hv = ltab[qh_hash(last)];
+                    e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
+                } else e[j] = a.qrows[(size_t)last * 64 + sym];
                 if (level <= 2) last = (b | (last << 6)) & mask12;         // qlts.hpp:52-57
                 else {                                                    // qlts.hpp:62-74
                     if (p1 > b) delta += p1 - b;
@@ -211,7 +241,8 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
     constexpr int T = 256;
     const u32 grid = (a.geo.nchains + T - 1) / T;
-    hipLaunchKernelGGL(k_qlt_encode_c<T>, dim3(grid), dim3(T), 0, st, a);
+    if (a.q_hot) hipLaunchKernelGGL((k_qlt_encode_c<T, true>), dim3(grid), dim3(T), (QH_SLOTS + a.q_hot * 64) * 4, st, a);
+    else hipLaunchKernelGGL((k_qlt_encode_c<T, false>), dim3(grid), dim3(T), 0, st, a);
 }
 
 // =========================================================================================================

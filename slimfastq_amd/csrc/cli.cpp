@@ -287,6 +287,7 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     const std::vector<uint8_t>* chn = a.find("chn.idx");
     const std::vector<uint8_t>* rpr = a.find("rec.pri");
     const bool frozen = a.get_long("blk.tables", 0) == 1;
+    const bool shared_prior = a.get_long("seg.shared_prior", 0) == 1;
     if (frozen && !chn) croak("archive says frozen tables but holds no chain index (chn.idx)");
     if (version >= kBlockVersion) {
         const std::vector<uint8_t>* idx = a.find("blk.idx");
@@ -361,10 +362,12 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             data.insert(data.end(), v->begin() + (ptrdiff_t)spos[s], v->begin() + (ptrdiff_t)(spos[s] + need[s]));
             spos[s] += need[s];
         }
+        // (seg.shared_prior: a segment without priors of its own codes from the previous segment's, e.g. the ranks of a multi-GPU job)
         if (g.prior_bytes) { if (sfq_set_qlt_prior(ctx, pri->data() + pri_off, g.prior_bytes)) croak("%s", sfq_last_error(ctx)); }
-        else sfq_set_qlt_prior(ctx, nullptr, 0);
+        else if (!shared_prior) sfq_set_qlt_prior(ctx, nullptr, 0);
         if (sfq_set_chain_index(ctx, g.chain_bytes ? chn->data() + chn_off : nullptr, g.chain_bytes)) croak("%s", sfq_last_error(ctx));
-        if (sfq_set_rec_prior(ctx, g.recpri_bytes ? rpr->data() + rpr_off : nullptr, g.recpri_bytes)) croak("%s", sfq_last_error(ctx));
+        if (g.recpri_bytes) { if (sfq_set_rec_prior(ctx, rpr->data() + rpr_off, g.recpri_bytes)) croak("%s", sfq_last_error(ctx)); }
+        else if (!shared_prior) sfq_set_rec_prior(ctx, nullptr, 0);
         uint64_t cap = g.raw_bytes, got = 0;
         if (!cap) cap = data.size() * 8 + (1 << 20);
         sfq_result res;

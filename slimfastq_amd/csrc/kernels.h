@@ -55,7 +55,9 @@ struct ChainArgs {
     // quality: frozen rows, total 2^16 each
     const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
     const u32* qcoarse;         // decode: [q_rows][8] cum of every 8th symbol
-    u32 q_hot;                  // rows staged in LDS per workgroup
+    u32 q_hot;                  // rows staged in LDS per workgroup (0 = none)
+    const u32* qh_tab;          // [1024] direct-mapped context -> (context | LDS slot << 16), 0xFFFFFFFF = empty
+    const u16* qh_ctx;          // [q_hot] the staged contexts
     const u32* qesc;            // escape row (256 entries), qlts.cpp:80-86
     // headers: frozen PowerRanger rows, total 2^16 each
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
@@ -68,6 +70,7 @@ struct ChainArgs {
     u32 g_bound[GEN_MAX_GENERATIONS + 1];      // generation g = blocks [g_bound[g], g_bound[g + 1])
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
 };
+void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);

@@ -3,16 +3,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         -m slimfastq_amd.dist_compress in.fastq out.sfq [-l 3] [-B 1024]
 
-Rank r compresses a contiguous, record-aligned byte range of the file on its GPU (the blocks are independent:
-no data-path collective), then ONE exchange: every rank's compressed streams, block index, first headers and
-quality prior go to rank 0 (slimfastq_amd.dist.gather_bytes: RCCL over xGMI with the "nccl" backend), which writes
-the archive -- one SEGMENT per rank, decodable by `slimfastq-amd -d`.
+Rank 0 builds ONE set of priors (quality prior, header prior) from its shard and broadcasts it (a few hundred KB); then
+rank r compresses a contiguous, record-aligned byte range of the file on its GPU from that prior (the blocks are
+independent: no data-path collective), and ONE exchange follows: every rank's compressed streams -- as they lie in
+HBM -- plus its block index, first headers and chain index go to rank 0 (slimfastq_amd.dist.gather_bytes: RCCL over
+xGMI with the "nccl" backend), which writes the archive: one SEGMENT per rank, the priors
+stored once, decodable by `slimfastq-amd -d`.
 """
 import argparse
 import ctypes as C
 import mmap
 import os
-import pickle
 import sys
 
 import numpy as np
@@ -71,9 +72,10 @@ def put_v(out: bytearray, v: int):
     out.append(v)
 
 
-def assemble(parts, level: int, block_reads: int, orig_name: str):
+def assemble(parts, level: int, block_reads: int, orig_name: str, frozen=True, shared_prior=False):
     """parts: per rank, in rank order: dict(streams=[bytes] * NSTREAMS, blocks=BlockInfo array, first=bytes,
-    prior=bytes, raw=int, records=int).  Returns (info_text, [(name, bytes)])."""
+    prior=bytes, chains=bytes, rec_prior=bytes, raw=int, records=int).  With shared_prior only the first part carries
+    the priors.  Returns (info_text, [(name, bytes)])."""
     L = capi.lib()
     parts = [p for p in parts if p["records"]]
     nblocks = sum(len(p["blocks"]) for p in parts)
@@ -100,15 +102,22 @@ def assemble(parts, level: int, block_reads: int, orig_name: str):
             streams.append((name, data))
     streams.append(("blk.idx", bytes(idx)))
     streams.append(("blk.hdr", b"".join(p["first"] for p in parts)))
-    prior = b"".join(p["prior"] for p in parts)
-    if prior:
-        streams.append(("qlt.pri", prior))
+    for key, name in (("prior", "qlt.pri"), ("chains", "chn.idx"), ("rec_prior", "rec.pri")):
+        data = b"".join(p[key] for p in parts)
+        if data:
+            streams.append((name, data))
+    if frozen:
+        info.append(("blk.tables", "1"))
     if len(parts) > 1:
         info.append(("seg.count", str(len(parts))))
+        if shared_prior:
+            info.append(("seg.shared_prior", "1"))
         si = bytearray()
         put_v(si, len(parts))
         for p in parts:
             put_v(si, len(p["blocks"])); put_v(si, len(p["prior"])); put_v(si, p["raw"])
+            if frozen:
+                put_v(si, len(p["chains"])); put_v(si, len(p["rec_prior"]))
         streams.append(("seg.idx", bytes(si)))
     return "".join("%s=%s\n" % kv for kv in info), streams
 
@@ -125,12 +134,54 @@ def write_archive(path: str, info_text: str, streams):
         raise capi.SfqError(rc, "cannot write " + path)
 
 
+META_WORDS = capi.NSTREAMS + 7        # stream sizes, then: blocks, first, prior, chains, rec_prior bytes, raw bytes, records
+
+
+def pack_part(streams_dev, res, blocks, first: bytes, prior: bytes, chains: bytes, rec_prior: bytes, raw: int):
+    """One rank's contribution as ONE byte tensor on its device: the compressed streams as they lie in HBM, then the small
+    index parts, then a trailer of int64 sizes (a flat layout: nothing is pickled)."""
+    bb = b"".join(bytes(b) for b in blocks)
+    tail = np.array([int(x) for x in res.stream_bytes] + [len(bb), len(first), len(prior), len(chains), len(rec_prior), raw, int(res.n_records)], np.int64)
+    small = np.frombuffer(bb + first + prior + chains + rec_prior + tail.tobytes(), np.uint8)
+    t = torch.from_numpy(small.copy()).to(streams_dev.device)
+    # the streams are packed stream after stream from offset 0 (sfq_result.stream_offset): total_bytes of them
+    return torch.cat([streams_dev[:int(res.total_bytes)], t])
+
+
+def unpack_part(raw: bytes):
+    tail = np.frombuffer(raw[-8 * META_WORDS:], np.int64)
+    sizes = [int(x) for x in tail[:capi.NSTREAMS]]
+    nbb, nfirst, nprior, nchains, nrp, rawbytes, records = (int(x) for x in tail[capi.NSTREAMS:])
+    off, streams = 0, []
+    for n in sizes:
+        streams.append(raw[off:off + n]); off += n
+    bsz = C.sizeof(capi.BlockInfo)
+    blocks = [capi.BlockInfo.from_buffer_copy(raw[off + i * bsz:off + (i + 1) * bsz]) for i in range(nbb // bsz)]
+    off += nbb
+    first = raw[off:off + nfirst]; off += nfirst
+    prior = raw[off:off + nprior]; off += nprior
+    chains = raw[off:off + nchains]; off += nchains
+    rec_prior = raw[off:off + nrp]
+    return dict(streams=streams, blocks=blocks, first=first, prior=prior, chains=chains, rec_prior=rec_prior, raw=rawbytes, records=records)
+
+
+def bcast_bytes(data: bytes, src: int, dev):
+    """Broadcast a byte string from rank src (sizes first)."""
+    n = torch.tensor([len(data) if dist.get_rank() == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src)
+    t = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev) if dist.get_rank() == src else torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if int(n.item()):
+        dist.broadcast(t, src)
+    return t.cpu().numpy().tobytes()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="slimfastq_amd.dist_compress", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("fastq")
     ap.add_argument("sfq")
     ap.add_argument("-l", "--level", type=int, default=3)
     ap.add_argument("-B", "--block_reads", type=int, default=-1, help="records per block (default: automatic, about 376 KiB of text)")
+    ap.add_argument("-A", "--adaptive", action="store_true", help="adaptive tables (a wavefront per block) instead of frozen tables")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL when every rank has its own GPU, else gloo)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +192,8 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
+    cdev = torch.device("cuda", dev)
+    xdev = cdev if backend == "nccl" else torch.device("cpu")          # where the exchanged tensors live
     with open(args.fastq, "rb") as f:
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         lo, hi = shard_bytes(mm, rank, world)
@@ -149,37 +202,45 @@ def main(argv=None):
     per_gpu = (world + max(ngpu, 1) - 1) // max(ngpu, 1)            # ranks sharing one GPU share its memory
     budget = int(torch.cuda.get_device_properties(dev).total_memory * 0.6 / per_gpu) if per_gpu > 1 else None
     ctx = capi.Context(dev, table_budget=budget)
-    part = dict(streams=[b""] * capi.NSTREAMS, blocks=[], first=b"", prior=b"", raw=len(text), records=0)
-    if text:
-        enc = ctx.encode_host(text, level=args.level, block_reads=capi.BLOCK_AUTO if args.block_reads < 0 else args.block_reads,
-                              prior_step=capi.PRIOR_AUTO)
-        part.update(streams=[enc.stream(s) for s in capi.STREAM_NAMES], blocks=list(enc.blocks), first=enc.first_hdrs,
-                    prior=enc.prior, records=int(enc.res.n_records))
+    tables = capi.TABLES_ADAPTIVE if args.adaptive else capi.TABLES_FROZEN
+    br = capi.BLOCK_AUTO if args.block_reads < 0 else args.block_reads
+    torch.cuda.set_device(dev)
+    d_in = torch.from_numpy(np.frombuffer(text, np.uint8).copy()).to(cdev) if text else torch.empty(0, dtype=torch.uint8, device=cdev)
+    # ONE prior for the whole file: rank 0 builds it from its shard, everybody codes from it
+    prior = rec_prior = b""
     if world > 1:
-        # the one exchange: stream bytes as one tensor per rank (RCCL / gloo), the small index as pickled bytes beside them
-        meta = pickle.dumps(dict(sizes=[len(s) for s in part["streams"]], blocks=[bytes(b) for b in part["blocks"]], first=part["first"],
-                                 prior=part["prior"], raw=part["raw"], records=part["records"]))
-        blob = b"".join(part["streams"]) + meta + len(meta).to_bytes(8, "little")
-        t = torch.from_numpy(np.frombuffer(blob, np.uint8).copy())
-        if backend == "nccl":
-            t = t.cuda(dev)
-        got = sdist.gather_bytes(t, dst=0)
-        if rank == 0:
-            parts = []
-            for g in got:
-                raw = g.cpu().numpy().tobytes()
-                mlen = int.from_bytes(raw[-8:], "little")
-                m = pickle.loads(raw[-8 - mlen:-8])
-                off, streams = 0, []
-                for n in m["sizes"]:
-                    streams.append(raw[off:off + n]); off += n
-                blocks = [capi.BlockInfo.from_buffer_copy(b) for b in m["blocks"]]
-                parts.append(dict(streams=streams, blocks=blocks, first=m["first"], prior=m["prior"], raw=m["raw"], records=m["records"]))
+        if rank == 0 and len(text):
+            prior, rec_prior = ctx.build_priors(d_in.data_ptr(), len(text), level=args.level, block_reads=br, tables=tables)
+        prior = bcast_bytes(prior, 0, xdev)
+        rec_prior = bcast_bytes(rec_prior, 0, xdev)
+    shared = bool(prior)
+    part_t = None
+    if len(text):
+        cap = capi.lib().sfq_encode_bound(len(text))
+        d_out = torch.empty(cap, dtype=torch.uint8, device=cdev)
+        if shared:
+            ctx.set_priors(prior, rec_prior)
+        res = ctx.encode_device(d_in.data_ptr(), len(text), d_out.data_ptr(), cap, level=args.level, block_reads=br,
+                                prior_step=capi.PRIOR_GIVEN if shared else capi.PRIOR_AUTO, tables=tables)
+        blocks = list(ctx.index(res.n_blocks))
+        # with a shared prior only rank 0's segment carries it
+        keep = (not shared) or rank == 0
+        part_t = pack_part(d_out, res, blocks, ctx.first_headers(res.first_hdr_bytes), ctx.prior() if keep else b"", ctx.chains(),
+                           ctx.rec_prior() if keep else b"", len(text))
     else:
-        parts = [part]
+        class _R:  # an empty shard
+            stream_bytes = [0] * capi.NSTREAMS; total_bytes = 0; n_records = 0
+        part_t = pack_part(torch.empty(0, dtype=torch.uint8, device=cdev), _R, [], b"", b"", b"", b"", 0)
+    if world > 1:
+        # the one exchange: every rank's bytes to the writer, device to device (RCCL over xGMI) when each rank has a GPU
+        got = sdist.gather_bytes(part_t.to(xdev), dst=0)
+        parts = [unpack_part(g.cpu().numpy().tobytes()) for g in got] if rank == 0 else None
+    else:
+        parts = [unpack_part(part_t.cpu().numpy().tobytes())]
     if rank == 0:
         first = [p for p in parts if p["records"]]
-        info, streams = assemble(parts, args.level, int(first[0]["blocks"][0].n_records) if first else 0, args.fastq)
+        info, streams = assemble(parts, args.level, int(first[0]["blocks"][0].n_records) if first else 0, args.fastq,
+                                 frozen=not args.adaptive, shared_prior=shared)
         write_archive(args.sfq, info, streams)
         raw = sum(p["raw"] for p in parts)
         print("%s: %d bytes -> %s: %d bytes of streams, %d segment(s)" % (args.fastq, raw, args.sfq, sum(len(s[1]) for s in streams),

@@ -95,8 +95,9 @@ def test_dist_compress_assembles_a_segmented_archive(cli, tmp_path):
             for s in range(3):
                 blocks[k].size[s] = 4 + s
         streams = [bytes([r]) * (2 * (4 + s)) if s < 3 else b"" for s in range(capi.NSTREAMS)]
-        parts.append(dict(streams=streams, blocks=list(blocks), first=b"hdr_%d" % r * 2, prior=b"P" * (r + 1), raw=1000 + r, records=21))
-    parts.append(dict(streams=[b""] * capi.NSTREAMS, blocks=[], first=b"", prior=b"", raw=0, records=0))   # a rank with no records
+        parts.append(dict(streams=streams, blocks=list(blocks), first=b"hdr_%d" % r * 2, prior=b"P" * (r + 1), chains=b"C" * r, rec_prior=b"",
+                          raw=1000 + r, records=21))
+    parts.append(dict(streams=[b""] * capi.NSTREAMS, blocks=[], first=b"", prior=b"", chains=b"", rec_prior=b"", raw=0, records=0))   # a rank with no records
     info, streams = dc.assemble(parts, 3, 1024, "x.fq")
     f = tmp_path / "seg.sfq"
     dc.write_archive(str(f), info, streams)
@@ -104,5 +105,15 @@ def test_dist_compress_assembles_a_segmented_archive(cli, tmp_path):
     text = p.stderr.decode()
     assert p.returncode == 0 and "seg.count" in text and "= 3" in text and "blk.count" in text and "= 6" in text
     d = dict(streams)
-    assert d["qlt.pri"] == b"PPPPPP" and len(d["rec"]) == 3 * 8 and d["seg.idx"][0] == 3
+    assert d["qlt.pri"] == b"PPPPPP" and d["chn.idx"] == b"CCC" and len(d["rec"]) == 3 * 8 and d["seg.idx"][0] == 3
+    # the flat exchange form of one rank's part (no pickle): streams, index parts, int64 trailer
+    import numpy as np
+    import torch
+
+    class R:
+        stream_bytes = [3, 0, 2] + [0] * (capi.NSTREAMS - 3); total_bytes = 5; n_records = 21
+    t = dc.pack_part(torch.from_numpy(np.frombuffer(b"abcde-----", np.uint8).copy()), R, list(blocks), b"first", b"prior", b"chains", b"rp", 1234)
+    u = dc.unpack_part(t.numpy().tobytes())
+    assert u["streams"][0] == b"abc" and u["streams"][2] == b"de" and u["first"] == b"first" and u["prior"] == b"prior" and u["chains"] == b"chains"
+    assert u["rec_prior"] == b"rp" and u["raw"] == 1234 and u["records"] == 21 and len(u["blocks"]) == 2 and u["blocks"][1].n_records == 11
     assert "num_records      = 63" in text

@@ -123,3 +123,22 @@ def test_frozen_automatic_parameters_round_trip(ctx):
     # the frozen rows code about as well as the adaptive ones
     ada = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO)
     assert enc.archive_bytes < 1.02 * ada.archive_bytes
+
+
+def test_given_prior_makes_block_bytes_independent_of_the_sharding(ctx):
+    """Multi-GPU contract: with ONE prior for the job (built by rank 0, installed everywhere) a record block's quality and
+    header bytes are the same whether one call coded the whole text or two calls coded its halves (what two ranks do)."""
+    import torch
+    fq = capi.synth_fastq(8000, 150, seed=77)
+    halves = util.split_records(fq, 4000)
+    d = torch.from_numpy(np.frombuffer(halves[0], np.uint8).copy()).cuda()
+    prior, rp = ctx.build_priors(d.data_ptr(), len(halves[0]), level=3, block_reads=500, tables=capi.TABLES_FROZEN)
+    assert prior and rp
+    ctx.set_priors(prior, rp)
+    whole = ctx.encode_host(fq, level=3, block_reads=500, prior_step=capi.PRIOR_GIVEN, tables=capi.TABLES_FROZEN, chain_reads=50)
+    assert whole.prior == prior and whole.rec_prior == rp
+    parts = [ctx.encode_host(h, level=3, block_reads=500, prior_step=capi.PRIOR_GIVEN, tables=capi.TABLES_FROZEN, chain_reads=50) for h in halves]
+    for name in ("qlt", "rec", "gen"):               # (iid bases: the generation tables stay off in either case)
+        assert whole.stream(name) == parts[0].stream(name) + parts[1].stream(name), name
+    assert ctx.decode_host(whole, level=3, out_cap=len(fq) + 4096) == fq
+    ctx.set_priors(b"", b"")
