@@ -387,11 +387,15 @@ def test_multi_file_driver(tmp_path):
     assert not (tmp_path / "SFQ" / "bad.sfq").exists()
 
 
-@pytest.mark.parametrize("kind,n,level", [(0, 10_000_000, 3), (2, 4_000_000, 4), (1, 20_000, 3)])
-def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level):
-    """BASELINE-size inputs (C3: 10 M x 150 bp; binned qualities at -l 4; C5 long reads), text resident in HBM.  The
-    oracle cannot run these in seconds, so the checks are the size-independent ones: decode(encode(x)) == x, the
-    block index adds up, a second encode gives the same bytes, the quality-only entry point gives the same stream."""
+# BASELINE configs at their full per-GPU sizes: C3 (10 M x 150 bp, -l 3), C4's per-GPU share (100 M reads over 8 GPUs = 12.5 M,
+# -l 4), binned qualities at -l 4, C5 long reads, the genome-sampled secondary workload; with frozen tables (the default
+# of block format 7) and with adaptive tables (a wavefront per block)
+@pytest.mark.parametrize("kind,n,level,tables", [(0, 10_000_000, 3, 1), (0, 12_500_000, 4, 1), (2, 4_000_000, 4, 1), (1, 20_000, 3, 1),
+                                                 (3, 2_000_000, 3, 1), (0, 10_000_000, 3, 0), (0, 12_500_000, 4, 0), (1, 20_000, 3, 0)])
+def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level, tables):
+    """BASELINE-size inputs, text resident in HBM.  The oracle cannot run these in seconds, so the checks are the
+    size-independent ones: decode(encode(x)) == x, the block and chain indexes add up, a second encode gives the same
+    bytes, the quality-only entry point gives the same stream."""
     import torch
     fq = capi.synth_fastq(n, 150, seed=3, kind=kind)
     nbytes = len(fq)
@@ -399,31 +403,46 @@ def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level):
     del fq
     cap = capi.lib().sfq_encode_bound(nbytes)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO)
+    kw = dict(level=level, block_reads=capi.BLOCK_AUTO if kind == 1 else 1024, prior_step=capi.PRIOR_AUTO, tables=tables)
+    res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, **kw)
     torch.cuda.synchronize()
     blocks = ctx.index(res.n_blocks)
     first = ctx.first_headers(res.first_hdr_bytes)
-    prior = ctx.prior()
-    assert res.n_records == n and sum(b.n_records for b in blocks) == n and res.n_blocks == (n + 1023) // 1024
+    prior, chains, rec_prior = ctx.prior(), ctx.chains(), ctx.rec_prior()
+    assert res.n_records == n and sum(b.n_records for b in blocks) == n
+    if kind != 1:
+        assert res.n_blocks == (n + 1023) // 1024
     for s in range(capi.NSTREAMS):
         assert sum(b.size[s] for b in blocks) == res.stream_bytes[s]
     assert sum(res.stream_bytes) == res.total_bytes and all(b.status == 0 for b in blocks)
+    if tables:
+        ci = util.unpack_chains(chains)
+        assert len(ci["qlt"]) == res.n_chains and int(ci["qlt"].sum()) == res.stream_bytes[2] and int(ci["gen"].sum()) == res.stream_bytes[1]
+        assert int(ci["rec"].sum()) == res.stream_bytes[0] and int(ci["rec_hdr_bytes"].sum()) == sum(b.hdr_bytes for b in blocks)
+        if kind == 3:
+            assert ci["flags"] & 1 and res.stream_bytes[1] * 8 < 1.7 * n * 150        # the generation tables learn the genome
+        if kind == 0:
+            assert not ci["flags"] & 1                                                  # iid bases: nothing to learn
+    else:
+        assert not chains and not rec_prior
     if kind == 0:
         assert 4.5 < nbytes / res.total_bytes < 5.5
     packed = d_out[:res.total_bytes].clone()
     soff, sbytes = list(res.stream_offset), list(res.stream_bytes)
-    # same input, same bytes (tables are reused under new epochs)
-    res2 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO)
+    # same input, same bytes (atomic counting passes and table reuse under new epochs included)
+    res2 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, **kw)
     torch.cuda.synchronize()
-    assert res2.total_bytes == res.total_bytes and torch.equal(d_out[:res.total_bytes], packed) and ctx.prior() == prior
+    assert res2.total_bytes == res.total_bytes and torch.equal(d_out[:res.total_bytes], packed)
+    assert ctx.prior() == prior and ctx.chains() == chains and ctx.rec_prior() == rec_prior
     # the quality model alone (BASELINE config C2) writes the same quality stream
-    res3 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=level, block_reads=1024, prior_step=capi.PRIOR_AUTO, qlt_only=True)
+    res3 = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, qlt_only=True, **kw)
     torch.cuda.synchronize()
     assert res3.stream_bytes[2] == sbytes[2]
     assert torch.equal(d_out[res3.stream_offset[2]: res3.stream_offset[2] + sbytes[2]], packed[soff[2]: soff[2] + sbytes[2]])
     # and back
     d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
-    got, _ = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=level)
+    got, _ = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=level,
+                               chains=chains, rec_prior=rec_prior)
     torch.cuda.synchronize()
     assert got == nbytes and torch.equal(d_back[:nbytes], d_in)
 
