@@ -409,3 +409,14 @@ def rec_encode_chains_frozen(buf: bytes, off, length, block_reads, chain_reads, 
     if got != nc:
         raise _err()
     return _take(out, n), sizes, hb
+
+
+def rec_encode_pre5(buf: bytes, off, length) -> bytes:
+    """A "rec" stream in the pre-version-5 layout (test input for load_pre5)."""
+    L = lib()
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    L.sfqo_rec_encode_pre5.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    if L.sfqo_rec_encode_pre5(buf, po, pl, len(off), C.byref(out), C.byref(n)) != 0:
+        raise _err()
+    return _take(out, n)

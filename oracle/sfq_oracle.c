@@ -1833,3 +1833,47 @@ long long sfqo_rec_encode_chains_frozen(const u8* base, const u64* off, const u3
     *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
     return g_failed ? -1 : (long long)nc;
 }
+
+
+/* ================================================================================================
+ * A "rec" stream in the PRE-VERSION-5 layout, for testing RecLoad::load_pre5 (recs.cpp:463-510).  The reference no longer
+ * has the encoder of that layout; this one is derived from the decoder: per changed field the type ST_DGT / ST_DLT
+ * (both the previous and the current text are numbers by is_number, recs.cpp:265-275, the gap between them) or ST_STR
+ * (length and characters); values come from the previous header's TEXT, nothing is cached.  Headers must keep their
+ * shape (no rec.x) and no numeric field may become 0 (sprintf("%lld") of 0 is "0", as the text was).
+ * ============================================================================================== */
+int sfqo_rec_encode_pre5(const u8* base, const u64* off, const u32* len, size_t nrec, u8** out, size_t* out_len) {
+    g_failed = 0; g_err[0] = 0;
+    recm r; rec_alloc(&r);
+    wr* w = wr_new_plain(); rc_init_save(&r.rc, w);
+    const u8* prev = NULL;
+    for (size_t k = 0; k < nrec && !g_failed; k++) {
+        const u8* buf = base + off[k];
+        if (k == 0) { map_space(&r, buf, 0); prev = buf; continue; }
+        space_map mp = r.smap[0];
+        map_space(&r, buf, 0);                                   /* the decoder maps the PREVIOUS header into smap[0]; we need both */
+        space_map mi = r.smap[0];
+        if (mi.len != mp.len || memcmp(mi.str, mp.str, (size_t)mi.len)) { fail("pre-5 test stream: the header shape changed"); break; }
+        u64 map = 0;
+        for (int i = 0; i < mi.len; i++)
+            if (mi.wln[i] != mp.wln[i] || memcmp(buf + mi.off[i], prev + mp.off[i], (size_t)mi.wln[i])) map |= 1ULL << i;
+        pwu_put(&r.ranger[0].num, &r.rc, map);
+        for (int i = 0; i < mi.len; i++) {
+            if (!(map & (1ULL << i))) continue;
+            long long pv, cv;
+            if (is_number(prev + mp.off[i], mp.wln[i], &pv) && is_number(buf + mi.off[i], mi.wln[i], &cv) && mp.wln[i] > 0 && mi.wln[i] > 0 && mi.wln[i] <= 18 && mp.wln[i] <= 18) {
+                if (cv >= pv) { pw_put(&r.ranger[i + 1].type, &r.rc, ST_DGT); pwu_put(&r.ranger[i + 1].num, &r.rc, (u64)(cv - pv)); }
+                else          { pw_put(&r.ranger[i + 1].type, &r.rc, ST_DLT); pwu_put(&r.ranger[i + 1].num, &r.rc, (u64)(pv - cv)); }
+            } else {
+                pw_put(&r.ranger[i + 1].type, &r.rc, ST_STR);
+                pwu_put(&r.ranger[i + 1].num, &r.rc, (u64)mi.wln[i]);
+                for (int j = 0; j < mi.wln[i]; j++) pw_put(&r.ranger[i + 1].str, &r.rc, buf[mi.off[i] + j]);
+            }
+        }
+        prev = buf;
+    }
+    rc_done(&r.rc);
+    free(r.ranger);
+    take(w, out, out_len);
+    return g_failed ? -1 : 0;
+}

@@ -113,6 +113,9 @@ int sfqo_rec_frozen_rows(const uint32_t* f, uint32_t* rows);
 long long sfqo_rec_encode_chains_frozen(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t block_reads, size_t chain_reads,
                                         const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* hdr_bytes);
 
+/* a "rec" stream in the pre-version-5 layout (what RecLoad::load_pre5, recs.cpp:463-510, reads): test input only */
+int sfqo_rec_encode_pre5(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, uint8_t** out, size_t* out_len);
+
 void sfqo_free(void* p);
 
 #ifdef __cplusplus

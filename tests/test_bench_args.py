@@ -26,7 +26,9 @@ def test_defaults_follow_the_workload_kind():
     b = load_bench()
     a = parse(b, [])
     assert (a.gpus, a.reads, a.read_len, a.level, a.block_reads, a.kind) == (1, 10_000_000, 150, 3, 1024, 0)
-    assert b.workload_name(a) == "synthetic 10M x 150 bp Illumina reads per GPU, full qlts+gens+recs, -l 3"
+    assert a.tables == 1
+    assert b.workload_name(a) == "synthetic 10M x 150 bp Illumina reads per GPU, full qlts+gens+recs, frozen tables (one chain per lane), -l 3"
+    assert "adaptive tables" in b.workload_name(parse(b, ["--tables", "0"]))
     a = parse(b, ["--kind", "1"])
     assert a.reads == 60_000 and a.block_reads == b.capi.BLOCK_AUTO and a.cpu_sample_reads <= 6_000
     assert "long reads" in b.workload_name(a)

@@ -97,6 +97,36 @@ def test_decode_reference_written_streams(ctx, name):
         assert out == gold.get("<decoded>", fq), (name, level)
 
 
+def test_decode_pre5_header_stream(ctx):
+    """RecLoad::load_pre5 (recs.cpp:463-510): archives of format versions < 5 code a numeric field as the gap to the number
+    read back from the previous header's TEXT.  No such archive ships with the reference, so the stream is written by an
+    encoder derived from that decoder (oracle sfqo_rec_encode_pre5); the other streams are the reference's as usual."""
+    fq = capi.synth_fastq(1500, 100, seed=44)
+    # no numeric header field of the synthetic reads is ever 0 or has a leading zero, and the shape is constant: what pre-5 can express
+    starts, lens = util.line_table(fq)
+    ref = O.compress(fq, 3).streams
+    info = util.info_of(ref)
+    rec4 = O.rec_encode_pre5(fq, starts[0::4] + 1, lens[0::4] - 1)
+    assert rec4 != ref["rec"]
+    bi = capi.BlockInfo()
+    bi.first_record = 0
+    bi.n_records = int(info["num_records"]); bi.llen = int(info["llen"])
+    bi.two_id = int(info["usr.2id"]); bi.gen_bits = LEVEL_BITS[3]
+    first = info["rec.first"].encode("latin1")
+    bi.first_hdr_off = 0; bi.first_hdr_len = len(first)
+    data = b""; soff = []
+    for i, name in enumerate(capi.STREAM_NAMES):
+        piece = rec4 if name == "rec" else ref.get(name, b"")
+        soff.append(len(data)); data += piece; bi.size[i] = len(piece)
+    blocks = (capi.BlockInfo * 1)(bi)
+    assert ctx.decode_host((blocks, first, data, soff), level=3, version=4, out_cap=len(fq) * 2 + 4096) == fq
+    # read as a version >= 5 stream the same bytes do not decode to the text
+    try:
+        assert ctx.decode_host((blocks, first, data, soff), level=3, version=6, out_cap=len(fq) * 2 + 4096) != fq
+    except capi.SfqError:
+        pass
+
+
 @pytest.mark.parametrize("level", (1, 2, 3, 4))
 def test_roundtrip_blocks(ctx, level):
     fq = capi.synth_fastq(4100, 150, seed=30 + level)
