@@ -48,8 +48,9 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags;
+    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf;
     u32 r_hot = 0;
+    void* pin = nullptr; size_t pin_cap = 0;       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
     bool prior_on = false;                 // the device prior tables are valid for the running call
@@ -87,6 +88,14 @@ int level_gen_bits(int level) {   // gens.hpp:43-53
 int clamp_level(int level) { return level > 4 ? 4 : level < 1 ? 1 : level; }   // config.cpp:232-237
 
 // Size the model tables for `want` concurrent block slots (or fewer if the budget says so).
+int reserve_pinned(sfq_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pin_cap && ctx->pin) return SFQ_OK;
+    if (ctx->pin) { HIPC(hipDeviceSynchronize()); HIPC(hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_cap = 0; }
+    HIPC(hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+    ctx->pin_cap = bytes;
+    return SFQ_OK;
+}
+
 int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u32* got) {
     const u64 per_q = (models & SFQ_M_QLT) ? (u64)q_rows * (L64_NSYM * 4 + sizeof(RowHdr)) : 0;
     const u64 per_p = (u64)PR_ROWS * (PW_NSYM * 4 + sizeof(RowHdr));
@@ -330,21 +339,31 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
 }
 // The header prior of an encode with frozen tables: counted over this call's text -- the header model run over short runs
 // of records spread over the call -- or the installed one (SFQ_PRIOR_GIVEN); leaves the frozen rows on the device.
-int rec_prior_for_encode(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipStream_t st) {
+// Two halves, so that the launching thread can queue other streams' work while the counting pass runs: _begin queues the
+// pass and the copy of its counts to pinned host memory (PIN_REC_OFF), _finish waits for them and builds the rows.
+#define PIN_GEN_OFF 0u
+#define PIN_REC_OFF 64u
+#define PIN_BYTES (PIN_REC_OFF + (size_t)PR_REC_ROWS * 256 * 4)
+int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipStream_t st) {
+    if (given) return SFQ_OK;
     int rc;
+    if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
+    HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, st));
+    const u32 run = 18;
+    const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
+    const u64 stride = std::max<u64>(run, nrec / nruns);
+    launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, st);
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
+    return SFQ_OK;
+}
+int rec_prior_finish(sfq_ctx* ctx, bool given, hipStream_t st) {
     std::vector<u32> hf;
     if (given) {
         if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
     } else {
-        if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
-        HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, st));
-        const u32 run = 18;
-        const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
-        const u64 stride = std::max<u64>(run, nrec / nruns);
-        launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, st);
-        std::vector<u32> hc((size_t)PR_REC_ROWS * 256);
-        HIPC(hipMemcpyAsync(hc.data(), ctx->hcnt.p, hc.size() * 4, hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
+        const u32* c = (const u32*)((const u8*)ctx->pin + PIN_REC_OFF);
+        std::vector<u32> hc(c, c + (size_t)PR_REC_ROWS * 256);
         ctx->rec_prior_blob = pack_rec_prior(hc, hf);
     }
     return upload_rec_rows(ctx, hf, st);
@@ -353,11 +372,10 @@ int rec_prior_for_encode(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given,
 // Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
 // of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
 // Leaves ca.g_* describing which rows every generation codes with.
-int gen_tables_encode(sfq_ctx* ctx, ChainArgs& ca, u32 nblocks, u32 g_bits, hipStream_t st, u32* gen_on) {
-    *gen_on = 0;
-    ca.g_ngen = 0;
-    u32 bound[GEN_MAX_GENERATIONS + 1];
-    const u32 ngen = gen_bounds(nblocks, bound);
+struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; };
+int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits, hipStream_t st, GenPlan& gp) {
+    u32* bound = gp.bound;
+    const u32 ngen = gp.ngen = gen_bounds(nblocks, bound);
     if (ngen < 3) return SFQ_OK;                                   // too few blocks to learn from
     const u64 nctx = 1ull << g_bits;
     int rc;
@@ -378,11 +396,21 @@ int gen_tables_encode(sfq_ctx* ctx, ChainArgs& ca, u32 nblocks, u32 g_bits, hipS
     launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
     launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
     launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
-    u64 h[2] = {0, 0};
-    // bases of generation 1: counted on the device as cost[1]?  cheaper: the host knows the text span; use the cost of the
-    // initial row instead -- 2 bits per base = 2048 units -- by letting the kernel report the base count
-    HIPC(hipMemcpyAsync(h, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
+    // the cost of generation 1 under generation 0's rows, and its bases (the initial row would cost 2 bits = 2048 units each)
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
+    return SFQ_OK;
+}
+int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, hipStream_t st, const GenPlan& gp, u32* gen_on) {
+    *gen_on = 0;
+    ca.g_ngen = 0;
+    const u32 ngen = gp.ngen; const u32* bound = gp.bound;
+    if (ngen < 3) return SFQ_OK;
+    const u64 nctx = 1ull << g_bits;
+    const u64 br = ca.block_reads;
+    auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };
+    u32* rows = (u32*)ctx->grows.p;
     HIPC(hipStreamSynchronize(st));
+    const u64* h = (const u64*)((const u8*)ctx->pin + PIN_GEN_OFF);
     const u64 cost = h[0], nbases = h[1];
     if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // no gain: every chain codes with the initial row
     *gen_on = 1;
@@ -441,8 +469,9 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf };
     for (DevBuf* b : all) release(*b);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
@@ -545,8 +574,84 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
     if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
     ctx->chain_blob.clear();
-    std::vector<u32> h_rows66;
     if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
+    u32 slots = 0;
+    const u32 KR = 2;                                                  // the default kernels take table slots in pairs (two blocks per wave)
+    const u32 nblocks_r = (nblocks + KR - 1) / KR * KR;
+    ModelArgs a;
+    u32* tickets = nullptr;
+    auto setup_tables = [&]() -> int {
+        int rc;
+        if ((rc = ensure_tables(ctx, nblocks_r, q_rows, (u32)g_bits, frozen ? (models & ~(SFQ_M_QLT | SFQ_M_GEN)) : models, &slots))) return rc;
+        if (p.kernel == 0) {
+            if (slots < KR) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B holds %u block slot(s); the kernels need %u", (unsigned long long)ctx->table_budget, slots, KR);
+            slots &= ~(KR - 1);
+        }
+        if ((rc = advance_epoch(ctx, nblocks))) return rc;
+        fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
+        a.fq = d_fastq;
+        // Default kernels are persistent: one workgroup per pair of table slots, blocks handed out through ticket counters.
+        if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
+        HIPC(hipMemsetAsync(ctx->tickets.p, 0, 64, st));
+        tickets = (u32*)ctx->tickets.p;
+        return SFQ_OK;
+    };
+    // The four models are independent chains over the same text: each runs on its own HIP stream, forked
+    // from / joined to the context's stream with events, so their kernels overlap on the chip.
+    // (frozen tables: the header and base models each need one host decision in the middle -- their counting passes are
+    //  queued first, ahead of the quality prior, and finished in the order they come back)
+    const u32 order[4] = { SFQ_M_QLT, frozen ? SFQ_M_REC : SFQ_M_GEN, SFQ_M_USR, frozen ? SFQ_M_GEN : SFQ_M_REC };
+    const int tslot[4] = { SFQ_T_QLT, frozen ? SFQ_T_REC : SFQ_T_GEN, SFQ_T_USR, frozen ? SFQ_T_GEN : SFQ_T_REC };
+    hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
+    // frozen tables: chain geometry; then everything that reads only the text starts now, beside the quality prior
+    ChainArgs ca;
+    memset(&ca, 0, sizeof ca);
+    u32 nchains = 0, nsub = 0;
+    GenPlan gplan;
+    if (frozen) {
+        const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
+        ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
+        ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
+        const u32 last_nrec = (u32)(nrec - (u64)(nblocks - 1) * block_reads);
+        const u64 nc = (u64)(nblocks - 1) * ca.geo.cpb + (last_nrec + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
+        if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
+        nchains = ca.geo.nchains = (u32)nc;
+        ca.nbytes = nbytes; ca.block_reads = block_reads;
+        // header chains: longer than the quality / base chains (each starts from the block's first header with cold field
+        // types, which costs it a few bytes)
+        {
+            const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(256u, ca.geo.chain_reads), block_reads), nrec);
+            ca.rgeo.chain_reads = rcr;
+            ca.rgeo.cpb = (block_reads + rcr - 1) / rcr;
+            nsub = ca.rgeo.nchains = (u32)((u64)(nblocks - 1) * ca.rgeo.cpb + (last_nrec + rcr - 1) / rcr);
+        }
+        if ((rc = reserve(ctx, ctx->csz, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4))) return rc;
+        HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
+        if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
+        if ((rc = setup_tables())) return rc;
+        // the pass over the N / quality-0 exceptions looks only at the records the quality and base chains mark
+        const bool exc_marks = (models & SFQ_M_QLT) && (models & SFQ_M_GEN);
+        if (exc_marks) {
+            if ((rc = reserve(ctx, ctx->excf, (size_t)nrec))) return rc;
+            HIPC(hipMemsetAsync(ctx->excf.p, 0, (size_t)nrec, st));
+            ca.exc_flag = (u8*)ctx->excf.p;
+        }
+        HIPC(hipEventRecord(ctx->ev[13], st));
+        if (!priors_only) {
+            for (int m = 1; m < 4; m++) { HIPC(hipStreamWaitEvent(mst[m], ctx->ev[13], 0)); HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m])); }
+            a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
+            ca.m = a;
+            if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc; }
+            if (models & SFQ_M_GEN) {
+                if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, mst[3], gplan))) return rc;
+                if (!ca.exc_flag) launch_gen_exc_w(a, nullptr, tickets + 1, mst[2]);       // nobody marks the records: all of them, beside the chains
+            }
+            if (models & SFQ_M_USR)
+                for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
+            HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
+        }
+    }
+    u32* h_rows66 = nullptr;
     // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
     // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
@@ -571,34 +676,14 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
-        h_rows66.resize((size_t)q_rows * 66);
-        HIPC(hipMemcpyAsync(h_rows66.data(), ctx->rows66.p, h_rows66.size() * 4, hipMemcpyDeviceToHost, st));
+        if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
+        h_rows66 = (u32*)((u8*)ctx->pin + PIN_BYTES);
+        HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, st));
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
-    // frozen tables: chain geometry, dense quality rows
-    ChainArgs ca;
-    memset(&ca, 0, sizeof ca);
-    u32 nchains = 0, nsub = 0;
+    // frozen tables: dense quality rows
     if (frozen) {
-        const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
-        ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
-        ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
-        const u32 last_nrec = (u32)(nrec - (u64)(nblocks - 1) * block_reads);
-        const u64 nc = (u64)(nblocks - 1) * ca.geo.cpb + (last_nrec + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
-        if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
-        nchains = ca.geo.nchains = (u32)nc;
-        ca.nbytes = nbytes; ca.block_reads = block_reads;
-        // header chains: longer than the quality / base chains (each starts from the block's first header with cold field
-        // types, which costs it a few bytes)
-        {
-            const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(256u, ca.geo.chain_reads), block_reads), nrec);
-            ca.rgeo.chain_reads = rcr;
-            ca.rgeo.cpb = (block_reads + rcr - 1) / rcr;
-            nsub = ca.rgeo.nchains = (u32)((u64)(nblocks - 1) * ca.rgeo.cpb + (last_nrec + rcr - 1) / rcr);
-        }
-        if ((rc = reserve(ctx, ctx->csz, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4))) return rc;
-        HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
         if (models & SFQ_M_QLT) {
             if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
             if ((rc = build_qesc(ctx, st))) return rc;
@@ -631,38 +716,50 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             HIPC(hipEventRecord(ctx->ev[1], st));
         }
     }
-    u32 slots = 0;
-    const u32 KR = 2;                                                  // the default kernels take table slots in pairs (two blocks per wave)
-    const u32 nblocks_r = (nblocks + KR - 1) / KR * KR;
-    if ((rc = ensure_tables(ctx, nblocks_r, q_rows, (u32)g_bits, frozen ? (models & ~(SFQ_M_QLT | SFQ_M_GEN)) : models, &slots))) return rc;
-    if (p.kernel == 0) {
-        if (slots < KR) return fail(ctx, SFQ_E_NOMEM, "table budget %llu B holds %u block slot(s); the kernels need %u", (unsigned long long)ctx->table_budget, slots, KR);
-        slots &= ~(KR - 1);
-    }
-    if ((rc = advance_epoch(ctx, nblocks))) return rc;
-    ModelArgs a;
-    fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
-    a.fq = d_fastq;
+    if (!frozen) { if ((rc = setup_tables())) return rc; }
     if (priors_only) {
-        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_for_encode(ctx, a, nrec, given, st))) return rc; }
+        if (frozen && (models & SFQ_M_REC)) {
+            if ((rc = rec_prior_begin(ctx, a, nrec, given, st))) return rc;
+            if ((rc = rec_prior_finish(ctx, given, st))) return rc;
+        }
         HIPC(hipStreamSynchronize(st));
-        if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
+        if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66, q_rows);
         ctx->prior_on = false;
         res->n_records = nrec; res->n_blocks = nblocks;
         return SFQ_OK;
     }
-    // The four models are independent chains over the same text: each runs on its own HIP stream, forked
-    // from / joined to the context's stream with events, so their kernels overlap on the chip.
-    // (frozen tables: the base model's generation tables need one host decision in the middle, so bases go last)
-    const u32 order[4] = { SFQ_M_QLT, frozen ? SFQ_M_REC : SFQ_M_GEN, SFQ_M_USR, frozen ? SFQ_M_GEN : SFQ_M_REC };
-    const int tslot[4] = { SFQ_T_QLT, frozen ? SFQ_T_REC : SFQ_T_GEN, SFQ_T_USR, frozen ? SFQ_T_GEN : SFQ_T_REC };
     u32 gen_on = 0;
-    hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
-    // Default kernels are persistent: one workgroup per pair of table slots, blocks handed out through ticket counters.
+    if (frozen) {
+        // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (bases) first
+        a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
+        HIPC(hipEventRecord(ctx->ev[2], st));
+        if (models & SFQ_M_QLT) { ca.m = a; ca.csz = (u32*)ctx->csz.p; launch_qlt_encode_c(ca, st); }
+        HIPC(hipEventRecord(ctx->ev[3], st));
+        if (models & SFQ_M_GEN) {
+            ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
+            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, mst[3], gplan, &gen_on))) return rc;
+            launch_gen_encode_c(ca, mst[3]);
+        }
+        HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
+        if (models & SFQ_M_REC) {
+            if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
+            ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
+            ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
+            if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
+            HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
+            ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
+            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[1]);
+        }
+        HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
+        if ((models & SFQ_M_GEN) && ca.exc_flag) {                  // the marks are complete once both chain kernels are through
+            HIPC(hipStreamWaitEvent(mst[3], ctx->ev[3], 0));
+            launch_gen_exc_w(a, ca.exc_flag, tickets + 1, mst[3]);
+            HIPC(hipEventRecord(ctx->ev[12], mst[3]));
+            HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
+        }
+        for (int m = 1; m < 4; m++) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
+    } else {
     // The lane-per-block reference kernels (kernel = 1, and usr) run in batches of `slots` blocks.
-    if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
-    HIPC(hipMemsetAsync(ctx->tickets.p, 0, 64, st));
-    u32* tickets = (u32*)ctx->tickets.p;
     if ((models & SFQ_M_GEN) && p.kernel == 1)   // first batch's Base2 tables (base2_ranger.hpp:68-71), while the chip is idle
         launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)std::min(slots, nblocks) << g_bits, 0x03030303u, st);
     HIPC(hipEventRecord(ctx->ev[1], st));
@@ -680,34 +777,10 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 if ((models & (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC)) == (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC) &&
                     (order[m] == SFQ_M_QLT || order[m] == SFQ_M_GEN))
                     a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * KR) & ~(KR - 1)));
-                if (frozen) a.nbatch = std::min(slots, nblocks_r);          // the chain kernels are short: nobody keeps to a share
                 switch (order[m]) {
-                case SFQ_M_QLT:
-                    if (frozen) { ca.m = a; ca.csz = (u32*)ctx->csz.p; launch_qlt_encode_c(ca, mst[m]); }
-                    else launch_qlt_encode_k(a, tickets + 0, mst[m]);
-                    break;
-                case SFQ_M_GEN:
-                    if (frozen) {
-                        ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
-                        if ((rc = gen_tables_encode(ctx, ca, nblocks, (u32)g_bits, mst[m], &gen_on))) return rc;
-                        launch_gen_encode_c(ca, mst[m]);
-                        // the N / quality-0 exceptions are independent of the chains: on the framing stream, beside them
-                        launch_gen_exc_w(a, tickets + 1, mst[2]);
-                        HIPC(hipEventRecord(ctx->ev[12], mst[2]));
-                        HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
-                    } else launch_gen_encode_k(a, tickets + 1, mst[m]);
-                    break;
-                case SFQ_M_REC:
-                    if (frozen) {
-                        if ((rc = rec_prior_for_encode(ctx, a, nrec, given, mst[m]))) return rc;
-                        ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
-                        ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
-                        if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
-                        HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[m]));
-                        ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
-                        launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[m]);
-                    } else launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]);
-                    break;
+                case SFQ_M_QLT: launch_qlt_encode_k(a, tickets + 0, mst[m]); break;
+                case SFQ_M_GEN: launch_gen_encode_k(a, tickets + 1, mst[m]); break;
+                case SFQ_M_REC: launch_rec_encode_w(a, tickets + 2, tickets + 3, mst[m]); break;
                 }
             } else {
                 for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
@@ -726,6 +799,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * m], mst[m]));
         if (m) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
+    }
     }
     HIPC(hipEventRecord(ctx->ev[10], st));
     ctx->epoch_base += nblocks;
@@ -788,7 +862,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
 
-    if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66.data(), q_rows);
+    if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66, q_rows);
     ctx->prior_on = false;
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes

@@ -110,7 +110,7 @@ __device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {     
 // character.  The lane takes them in 16-byte pieces that are aligned in memory; next() describes the coming piece from
 // the line bounds alone, so the caller can have the piece after the one it is working on in flight, and the bounds of
 // a line are themselves fetched a record ahead: no memory round trip sits on the lane's critical path.
-struct Piece { u64 at; u32 j0, j1; bool valid, newline; };      // bytes [j0, j1) of the 16 at offset `at` are the lane's; newline: they start a line
+struct Piece { u64 at; u32 j0, j1, rk; bool valid, newline; };  // bytes [j0, j1) of the 16 at offset `at` are the lane's, of the walk's record rk; newline: they start a line
 struct LineWalk {
     const u64* line_off; const u64* st_off; const u32* st_len;   // FASTQ text (line_off) or the decoder's staged lines (st_off / st_len)
     const u8* buf; u64 nbytes; u32 mis;
@@ -134,7 +134,7 @@ struct LineWalk {
             if (k < nrec) bounds(k, npos, nend);                   // used a whole line later
             if (end < pos) end = pos;
         }
-        Piece p; p.valid = pos < end; p.newline = false; p.at = 0; p.j0 = 16; p.j1 = 0;
+        Piece p; p.valid = pos < end; p.newline = false; p.at = 0; p.j0 = 16; p.j1 = 0; p.rk = k - 1;
         if (p.valid) {
             p.at = ((pos + mis) & ~15ull) - mis;                   // aligned in memory; "negative" (wrapped) only in front of the buffer
             p.j0 = (u32)(pos - p.at);
@@ -196,12 +196,14 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
         if (pc.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
         // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once
         u32 e[16];
+        u32 lowest = 255;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             e[j] = 0;
             if (j >= pc.j0 && j < pc.j1) {
                 const u32 b = (piece_byte(w, j) - '!') & 0xffu;
                 const u32 sym = b < LAST_QLT ? b : LAST_QLT;
+                lowest = b < lowest ? b : lowest;
                 if constexpr (LDS) {
                     const u32 hv = ltab[qh_hash(last)];
                     e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 }
             }
         }
+        // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
+        if (a.exc_flag && lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
         // (b) the serial part: the range coder
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
@@ -371,7 +375,7 @@ __device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0.
 // caller can start its table lookups together), then code(j, code) for each base in order.  The bases come from the FASTQ
 // text or from the decoder's staged bases (ChainArgs::st_*).  N is coded as 0 (gens.cpp:116-136).
 template <typename LOOK, typename CODE>
-__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, LOOK&& look, CODE&& code) {
+__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, LOOK&& look, CODE&& code, u8* exc_flag = nullptr) {
     LineWalk lw; lw.init(a, r0, nrec, 1, solid);
     u32 last = 0;
     Piece pc = lw.next();
@@ -381,15 +385,20 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
         const uint4 wn = lw.fetch(pn);
         if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
         u32 codes = 0;                                             // 2 bits per base of the piece
+        u32 odd = 0;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             if (j >= pc.j0 && j < pc.j1) {
-                const u32 cd = gen_code_of(piece_byte(w, j)) & 3u;
+                const u32 cd4 = gen_code_of(piece_byte(w, j));
+                const u32 cd = cd4 & 3u;
+                odd |= cd4;
                 look(j, last & mask);
                 last = (last << 2) | cd;
                 codes |= cd << (2 * j);
             }
         }
+        // an N or an illegal character marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
+        if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) code(j, (codes >> (2 * j)) & 3u);
         pc = pn; w = wn;
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     if (!__any(rows != nullptr)) {
         // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
         const u32 r12 = fz_recip(12u);
-        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, [&](u32, u32) {}, [&](u32, u32 code) { rc.encode(3u * code, 3u, 12u, r12); });
+        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, [&](u32, u32) {}, [&](u32, u32 code) { rc.encode(3u * code, 3u, 12u, r12); }, a.exc_flag);
     } else {
         u32 rv[16];
         walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u,
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
                 const u32 tot = (f0 + f1) + (f2 + f3);
                 const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
                 rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                // base2_ranger.hpp:74-84 without the update
-            });
+            }, a.exc_flag);
     }
     if (live) {
         a.csz[c] = rc.finish();

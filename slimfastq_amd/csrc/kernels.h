@@ -63,6 +63,7 @@ struct ChainArgs {
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
     const u32* rcoarse;         // [PR_REC_ROWS][16] cum at every 16th symbol (decode)
     const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> slot (0xFFFF = none), slot -> row, how many
+    u8* exc_flag;               // encode: [records] set to 1 by the quality / base chains where a record holds a '!' / an N (null = not wanted)
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
     // bases: generation tables
@@ -76,7 +77,8 @@ void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
-void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st);       // gen.Ns / gen.Nn side streams, a wave per block (models_k.hip)
+// gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
+void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st);
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, hipStream_t st);   // one header chain per lane; a.csz / a.rhb per chain

@@ -172,7 +172,9 @@ struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
 // each gap through the wave-cooperative PowerRanger rows (a gap is 1-2 symbols of a 256-slot row: on one lane the row
 // search is a walk of dependent HBM reads, ~100 us per gap)
 // =========================================================================================================
-__global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
+// flags (from the quality and base chains, which have read every byte anyway): the records that may hold an N or a '!';
+// the others only move the base offset on, 64 records a step.  Null: every record is looked at.
+__global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restrict__ flags, u32* ticket) {
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
@@ -184,12 +186,24 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
         const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
         u64 genofs = 0, ns_index = 0, nn_index = 0;
         u32 n_byte = 0; int bad = 0;
-        // the next record's line bounds are fetched a record ahead; a record is taken 256 bases at a time (four loads
-        // per lane in flight), so a 150-base read costs one memory round trip, not three
-        u64 ng0 = a.line_off[4 * rec0 + 1], ng1 = a.line_off[4 * rec0 + 2], nq0 = a.line_off[4 * rec0 + 3], nq1 = a.line_off[4 * rec0 + 4];
-        for (u32 k = 0; k < nrec; k++) {
-            const u64 g0 = ng0 + solid, g1 = ng1 - 1, q0 = nq0 + solid, q1 = nq1 - 1;
-            if (k + 1 < nrec) { const u64 r1 = rec0 + k + 1; ng0 = a.line_off[4 * r1 + 1]; ng1 = a.line_off[4 * r1 + 2]; nq0 = a.line_off[4 * r1 + 3]; nq1 = a.line_off[4 * r1 + 4]; }
+        // 64 records a step: lane = record; the base offsets of the marked ones come from a wave scan over the line lengths.
+        // A marked record is taken 256 bases at a time (four loads per lane in flight).
+        for (u32 k0 = 0; k0 < nrec; k0 += 64) {
+          const u32 kk = k0 + lane;
+          const bool have = kk < nrec;
+          const u64 rr = rec0 + (have ? kk : 0);
+          const u64 lg0 = a.line_off[4 * rr + 1] + solid, lg1 = a.line_off[4 * rr + 2] - 1;
+          const u32 my_llen = have && lg1 > lg0 ? (u32)(lg1 - lg0) : 0u;
+          const u32 incl = wave_incl_scan(my_llen);
+          const u32 excl = incl - my_llen;
+          u64 todo = __ballot(have && (flags ? flags[rr] != 0 : true));
+          const u64 genofs0 = genofs;
+          while (todo) {
+            const u32 pick = (u32)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            const u64 r = rec0 + k0 + pick;
+            genofs = genofs0 + rl(excl, pick);
+            const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1, q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
             const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
             const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
             for (u32 base0 = 0; base0 < llen; base0 += 256) {
@@ -228,6 +242,8 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
                     genofs += m;
                 }
             }
+          }
+          genofs = genofs0 + rl(incl, 63);
         }
         const u32 sz_ns = x_ns.finish(pw, lane), sz_nn = x_nn.finish(pw, lane);
         if (lane == 0) {
@@ -240,8 +256,8 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, u32* ticket) {
         }
     }
 }
-void launch_gen_exc_w(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, ticket);
+void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, flags, ticket);
 }
 
 
