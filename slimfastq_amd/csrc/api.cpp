@@ -383,8 +383,9 @@ int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits,
     if ((rc = reserve(ctx, ctx->grows, (size_t)nctx * 4 * ngen))) return rc;
     if ((rc = reserve(ctx, ctx->gcost, 64))) return rc;
     if (!ctx->glog.p) {
-        if ((rc = reserve(ctx, ctx->glog, 1024 * 2))) return rc;
-        u16 t[1024]; log2_table(t);
+        if ((rc = reserve(ctx, ctx->glog, 1024 * 2 + 64))) return rc;
+        u16 t[1024 + 32] = {0}; log2_table(t);
+        t[1024] = t[1025] = 0x0303;                               // the initial row, for ChainArgs::g_init
         HIPC(hipMemcpyAsync(ctx->glog.p, t, sizeof t, hipMemcpyHostToDevice, st));
         HIPC(hipStreamSynchronize(st));
     }
@@ -415,6 +416,7 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, hipStream_t st, c
     if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // no gain: every chain codes with the initial row
     *gen_on = 1;
     ca.g_ngen = ngen;
+    ca.g_init = (const u32*)((const u8*)ctx->glog.p + 2048);
     for (u32 g = 0; g <= ngen; g++) ca.g_bound[g] = bound[g];
     ca.g_rows[0] = nullptr; ca.g_rows[1] = nullptr;                             // generations 0 and 1: the initial row
     for (u32 g = 2; g < ngen; g++) {
@@ -554,7 +556,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (g_bits < 2 || g_bits > 26 ) return fail(ctx, SFQ_E_ARG, "gen_bits %d out of range", g_bits);
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
-    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 7 + (size_t)nblocks * 1024 + 4096))) return rc;
+    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 8 + (size_t)nblocks * 1024 + 4096))) return rc;
     u32 h_status = 0;
     HIPC(hipMemcpyAsync(&h_status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
@@ -848,7 +850,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     std::vector<u32> h_csz;
     if (frozen) {
         if (chain_streams & (1u << SFQ_S_QLT))
-            launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 1, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+            launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         if (chain_streams & (1u << SFQ_S_GEN))
             launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         if (chain_streams & (1u << SFQ_S_REC))

@@ -91,7 +91,7 @@ __device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
 __device__ __forceinline__ u8* chain_region(const ChainArgs& a, const ChainPos& p, int stream, u32 num, u32 den, u32& cap) {
     const BlockDesc* d = &a.m.blocks[p.b];
     const u64 t0 = a.m.line_off[4 * d->rec0], tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
-    const u64 lo = ((tc - t0) * num / den + 3) & ~3ull, hi = ((te - t0) * num / den) & ~3ull;
+    const u64 lo = ((tc - t0) * num / den + 3) & ~3ull, hi = ((te - t0) * num / den) & ~3ull;        // (dword-aligned: LaneEncB::drain stores 16 bytes at such addresses)
     cap = hi > lo ? (u32)(hi - lo) : 0u;
     return a.m.arena + d->out_off[stream] + lo;
 }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     if (live) cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
     LaneEnc rc; u32 cap = 0;
-    u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 1, 1, cap) : nullptr;
+    u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 2, 1, cap) : nullptr;
     rc.init(outp, cap);
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
@@ -405,6 +405,40 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
     }
 }
 
+// The encoder's walk, without branches inside a piece: the codes come from a 256-entry table in LDS (code | 4 for an
+// N-like character | 0x10 for an illegal one), look(j, ctx) runs for all 16 positions (a position outside the lane's
+// bytes repeats the context before it, so its lookup is harmless), code(j, code, valid) likewise with a flag, and
+// piece_end() once per piece.
+template <typename LOOK, typename CODE, typename PEND>
+__device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, const u8* lut, LOOK&& look, CODE&& code, PEND&& piece_end, u8* exc_flag) {
+    LineWalk lw; lw.init(a, r0, nrec, 1, solid);
+    u32 last = 0;
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    while (__any(pc.valid)) {
+        const Piece pn = lw.next();
+        const uint4 wn = lw.fetch(pn);
+        if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
+        u32 cd4[16];
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) cd4[j] = lut[piece_byte(w, j)];
+        u32 codes = 0, odd = 0;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
+            look(j, last & mask);
+            last ^= (last ^ ((last << 2) | (cd4[j] & 3u))) & vm;
+            codes |= (cd4[j] & 3u) << (2 * j);
+            odd |= cd4[j] & vm;
+        }
+        if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) code(j, (codes >> (2 * j)) & 3u, (j >= pc.j0 && j < pc.j1) ? ~0u : 0u);
+        piece_end();
+        pc = pn; w = wn;
+    }
+}
+
 // counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
 // cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
 __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32* __restrict__ cnt, const u32* __restrict__ rows,
@@ -470,35 +504,47 @@ __device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
     return a.g_rows[g];
 }
 
+#define GEN_RING 16      // ring dwords per lane: a piece adds at most 16 bases x 2 bytes
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     __shared__ u32 rcp[1024];                                 // reciprocals of the row totals (<= 1020)
+    __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
+    __shared__ u32 ring[(GEN_RING + 1) * THREADS];
     for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
+    for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)gen_code_of(i);
     __syncthreads();
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < a.geo.nchains;
     ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
     if (live) cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
-    LaneEnc rc; u32 cap = 0;
+    LaneEncB<THREADS, GEN_RING> rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
-    rc.init(outp, cap);
+    rc.init(ring, threadIdx.x, outp, cap);
     const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
     if (!__any(rows != nullptr)) {
         // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
         const u32 r12 = fz_recip(12u);
-        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, [&](u32, u32) {}, [&](u32, u32 code) { rc.encode(3u * code, 3u, 12u, r12); }, a.exc_flag);
+        walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
+            [&](u32, u32 code, u32 vm) { rc.encode_if(vm, 3u * code, 3u, 12u, r12); },
+            [&]() { rc.drain(); }, a.exc_flag);
     } else {
+        // a lane whose generation has no rows yet reads the initial row from a one-entry table
+        const u32* rp = rows ? rows : a.g_init;
+        const u32 mask = (live && rows) ? (1u << d->gen_bits) - 1u : 0u;
         u32 rv[16];
-        walk_bases(a, cp.r0, cp.nrec, live ? d->solid : 0u, live ? (1u << d->gen_bits) - 1u : 0u,
-            [&](u32 j, u32 ctx) { rv[j] = rows ? rows[ctx] : B2_INIT; },
-            [&](u32 j, u32 code) {
+        walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, mask, lut,
+            [&](u32 j, u32 ctx) { rv[j] = rp[ctx]; },
+            [&](u32 j, u32 code, u32 vm) {
                 const u32 v = rv[j];
                 const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
                 const u32 tot = (f0 + f1) + (f2 + f3);
-                const u32 cum = code == 0 ? 0u : code == 1 ? f0 : code == 2 ? f0 + f1 : f0 + f1 + f2;
-                rc.encode(cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);                // base2_ranger.hpp:74-84 without the update
-            }, a.exc_flag);
+                // cum = the sum of the bytes of v below byte `code`
+                const u32 below = v & ((1u << (8 * code)) - 1u);
+                const u32 cum = (below & 0xff) + ((below >> 8) & 0xff) + (below >> 16);
+                rc.encode_if(vm, cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);          // base2_ranger.hpp:74-84 without the update
+            },
+            [&]() { rc.drain(); }, a.exc_flag);
     }
     if (live) {
         a.csz[c] = rc.finish();
@@ -583,7 +629,7 @@ __device__ __forceinline__ RecChainPos rec_chain_pos(const ChainArgs& a, u32 c) 
 __device__ __forceinline__ u8* rec_chain_region(const ChainArgs& a, const RecChainPos& p, u32& cap) {
     const BlockDesc* d = &a.m.blocks[p.b];
     const u64 t0 = a.m.line_off[4 * d->rec0], tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
-    const u64 lo = ((tc - t0) * 3 / 2 + 3) & ~3ull, hi = ((te - t0) * 3 / 2) & ~3ull;
+    const u64 lo = ((tc - t0) * 3 / 2 + 3) & ~3ull, hi = ((te - t0) * 3 / 2) & ~3ull;             // as chain_region(.., 3, 2, ..): k_compact_chains reads through that
     cap = hi > lo ? (u32)(hi - lo) : 0u;
     return a.m.arena + d->out_off[SFQ_S_REC] + lo;
 }

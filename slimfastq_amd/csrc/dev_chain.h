@@ -81,6 +81,112 @@ struct LaneEnc {
     }
 };
 
+// The same coder without branches in the per-symbol path: a renormalisation step is executed by every lane and takes
+// effect where the lane needs it (selects, a shift by 0 or 8), its output byte goes to a per-lane ring in LDS (or to a
+// dummy slot), and the ring is drained to the chain's region 16 bytes at a time, once per piece of text.  A lone
+// wavefront pays ~20 cycles for every exec-mask branch (compare -> SALU -> branch -> VALU); with two or three
+// wavefronts per SIMD -- all the chains of a call give -- nothing hides that, so the branches were most of the time.
+// R = ring dwords per lane (a power of two); the ring is laid out [slot][thread] so that a wavefront's accesses fall
+// into different banks.  The byte stream is exactly LaneEnc's.
+template <int THREADS, int R>
+struct LaneEncB {
+    u64 low; u32 range;
+    u32 q;          // ring position of the next byte: bytes produced + 12 (the first stored byte sits at q = 16)
+    u32 dq;         // ring position drained so far (a multiple of 16)
+    u8* ring;       // LDS: (R + 1) * THREADS dwords, slot R = the dummy
+    u32 tb;         // this thread's byte offset inside a slot row
+    u8* out; u32 cap;
+    u32 err;
+    __device__ __forceinline__ void init(u32* lds_ring, u32 tid, u8* p, u32 c) {
+        low = 0; range = 0xFFFFFFFFu; q = 12; dq = 16; ring = reinterpret_cast<u8*>(lds_ring); tb = tid * 4u; out = p; cap = c; err = 0;
+    }
+    __device__ __forceinline__ u32 slot_addr(u32 pos) const { return (((pos >> 2) & (u32)(R - 1)) * (u32)THREADS * 4u) + tb + (pos & 3u); }
+    // (masks, not selects: the compiler turns a select between two computed values back into a branch)
+    __device__ __forceinline__ void put_if(u32 nm /* all ones = store, 0 = not */, u32 byte) {
+        const u32 dummy = (u32)R * (u32)THREADS * 4u + tb;
+        const u32 addr = dummy ^ ((dummy ^ slot_addr(q)) & nm);
+        ring[addr] = (u8)byte;
+        q -= nm;                                                               // + 1 where nm = -1
+    }
+    __device__ __forceinline__ void step() {                                  // one round of coder.hpp:74-80, where range < TOP
+        const u32 nm = range < RC_TOP ? ~0u : 0u;
+        const u32 lo = (u32)low, hi = (u32)(low >> 32);
+        const u32 thi = (u32)((low + range) >> 32);
+        const u32 sm = ((thi ^ hi) >> 24) ? ~0u : 0u;
+        const u32 alt = ~lo & (RC_TOP - 1);                                    // (lo | (TOP - 1)) - lo
+        range ^= (range ^ alt) & (nm & sm);
+        put_if(nm, hi >> 24);
+        const u32 sh = 8u & nm;
+        range <<= sh; low <<= sh;
+    }
+    __device__ __forceinline__ void renorm() {
+        step();
+        int guard = 0;
+#pragma nounroll
+        while (__any(range < RC_TOP)) {                                       // rare: a symbol of probability < 2^-8
+            step();
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+    // the arithmetic of encode() for the lanes whose mask vm is all ones; the others keep their state
+    __device__ __forceinline__ void encode_if(u32 vm, u32 cum, u32 freq, u32 tot, u32 recip) {
+        u32 r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        low += (u64)(cum & vm) * r;
+        range ^= (range ^ (r * freq)) & vm;
+        renorm();
+    }
+    __device__ __forceinline__ void encode16_if(u32 vm, u32 cum, u32 freq) {
+        const u32 r = range >> 16;
+        low += (u64)(cum & vm) * r;
+        range ^= (range ^ (r * freq)) & vm;
+        renorm();
+    }
+    __device__ __forceinline__ void encode(u32 cum, u32 freq, u32 tot, u32 recip) {
+        u32 r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        low += (u64)cum * r;
+        range = r * freq;
+        renorm();
+    }
+    __device__ __forceinline__ void encode16(u32 cum, u32 freq) {
+        const u32 r = range >> 16;
+        low += (u64)cum * r;
+        range = r * freq;
+        renorm();
+    }
+    // 16-byte rows of the ring that are complete go to the chain's region; call once per piece of text (the ring holds
+    // 4 R bytes: at most 15 stay behind, so a piece may add 4 R - 15)
+    __device__ __forceinline__ void drain() {
+        while (q >= dq + 16u) {                                                // (q starts below dq: the four elided bytes)
+            const u32* r32 = reinterpret_cast<const u32*>(ring);
+            uint4 v;
+            v.x = r32[(((dq >> 2) + 0u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
+            v.y = r32[(((dq >> 2) + 1u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
+            v.z = r32[(((dq >> 2) + 2u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
+            v.w = r32[(((dq >> 2) + 3u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
+            const u32 at = dq - 16u;
+            if (at + 16u <= cap) *reinterpret_cast<uint4*>(out + at) = v; else err |= 2;
+            dq += 16u;
+        }
+    }
+    // flush; returns the stream's size (the flush's own trailing zero bytes are dropped)
+    __device__ __forceinline__ u32 finish() {
+        const u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;
+        const u32 n = q - 12u;
+        if (n < 4 && (v >> (32 + 8 * n))) err = 1;            // cannot happen: the elided bytes are zero
+        const u32 top5_lo = (u32)(v >> 24);
+        u32 tz = 0;
+        if (top5_lo == 0) tz = (v >> 56) ? 4u : 5u; else tz = ((u32)__builtin_ctz(top5_lo)) >> 3;
+        u64 t = v;
+        for (int i = 0; i < 5; i++) { put_if(~0u, (u32)(t >> 56)); t <<= 8; }
+        drain();
+        for (u32 pos = dq; pos < q; pos++) { const u32 at = pos - 16u; if (at < cap) out[at] = ring[slot_addr(pos)]; else err |= 2; }
+        const u32 stored = q - 16u;                          // q >= 17
+        return stored - (tz < stored ? tz : stored);
+    }
+};
+
 struct LaneDec {
     u64 low, code; u32 range;
     const u8* p; u32 pos, n;

@@ -205,11 +205,11 @@ __global__ __launch_bounds__(64) void k_block_prepare(const u8* fq, const u64* l
     // scratch-arena regions: sized from the block's text bytes (overflow is detected, never silent)
     const u64 t0 = l0, t1 = line_off[4 * rend];
     const u64 bb = t1 - t0;
-    u64 off = (t0 * 7 + (u64)b * 1024 + 15) & ~15ull;
+    u64 off = (t0 * 8 + (u64)b * 1024 + 15) & ~15ull;          // the ten caps below add up to 7.75 bb + 640, 16-byte rounding included < 8 bb + 1024
     const u32 caps[SFQ_NSTREAMS] = {
         (u32)(bb + bb / 2 + 64),   // rec
         (u32)(bb * 3 / 4 + 64),    // gen
-        (u32)(bb + 64),            // qlt
+        (u32)(2 * bb + 64),        // qlt (a quality over 62 costs an escape: up to 4 bytes a symbol, twice the text)
         (u32)(bb / 2 + 64),        // gen.Ns
         (u32)(bb / 2 + 64),        // gen.Nn
         (u32)(bb + 64),            // rec.x

@@ -70,6 +70,7 @@ struct ChainArgs {
     u32 g_ngen;                 // 0 = every chain codes with the initial row
     u32 g_bound[GEN_MAX_GENERATIONS + 1];      // generation g = blocks [g_bound[g], g_bound[g + 1])
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
+    const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
 };
 void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse /* decode; may be null */, hipStream_t st);
