@@ -12,8 +12,8 @@ int main() {
         std::vector<uint8_t> o1(nsym * 4 + 64, 0xAA), o2(nsym * 4 + 64, 0xBB);
         const u32 cap = (u32)((nsym * 4 + 32) & ~15);
         LaneEnc a; a.init(o1.data(), cap);
-        static u32 ring[(32 + 1) * 1];
-        LaneEncB<1, 32> b; b.init(ring, 0, o2.data(), cap);
+        static u32 ring[LaneEncB<1, 8>::LDS_DWORDS];
+        LaneEncB<1, 8> b; b.init(ring, 0, o2.data(), cap);
         int since = 0;
         for (int i = 0; i < nsym; i++) {
             const bool valid = rand() % 8 != 0;
@@ -23,7 +23,7 @@ int main() {
             else { tot = 4 + rand() % 1017; freq = 1 + rand() % (tot < 256 ? tot : 255); if (freq > tot) freq = tot; cum = rand() % (tot - freq + 1); }
             if (mode == 0) { if (valid) a.encode16(cum, freq); b.encode16_if(valid ? ~0u : 0u, cum, freq); }
             else { const u32 rc = fz_recip(tot); if (valid) a.encode(cum, freq, tot, rc); b.encode_if(valid ? ~0u : 0u, cum, freq, tot, rc); }
-            if (++since == 16) { b.drain(); since = 0; }
+            if (++since == 4) { b.drain(); since = 0; }
         }
         const u32 s1 = a.finish(), s2 = b.finish();
         if (s1 != s2 || a.err != b.err || memcmp(o1.data(), o2.data(), s1)) { printf("MISMATCH trial %d nsym %d mode %d sizes %u %u err %u %u\n", trial, nsym, mode, s1, s2, a.err, b.err); return 1; }

@@ -48,8 +48,9 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf;
+    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf, cflags;
     u32 r_hot = 0;
+    bool unsettled = false;                // a call returned with an error: its side streams may still be running
     void* pin = nullptr; size_t pin_cap = 0;       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
@@ -136,6 +137,7 @@ void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_b
     a.arena = (u8*)ctx->arena.p;
     a.level = level;
     a.epoch_base = ctx->epoch_base;
+    ctx->epoch_base += nblocks;            // taken now: a call that fails half-way has used them all the same
     a.q_slots = (u32*)t.q_slots.p; a.q_hdr = (RowHdr*)t.q_hdr.p; a.q_rows = t.q_rows;
     a.p_slots = (u32*)t.p_slots.p; a.p_hdr = (RowHdr*)t.p_hdr.p;
     a.g_tab = (u32*)t.g_tab.p; a.g_bits = g_bits;
@@ -278,7 +280,7 @@ int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
         std::stable_sort(w.begin(), w.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
         u16 map[PR_REC_ROWS], hot[64];
         for (u32 r = 0; r < PR_REC_ROWS; r++) map[r] = 0xFFFFu;
-        const u32 nh = (u32)std::min<size_t>(w.size(), 16);       // REC_LDS_ROWS (chains.hip)
+        const u32 nh = (u32)std::min<size_t>(w.size(), 8);        // REC_LDS_ROWS (chains.hip)
         for (u32 i = 0; i < nh; i++) { hot[i] = (u16)w[i].second; map[w[i].second] = (u16)i; }
         if ((rc = reserve(ctx, ctx->rmap, sizeof map + sizeof hot))) return rc;
         HIPC(hipMemcpyAsync(ctx->rmap.p, map, sizeof map, hipMemcpyHostToDevice, st));
@@ -297,6 +299,7 @@ int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
 // the escape row (qualities >= 63, qlts.cpp:80-86): all 256 values equally likely
 int build_qesc(sfq_ctx* ctx, hipStream_t st) {
     int rc;
+    if (ctx->qesc.p) return SFQ_OK;                      // the same for every call: built once per context
     if ((rc = reserve(ctx, ctx->qesc, 256 * 4))) return rc;
     u32 row[256];
     for (u32 i = 0; i < 256; i++) row[i] = (i << 8) | (256u << 16);          // cum | freq << 16, total 2^16
@@ -352,7 +355,9 @@ int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipS
     const u32 run = 18;
     const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
     const u64 stride = std::max<u64>(run, nrec / nruns);
-    launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, st);
+    if ((rc = reserve(ctx, ctx->cflags, (size_t)8192 * 4))) return rc;
+    HIPC(hipMemsetAsync(ctx->cflags.p, 0, (size_t)nruns * 4, st));
+    launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, (u32*)ctx->cflags.p, st);
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
     return SFQ_OK;
 }
@@ -471,7 +476,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
     for (DevBuf* b : all) release(*b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -496,11 +501,27 @@ uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
 // compress
 // -------------------------------------------------------------------------------------------------
 // priors_only: stop once the call's priors ("qlt.pri", and "rec.pri" with frozen tables) are built (sfq_build_priors)
+// A call that fails returns from wherever it is, possibly between the fork of the model streams and their join: the next
+// call then starts by waiting for the device, so that nothing of the failed one still runs over the shared scratch.
+struct Settle {
+    sfq_ctx* ctx; bool ok = false;
+    explicit Settle(sfq_ctx* c) : ctx(c) { if (ctx->unsettled) { (void)hipDeviceSynchronize(); ctx->unsettled = false; } }
+    ~Settle() { if (!ok) ctx->unsettled = true; }
+};
+static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+                       sfq_result* res, u32 force_models, bool priors_only);
 static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
                        sfq_result* res, u32 force_models, bool priors_only = false) {
     if (!ctx || !d_fastq || !pp || (!d_out && !priors_only) || !res) return fail(ctx, SFQ_E_ARG, "null argument");
     if (nbytes == 0) return fail(ctx, SFQ_E_FORMAT, "empty input");
     HIPC(hipSetDevice(ctx->dev));
+    Settle settle(ctx);
+    const int rc = encode_body(ctx, d_fastq, nbytes, pp, d_out, out_cap, res, force_models, priors_only);
+    settle.ok = rc == SFQ_OK;
+    return rc;
+}
+static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+                       sfq_result* res, u32 force_models, bool priors_only) {
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
@@ -557,10 +578,11 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
     if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 8 + (size_t)nblocks * 1024 + 4096))) return rc;
-    u32 h_status = 0;
-    HIPC(hipMemcpyAsync(&h_status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+    u32 h_status2[2] = {0, 0};
+    HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 8, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
+    const u32 h_status = h_status2[0], max_hdr = h_status2[1];
     if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
     if (h_status) return fail(ctx, -(int)h_status, "record over the model path's line limits (usrs.hpp:34-36): oversize side streams are not implemented");
 
@@ -622,7 +644,11 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         // header chains: longer than the quality / base chains (each starts from the block's first header with cold field
         // types, which costs it a few bytes)
         {
-            const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(256u, ca.geo.chain_reads), block_reads), nrec);
+            // (at least 128 records; above that as many chains as the chip holds at once -- 60 k lanes of the LDS-heavy
+            //  header kernel -- since a second round of chains would double its time)
+            const u32 cpb_want = std::max<u32>(1u, 61440u / nblocks);
+            const u32 rcr0 = std::max<u32>(128u, (block_reads + cpb_want - 1) / cpb_want);
+            const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(rcr0, ca.geo.chain_reads), block_reads), nrec);
             ca.rgeo.chain_reads = rcr;
             ca.rgeo.cpb = (block_reads + rcr - 1) / rcr;
             nsub = ca.rgeo.nchains = (u32)((u64)(nblocks - 1) * ca.rgeo.cpb + (last_nrec + rcr - 1) / rcr);
@@ -732,17 +758,11 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     u32 gen_on = 0;
     if (frozen) {
-        // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (bases) first
+        // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (headers) first
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
         HIPC(hipEventRecord(ctx->ev[2], st));
         if (models & SFQ_M_QLT) { ca.m = a; ca.csz = (u32*)ctx->csz.p; launch_qlt_encode_c(ca, st); }
         HIPC(hipEventRecord(ctx->ev[3], st));
-        if (models & SFQ_M_GEN) {
-            ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
-            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, mst[3], gplan, &gen_on))) return rc;
-            launch_gen_encode_c(ca, mst[3]);
-        }
-        HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
             ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
@@ -750,9 +770,15 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
-            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, mst[1]);
+            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, max_hdr, mst[1]);
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
+        if (models & SFQ_M_GEN) {
+            ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
+            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, mst[3], gplan, &gen_on))) return rc;
+            launch_gen_encode_c(ca, mst[3]);
+        }
+        HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if ((models & SFQ_M_GEN) && ca.exc_flag) {                  // the marks are complete once both chain kernels are through
             HIPC(hipStreamWaitEvent(mst[3], ctx->ev[3], 0));
             launch_gen_exc_w(a, ca.exc_flag, tickets + 1, mst[3]);
@@ -804,7 +830,6 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     }
     HIPC(hipEventRecord(ctx->ev[10], st));
-    ctx->epoch_base += nblocks;
 
     // ---- pack ----------------------------------------------------------------------------------
     if ((rc = reserve(ctx, ctx->blk_stream_off, (size_t)nblocks * SFQ_NSTREAMS * 8))) return rc;
@@ -973,6 +998,10 @@ int sfq_set_chain_index(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
 // -------------------------------------------------------------------------------------------------
 // decompress
 // -------------------------------------------------------------------------------------------------
+static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* h_blocks, uint32_t nblocks,
+                       const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                       const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
+                       uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* res);
 int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* h_blocks, uint32_t nblocks,
                       const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
                       const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
@@ -980,6 +1009,15 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
     if (!ctx || !pp || !h_blocks || !nblocks || !d_streams || !stream_offset || !d_out || !out_bytes)
         return fail(ctx, SFQ_E_ARG, "null argument");
     HIPC(hipSetDevice(ctx->dev));
+    Settle settle(ctx);
+    const int rc = decode_body(ctx, pp, h_blocks, nblocks, h_first_hdrs, first_hdr_bytes, d_streams, stream_offset, d_out, out_cap, out_bytes, res);
+    settle.ok = rc == SFQ_OK;
+    return rc;
+}
+static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* h_blocks, uint32_t nblocks,
+                       const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
+                       const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
+                       uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* res) {
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     const u32 version = p.version ? p.version : 6;
@@ -1231,7 +1269,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
         HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
-        if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; ctx->epoch_base += nblocks; da.m.epoch_base = ctx->epoch_base; }
+        if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; da.m.epoch_base = ctx->epoch_base; ctx->epoch_base += nblocks; }
         if (frozen_rec) {
             ChainArgs cr; memset(&cr, 0, sizeof cr);
             cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rcoarse = (const u32*)ctx->rcoarse.p;
@@ -1255,7 +1293,6 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         for (u32 b = 0; b < nblocks; b++) hb[b].status = 0;
         HIPC(hipMemcpyAsync(ctx->blocks.p, hb.data(), (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
     }
-    ctx->epoch_base += nblocks;
     HIPC(hipEventRecord(ctx->ev[5], st));
 
     // 4. lay the records out

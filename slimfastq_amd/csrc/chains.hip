@@ -166,8 +166,10 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 #define QH_SLOTS 1024u
 #define QH_EMPTY 0xFFFFFFFFu
 __device__ __forceinline__ u32 qh_hash(u32 ctx) { return (ctx * 0x9E3Bu >> 4) & (QH_SLOTS - 1); }
+#define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
+    __shared__ u32 ring[LaneEncB<THREADS, QLT_RING>::LDS_DWORDS];
     extern __shared__ u32 lds[];                              // [QH_SLOTS] the context table, then [q_hot][64] row entries
     u32* const ltab = lds; u32* const lrows = lds + QH_SLOTS;
     if constexpr (LDS) {
@@ -180,9 +182,9 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
     if (live) cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
-    LaneEnc rc; u32 cap = 0;
+    LaneEncB<THREADS, QLT_RING> rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 2, 1, cap) : nullptr;
-    rc.init(outp, cap);
+    rc.init(ring, threadIdx.x, outp, cap);
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
     LineWalk lw; lw.init(a, cp.r0, cp.nrec, 3, live ? d->solid : 0u);
@@ -194,42 +196,54 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
         const Piece pn = lw.next();                   // the next piece is in flight while this one is coded
         const uint4 wn = lw.fetch(pn);
         if (pc.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
-        // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once
+        // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once.
+        // No branches: a position outside the lane's bytes looks up the context before it and leaves the state alone
+        // (masks, vm = all ones inside).
         u32 e[16];
-        u32 lowest = 255;
+        u32 lowest = 255, high = 0;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            e[j] = 0;
-            if (j >= pc.j0 && j < pc.j1) {
-                const u32 b = (piece_byte(w, j) - '!') & 0xffu;
-                const u32 sym = b < LAST_QLT ? b : LAST_QLT;
-                lowest = b < lowest ? b : lowest;
-                if constexpr (LDS) {
-                    const u32 hv = ltab[qh_hash(last)];
-                    e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
-                } else e[j] = a.qrows[(size_t)last * 64 + sym];
-                if (level <= 2) last = (b | (last << 6)) & mask12;         // qlts.hpp:52-57
-                else {                                                    // qlts.hpp:62-74
-                    if (p1 > b) delta += p1 - b;
-                    const u32 d3 = delta >> 3;
-                    last = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
-                    p2 = p1; p1 = b;
-                }
+            const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
+            const u32 b = (piece_byte(w, j) - '!') & 0xffu;
+            const u32 sym = b < LAST_QLT ? b : LAST_QLT;
+            lowest = min(lowest, b | ~vm);
+            high |= (b >= LAST_QLT ? ~0u : 0u) & vm;
+            if constexpr (LDS) {
+                const u32 hv = ltab[qh_hash(last)];
+                e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
+            } else e[j] = a.qrows[(size_t)last * 64 + sym];
+            if (level <= 2) last ^= (last ^ ((b | (last << 6)) & mask12)) & vm;         // qlts.hpp:52-57
+            else {                                                                       // qlts.hpp:62-74
+                delta += (p1 > b ? p1 - b : 0u) & vm;
+                const u32 d3 = delta >> 3;
+                const u32 nl = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                last ^= (last ^ nl) & vm;
+                p2 ^= (p2 ^ p1) & vm; p1 ^= (p1 ^ b) & vm;
             }
         }
         // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
         if (a.exc_flag && lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
         // (b) the serial part: the range coder
+        if (!__any(high != 0)) {
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) {
-            if (j >= pc.j0 && j < pc.j1) {
-                rc.encode16(FZ_CUM(e[j]), FZ_FREQ(e[j]));
+            for (u32 j = 0; j < 16; j++) {
+                rc.encode16_if((j >= pc.j0 && j < pc.j1) ? ~0u : 0u, FZ_CUM(e[j]), FZ_FREQ(e[j]));
+                if ((j & 3u) == 3u) rc.drain();
+            }
+        } else {
+            // a quality over 62 somewhere in the wave: the escape symbol, then the raw value through the frozen escape row (qlts.cpp:80-86)
+#pragma unroll
+            for (u32 j = 0; j < 16; j++) {
+                const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
+                rc.encode16_if(vm, FZ_CUM(e[j]), FZ_FREQ(e[j]));
                 const u32 b = (piece_byte(w, j) - '!') & 0xffu;
-                if (b >= LAST_QLT) {                                       // escape: the raw value through the frozen escape row (qlts.cpp:80-86)
+                const u32 em = (b >= LAST_QLT ? ~0u : 0u) & vm;
+                if (__any(em != 0)) {
                     const u32 ee = a.qesc[b];
-                    rc.encode16(FZ_CUM(ee), FZ_FREQ(ee));
-                    extra++;
+                    rc.encode16_if(em, FZ_CUM(ee), FZ_FREQ(ee));
+                    extra -= em;
                 }
+                if ((j & 3u) == 3u) rc.drain();
             }
         }
         pc = pn; w = wn;
@@ -433,8 +447,10 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
         }
         if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) code(j, (codes >> (2 * j)) & 3u, (j >= pc.j0 && j < pc.j1) ? ~0u : 0u);
-        piece_end();
+        for (u32 j = 0; j < 16; j++) {
+            code(j, (codes >> (2 * j)) & 3u, (j >= pc.j0 && j < pc.j1) ? ~0u : 0u);
+            if ((j & 3u) == 3u) piece_end();                       // every four bases (the size of LaneEncB's ring follows from this)
+        }
         pc = pn; w = wn;
     }
 }
@@ -504,12 +520,12 @@ __device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
     return a.g_rows[g];
 }
 
-#define GEN_RING 16      // ring dwords per lane: a piece adds at most 16 bases x 2 bytes
+#define GEN_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four bases add at most 4 x 2
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     __shared__ u32 rcp[1024];                                 // reciprocals of the row totals (<= 1020)
     __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
-    __shared__ u32 ring[(GEN_RING + 1) * THREADS];
+    __shared__ u32 ring[LaneEncB<THREADS, GEN_RING>::LDS_DWORDS];
     for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
     for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)gen_code_of(i);
     __syncthreads();
@@ -635,7 +651,7 @@ __device__ __forceinline__ u8* rec_chain_region(const ChainArgs& a, const RecCha
 }
 
 #define REC_HBUF 128u                    // bytes of LDS per staged header (two per lane: the current and the previous one)
-#define REC_LDS_ROWS 16u                 // frozen rows staged in LDS per wave (1 KiB each): a handful of rows take nearly all symbols
+#define REC_LDS_ROWS 8u                  // frozen rows staged in LDS per wave (1 KiB each): a handful of rows take nearly all symbols
 struct RecFrozenEnc {
     static constexpr bool inband = true;
     const u32* rows; LaneEnc rc;
@@ -668,9 +684,10 @@ struct RecCountEnc {
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
 // counting pass: lane i walks records [i * stride, i * stride + run): the first is the run's base
-__global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt) {
+__global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, const u32* flags /* the runs to take; null = all */) {
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nruns) return;
+    if (flags && !flags[i]) return;
     const u64 r0 = (u64)i * stride;
     if (r0 >= nrec) return;
     const u32 n = (u32)(nrec - r0 < run ? nrec - r0 : run);
@@ -679,9 +696,6 @@ __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 str
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     u32 hb; int bad;
     rec_encode_lane(a, r0, r0, n, cd, x_rec, none, hb, bad);
-}
-void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_count, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt);
 }
 // frozen rows from the prior's scaled frequencies f[row][256]: x = f + 1, g = max(1, floor(x * 65536 / sum x)), the
 // remainder to the largest g (the first of them); entry = cum | g << 16; coarse[row][16] = cum at every 16th symbol
@@ -761,18 +775,22 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* fla
 // previous), the field tables of both, the field types / values, and the hottest frozen rows.  The general path above
 // keeps those in per-lane scratch and reads the text through generic pointers: ~300 memory instructions per record,
 // which is what its time is made of.  A chain with a longer header or more fields is handed over (flags[c] = 1).
-#define RF_MAXLEN 127u
-#define RF_NF 16u                        // (the whole LDS image is ~50 KiB: three waves per CU)
+// LDS is what limits how many of these waves a CU holds (and, beside them, the quality and base chains): the image is
+// sized by the call's longest header -- ML = 62: 31.9 KiB, five waves per CU; 94: 35.9 KiB; 127: 40.1 KiB, three.
+#define RF_NF 16u
+template <u32 ML>
 struct RecFastLds {
-    u8  text[2][RF_MAXLEN + 1][64];
-    u8  off[2][RF_NF][64], wln[2][RF_NF][64], sep[2][RF_NF][64];
-    u8  ctype[RF_NF][64];
+    static constexpr u32 maxlen = ML;
     u64 cnumb[RF_NF][64];
     u32 rows[REC_LDS_ROWS * 256];
-    u16 map[PR_REC_ROWS];
+    u8  text[2][ML + 1][64];
+    u8  off[2][RF_NF][64], wln[2][RF_NF][64], sep[2][RF_NF][64];
+    u8  ctype[RF_NF][64];
+    u8  map[PR_REC_ROWS];                // row -> LDS slot, 0xFF = not staged
 };
 // numberwang (recs.cpp:192-262) over text[buf][off ..][lane]
-__device__ __forceinline__ u32 nw_lds(const RecFastLds& L, u32 buf, u32 lane, u32 off, int len, u64& num, u32 pctype) {
+template <typename LT>
+__device__ __forceinline__ u32 nw_lds(const LT& L, u32 buf, u32 lane, u32 off, int len, u64& num, u32 pctype) {
     int i = 0;
     const bool has_z = L.text[buf][off][lane] == '0';
     if (has_z) if (L.text[buf][off + (++i)][lane] == '0') return ST_STR;
@@ -805,19 +823,22 @@ __device__ __forceinline__ u32 nw_lds(const RecFastLds& L, u32 buf, u32 lane, u3
     }
     return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
 }
+template <typename LT>
 struct RecFastEnc {
-    const u32* rows; const RecFastLds* L; LaneEnc rc;
+    const u32* rows; const LT* L; LaneEnc rc;
     __device__ __forceinline__ void put(u32 row, u32 sym) {
         const u32 slot = L->map[row];
-        const u32 e = slot != 0xFFFFu ? L->rows[slot * 256 + sym] : rows[(size_t)row * 256 + sym];
+        const u32 e = slot != 0xFFu ? L->rows[slot * 256 + sym] : rows[(size_t)row * 256 + sym];
         rc.encode16(FZ_CUM(e), FZ_FREQ(e));
     }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+    __device__ __forceinline__ void record(u32) {}
 };
 // a header line into LDS, tokenised on the way (map_space, recs.cpp:141-157): a separator closes a field; the byte behind
 // the text is the line's '\n', the last separator; a NUL ends the scan.  Eight dwords are fetched at a time, so a header
 // costs a memory round trip or two, not one per dword.  Returns the number of fields (more than RF_NF: not all recorded).
-__device__ __forceinline__ u32 rf_stage(RecFastLds& L, u32 buf, u32 lane, const u8* text, u32 n) {
+template <typename LT>
+__device__ __forceinline__ u32 rf_stage(LT& L, u32 buf, u32 lane, const u8* text, u32 n) {
     const u32* g = reinterpret_cast<const u32*>(text);             // (global loads need no alignment on gfx9; the text goes on behind the line)
     const u32 nw = (n + 4) / 4;
     u32 nf = 0, start = 0; bool stop = false;
@@ -843,45 +864,34 @@ __device__ __forceinline__ u32 rf_stage(RecFastLds& L, u32 buf, u32 lane, const 
     }
     return nf;
 }
-__global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
-    __shared__ RecFastLds L;
-    const u32 lane = threadIdx.x;
-    for (u32 i = lane; i < PR_REC_ROWS; i += 64) L.map[i] = a.rmap[i];
-    for (u32 i = lane; i < a.r_hot * 256; i += 64) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
-    __syncthreads();
-    const u32 c = blockIdx.x * 64 + lane;
-    if (c >= a.rgeo.nchains) return;
-    const RecChainPos cp = rec_chain_pos(a, c);
-    BlockDesc* d = &a.m.blocks[cp.b];
-    u32 cap = 0;
-    u8* outp = rec_chain_region(a, cp, cap);
-    RecFastEnc cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(outp, cap);
-    u32 cur = 0, nf_prev = 0, hdr_bytes = 0;
-    bool slow = false;
-    const u64 base_rec = d->rec0;
-    {                                                                         // recs.cpp:279-287: the base, the block's first header
-        const u64 h0 = a.m.line_off[4 * base_rec] + 1, h1 = a.m.line_off[4 * base_rec + 1] - 1;
+// one chain (or one run of the counting pass) on the fast path; returns false where a header is too long / has too many
+// fields for it (the coder has then seen part of the chain: an encoder starts over on the general path, the counting
+// pass looks at its run beforehand)
+template <typename LT, typename CD>
+__device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lane, u64 base_rec, u64 r0, u32 nrec, CD& cd, u32& hdr_bytes_out) {
+    u32 cur = 0, nf_prev = 0, hdr_bytes = 0, coded = 0;
+    {                                                                         // recs.cpp:279-287: the base
+        const u64 h0 = m.line_off[4 * base_rec] + 1, h1 = m.line_off[4 * base_rec + 1] - 1;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
-        if (n > RF_MAXLEN) slow = true;
-        else {
-            nf_prev = rf_stage(L, cur, lane, a.m.fq + h0, n);
-            if (nf_prev > RF_NF) slow = true;
-            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
-            cur ^= 1u;
-        }
+        if (n > LT::maxlen) return false;
+        nf_prev = rf_stage(L, cur, lane, m.fq + h0, n);
+        if (nf_prev > RF_NF) return false;
+        for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+        cur ^= 1u;
     }
     u64 nh0 = 0, nh1 = 0;                                                     // the next record's header line, fetched a record ahead
-    if (cp.nrec) { nh0 = a.m.line_off[4 * cp.r0] + 1; nh1 = a.m.line_off[4 * cp.r0 + 1] - 1; }
-    for (u32 k = 0; k < cp.nrec && !slow; k++) {
-        const u64 r = cp.r0 + k;
+    if (nrec) { nh0 = m.line_off[4 * r0] + 1; nh1 = m.line_off[4 * r0 + 1] - 1; }
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = r0 + k;
         const u64 h0 = nh0, h1 = nh1;
-        if (k + 1 < cp.nrec) { nh0 = a.m.line_off[4 * (r + 1)] + 1; nh1 = a.m.line_off[4 * (r + 1) + 1] - 1; }
+        if (k + 1 < nrec) { nh0 = m.line_off[4 * (r + 1)] + 1; nh1 = m.line_off[4 * (r + 1) + 1] - 1; }
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
         hdr_bytes += n;
         if (r == base_rec) continue;                                          // the base itself
-        if (n > RF_MAXLEN) { slow = true; break; }
-        const u32 nf = rf_stage(L, cur, lane, a.m.fq + h0, n);
-        if (nf > RF_NF) { slow = true; break; }
+        cd.record(coded++);
+        if (n > LT::maxlen) return false;
+        const u32 nf = rf_stage(L, cur, lane, m.fq + h0, n);
+        if (nf > RF_NF) return false;
         const u32 prv = cur ^ 1u;
         bool shape = nf != nf_prev;
         for (u32 f = 0; !shape && f < nf; f++) shape = L.sep[cur][f][lane] != L.sep[prv][f][lane];
@@ -928,15 +938,68 @@ __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
         }
         nf_prev = nf; cur = prv;
     }
-    if (slow) { flags[c] = 1; return; }                                       // the general kernel starts this chain over
+    hdr_bytes_out = hdr_bytes;
+    return true;
+}
+template <u32 ML>
+__global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
+    __shared__ RecFastLds<ML> L;
+    const u32 lane = threadIdx.x;
+    for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < REC_LDS_ROWS ? sl : 0xFFu); }
+    for (u32 i = lane; i < a.r_hot * 256; i += 64) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
+    __syncthreads();
+    const u32 c = blockIdx.x * 64 + lane;
+    if (c >= a.rgeo.nchains) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    BlockDesc* d = &a.m.blocks[cp.b];
+    u32 cap = 0;
+    u8* outp = rec_chain_region(a, cp, cap);
+    RecFastEnc<RecFastLds<ML>> cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(outp, cap);
+    u32 hdr_bytes = 0;
+    if (!rec_fast_lane(a.m, L, lane, d->rec0, cp.r0, cp.nrec, cd, hdr_bytes)) { flags[c] = 1; return; }     // the general kernel starts this chain over
     a.rhb[c] = hdr_bytes;
     a.csz[c] = cd.rc.finish();
     if (cd.rc.err & 2) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
     if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
+// the counting pass on the fast path: a run whose headers all fit (looked at first: counts cannot be taken back) is
+// counted here, the others are marked for k_rec_count
+struct RecFastCount {
+    u32* cnt; bool on;
+    __device__ __forceinline__ void record(u32 k) { on = k >= 1; }       // the run's first coded record only warms the field types up
+    __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
+    __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+};
+__global__ __launch_bounds__(64) void k_rec_count_f(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags) {
+    __shared__ RecFastLds<127> L;
+    const u32 lane = threadIdx.x;
+    const u32 i = blockIdx.x * 64 + lane;
+    if (i >= nruns) return;
+    const u64 r0 = (u64)i * stride;
+    if (r0 >= nrec) return;
+    const u32 n = (u32)(nrec - r0 < run ? nrec - r0 : run);
+    bool fits = true;
+    for (u32 k = 0; k < n && fits; k++) {
+        const u64 h0 = a.line_off[4 * (r0 + k)] + 1, h1 = a.line_off[4 * (r0 + k) + 1] - 1;
+        const u32 len = h1 > h0 ? (u32)(h1 - h0) : 0;
+        fits = len <= 127u && rf_stage(L, 0, lane, a.fq + h0, len) <= RF_NF;
+    }
+    if (!fits) { flags[i] = 1; return; }
+    RecFastCount cd; cd.cnt = cnt; cd.on = false;
+    u32 hb = 0;
+    rec_fast_lane(a, L, lane, r0, r0, n, cd, hb);
+}
+// flags: one dword per run, zeroed by the caller
+void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_count_f, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt, flags);
+    hipLaunchKernelGGL(k_rec_count, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt, (const u32*)flags);
+}
 // flags: one dword per header chain, zeroed by the caller
-void launch_rec_encode_c(const ChainArgs& a, u32* flags, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_encode_f, dim3((a.rgeo.nchains + 63) / 64), dim3(64), 0, st, a, flags);
+void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32 max_hdr, hipStream_t st) {
+    const dim3 grid((a.rgeo.nchains + 63) / 64);
+    if (max_hdr <= 62) hipLaunchKernelGGL(k_rec_encode_f<62>, grid, dim3(64), 0, st, a, flags);
+    else if (max_hdr <= 94) hipLaunchKernelGGL(k_rec_encode_f<94>, grid, dim3(64), 0, st, a, flags);
+    else hipLaunchKernelGGL(k_rec_encode_f<127>, grid, dim3(64), 0, st, a, flags);
     hipLaunchKernelGGL(k_rec_encode_c, dim3((a.rgeo.nchains + 63) / 64), dim3(64), 0, st, a, (const u32*)flags);
 }
 

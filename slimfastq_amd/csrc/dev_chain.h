@@ -86,26 +86,26 @@ struct LaneEnc {
 // dummy slot), and the ring is drained to the chain's region 16 bytes at a time, once per piece of text.  A lone
 // wavefront pays ~20 cycles for every exec-mask branch (compare -> SALU -> branch -> VALU); with two or three
 // wavefronts per SIMD -- all the chains of a call give -- nothing hides that, so the branches were most of the time.
-// R = ring dwords per lane (a power of two); the ring is laid out [slot][thread] so that a wavefront's accesses fall
-// into different banks.  The byte stream is exactly LaneEnc's.
+// R = ring dwords per lane (a power of two, at most 8... any power of two); a lane's ring is 4 R contiguous bytes at a
+// stride of 4 R + 4 bytes -- an odd number of dwords, so the lanes of a wavefront spread over the banks.  The byte
+// stream is exactly LaneEnc's.
 template <int THREADS, int R>
 struct LaneEncB {
+    static constexpr u32 RB = 4u * (u32)R;                 // ring bytes
+    static constexpr u32 LDS_DWORDS = (u32)THREADS * ((u32)R + 1u);
     u64 low; u32 range;
     u32 q;          // ring position of the next byte: bytes produced + 12 (the first stored byte sits at q = 16)
     u32 dq;         // ring position drained so far (a multiple of 16)
-    u8* ring;       // LDS: (R + 1) * THREADS dwords, slot R = the dummy
-    u32 tb;         // this thread's byte offset inside a slot row
+    u8* ring;       // LDS: this lane's ring
     u8* out; u32 cap;
     u32 err;
     __device__ __forceinline__ void init(u32* lds_ring, u32 tid, u8* p, u32 c) {
-        low = 0; range = 0xFFFFFFFFu; q = 12; dq = 16; ring = reinterpret_cast<u8*>(lds_ring); tb = tid * 4u; out = p; cap = c; err = 0;
+        low = 0; range = 0xFFFFFFFFu; q = 12; dq = 16; ring = reinterpret_cast<u8*>(lds_ring) + tid * (RB + 4u); out = p; cap = c; err = 0;
     }
-    __device__ __forceinline__ u32 slot_addr(u32 pos) const { return (((pos >> 2) & (u32)(R - 1)) * (u32)THREADS * 4u) + tb + (pos & 3u); }
     // (masks, not selects: the compiler turns a select between two computed values back into a branch)
-    __device__ __forceinline__ void put_if(u32 nm /* all ones = store, 0 = not */, u32 byte) {
-        const u32 dummy = (u32)R * (u32)THREADS * 4u + tb;
-        const u32 addr = dummy ^ ((dummy ^ slot_addr(q)) & nm);
-        ring[addr] = (u8)byte;
+    // the byte always goes to the ring's next free position (nothing live is there); it counts where nm is all ones
+    __device__ __forceinline__ void put_if(u32 nm, u32 byte) {
+        ring[q & (RB - 1u)] = (u8)byte;
         q -= nm;                                                               // + 1 where nm = -1
     }
     __device__ __forceinline__ void step() {                                  // one round of coder.hpp:74-80, where range < TOP
@@ -155,16 +155,14 @@ struct LaneEncB {
         range = r * freq;
         renorm();
     }
-    // 16-byte rows of the ring that are complete go to the chain's region; call once per piece of text (the ring holds
-    // 4 R bytes: at most 15 stay behind, so a piece may add 4 R - 15)
+    // 16-byte rows of the ring that are complete go to the chain's region (the ring holds 4 R bytes and at most 15 stay
+    // behind: between two calls the coder may add 4 R - 15)
     __device__ __forceinline__ void drain() {
+        if (!__any(q >= dq + 16u)) return;                                    // (one scalar branch for the wavefront)
         while (q >= dq + 16u) {                                                // (q starts below dq: the four elided bytes)
-            const u32* r32 = reinterpret_cast<const u32*>(ring);
+            const u32* r32 = reinterpret_cast<const u32*>(ring + (dq & (RB - 1u)));      // (RB is a multiple of 16: the row does not wrap)
             uint4 v;
-            v.x = r32[(((dq >> 2) + 0u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
-            v.y = r32[(((dq >> 2) + 1u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
-            v.z = r32[(((dq >> 2) + 2u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
-            v.w = r32[(((dq >> 2) + 3u) & (u32)(R - 1)) * (u32)THREADS + (tb >> 2)];
+            v.x = r32[0]; v.y = r32[1]; v.z = r32[2]; v.w = r32[3];
             const u32 at = dq - 16u;
             if (at + 16u <= cap) *reinterpret_cast<uint4*>(out + at) = v; else err |= 2;
             dq += 16u;
@@ -181,7 +179,7 @@ struct LaneEncB {
         u64 t = v;
         for (int i = 0; i < 5; i++) { put_if(~0u, (u32)(t >> 56)); t <<= 8; }
         drain();
-        for (u32 pos = dq; pos < q; pos++) { const u32 at = pos - 16u; if (at < cap) out[at] = ring[slot_addr(pos)]; else err |= 2; }
+        for (u32 pos = dq; pos < q; pos++) { const u32 at = pos - 16u; if (at < cap) out[at] = ring[pos & (RB - 1u)]; else err |= 2; }
         const u32 stored = q - 16u;                          // q >= 17
         return stored - (tz < stored ? tz : stored);
     }

@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u6
         bad = (u32)(-SFQ_E_UNSUPPORTED);
     else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);               // empty base line: usrs.cpp:217-222 mis-frames it
     if (bad) atomicMax(status, bad);
+    // status[1] = the longest header of the call (the header kernel sizes its LDS image by it)
+    u32 hl = (u32)(l1 - l0 - 2);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)hl, dd, 64); hl = o > hl ? o : hl; }
+    if ((threadIdx.x & 63) == 0 && hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
 }
 void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status, hipStream_t st) {
     hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, status);

@@ -48,7 +48,9 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     assert np.array_equal(util.unpack_rec_prior(enc.rec_prior), f), what
     assert flags & 2
     rcr = ci["rec_chain_reads"]
-    assert rcr == min(max(256, got_cr), br, nrec)
+    nblocks = -(-nrec // br)
+    cpb_want = max(1, 61440 // nblocks)
+    assert rcr == min(max(128, -(-br // cpb_want), got_cr), br, nrec)          # api.cpp: header chains
     want, sizes, hb = O.rec_encode_chains_frozen(fq, hoff, hlen, br, rcr, O.rec_frozen_rows(f))
     assert list(ci["rec"]) == list(sizes) and list(ci["rec_hdr_bytes"]) == list(hb), what
     assert enc.stream("rec") == want, what
