@@ -551,7 +551,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
     if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
     launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
-    launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, (u32*)ctx->status.p, st);
+    // format 6 (one block, the reference's own): its line limits, beyond which it writes "oversize" side streams this
+    // library does not; the block format has no such limit on base / quality lines (a block's regions are sized by its text)
+    launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, p.block_reads ? 0x3ffffffeu : 0xfffeu, (u32*)ctx->status.p, st);
 
     // SFQ_BLOCK_AUTO: blocks of about 376 KiB of text (1024 records of 150 bp; ~6 records of 60 kb): the unit of
     // parallelism is the block, and a fixed record count would leave long-read inputs with a handful of huge blocks
@@ -584,7 +586,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     HIPC(hipStreamSynchronize(st));
     const u32 h_status = h_status2[0], max_hdr = h_status2[1];
     if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
-    if (h_status) return fail(ctx, -(int)h_status, "record over the model path's line limits (usrs.hpp:34-36): oversize side streams are not implemented");
+    if (h_status) return fail(ctx, -(int)h_status, "record over the line limits: headers up to 8190 bytes; base and quality lines up to 65534 in format 6 (-B 0; the reference would write oversize side streams, usrs.cpp:269-301, which this library does not), up to 1 Gi in the block format");
 
     // ---- models --------------------------------------------------------------------------------
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);       // qlts.hpp:36-40
@@ -1158,7 +1160,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     da.slen = (u32*)ctx->slen.p; da.qlen = (u32*)ctx->qlen.p; da.pfg = (u8*)ctx->pfg.p; da.pfq = (u8*)ctx->pfq.p;
     da.soff = (const u64*)ctx->soff.p; da.qoff = (const u64*)ctx->qoff.p;
     da.hlen = (u32*)ctx->hlen.p; da.hoff = (u64*)ctx->hoff.p;
-    da.block_reads = block_reads; da.version = version;
+    da.block_reads = block_reads; da.version = version; da.max_line = (u32)std::min<u64>(out_cap, 0x3ffffffeull);
 
     // 1. framing exceptions -> per-record line lengths
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_usr_decode_l(da, st); }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_usr_decode_l(DecodeArgs a) {
         else if (qlen != llen) qlen = llen;
         if (solid && i_sgen == rcnt) { pfg = x_sgen.get_chr(sl.pw); i_sgen += x_sgen.get(sl.pw); }
         if (solid && i_sqlt == rcnt) { pfq = x_sqlt.get_chr(sl.pw); i_sqlt += x_sqlt.get(sl.pw); }
-        if (llen > 0xffff || qlen > 0xffff) { bad = 1; llen = qlen = 0; }
+        if (llen > a.max_line || qlen > a.max_line) { bad = 1; llen = qlen = 0; }
         a.slen[r] = llen; a.qlen[r] = qlen; a.pfg[r] = (u8)pfg; a.pfq[r] = (u8)pfq;
     }
     if (bad | x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) dset_status(d, SFQ_E_CORRUPT);

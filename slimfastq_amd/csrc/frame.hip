@@ -161,14 +161,15 @@ void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
 }
 
 // ---- record validation ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status) {
+__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line, u32* status) {
     u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrec) return;
     const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
     u32 bad = 0;
     if (fq[l0] != '@' || fq[l2] != '+') bad = (u32)(-SFQ_E_FORMAT);           // usrs.cpp:311, 346
-    // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367)
-    else if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > 0xfffe)
+    // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367): max_line = 0xfffe
+    // where its format is written; the block format codes base / quality lines of any length the usual way
+    else if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line)
         bad = (u32)(-SFQ_E_UNSUPPORTED);
     else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);               // empty base line: usrs.cpp:217-222 mis-frames it
     if (bad) atomicMax(status, bad);
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u6
     for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)hl, dd, 64); hl = o > hl ? o : hl; }
     if ((threadIdx.x & 63) == 0 && hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
 }
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status, hipStream_t st) {
-    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, status);
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_line, status);
 }
 
 // ---- block descriptors: UsrSave::determine_record (usrs.cpp:186-267) on each block's first record ----

@@ -38,6 +38,7 @@ struct DecodeArgs {
     u64* hoff;                              // per record offset into hdr_stage (filled by rec decode)
     u32  block_reads;                       // records per block (uniform; the last block may be short)
     u32  version;                           // archive format version (recs.cpp:400: < 5 takes load_pre5)
+    u32  max_line;                          // a base / quality line longer than this is a corrupt stream (the caller's output capacity bounds it)
 };
 
 // ---- lane-per-chain kernels with frozen tables (chains.hip, dev_chain.h) ----------------------------------------
@@ -92,7 +93,7 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
 void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32* status, hipStream_t st);
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line /* longest base / quality line taken */, u32* status, hipStream_t st);
 void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
                           u64 nbytes, i32 level, i32 gen_bits_req, hipStream_t st);
 #define FRAME_CHUNK 16384u

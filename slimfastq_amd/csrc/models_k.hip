@@ -222,9 +222,9 @@ __global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
                 mx &= mx - 1;
                 const u64 rcnt = (u64)k0 + bit + 1;
                 if ((mG >> bit) & 1) { const u32 c = rl(cg, bit); if (lane == 0) { x_sgen.put(pw, rcnt - i_sgen); x_sgen.put_chr(pw, c); } i_sgen = rcnt; }   // usrs.cpp:323-327
-                if ((mL >> bit) & 1) { const u32 v = rl(sl_len, bit); if (lane == 0) { x_llen.put(pw, rcnt - i_llen); x_llen.put(pw, (u16)v); } i_llen = rcnt; }   // usrs.cpp:342-343
+                if ((mL >> bit) & 1) { const u32 v = rl(sl_len, bit); if (lane == 0) { x_llen.put(pw, rcnt - i_llen); x_llen.put(pw, v); } i_llen = rcnt; }   // usrs.cpp:342-343
                 if ((mS >> bit) & 1) { const u32 c = rl(cq, bit); if (lane == 0) { x_sqlt.put(pw, rcnt - i_sqlt); x_sqlt.put_chr(pw, c); } i_sqlt = rcnt; }   // usrs.cpp:356-360
-                if ((mQ >> bit) & 1) { const u32 v = rl(ql, bit); if (lane == 0) { x_qlen.put(pw, rcnt - i_qlen); x_qlen.put(pw, (u16)v); } i_qlen = rcnt; }     // usrs.cpp:371-372
+                if ((mQ >> bit) & 1) { const u32 v = rl(ql, bit); if (lane == 0) { x_qlen.put(pw, rcnt - i_qlen); x_qlen.put(pw, v); } i_qlen = rcnt; }     // usrs.cpp:371-372
             }
             c_llen = rl(sl_len, m - 1); c_pfg = rl(cg, m - 1); c_pfq = rl(cq, m - 1);
         }

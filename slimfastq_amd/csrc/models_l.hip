@@ -210,14 +210,14 @@ __global__ __launch_bounds__(64) void k_usr_encode_l(ModelArgs a) {
         }
         const u32 sl_len = (u32)(g1 - g0) - solid;
         if (sl_len != llen) {                                                  // usrs.cpp:342-343
-            x_llen.put(sl.pw, rcnt - i_llen); x_llen.put(sl.pw, (u16)sl_len); i_llen = rcnt; llen = sl_len;
+            x_llen.put(sl.pw, rcnt - i_llen); x_llen.put(sl.pw, sl_len); i_llen = rcnt; llen = sl_len;
         }
         if (solid) {
             const u32 c = a.fq[q0];                                            // usrs.cpp:356-360
             if (c != pf_qlt) { x_sqlt.put(sl.pw, rcnt - i_sqlt); x_sqlt.put_chr(sl.pw, c); i_sqlt = rcnt; pf_qlt = c; }
         }
         const u32 ql = (q1 - q0) >= solid ? (u32)(q1 - q0) - solid : 0;
-        if (ql != llen) { x_qlen.put(sl.pw, rcnt - i_qlen); x_qlen.put(sl.pw, (u16)ql); i_qlen = rcnt; }   // usrs.cpp:371-372
+        if (ql != llen) { x_qlen.put(sl.pw, rcnt - i_qlen); x_qlen.put(sl.pw, ql); i_qlen = rcnt; }   // usrs.cpp:371-372
     }
     d->size[SFQ_S_USR_X]   = x_llen.finish(sl.pw);
     d->size[SFQ_S_USR_XQ]  = x_qlen.finish(sl.pw);

@@ -147,6 +147,30 @@ def test_roundtrip_long_reads_and_samples(ctx):
         assert ctx.decode_host(enc, level=2, out_cap=len(fq) * 2 + 4096) == fq, name
 
 
+def test_reads_beyond_the_reference_line_limit(ctx):
+    """Base / quality lines over 65 534 bytes: the reference diverts such records to its raw usr.lrec / usr.lgen / usr.lqlt
+    streams (usrs.cpp:269-301); format 6 (-B 0) therefore refuses them here, the block format codes them like any other."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i, n in enumerate((150, 70_000, 200, 300_001, 65_534, 65_535, 151, 131_072, 90)):
+        seq = "".join(rnd.choice("ACGT") for _ in range(n))
+        if n > 1000:
+            seq = seq[:500] + "N" * 7 + seq[507:]
+        qual = "".join(chr(33 + min(60, max(0, int(rnd.gauss(30, 8))))) for _ in range(n))
+        if n > 1000:
+            qual = qual[:500] + "!" * 7 + qual[507:]
+        recs.append("@long.%d ch=%d len=%d\n%s\n+\n%s\n" % (i + 1, 100 + i, n, seq, qual))
+    fq = "".join(recs).encode()
+    for tables in (capi.TABLES_FROZEN, 0):
+        for br in (capi.BLOCK_AUTO, 2, 4):
+            enc = ctx.encode_host(fq, level=3, block_reads=br, tables=tables)
+            assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq, (tables, br)
+    with pytest.raises(capi.SfqError) as e:
+        ctx.encode_host(fq, level=3, block_reads=0)
+    assert e.value.code == -7          # SFQ_E_UNSUPPORTED
+
+
 def test_ragged_and_error_inputs(ctx):
     one = b"@only 1\nACGT\n+\nIIII\n"
     enc = ctx.encode_host(one, level=3)
