@@ -146,6 +146,11 @@ uint64_t sfq_ctx_device_memory(const sfq_ctx* ctx);
 /* The HIP stream the context launches on (a hipStream_t), for callers that order work against it. */
 void* sfq_ctx_stream(sfq_ctx* ctx);
 int  sfq_ctx_synchronize(sfq_ctx* ctx);
+/* Page-locked host memory for the buffers handed to the *_host entry points: the copy engine reads / writes it at the
+ * link's rate (a pageable buffer is staged through the driver page by page).  The reference has no counterpart: its
+ * I/O is fread / fwrite into static buffers (usrs.cpp:95-118, filer.cpp).  NULL when the allocation fails. */
+void* sfq_host_alloc(sfq_ctx* ctx, uint64_t bytes);
+void  sfq_host_free(sfq_ctx* ctx, void* p);
 
 /* ---- compress ------------------------------------------------------------------------------
  * Replaces the body of UsrSave::encode()'s record loop (usrs.cpp:400-404: gen.save / rec.save /

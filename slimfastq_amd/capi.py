@@ -23,6 +23,7 @@ EXPORTS = [
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
     "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index", "sfq_get_rec_prior", "sfq_set_rec_prior", "sfq_build_priors",
+    "sfq_host_alloc", "sfq_host_free",
 ]
 
 
@@ -94,6 +95,8 @@ def lib():
         L.sfq_ctx_stream.argtypes = [vp]
         L.sfq_ctx_stream.restype = vp
         L.sfq_ctx_synchronize.argtypes = [vp]
+        L.sfq_host_alloc.argtypes = [vp, C.c_uint64]; L.sfq_host_alloc.restype = C.c_void_p
+        L.sfq_host_free.argtypes = [vp, C.c_void_p]; L.sfq_host_free.restype = None
         L.sfq_encode_bound.argtypes = [u64]
         L.sfq_encode_bound.restype = u64
         for f in (L.sfq_encode_blocks, L.sfq_encode_qlt_blocks, L.sfq_encode_blocks_host):

@@ -495,6 +495,19 @@ int sfq_ctx_synchronize(sfq_ctx* ctx) {
     return SFQ_OK;
 }
 
+void* sfq_host_alloc(sfq_ctx* ctx, uint64_t bytes) {
+    if (!ctx || !bytes) return nullptr;
+    if (hipSetDevice(ctx->dev) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void sfq_host_free(sfq_ctx* ctx, void* p) {
+    if (!ctx || !p) return;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipHostFree(p);
+}
+
 uint64_t sfq_encode_bound(uint64_t n) { return n + n / 2 + 4096; }
 
 // -------------------------------------------------------------------------------------------------

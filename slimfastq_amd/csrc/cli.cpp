@@ -33,6 +33,8 @@ struct JobError { std::string msg; };
 
 // SFQ_TIMING=1: where a run spends its wall time (stderr)
 #include <chrono>
+#include <thread>
+#include <atomic>
 static void tick(const char* what) {
     static const bool on = getenv("SFQ_TIMING") != nullptr;
     static auto t0 = std::chrono::steady_clock::now(), last = t0;
@@ -65,7 +67,9 @@ static void usage() {
            "-A               : adaptive tables: every block updates its rows per symbol, as the reference does (slower);\n"
            "                   default: frozen tables, built by counting passes, one coding chain per GPU lane\n"
            "-C reads         : frozen tables: records per chain (default: automatic)\n"
-           "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 2048)\n"
+           "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 512 for a\n"
+           "                   regular file, read ahead while the GPU codes the slab before; 2048 for a pipe)\n"
+           "-t threads       : threads reading a slab (default 6)\n"
            "-g device        : HIP device index (default 0)\n"
            "-T percent       : share of the device memory this process may use for model tables (several processes on one GPU)\n"
            "-b               : batch: read '<fastq>\\t<sfq>' jobs (with -d: '<sfq>\\t<fastq>') from stdin, answer 'ok|fail\\t...' per job on stdout\n"
@@ -84,7 +88,8 @@ struct Opts {
     int level = 3, device = 0;
     long block_reads = -1;                                             // -1 = automatic (about 376 KiB of text per block)
     bool overwrite = false, quiet = false;
-    uint64_t slab_bytes = 2048ull << 20;
+    uint64_t slab_bytes = 0;                      // -S; 0 = 512 MiB for a regular file (read ahead into pinned buffers), 2 GiB otherwise
+    int io_threads = 6;                           // -t: threads that read a slab
     int table_pct = 0;                                                 // -T: share of the device memory for model tables (0 = the library's default)
     bool adaptive = false;                                             // -A
     long chain_reads = 0;                                              // -C
@@ -168,17 +173,150 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     // A one-shot process pays for every byte of model tables it allocates (device allocations of tens of GB take
     // seconds), and its time is file I/O anyway: size the tables for a fraction of the block slots the text could use.
     if (!g_batch) {
-        const uint64_t text = std::min<uint64_t>(file_left == SIZE_MAX ? o.slab_bytes : file_left, legacy ? UINT64_MAX : o.slab_bytes);
+        const uint64_t slab0 = o.slab_bytes ? o.slab_bytes : (!legacy && in != stdin && file_left != SIZE_MAX) ? (512ull << 20) : (2048ull << 20);
+        const uint64_t text = std::min<uint64_t>(file_left == SIZE_MAX ? slab0 : file_left, legacy ? UINT64_MAX : slab0);
         uint64_t budget = std::max<uint64_t>(2ull << 30, 8 * text);
         if (o.table_pct) budget = std::min<uint64_t>(budget, sfq_ctx_device_memory(ctx) / 100 * (uint64_t)o.table_pct);
         sfq_ctx_set_table_budget(ctx, budget);
     }
+    // A regular file in the block format: slabs are read AHEAD -- several threads pread the next slab into one of two
+    // page-locked buffers while the GPU codes the current one -- and the streams come back into a page-locked buffer too.
+    // (File to file the time is the host's: one thread fread()s at ~5 GB/s, pageable H2D/D2H copies crawl.)
+    const bool ahead = !legacy && in != stdin && file_left != SIZE_MAX;
+    const size_t slab = (size_t)(o.slab_bytes ? o.slab_bytes : ahead ? (512ull << 20) : (2048ull << 20));
     Bytes fq, out;
     bool eof = false;
+    sfqc::PagedWriter pw; bool streamed = false;                       // the archive written as the slabs come back
+    if (ahead) {
+        const int fd = fileno(in);
+        const size_t fsize = file_left;
+        const size_t cap = slab + (64u << 20);                          // room for the carried-over partial record
+        const size_t out_cap = (size_t)sfq_encode_bound(cap);
+        // (kept for the life of the process: a -b worker reuses them, a one-shot run exits without the 0.2 s of unpinning)
+        static uint8_t* pinned[4] = { nullptr, nullptr, nullptr, nullptr }; static size_t pinned_cap = 0;
+        // the streams of a slab are rarely a third of its text: that much is page-locked, twice (one buffer is written to
+        // the archive while the next slab's streams arrive in the other); a slab that needs more goes through a plain buffer
+        const size_t out_pin = cap / 3 + (16u << 20);
+        if (pinned_cap < cap) {
+            for (auto& q : pinned) { if (q) sfq_host_free(ctx, q); q = nullptr; }
+            pinned[0] = (uint8_t*)sfq_host_alloc(ctx, cap); pinned[1] = (uint8_t*)sfq_host_alloc(ctx, cap);
+            pinned[2] = (uint8_t*)sfq_host_alloc(ctx, out_pin); pinned[3] = (uint8_t*)sfq_host_alloc(ctx, out_pin);
+            pinned_cap = (pinned[0] && pinned[1] && pinned[2] && pinned[3]) ? cap : 0;
+        }
+        uint8_t* buf[2] = { pinned[0], pinned[1] };
+        if (!pinned_cap) croak("out of page-locked memory (-S sets the slab size)");
+        Bytes big_out;                                                  // only for a slab whose streams outgrow the pinned buffer
+        std::string werr;
+        if (!pw.open(fil, werr)) croak("%s", werr.c_str());
+        int sid[SFQ_NSTREAMS];
+        for (int s2 = 0; s2 < SFQ_NSTREAMS; s2++) sid[s2] = -1;           // a stream gets its directory entry with its first bytes
+        std::thread writer;                                             // appends the previous slab's streams to the archive
+        int ob = 0;
+        tick("pinned buffers");
+        // read file bytes [off, off + len) to dst with o.io_threads threads; newlines counted on the way
+        struct Read { std::vector<std::thread> th; std::atomic<uint64_t> nl{0}; std::atomic<int> bad{0}; };
+        auto start_read = [&](Read& r, uint8_t* dst, size_t off, size_t len) {
+            r.nl = 0; r.bad = 0;
+            const int nt = std::max(1, o.io_threads);
+            const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
+            for (int t = 0; t < nt; t++) {
+                const size_t a0 = std::min(len, per * t), a1 = std::min(len, per * (t + 1));
+                if (a0 >= a1) break;
+                r.th.emplace_back([&r, fd, dst, off, a0, a1]() {
+                    size_t at = a0; uint64_t nl = 0;
+                    while (at < a1) {
+                        const ssize_t got = pread(fd, dst + at, std::min<size_t>(a1 - at, 8u << 20), (off_t)(off + at));
+                        if (got <= 0) { r.bad = 1; return; }
+                        for (const uint8_t* q = dst + at, *e = q + got; q < e; q++) nl += *q == '\n';
+                        at += (size_t)got;
+                    }
+                    r.nl += nl;
+                });
+            }
+        };
+        auto join_read = [&](Read& r) { for (auto& t : r.th) t.join(); r.th.clear(); if (r.bad) croak("read error"); };
+        size_t off = 0;                                                 // file bytes handed to a reader so far
+        size_t have[2] = {0, 0}; uint64_t nls[2] = {0, 0};
+        int cur = 0;
+        {
+            Read r; const size_t len = std::min(slab, fsize);
+            start_read(r, buf[0], 0, len); join_read(r);
+            have[0] = len; nls[0] = r.nl; off = len;
+        }
+        tick("read slab");
+        while (have[cur]) {
+            const bool last = off >= fsize;
+            uint8_t* text = buf[cur];
+            size_t use = have[cur];
+            if (!last) {                                                // whole records only: drop the partial last line and nl % 4 lines more
+                size_t drop = (size_t)(nls[cur] & 3), end = use;
+                while (end > 0 && text[end - 1] != '\n') end--;
+                while (drop && end > 0) { end--; while (end > 0 && text[end - 1] != '\n') end--; drop--; }
+                use = end;
+                if (use == 0) croak("a record longer than the slab (%zu MiB): raise -S", slab >> 20);
+            }
+            // the next slab: the carried-over tail, then file bytes read by the threads while this one is coded
+            const int nxt = cur ^ 1;
+            const size_t carry = have[cur] - use;
+            Read r;
+            size_t len = 0;
+            if (carry > (64u << 20)) croak("a record longer than 64 MiB next to a slab boundary: raise -S");
+            memcpy(buf[nxt], text + use, carry);
+            uint64_t carry_nl = 0; for (size_t i = 0; i < carry; i++) carry_nl += buf[nxt][i] == '\n';
+            if (!last) { len = std::min(slab, fsize - off); start_read(r, buf[nxt] + carry, off, len); }
+            sfq_result res;
+            uint8_t* outp = pinned[2 + ob];
+            int rc = sfq_encode_blocks_host(ctx, text, use, &p, outp, out_pin, &res);
+            if (rc == SFQ_E_OVERFLOW) {
+                if (!big_out.reserve(out_cap)) { join_read(r); croak("out of memory"); }
+                if (writer.joinable()) writer.join();
+                outp = big_out.p;
+                rc = sfq_encode_blocks_host(ctx, text, use, &p, outp, out_cap, &res);
+            }
+            if (rc) { join_read(r); if (writer.joinable()) writer.join(); croak("%s", sfq_last_error(ctx)); }
+            tick("sfq_encode_blocks_host");
+            const size_t b0 = blocks_all.size();
+            blocks_all.resize(b0 + res.n_blocks);
+            sfq_get_block_index(ctx, blocks_all.data() + b0, res.n_blocks);
+            for (size_t b = b0; b < blocks_all.size(); b++) { blocks_all[b].first_record += total_records; blocks_all[b].first_hdr_off += first_all.size(); }
+            const size_t f0 = first_all.size();
+            first_all.resize(f0 + (size_t)res.first_hdr_bytes + 1);
+            sfq_get_first_headers(ctx, first_all.data() + f0, res.first_hdr_bytes);
+            first_all.resize(f0 + (size_t)res.first_hdr_bytes);
+            if (writer.joinable()) writer.join();
+            {
+                const sfq_result rr = res; sfqc::PagedWriter* w = &pw; int* ids = sid; const uint8_t* src = outp;
+                writer = std::thread([rr, w, ids, src]() {
+                    for (int s2 = 0; s2 < SFQ_NSTREAMS; s2++) if (rr.stream_bytes[s2]) {
+                        if (ids[s2] < 0) ids[s2] = w->stream(sfq_stream_name(s2));
+                        w->append(ids[s2], src + rr.stream_offset[s2], (size_t)rr.stream_bytes[s2]);
+                    }
+                });
+                if (outp == big_out.p) writer.join(); else ob ^= 1;
+            }
+            Segment sg{res.n_blocks, 0, use, 0, 0};
+            const int64_t pn = sfq_get_qlt_prior(ctx, nullptr, 0);
+            if (pn > 0) { const size_t q0 = prior_all.size(); prior_all.resize(q0 + (size_t)pn); sfq_get_qlt_prior(ctx, prior_all.data() + q0, (uint64_t)pn); sg.prior_bytes = (uint64_t)pn; }
+            const int64_t cn = sfq_get_chain_index(ctx, nullptr, 0);
+            if (cn > 0) { const size_t q0 = chain_all.size(); chain_all.resize(q0 + (size_t)cn); sfq_get_chain_index(ctx, chain_all.data() + q0, (uint64_t)cn); sg.chain_bytes = (uint64_t)cn; }
+            const int64_t rn = sfq_get_rec_prior(ctx, nullptr, 0);
+            if (rn > 0) { const size_t q0 = recpri_all.size(); recpri_all.resize(q0 + (size_t)rn); sfq_get_rec_prior(ctx, recpri_all.data() + q0, (uint64_t)rn); sg.recpri_bytes = (uint64_t)rn; }
+            segs.push_back(sg);
+            total_in += use; total_records += res.n_records;
+            tick("collect slab");
+            join_read(r);
+            tick("wait for the next slab");
+            have[nxt] = carry + len; nls[nxt] = carry_nl + r.nl; off += len;
+            cur = nxt;
+        }
+        if (writer.joinable()) writer.join();
+        streamed = true;
+        eof = true;                                                     // nothing left for the loop below
+    }
     for (;;) {
         if (eof && fq.n == 0) break;
         // the reference's single adaptive state (format 6) cannot be cut: one slab holds the whole file
-        size_t want = legacy ? std::max<size_t>(fq.n * 2, 64u << 20) : (size_t)o.slab_bytes;
+        size_t want = legacy ? std::max<size_t>(fq.n * 2, 64u << 20) : slab;
         if (want <= fq.n) want = fq.n * 2;                              // a record longer than the slab: grow
         if (file_left != SIZE_MAX) want = legacy ? fq.n + file_left + 1 : std::min(want, fq.n + file_left + 1);   // +1: see the end of the file
         const size_t before = fq.n;
@@ -246,6 +384,27 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         a.set("num_records", (long long)total_records);
         if (segs.size() > 1) a.set("seg.count", (long long)segs.size());
         if (frozen) a.set("blk.tables", 1);                                // frozen tables: chn.idx / rec.pri per segment
+    }
+    if (streamed) {
+        auto add = [&](const char* name, const std::vector<uint8_t>& v) { const int id = pw.stream(name); pw.append(id, v.data(), v.size()); };
+        add("blk.idx", sfqc::pack_block_index(blocks_all));
+        add("blk.hdr", first_all);
+        if (!prior_all.empty()) add("qlt.pri", prior_all);
+        if (!chain_all.empty()) add("chn.idx", chain_all);
+        if (!recpri_all.empty()) add("rec.pri", recpri_all);
+        if (segs.size() > 1) {
+            std::vector<uint8_t> si;
+            put_v(si, segs.size());
+            for (auto& g : segs) {
+                put_v(si, g.nblocks); put_v(si, g.prior_bytes); put_v(si, g.raw_bytes);
+                if (frozen) { put_v(si, g.chain_bytes); put_v(si, g.recpri_bytes); }
+            }
+            add("seg.idx", si);
+        }
+        std::string werr;
+        if (!pw.finish(a.info, werr)) croak("%s", werr.c_str());
+        tick("finish archive");
+        return;
     }
     for (int s = 0; s < SFQ_NSTREAMS; s++) if (!streams[s].empty()) a.add(sfq_stream_name(s), std::move(streams[s]));
     if (!legacy) {
@@ -394,7 +553,7 @@ int main(int argc, char** argv) {
     Opts o;
     bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdObA1234u:f:l:B:g:S:T:C:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdObA1234u:f:l:B:g:S:T:C:t:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
@@ -411,6 +570,7 @@ int main(int argc, char** argv) {
         case 'b': g_batch = true; break;
         case 'A': o.adaptive = true; break;
         case 'C': o.chain_reads = strtol(optarg, 0, 0); break;
+        case 't': o.io_threads = std::min(64, std::max(1, atoi(optarg))); break;
         case 'v': printf("Version %s\nInternal format version=%u (block format %u)\n", kUserVersion, kInternalVersion, kBlockVersion); exit(0);
         case 'h': usage();
         case 's': statistics = true; g_encode = false; break;

@@ -1,5 +1,8 @@
 // container.cpp -- see container.h.  Host-side file plumbing only; no entropy coding here.
 #include "container.h"
+#include <fcntl.h>
+#include <unistd.h>
+#include <algorithm>
 
 #include <cstdio>
 #include <cstdlib>
@@ -169,6 +172,85 @@ bool write_file(const std::string& path, const Archive& a, std::string& err) {
     bool ok = fwrite(img.data(), 1, img.size(), f) == img.size();
     ok = fclose(f) == 0 && ok;
     if (!ok) err = "write error on '" + path + "'";
+    return ok;
+}
+
+// ---- writing as the streams grow ---------------------------------------------------------------------------
+PagedWriter::~PagedWriter() { if (fd_ >= 0) close(fd_); }
+bool PagedWriter::open(const std::string& path, std::string& err) {
+    fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd_ < 0) { err = "Can't write file '" + path + "'"; return false; }
+    wbuf_.reserve(17u << 20);
+    return true;
+}
+int PagedWriter::stream(const std::string& name) { st_.emplace_back(); st_.back().name = name; st_.back().cur.reserve(PAGE); return (int)st_.size() - 1; }
+bool PagedWriter::flush() {
+    size_t at = 0;
+    while (at < wbuf_.size() && !bad_) {
+        const ssize_t w = pwrite(fd_, wbuf_.data() + at, wbuf_.size() - at, (off_t)(wbuf_page_ * PAGE + at));
+        if (w <= 0) { bad_ = true; break; }
+        at += (size_t)w;
+    }
+    wbuf_page_ += wbuf_.size() / PAGE;
+    wbuf_.clear();
+    return !bad_;
+}
+void PagedWriter::emit(const uint8_t* page) {                       // the page with id next_ - 1 (ids are handed out in emission order)
+    wbuf_.insert(wbuf_.end(), page, page + PAGE);
+    if (wbuf_.size() >= (16u << 20)) flush();
+}
+void PagedWriter::append(int id, const uint8_t* p, size_t n) {
+    St& s = st_[(size_t)id];
+    s.size += n;
+    while (n) {
+        if (s.cur.empty() && n >= PAGE) { s.pages.push_back(next_++); emit(p); p += PAGE; n -= PAGE; continue; }   // whole pages straight through
+        const size_t take = std::min(n, PAGE - s.cur.size());
+        s.cur.insert(s.cur.end(), p, p + take); p += take; n -= take;
+        if (s.cur.size() == PAGE) { s.pages.push_back(next_++); emit(s.cur.data()); s.cur.clear(); }
+    }
+}
+bool PagedWriter::finish(const std::vector<std::pair<std::string, std::string>>& info, std::string& err) {
+    if (st_.size() + 1 > MAX_FILES) { err = "too many streams"; return false; }
+    std::vector<uint8_t> page(PAGE);
+    for (St& s : st_) {                                             // the partial last page (an empty stream still owns one page, as build_image lays it out)
+        if (!s.cur.empty() || s.pages.empty()) {
+            std::fill(page.begin(), page.end(), 0);
+            if (!s.cur.empty()) memcpy(page.data(), s.cur.data(), s.cur.size());
+            s.pages.push_back(next_++); emit(page.data()); s.cur.clear();
+        }
+    }
+    std::vector<DirEnt> dir(MAX_FILES);
+    memset(dir.data(), 0, dir.size() * sizeof(DirEnt));
+    for (size_t i = 0; i < st_.size(); i++) {                       // node pages: the ids of a stream's pages after the first
+        St& s = st_[i];
+        DirEnt& e = dir[i + 1];
+        memcpy(e.name, s.name.data(), std::min<size_t>(8, s.name.size()));
+        e.size = s.size; e.first = s.pages[0]; e.node = 0;
+        const size_t rest = s.pages.size() - 1;
+        const size_t nodes = (rest + NODE_IDS - 1) / NODE_IDS;
+        const uint32_t node0 = next_;
+        if (nodes) e.node = node0;
+        for (size_t q = 0; q < nodes; q++) {
+            uint32_t* node = (uint32_t*)page.data();
+            for (size_t k = 0; k < NODE_IDS; k++) { const size_t pi = 1 + q * NODE_IDS + k; node[k] = pi < s.pages.size() ? s.pages[pi] : 0; }
+            node[NODE_IDS] = q + 1 < nodes ? (uint32_t)(node0 + q + 1) : 0;
+            next_++; emit(page.data());
+        }
+    }
+    if (!flush()) { err = "write error"; return false; }
+    std::string text;
+    bool has_size = false;
+    for (auto& kv : info) if (kv.first == "comp.size") has_size = true;
+    for (auto& kv : info) text += kv.first + "=" + kv.second + "\n";
+    if (!has_size) text += "comp.size=" + std::to_string((unsigned long long)next_ * PAGE) + "\n";      // config.cpp:381-389
+    if (text.size() > PAGE) text.resize(PAGE);
+    std::vector<uint8_t> head(2 * PAGE, 0);
+    memcpy(head.data(), text.data(), text.size());
+    dir[0].size = text.size(); dir[0].first = (uint32_t)(st_.size() + 1);
+    memcpy(head.data() + PAGE, dir.data(), MAX_FILES * sizeof(DirEnt));
+    if (pwrite(fd_, head.data(), head.size(), 0) != (ssize_t)head.size()) { err = "write error"; return false; }
+    const bool ok = close(fd_) == 0; fd_ = -1;
+    if (!ok) err = "write error";
     return ok;
 }
 

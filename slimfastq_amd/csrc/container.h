@@ -40,6 +40,27 @@ bool parse_image(const uint8_t* img, size_t n, Archive& a, std::string& err);
 bool write_file(const std::string& path, const Archive& a, std::string& err);   // sets comp.size
 std::vector<uint8_t> build_image(const Archive& a);
 
+// The same file written as the streams grow (the reference's FilerSave does the same: pages are handed out in the order
+// they fill, so the streams' pages interleave; filer.cpp:217-242): append() as data arrives, finish() writes the partial
+// pages, the node pages, the directory and the info page.  Nothing of a stream is kept in memory but its page list.
+class PagedWriter {
+public:
+    ~PagedWriter();
+    bool open(const std::string& path, std::string& err);
+    int  stream(const std::string& name);                                  // a new directory entry; returns its id
+    void append(int id, const uint8_t* p, size_t n);
+    bool finish(const std::vector<std::pair<std::string, std::string>>& info, std::string& err);   // adds comp.size
+private:
+    struct St { std::string name; uint64_t size = 0; std::vector<uint32_t> pages; std::vector<uint8_t> cur; };
+    void emit(const uint8_t* page);
+    bool flush();
+    int fd_ = -1; bool bad_ = false;
+    uint32_t next_ = 2;                  // page ids 0 and 1 are the info page and the directory
+    uint64_t wbuf_page_ = 2;             // page id of wbuf_'s first page
+    std::vector<uint8_t> wbuf_;
+    std::vector<St> st_;
+};
+
 // block index <-> "blk.idx"
 std::vector<uint8_t> pack_block_index(const std::vector<sfq_block_info>& blocks);
 bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks);
