@@ -34,7 +34,7 @@ extern "C" {
 #define SFQ_E_FORMAT       -4   /* input is not 4-line FASTQ (reference: croak, usrs.cpp:162-172) */
 #define SFQ_E_OVERFLOW     -5   /* an output arena was too small                             */
 #define SFQ_E_CORRUPT      -6   /* compressed stream inconsistent                            */
-#define SFQ_E_UNSUPPORTED  -7   /* e.g. records over the reference's 65535-base model limit (usrs.hpp:34-36) */
+#define SFQ_E_UNSUPPORTED  -7   /* e.g. format 6 and a record over the reference's line limits (usrs.hpp:34-36), whose oversize side streams are not written */
 #define SFQ_E_GENCHAR      -8   /* unexpected genome char (gens.cpp:125-126) / switched N byte (gens.cpp:107-108) */
 
 /* Stream ids: the reference's stream names (FilerSave(name) call sites). */
@@ -81,7 +81,7 @@ typedef struct sfq_params {
                               (Log64Ranger / Base2Ranger updated per symbol), a wavefront per block;
                               SFQ_TABLES_FROZEN (1) = the rows are built by counting passes and frozen while a chain
                               is coded -- qualities from the transmitted prior, bases from the counts of the earlier
-                              generations of the same call -- one chain per LANE (DESIGN.md section 5)               */
+                              generations of the same call -- one chain per LANE (DESIGN.md section 4)               */
     uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic                                    */
     uint32_t lds_rows;     /* frozen tables, encode: the N most used quality rows are staged in LDS by every workgroup
                               (0 or SFQ_LDS_ROWS_NONE = none: measured no faster than the L2-resident table) */
