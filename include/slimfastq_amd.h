@@ -122,7 +122,11 @@ typedef struct sfq_result {
     uint64_t first_hdr_bytes;              /* size of the first-header blob (see sfq_get_first_headers) */
     uint32_t n_chains;                     /* frozen tables: chains per chain-coded stream (else 0)   */
     uint32_t reserved;
-    double   kernel_ms[8];                 /* device time of the last call, by phase (see SFQ_T_*) */
+    double   kernel_ms[8];                 /* device time of the last call, by phase (see SFQ_T_*): a model's phase is
+                                              everything on its stream -- counting passes, row building, the coding kernel */
+    double   coder_ms[4];                  /* encode: the coding kernel alone (HIP events around its launch on its stream):
+                                              [0] quality, [1] bases, [2] headers, [3] unused.  What a kernel trace shows as
+                                              k_qlt_encode_c / k_gen_encode_c / k_rec_encode_f (k_*_encode_k / _w with adaptive tables) */
 } sfq_result;
 
 #define SFQ_T_FRAME   0   /* line index + block descriptors                     */

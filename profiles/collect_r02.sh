@@ -13,6 +13,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   name=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${name} -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_${name}.log 2>&1
 done
+python3 $ROOT/bench.py --steps 3 --warmup 1 > $OUT/${TAG}_default_bench_with_cpu_baseline.json 2> $OUT/${TAG}_bench.err
 python3 - <<PY
 import csv, glob, collections, json
 agg=collections.defaultdict(lambda: [0,0.0])
@@ -24,13 +25,14 @@ lines=[]
 for (kn,cn),(n,v) in sorted(agg.items()):
     if v>0 and kn.startswith("k_"): lines.append("%-34s %-22s calls=%d sum=%.4g per_call=%.4g"%(kn,cn,n,v,v/n))
 open("$OUT/${TAG}_pmc_summary.txt","w").write("\n".join(lines)+"\n")
-def per(kn, cn):
-    n, v = agg.get((kn, cn), (0, 0.0))
-    return int(v / n * 1024) if n else 0
-kern = {"qlt_encode": "k_qlt_encode_c<256, false>", "gen_encode": "k_gen_encode_c<256>", "rec_encode": "k_rec_encode_f"}
+def per(prefix, cn):
+    for (kn, c), (n, v) in agg.items():
+        if c == cn and kn.startswith(prefix) and n: return int(v / n * 1024)
+    return 0
+kern = {"qlt_encode": "k_qlt_encode_c", "gen_encode": "k_gen_encode_c", "rec_encode": "k_rec_encode_f"}
 out = {"source": "profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per launch)",
        "config": {"reads": 10000000, "read_len": 150, "level": 3, "kind": 0, "block_reads": 1024, "kernel": 0, "tables": 1},
-       "note": "bytes = counter (KB) x 1024, as reported.  The guide's gfx950 correction (FETCH_SIZE reads half of a wide coalesced stream) is "
+       "note": "bytes = counter (KB) x 1024, as reported; kernels matched by name prefix (template arguments vary with the input).  The guide's gfx950 correction (FETCH_SIZE reads half of a wide coalesced stream) is "
                "calibrated for 16 B/lane coalesced loads; these kernels read 16-byte pieces per LANE from 64 different lines, for which the counter is "
                "uncalibrated: the true fetch lies between the reported figure and twice it.", "kernels": {}}
 for key, name in kern.items():

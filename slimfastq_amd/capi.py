@@ -44,7 +44,7 @@ class Result(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_blocks", C.c_uint32), ("abi_version", C.c_uint32),
                 ("stream_bytes", C.c_uint64 * NSTREAMS), ("stream_offset", C.c_uint64 * NSTREAMS),
                 ("total_bytes", C.c_uint64), ("first_hdr_bytes", C.c_uint64), ("n_chains", C.c_uint32), ("reserved", C.c_uint32),
-                ("kernel_ms", C.c_double * 8)]
+                ("kernel_ms", C.c_double * 8), ("coder_ms", C.c_double * 4)]
 
 
 class SfqError(RuntimeError):

@@ -33,7 +33,7 @@ struct sfq_ctx {
     int dev = 0;
     hipStream_t st = nullptr;
     hipStream_t st_aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev[16] = {};
+    hipEvent_t ev[24] = {};
     std::string err;
     u64 table_budget = 0;
     u64 dev_total = 0;
@@ -776,7 +776,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (headers) first
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
         HIPC(hipEventRecord(ctx->ev[2], st));
-        if (models & SFQ_M_QLT) { ca.m = a; ca.csz = (u32*)ctx->csz.p; launch_qlt_encode_c(ca, st); }
+        if (models & SFQ_M_QLT) {
+            ca.m = a; ca.csz = (u32*)ctx->csz.p;
+            HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
+        }
         HIPC(hipEventRecord(ctx->ev[3], st));
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
@@ -785,13 +788,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
-            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, max_hdr, mst[1]);
+            HIPC(hipEventRecord(ctx->ev[18], mst[1])); launch_rec_encode_c(ca, (u32*)ctx->rflags.p, max_hdr, mst[1]); HIPC(hipEventRecord(ctx->ev[19], mst[1]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
             if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, mst[3], gplan, &gen_on))) return rc;
-            launch_gen_encode_c(ca, mst[3]);
+            HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3]); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if ((models & SFQ_M_GEN) && ca.exc_flag) {                  // the marks are complete once both chain kernels are through
@@ -934,6 +937,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     for (int m = 0; m < 4; m++) res->kernel_ms[tslot[m]] = ev_ms(ctx->ev[2 + 2 * m], ctx->ev[3 + 2 * m]);     // the models overlap: these do not add up
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
+    if (frozen) {
+        if (models & SFQ_M_QLT) res->coder_ms[0] = ev_ms(ctx->ev[14], ctx->ev[15]);
+        if (models & SFQ_M_GEN) res->coder_ms[1] = ev_ms(ctx->ev[16], ctx->ev[17]);
+        if (models & SFQ_M_REC) res->coder_ms[2] = ev_ms(ctx->ev[18], ctx->ev[19]);
+    } else {                                       // one persistent kernel per model: the phase is the kernel
+        res->coder_ms[0] = res->kernel_ms[SFQ_T_QLT]; res->coder_ms[1] = res->kernel_ms[SFQ_T_GEN]; res->coder_ms[2] = res->kernel_ms[SFQ_T_REC];
+    }
     return SFQ_OK;
 }
 

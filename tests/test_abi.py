@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Params) == 40
     assert ctypes.sizeof(capi.BlockInfo) == 88
-    assert ctypes.sizeof(capi.Result) == 8 + 4 + 4 + 80 + 80 + 8 + 8 + 4 + 4 + 64
+    assert ctypes.sizeof(capi.Result) == 8 + 4 + 4 + 80 + 80 + 8 + 8 + 4 + 4 + 64 + 32
     assert [capi.lib().sfq_stream_name(i).decode() for i in range(capi.NSTREAMS)] == capi.STREAM_NAMES
 
 
