@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--reads", type=int, default=0, help="records per GPU (default: 10M x 150 bp, the BASELINE config; 60k for --kind 1 long reads)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--block-reads", type=int, default=int(os.environ.get("SFQ_BLOCK_READS", "0")),
+    ap.add_argument("--block-reads", type=int, default=0,
                     help="records per block (default: 1024, which is also what the library's automatic choice gives for 150 bp reads; "
                          "automatic for --kind 1 long reads)")
     ap.add_argument("--workload", choices=["full", "qlt"], default="full")

@@ -8,9 +8,9 @@ d = '/tmp/sfq_e2e'; os.makedirs(d, exist_ok=True)
 fq = capi.synth_fastq(n, 150, seed=2)
 src, sfq, back = d + '/in.fq', d + '/out.sfq', d + '/back.fq'
 open(src, 'wb').write(fq)
-for label, cmd in (('compress', [cli, '-u', src, '-f', sfq, '-O']), ('compress again (tables allocated per process)', [cli, '-u', src, '-f', sfq, '-O']),
-                   ('decompress', [cli, '-d', '-f', sfq, '-u', back, '-O'])):
-    t0 = time.time(); subprocess.check_call(cmd, env=dict(os.environ, SFQ_TIMING="1")); dt = time.time() - t0
+for label, cmd in (('compress', [cli, '-z', '-u', src, '-f', sfq, '-O']), ('compress again (tables allocated per process)', [cli, '-z', '-u', src, '-f', sfq, '-O']),
+                   ('decompress', [cli, '-z', '-d', '-f', sfq, '-u', back, '-O'])):
+    t0 = time.time(); subprocess.check_call(cmd); dt = time.time() - t0
     print('%-48s %6.2f s  %7.1f MB/s of FASTQ' % (label, dt, len(fq) / dt / 1e6), flush=True)
 assert open(back, 'rb').read() == fq
 print('sizes: fastq %d, sfq %d' % (len(fq), os.path.getsize(sfq)))

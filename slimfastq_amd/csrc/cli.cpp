@@ -35,10 +35,10 @@ struct JobError { std::string msg; };
 #include <chrono>
 #include <thread>
 #include <atomic>
+static bool g_timing = false;                 // -z: phase timings on stderr
 static void tick(const char* what) {
-    static const bool on = getenv("SFQ_TIMING") != nullptr;
     static auto t0 = std::chrono::steady_clock::now(), last = t0;
-    if (!on) return;
+    if (!g_timing) return;
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[timing] %-28s +%7.3f s  (%7.3f s)\n", what, std::chrono::duration<double>(now - last).count(), std::chrono::duration<double>(now - t0).count());
     last = now;
@@ -70,6 +70,7 @@ static void usage() {
            "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 512 for a\n"
            "                   regular file, read ahead while the GPU codes the slab before; 2048 for a pipe)\n"
            "-t threads       : threads reading a slab (default 6)\n"
+           "-z               : print the time of every phase on stderr\n"
            "-g device        : HIP device index (default 0)\n"
            "-T percent       : share of the device memory this process may use for model tables (several processes on one GPU)\n"
            "-b               : batch: read '<fastq>\\t<sfq>' jobs (with -d: '<sfq>\\t<fastq>') from stdin, answer 'ok|fail\\t...' per job on stdout\n"
@@ -553,7 +554,7 @@ int main(int argc, char** argv) {
     Opts o;
     bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdObA1234u:f:l:B:g:S:T:C:t:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdObzA1234u:f:l:B:g:S:T:C:t:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
@@ -568,6 +569,7 @@ int main(int argc, char** argv) {
         case 'g': o.device = atoi(optarg); break;
         case 'T': o.table_pct = std::min(90, std::max(1, atoi(optarg))); break;
         case 'b': g_batch = true; break;
+        case 'z': g_timing = true; break;
         case 'A': o.adaptive = true; break;
         case 'C': o.chain_reads = strtol(optarg, 0, 0); break;
         case 't': o.io_threads = std::min(64, std::max(1, atoi(optarg))); break;
