@@ -16,6 +16,10 @@ int main() {
         LaneEncB<1, 8> b; b.init(ring, 0, o2.data(), cap);
         int since = 0;
         for (int i = 0; i < nsym; i++) {
+            if (rand() % 97 == 0) {          // force the carry-less corner (coder.hpp:76-77): bits 24..55 of low all ones
+                const u64 forced = ((u64)(rand() & 0xff) << 56) | 0x00FFFFFFFF000000ull | (u64)(rand() & 0xFFFFFF);
+                a.low = b.low = forced;
+            }
             const bool valid = rand() % 8 != 0;
             u32 cum, freq, tot;
             if (mode == 0) { tot = 65536; freq = 1 + rand() % (rand() % 4 ? 60000 : 3); cum = rand() % (tot - freq + 1); }

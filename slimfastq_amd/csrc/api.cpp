@@ -453,8 +453,10 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     if (hipSetDevice(hip_device) != hipSuccess) return SFQ_E_HIP;
     sfq_ctx* ctx = new sfq_ctx();
     ctx->dev = hip_device;
-    // one stream per model (quality, bases, headers, framing); stream priorities were measured to change nothing
+    // one stream per model (quality, bases, headers, framing)
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    // (the runtime maps streams of one priority onto three hardware queues: the framing stream shares one with the base
+    //  model's, and two streams that share a queue run one after the other -- keep long kernels off the framing stream)
     for (int i = 0; i < 3; i++) if (hipStreamCreateWithFlags(&ctx->st_aux[i], hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     size_t fr = 0, tot = 0;
@@ -672,7 +674,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
         if ((rc = setup_tables())) return rc;
+        // the pass over the N / quality-0 exceptions looks only at the records k_exc_mark marks
         // the pass over the N / quality-0 exceptions looks only at the records the quality and base chains mark
+        // (marking them ahead -- a pass of its own over the text, then the exception pass while the counting passes run
+        //  -- was measured: the extra pass costs more chip time than the 2 ms the exception pass takes behind the chains)
         const bool exc_marks = (models & SFQ_M_QLT) && (models & SFQ_M_GEN);
         if (exc_marks) {
             if ((rc = reserve(ctx, ctx->excf, (size_t)nrec))) return rc;
@@ -722,6 +727,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
         h_rows66 = (u32*)((u8*)ctx->pin + PIN_BYTES);
         HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipEventRecord(ctx->ev[20], st));
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
@@ -873,6 +879,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     launch_gather_first_hdrs((const BlockDesc*)ctx->blocks.p, nblocks, d_fastq, (const u64*)ctx->blob_off.p, (u8*)ctx->blob.p, blob_cap, st);
     u64 totals[SFQ_NSTREAMS];
     HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, sizeof totals, hipMemcpyDeviceToHost, st));
+    // host work that needs nothing of what is still running goes here, while the chains are coded: "qlt.pri"
+    if (ctx->prior_on && !given && h_rows66) {
+        HIPC(hipEventSynchronize(ctx->ev[20]));
+        ctx->prior_blob = pack_prior(h_rows66, q_rows);
+    }
     std::vector<BlockDesc> hb(nblocks);
     HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     std::vector<u64> hboff((size_t)nblocks + 1);
@@ -907,7 +918,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
 
-    if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66, q_rows);
     ctx->prior_on = false;
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes

@@ -97,9 +97,12 @@ __device__ __forceinline__ u8* chain_region(const ChainArgs& a, const ChainPos& 
 }
 
 // 16 text bytes of a lane: aligned loads, nothing read outside [fq, fq_end)
-__device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {          // at is 16-byte aligned relative to address 0
+__device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {          // any alignment (global loads need none on gfx9)
     const u8* p = fq + at;
-    if ((((uintptr_t)p) & 15) == 0 && at + 16 <= nbytes) return *reinterpret_cast<const uint4*>(p);
+    if (at + 16 <= nbytes) {
+        const u32* q = reinterpret_cast<const u32*>(p);
+        return make_uint4(q[0], q[1], q[2], q[3]);
+    }
     u32 w[4] = {0, 0, 0, 0};
     for (u32 i = 0; i < 16; i++) if (at + i < nbytes) w[i >> 2] |= (u32)p[i] << ((i & 3) * 8);
     return make_uint4(w[0], w[1], w[2], w[3]);
@@ -107,13 +110,13 @@ __device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {     
 
 // ---- a lane's text, piece by piece -----------------------------------------------------------------------------------
 // A chain's symbols are the LINE-th lines (1 = bases, 3 = qualities) of records [r0, r0 + nrec), minus a SOLiD prefix
-// character.  The lane takes them in 16-byte pieces that are aligned in memory; next() describes the coming piece from
+// character.  The lane takes them sixteen bytes at a time; next() describes the coming piece from
 // the line bounds alone, so the caller can have the piece after the one it is working on in flight, and the bounds of
 // a line are themselves fetched a record ahead: no memory round trip sits on the lane's critical path.
 struct Piece { u64 at; u32 j0, j1, rk; bool valid, newline; };  // bytes [j0, j1) of the 16 at offset `at` are the lane's, of the walk's record rk; newline: they start a line
 struct LineWalk {
     const u64* line_off; const u64* st_off; const u32* st_len;   // FASTQ text (line_off) or the decoder's staged lines (st_off / st_len)
-    const u8* buf; u64 nbytes; u32 mis;
+    const u8* buf; u64 nbytes;
     u64 r0; u32 nrec, k, line, solid;
     u64 pos, end, npos, nend;
     bool fresh;
@@ -124,7 +127,7 @@ struct LineWalk {
     }
     __device__ __forceinline__ void init(const ChainArgs& a, u64 r0_, u32 nrec_, u32 line_, u32 solid_) {
         line_off = a.m.line_off; st_off = a.st_off; st_len = a.st_len;
-        buf = st_off ? a.st_buf : a.m.fq; nbytes = st_off ? a.st_bytes : a.nbytes; mis = (u32)((uintptr_t)buf & 15);
+        buf = st_off ? a.st_buf : a.m.fq; nbytes = st_off ? a.st_bytes : a.nbytes;
         r0 = r0_; nrec = nrec_; line = line_; solid = solid_; k = 0; pos = end = 0; npos = nend = 0; fresh = false;
         if (nrec) bounds(0, npos, nend);
     }
@@ -134,22 +137,21 @@ struct LineWalk {
             if (k < nrec) bounds(k, npos, nend);                   // used a whole line later
             if (end < pos) end = pos;
         }
-        Piece p; p.valid = pos < end; p.newline = false; p.at = 0; p.j0 = 16; p.j1 = 0; p.rk = k - 1;
+        // line-relative pieces: the next (up to) sixteen bytes of the line, wherever they lie in memory -- only a line's
+        // LAST piece is short, so a model may run its state over all sixteen positions without masks (what the state
+        // becomes behind a line's last symbol does not matter: the next piece starts a line)
+        Piece p; p.valid = pos < end; p.newline = false; p.at = 0; p.j0 = 0; p.j1 = 0; p.rk = k - 1;
         if (p.valid) {
-            p.at = ((pos + mis) & ~15ull) - mis;                   // aligned in memory; "negative" (wrapped) only in front of the buffer
-            p.j0 = (u32)(pos - p.at);
-            p.j1 = (u32)((end - p.at) < 16 ? (end - p.at) : 16);
+            p.at = pos;
+            p.j1 = (u32)((end - pos) < 16 ? (end - pos) : 16);
             p.newline = fresh; fresh = false;
-            pos = p.at + p.j1;
+            pos += p.j1;
         }
         return p;
     }
     __device__ __forceinline__ uint4 fetch(const Piece& p) const {
         if (!p.valid) return make_uint4(0, 0, 0, 0);
-        if ((i64)p.at >= 0) return load16(buf, nbytes, p.at);
-        u32 t[4] = {0, 0, 0, 0};
-        for (u32 i = 0; i < 16; i++) { const i64 at = (i64)p.at + i; if (at >= 0 && (u64)at < nbytes) t[i >> 2] |= (u32)buf[at] << ((i & 3) * 8); }
-        return make_uint4(t[0], t[1], t[2], t[3]);
+        return load16(buf, nbytes, p.at);
     }
 };
 __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j is a compile-time constant where this is used
@@ -197,46 +199,47 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
         const uint4 wn = lw.fetch(pn);
         if (pc.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
         // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once.
-        // No branches: a position outside the lane's bytes looks up the context before it and leaves the state alone
-        // (masks, vm = all ones inside).
+        // No branches and no masks on the model's state: whatever follows the lane's bytes in a line's last piece runs
+        // through the same instructions and is dropped by the coder's mask.
+        const uint4& f = w;
+        const u32 len = pc.j1;
         u32 e[16];
-        u32 lowest = 255, high = 0;
+        u32 lowest = 255, top = 0;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
-            const u32 b = (piece_byte(w, j) - '!') & 0xffu;
+            const u32 vm = j < len ? ~0u : 0u;
+            const u32 b = (piece_byte(f, j) - '!') & 0xffu;
             const u32 sym = b < LAST_QLT ? b : LAST_QLT;
             lowest = min(lowest, b | ~vm);
-            high |= (b >= LAST_QLT ? ~0u : 0u) & vm;
+            top = max(top, b & vm);
             if constexpr (LDS) {
                 const u32 hv = ltab[qh_hash(last)];
                 e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
             } else e[j] = a.qrows[(size_t)last * 64 + sym];
-            if (level <= 2) last ^= (last ^ ((b | (last << 6)) & mask12)) & vm;         // qlts.hpp:52-57
+            if (level <= 2) last = (b | (last << 6)) & mask12;                           // qlts.hpp:52-57
             else {                                                                       // qlts.hpp:62-74
-                delta += (p1 > b ? p1 - b : 0u) & vm;
+                delta += max(p1, b) - b;                                                 // if (p1 > b) delta += p1 - b
                 const u32 d3 = delta >> 3;
-                const u32 nl = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
-                last ^= (last ^ nl) & vm;
-                p2 ^= (p2 ^ p1) & vm; p1 ^= (p1 ^ b) & vm;
+                last = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                p2 = p1; p1 = b;
             }
         }
         // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
         if (a.exc_flag && lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
         // (b) the serial part: the range coder
-        if (!__any(high != 0)) {
+        if (!__any(top >= LAST_QLT)) {
 #pragma unroll
             for (u32 j = 0; j < 16; j++) {
-                rc.encode16_if((j >= pc.j0 && j < pc.j1) ? ~0u : 0u, FZ_CUM(e[j]), FZ_FREQ(e[j]));
+                rc.encode16_if(j < len ? ~0u : 0u, FZ_CUM(e[j]), FZ_FREQ(e[j]));
                 if ((j & 3u) == 3u) rc.drain();
             }
         } else {
             // a quality over 62 somewhere in the wave: the escape symbol, then the raw value through the frozen escape row (qlts.cpp:80-86)
 #pragma unroll
             for (u32 j = 0; j < 16; j++) {
-                const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
+                const u32 vm = j < len ? ~0u : 0u;
                 rc.encode16_if(vm, FZ_CUM(e[j]), FZ_FREQ(e[j]));
-                const u32 b = (piece_byte(w, j) - '!') & 0xffu;
+                const u32 b = (piece_byte(f, j) - '!') & 0xffu;
                 const u32 em = (b >= LAST_QLT ? ~0u : 0u) & vm;
                 if (__any(em != 0)) {
                     const u32 ee = a.qesc[b];
@@ -375,16 +378,6 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 // N / quality-0 exceptions (gens.cpp:91-136) do not touch the model (an N is coded as 'A'): a wave per block
 // scans for them and codes the reference's gen.Ns / gen.Nn side streams.
 // =========================================================================================================
-__device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0..3, N-like -> 4, illegal -> 0x10
-    const u32 l = c | 0x20u;
-    u32 n = 0x10u;
-    n = (l == 'a' || c == '0') ? 0u : n;
-    n = (l == 'c' || c == '1') ? 1u : n;
-    n = (l == 'g' || c == '2') ? 2u : n;
-    n = (l == 't' || c == '3') ? 3u : n;
-    n = (l == 'n' || c == '.') ? 4u : n;
-    return n;
-}
 // per-lane walk over the base lines of records [r0, r0 + nrec): look(ctx) for every base of a piece first (so that a
 // caller can start its table lookups together), then code(j, code) for each base in order.  The bases come from the FASTQ
 // text or from the decoder's staged bases (ChainArgs::st_*).  N is coded as 0 (gens.cpp:116-136).
@@ -433,22 +426,24 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
         const Piece pn = lw.next();
         const uint4 wn = lw.fetch(pn);
         if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
+        const uint4& f = w;                                        // (a line's last piece carries other bytes behind the lane's)
+        const u32 len = pc.j1;
         u32 cd4[16];
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) cd4[j] = lut[piece_byte(w, j)];
+        for (u32 j = 0; j < 16; j++) cd4[j] = lut[piece_byte(f, j)];
         u32 codes = 0, odd = 0;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            const u32 vm = (j >= pc.j0 && j < pc.j1) ? ~0u : 0u;
             look(j, last & mask);
-            last ^= (last ^ ((last << 2) | (cd4[j] & 3u))) & vm;
+            last = (last << 2) | (cd4[j] & 3u);                    // (behind the line's last base the context no longer matters)
             codes |= (cd4[j] & 3u) << (2 * j);
-            odd |= cd4[j] & vm;
+            odd |= cd4[j] & (j < len ? ~0u : 0u);
         }
+        // an N or an illegal character marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
         if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
-            code(j, (codes >> (2 * j)) & 3u, (j >= pc.j0 && j < pc.j1) ? ~0u : 0u);
+            code(j, (codes >> (2 * j)) & 3u, j < len ? ~0u : 0u);
             if ((j & 3u) == 3u) piece_end();                       // every four bases (the size of LaneEncB's ring follows from this)
         }
         pc = pn; w = wn;

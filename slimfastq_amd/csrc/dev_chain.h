@@ -111,10 +111,14 @@ struct LaneEncB {
     __device__ __forceinline__ void step() {                                  // one round of coder.hpp:74-80, where range < TOP
         const u32 nm = range < RC_TOP ? ~0u : 0u;
         const u32 lo = (u32)low, hi = (u32)(low >> 32);
-        const u32 thi = (u32)((low + range) >> 32);
-        const u32 sm = ((thi ^ hi) >> 24) ? ~0u : 0u;
-        const u32 alt = ~lo & (RC_TOP - 1);                                    // (lo | (TOP - 1)) - lo
-        range ^= (range ^ alt) & (nm & sm);
+        // coder.hpp:76-77: [low, low + range) crosses a multiple of 2^56 -- with range < 2^24 only where bits 24..55 of low
+        // are all ones, once in 2^32 renormalisations: a cheap necessary test for the whole wavefront, the fix behind it
+        if (__any((hi | 0xFF000000u) == 0xFFFFFFFFu)) {
+            const u32 thi = (u32)((low + range) >> 32);
+            const u32 sm = ((thi ^ hi) >> 24) ? ~0u : 0u;
+            const u32 alt = ~lo & (RC_TOP - 1);                                // (lo | (TOP - 1)) - lo
+            range ^= (range ^ alt) & (nm & sm);
+        }
         put_if(nm, hi >> 24);
         const u32 sh = 8u & nm;
         range <<= sh; low <<= sh;

@@ -68,3 +68,16 @@ struct BlockDesc {
     u32 out_cap[SFQ_NSTREAMS];
     u32 hdr_bytes;      // sum of header lengths in the block
 };
+
+// character of a base line -> code (gens.cpp:72-77): 0..3, N-like -> 4, illegal -> 0x10
+__device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0..3, N-like -> 4, illegal -> 0x10
+    const u32 l = c | 0x20u;
+    u32 n = 0x10u;
+    n = (l == 'a' || c == '0') ? 0u : n;
+    n = (l == 'c' || c == '1') ? 1u : n;
+    n = (l == 'g' || c == '2') ? 2u : n;
+    n = (l == 't' || c == '3') ? 3u : n;
+    n = (l == 'n' || c == '.') ? 4u : n;
+    return n;
+}
+
