@@ -192,19 +192,14 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     LineWalk lw; lw.init(a, cp.r0, cp.nrec, 3, live ? d->solid : 0u);
     u32 last = 0, p1 = 0, p2 = 0, delta = 5;
     u32 extra = 0;
-    Piece pc = lw.next();
-    uint4 w = lw.fetch(pc);
-    while (__any(pc.valid)) {
-        const Piece pn = lw.next();                   // the next piece is in flight while this one is coded
-        const uint4 wn = lw.fetch(pn);
-        if (pc.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
-        // (a) the contexts of the piece's symbols depend on the text alone: all of its row entries are fetched at once.
-        // No branches and no masks on the model's state: whatever follows the lane's bytes in a line's last piece runs
-        // through the same instructions and is dropped by the coder's mask.
-        const uint4& f = w;
-        const u32 len = pc.j1;
-        u32 e[16];
-        u32 lowest = 255, top = 0;
+    // (a) the contexts of a piece's symbols depend on the text alone: all of its row entries are fetched at once -- and a
+    // piece AHEAD of the one being coded, so the gathers' latency hides behind sixteen coder steps.  No branches and no
+    // masks on the model's state: whatever follows the lane's bytes in a line's last piece runs through the same
+    // instructions and is dropped by the coder's mask.
+    auto look = [&](const Piece& p, const uint4& f, u32 (&e)[16], u32& lowest, u32& top) {
+        if (p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
+        const u32 len = p.j1;
+        lowest = 255; top = 0;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             const u32 vm = j < len ? ~0u : 0u;
@@ -224,6 +219,20 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 p2 = p1; p1 = b;
             }
         }
+    };
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    Piece pn = lw.next();
+    uint4 wn = lw.fetch(pn);
+    u32 e[16], lowest, top;
+    look(pc, w, e, lowest, top);
+    while (__any(pc.valid)) {
+        const Piece pnn = lw.next();                  // the text two pieces ahead, the rows one piece ahead
+        const uint4 wnn = lw.fetch(pnn);
+        u32 e2[16], lowest2, top2;
+        look(pn, wn, e2, lowest2, top2);
+        const uint4& f = w;
+        const u32 len = pc.j1;
         // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
         if (a.exc_flag && lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
         // (b) the serial part: the range coder
@@ -249,7 +258,10 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 if ((j & 3u) == 3u) rc.drain();
             }
         }
-        pc = pn; w = wn;
+        pc = pn; w = wn; pn = pnn; wn = wnn;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) e[j] = e2[j];
+        lowest = lowest2; top = top2;
     }
     if (live) {
         const u32 size = rc.finish();
