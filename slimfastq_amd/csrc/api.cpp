@@ -51,7 +51,8 @@ struct sfq_ctx {
     DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf, cflags;
     u32 r_hot = 0;
     bool unsettled = false;                // a call returned with an error: its side streams may still be running
-    void* pin = nullptr; size_t pin_cap = 0;       // pinned host scratch: device -> host copies that must not block the launching thread
+    void* pin = nullptr; size_t pin_cap = 0;
+    void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
     bool prior_on = false;                 // the device prior tables are valid for the running call
@@ -89,13 +90,15 @@ int level_gen_bits(int level) {   // gens.hpp:43-53
 int clamp_level(int level) { return level > 4 ? 4 : level < 1 ? 1 : level; }   // config.cpp:232-237
 
 // Size the model tables for `want` concurrent block slots (or fewer if the budget says so).
-int reserve_pinned(sfq_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->pin_cap && ctx->pin) return SFQ_OK;
-    if (ctx->pin) { HIPC(hipDeviceSynchronize()); HIPC(hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_cap = 0; }
-    HIPC(hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
-    ctx->pin_cap = bytes;
+int reserve_pinned_buf(sfq_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap && p) return SFQ_OK;
+    if (p) { HIPC(hipDeviceSynchronize()); HIPC(hipHostFree(p)); p = nullptr; cap = 0; }
+    bytes += bytes / 4;                                    // (grow-only, with headroom: re-pinning costs milliseconds)
+    HIPC(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
     return SFQ_OK;
 }
+int reserve_pinned(sfq_ctx* ctx, size_t bytes) { return reserve_pinned_buf(ctx, ctx->pin, ctx->pin_cap, bytes); }
 
 int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u32* got) {
     const u64 per_q = (models & SFQ_M_QLT) ? (u64)q_rows * (L64_NSYM * 4 + sizeof(RowHdr)) : 0;
@@ -481,6 +484,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
     for (DevBuf* b : all) release(*b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin2) (void)hipHostFree(ctx->pin2);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->st_aux) if (s) (void)hipStreamDestroy(s);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
@@ -554,6 +558,15 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nchunks / 1024 + 4) * 8 + 65536))) return rc;
     if ((rc = reserve(ctx, ctx->status, 256))) return rc;
     HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
+    // the quality sample's counters (16 MiB) are cleared here, ahead of the framing kernels: behind them the memset sat on
+    // the quality model's critical path for a millisecond (it shares the chip with the counting passes by then)
+    const u32 q_rows0 = p.level == 1 ? (1u << 12) : (1u << 16);
+    bool hist_cleared = false;
+    if (p.block_reads && (models & SFQ_M_QLT) && (p.prior_step || p.tables == SFQ_TABLES_FROZEN) && p.kernel == 0) {
+        if ((rc = ensure_prior_buffers(ctx, q_rows0))) return rc;
+        HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows0 * 64 * 4, st));
+        hist_cleared = true;
+    }
     launch_count_newlines(d_fastq, nbytes, (u32*)ctx->chunk_counts.p, nchunks, st);
     launch_scan_u32((const u32*)ctx->chunk_counts.p, (u64*)ctx->chunk_base.p, nchunks, (u64*)ctx->scan_tmp.p, st);
     u64 nlines = 0; u8 last_byte = 0;
@@ -712,7 +725,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         std::vector<u32> rows;
         if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
-        HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
+        if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
         HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
         launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
         HIPC(hipStreamSynchronize(st));            // `rows` is a local
@@ -720,7 +733,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         ctx->prior_on = true;
     } else if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
-        HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
+        if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
         launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
@@ -877,17 +890,22 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     launch_first_hdr_lens((const BlockDesc*)ctx->blocks.p, nblocks, (u32*)ctx->lens.p, st);
     launch_scan_u32((const u32*)ctx->lens.p, (u64*)ctx->blob_off.p, nblocks, (u64*)ctx->scan_tmp.p, st);
     launch_gather_first_hdrs((const BlockDesc*)ctx->blocks.p, nblocks, d_fastq, (const u64*)ctx->blob_off.p, (u8*)ctx->blob.p, blob_cap, st);
-    u64 totals[SFQ_NSTREAMS];
-    HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, sizeof totals, hipMemcpyDeviceToHost, st));
+    // what comes back to the host at the end lands in page-locked memory: [totals][block descriptors][blob offsets][chain sizes]
+    const size_t p2_hb = 128, p2_off = p2_hb + (((size_t)nblocks * sizeof(BlockDesc) + 63) & ~(size_t)63);
+    const size_t p2_csz = p2_off + ((((size_t)nblocks + 1) * 8 + 63) & ~(size_t)63);
+    const size_t p2_end = p2_csz + ((size_t)nchains * 2 + (size_t)nsub * 2) * 4 + 64;
+    if ((rc = reserve_pinned_buf(ctx, ctx->pin2, ctx->pin2_cap, p2_end))) return rc;
+    u64* totals = (u64*)ctx->pin2;
+    HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, SFQ_NSTREAMS * 8, hipMemcpyDeviceToHost, st));
     // host work that needs nothing of what is still running goes here, while the chains are coded: "qlt.pri"
     if (ctx->prior_on && !given && h_rows66) {
         HIPC(hipEventSynchronize(ctx->ev[20]));
         ctx->prior_blob = pack_prior(h_rows66, q_rows);
     }
-    std::vector<BlockDesc> hb(nblocks);
-    HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
-    std::vector<u64> hboff((size_t)nblocks + 1);
-    HIPC(hipMemcpyAsync(hboff.data(), ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
+    BlockDesc* hb = (BlockDesc*)((u8*)ctx->pin2 + p2_hb);
+    HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+    u64* hboff = (u64*)((u8*)ctx->pin2 + p2_off);
+    HIPC(hipMemcpyAsync(hboff, ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
     u64 bases[SFQ_NSTREAMS], run = 0;
     for (int s = 0; s < SFQ_NSTREAMS; s++) { bases[s] = run; run += totals[s]; res->stream_bytes[s] = totals[s]; res->stream_offset[s] = bases[s]; }
@@ -901,7 +919,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
     launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
                    (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st);
-    std::vector<u32> h_csz;
+    u32* h_csz = (u32*)((u8*)ctx->pin2 + p2_csz);
     if (frozen) {
         if (chain_streams & (1u << SFQ_S_QLT))
             launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
@@ -909,8 +927,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         if (chain_streams & (1u << SFQ_S_REC))
             launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        h_csz.assign((size_t)nchains * 2 + (size_t)nsub * 2, 0);
-        HIPC(hipMemcpyAsync(h_csz.data(), ctx->csz.p, h_csz.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
     }
     HIPC(hipEventRecord(ctx->ev[11], st));
     ctx->first_hdrs.resize((size_t)hboff[nblocks]);
@@ -922,6 +939,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
         std::vector<u8>& o = ctx->chain_blob;
+        o.reserve(((size_t)nchains * 2 + (size_t)nsub * 2) * 2 + 64);
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
         put_v(o, ca.geo.chain_reads); put_v(o, gen_on | (rec_chains ? 2u : 0u)); put_v(o, nchains);
         for (u32 c = 0; c < 2 * nchains; c++) put_v(o, h_csz[c]);
