@@ -791,6 +791,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         return SFQ_OK;
     }
     u32 gen_on = 0;
+    bool side_late = false;                            // the exception pass is still running when the packing starts
     if (frozen) {
         // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (headers) first
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
@@ -816,13 +817,16 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3]); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
+        side_late = false;
         if ((models & SFQ_M_GEN) && ca.exc_flag) {                  // the marks are complete once both chain kernels are through
             HIPC(hipStreamWaitEvent(mst[3], ctx->ev[3], 0));
             launch_gen_exc_w(a, ca.exc_flag, tickets + 1, mst[3]);
             HIPC(hipEventRecord(ctx->ev[12], mst[3]));
-            HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
+            side_late = true;                                       // joined in the second half of the packing (below)
         }
-        for (int m = 1; m < 4; m++) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
+        HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 1], 0));        // header chains
+        HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 3], 0));        // base chains
+        if (!side_late) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 2], 0));
     } else {
     // The lane-per-block reference kernels (kernel = 1, and usr) run in batches of `slots` blocks.
     if ((models & SFQ_M_GEN) && p.kernel == 1)   // first batch's Base2 tables (base2_ranger.hpp:68-71), while the chip is idle
@@ -881,7 +885,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             launch_chain_block_sizes(ca, ca.rgeo, SFQ_S_REC, rs, rs + nsub, st); chain_streams |= 1u << SFQ_S_REC;
         }
     }
-    launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, st);
+    // The three chain-coded streams come first in the output (rec, gen, qlt: enum sfq_stream), so their offsets need
+    // nothing of the side streams: with the exception pass still running (side_late) they are packed beside it, and
+    // the side streams -- a few MB -- when it is through.
+    const bool two_halves = side_late && chain_streams == 7u;
+    launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, 0, two_halves ? 3 : SFQ_NSTREAMS, st);
     // first headers -> blob
     if ((rc = reserve(ctx, ctx->lens, (size_t)nblocks * 4))) return rc;
     if ((rc = reserve(ctx, ctx->blob_off, ((size_t)nblocks + 1) * 8))) return rc;
@@ -903,11 +911,28 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         ctx->prior_blob = pack_prior(h_rows66, q_rows);
     }
     BlockDesc* hb = (BlockDesc*)((u8*)ctx->pin2 + p2_hb);
-    HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     u64* hboff = (u64*)((u8*)ctx->pin2 + p2_off);
+    u32* h_csz = (u32*)((u8*)ctx->pin2 + p2_csz);
+    u64 bases[SFQ_NSTREAMS], run = 0;
+    if (two_halves) {
+        HIPC(hipStreamSynchronize(st));                                 // the chains are through; totals[0..2] are here
+        for (int s = 0; s < 3; s++) { bases[s] = run; run += totals[s]; }
+        if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs more than %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
+        HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, 3 * 8, hipMemcpyHostToDevice, st));
+        launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
+        // the side streams: behind the exception pass and the framing exceptions
+        HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
+        HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 2], 0));
+        launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, 3, SFQ_NSTREAMS, st);
+        HIPC(hipMemcpyAsync(totals + 3, (u64*)ctx->stream_total.p + 3, (SFQ_NSTREAMS - 3) * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(hboff, ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
-    u64 bases[SFQ_NSTREAMS], run = 0;
+    run = 0;
     for (int s = 0; s < SFQ_NSTREAMS; s++) { bases[s] = run; run += totals[s]; res->stream_bytes[s] = totals[s]; res->stream_offset[s] = bases[s]; }
     res->total_bytes = run;
     // per-block status first: an overflowed block has a meaningless size
@@ -919,8 +944,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
     launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
                    (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st);
-    u32* h_csz = (u32*)((u8*)ctx->pin2 + p2_csz);
-    if (frozen) {
+    if (frozen && !two_halves) {
         if (chain_streams & (1u << SFQ_S_QLT))
             launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         if (chain_streams & (1u << SFQ_S_GEN))

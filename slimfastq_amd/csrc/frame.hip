@@ -251,10 +251,10 @@ void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t st) {
 
 // ---- packing: per-block stream sizes -> offsets -> compact copy ---------------------------------------
 // One workgroup per stream walks the blocks in order (nblocks is in the thousands).
-__global__ __launch_bounds__(256) void k_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total) {
+__global__ __launch_bounds__(256) void k_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, u32 s0) {
     __shared__ u64 carry_s;
     __shared__ u64 wsum[4];
-    const u32 s = blockIdx.x;
+    const u32 s = s0 + blockIdx.x;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void k_block_stream_offsets(BlockDesc* blocks,
     }
     if (threadIdx.x == 0) stream_total[s] = carry_s;
 }
-void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, hipStream_t st) {
-    hipLaunchKernelGGL(k_block_stream_offsets, dim3(SFQ_NSTREAMS), dim3(256), 0, st, blocks, nblocks, blk_stream_off, stream_total);
+void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, u32 s0, u32 s1, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_stream_offsets, dim3(s1 - s0), dim3(256), 0, st, blocks, nblocks, blk_stream_off, stream_total, s0);
 }
 // grid = (nblocks, SFQ_NSTREAMS); stream_base[s] = offset of stream s in out
 __global__ __launch_bounds__(256) void k_compact(const BlockDesc* blocks, const u8* arena, const u64* blk_stream_off,

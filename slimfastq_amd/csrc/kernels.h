@@ -125,7 +125,7 @@ void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st);
 
 // packing
-void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, hipStream_t st);
+void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, u32 s0, u32 s1 /* streams [s0, s1) */, hipStream_t st);
 void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
                     const u64* stream_base, u8* out, u32 skip_streams /* bit s: stream s is packed by launch_compact_chains */, hipStream_t st);
 void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st);
