@@ -292,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
     for (u32 k = 0; k < cp.nrec; k++) {
         const u64 r = cp.r0 + k;
         const u32 n = da.qlen[r];
-        u8* p = da.qual_stage + da.qoff[r];
+        LaneOut out; out.begin(da.qual_stage + da.qoff[r]);
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {
             const u32 prob = rc.get_freq16();
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
                 rc.decode(FZ_CUM(ee), FZ_FREQ(ee));
                 b = x;
             }
-            p[i] = (u8)('!' + b);
+            out.put(('!' + b) & 0xffu);
             if (level <= 2) last = (b | (last << 6)) & mask12;
             else {
                 if (p1 > b) delta += p1 - b;
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
                 p2 = p1; p1 = b;
             }
         }
+        out.end();
     }
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
 }
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     for (u32 k = 0; k < cp.nrec; k++) {
         const u64 r = cp.r0 + k;
         const u32 llen = da.slen[r];
-        u8* g = da.seq_stage + da.soff[r];
+        LaneOut out; out.begin(da.seq_stage + da.soff[r]);
         u32 last = 0x007616c7u;
         for (u32 i = 0; i < llen; i++) {
             const u32 v = rows ? rows[last & mask] : B2_INIT;
@@ -610,9 +611,10 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
             else if (f0 + f1 + f2 > prob) { b = 2; cum = f0 + f1;      f = f2; }
             else                          { b = 3; cum = f0 + f1 + f2; f = f3; if (prob >= tot) rc.err = 1; }
             rc.decode(cum, f);
-            g[i] = (u8)((alphabet >> (8 * b)) & 0xff);
+            out.put((alphabet >> (8 * b)) & 0xff);
             last = (last << 2) | b;
         }
+        out.end();
     }
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
 }
