@@ -1255,9 +1255,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipEventRecord(ctx->ev[2], st));
     HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
     HIPC(hipStreamWaitEvent(ctx->st_aux[1], ctx->ev[2], 0));
-    // (frozen tables: the header chains go BEHIND the base chains on one stream -- three latency-bound decoders at once
-    //  were measured slower than the sum of their times alone, two at once are not)
-    hipStream_t st_gen = ctx->st_aux[1], st_rec = frozen ? ctx->st_aux[1] : ctx->st_aux[0];
+    hipStream_t st_rec = ctx->st_aux[0], st_gen = ctx->st_aux[1];
     if (frozen) {
         // quality: dense frozen rows from the prior, one chain per lane
         ChainArgs ca;

@@ -287,8 +287,11 @@ __global__ __launch_bounds__(256) void k_record_sizes(DecodeArgs a, u64 nrec, u3
 void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st) {
     hipLaunchKernelGGL(k_record_sizes, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, a, nrec, rsize);
 }
+// a wave copies n bytes, a dword per lane and step (global loads and stores need no alignment on gfx9), the last 0..3 singly
 __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 n, u32 lane) {
-    for (u32 i = lane; i < n; i += 64) dst[i] = src[i];
+    const u32 nd = n >> 2;
+    for (u32 i = lane; i < nd; i += 64) *reinterpret_cast<u32*>(dst + 4 * i) = *reinterpret_cast<const u32*>(src + 4 * i);
+    if (lane < (n & 3u)) dst[4 * nd + lane] = src[4 * nd + lane];
 }
 // one wave per record; 4 records per 256-thread workgroup
 __global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const u64* roff, u8* out) {
@@ -307,7 +310,17 @@ __global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const 
     {   // bases, with the quality-'!'-means-N rule of normalize_gen (gens.cpp:206-208)
         const u8* sp = a.seq_stage + a.soff[r]; const u8* qp = a.qual_stage + a.qoff[r];
         const u32 n_byte = d->n_byte ? d->n_byte : 'N';
-        for (u32 i = lane; i < sl; i += 64) {
+        // four bases a lane and step: bit 7 = "keep this base" (gen.Nn), else a quality '!' makes it the N byte
+        const u32 nd = (sl < ql ? sl : ql) >> 2;
+        const u32 nb4 = n_byte * 0x01010101u;
+        for (u32 i = lane; i < nd; i += 64) {
+            const u32 c = *reinterpret_cast<const u32*>(sp + 4 * i), q = *reinterpret_cast<const u32*>(qp + 4 * i);
+            const u32 keep = ((c >> 7) & 0x01010101u) * 0xFFu;                                    // 0xFF in the bytes with bit 7
+            const u32 x = q ^ 0x21212121u;
+            const u32 bang = ((~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;   // 0xFF where the quality is '!'
+            *reinterpret_cast<u32*>(o + 4 * i) = (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & nb4) | (~bang & c)));
+        }
+        for (u32 i = 4 * nd + lane; i < sl; i += 64) {
             const u32 c = sp[i];
             o[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
         }
