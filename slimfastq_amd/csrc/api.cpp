@@ -1294,7 +1294,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
             }
         }
-        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_l(da, st_gen); }
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_w(da, st_gen); }
     } else {
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
     HIPC(hipEventRecord(ctx->ev[3], st));

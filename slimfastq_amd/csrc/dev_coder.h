@@ -45,6 +45,17 @@ struct ByteSrc {
     }
 };
 
+// The same for code that runs wave-UNIFORM (every lane the same stream position): there the compiler turns the eight-byte
+// fetch above into scalar loads, and scalar loads drop the low two address bits -- an unaligned stream would be read from
+// the wrong place.  Byte loads have no such trap.
+struct ByteSrc1 {
+    const u8* p;
+    u32 pos;
+    u32 n;
+    __device__ __forceinline__ void init(const u8* ptr, u32 len) { p = ptr; pos = 0; n = len; }
+    __device__ __forceinline__ u32 get() { const u32 b = pos < n ? p[pos] : 0u; pos++; return b; }
+};
+
 struct RcEnc {
     u64 low;
     u32 range;
@@ -77,7 +88,8 @@ struct RcDec {
     u32 range;
     u32 err;
     // coder.hpp:41-49
-    __device__ __forceinline__ void init(ByteSrc& s) {
+    template <typename SRC>
+    __device__ __forceinline__ void init(SRC& s) {
         low = 0; range = 0xFFFFFFFFu; code = 0; err = 0;
         for (int i = 0; i < 8; i++) code = (code << 8) | s.get();
     }
@@ -89,7 +101,8 @@ struct RcDec {
         return (u32)(code / range);
     }
     // coder.hpp:88-102
-    __device__ __forceinline__ void decode(ByteSrc& s, u32 cum, u32 freq) {
+    template <typename SRC>
+    __device__ __forceinline__ void decode(SRC& s, u32 cum, u32 freq) {
         u32 temp = cum * range;
         low += temp;
         code -= temp;

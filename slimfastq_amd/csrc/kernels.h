@@ -119,6 +119,7 @@ void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t s
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
 void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st);
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
+void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st);          // the same, a wave per block (models_w.hip); blocks [batch0, batch0 + nbatch), slot = workgroup
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);

@@ -61,36 +61,10 @@ struct RcEncU {                // RCoder (coder.hpp) on uniform values, one symb
 struct WavePw {
     u32* slots; RowHdr* hdr; u32 epoch;
     __device__ __forceinline__ u32 comp(const uint4& v, u32 c) const { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-    // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
-    __device__ __forceinline__ Triple model(u32 row, u32 sym, u32 lane) {
-        u32* rs = slots + (size_t)row * PW_NSYM;
-        const RowHdr h = hdr[row];
-        const bool live = rl(h.epoch, 0) == epoch;
-        u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
+    // update_freq (power_ranger.hpp:66-84) of slot i = 4 hl + c (value cur), then the row and its header back to HBM
+    __device__ __forceinline__ void update(u32* rs, u32 row, u32 lane, u32 i, u32 hl, u32 c, u32 cur, u32 total, u32 iend, u32 count, uint4 v, u64 dirty) {
         const u32 i0 = 4 * lane;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);       // only the lanes that hold live slots
-        u64 dirty = 0;                                                     // lanes to store back
-        if (iend <= sym) {                                                 // :94-96
-            if (i0 + 0 >= iend && i0 + 0 <= sym) v.x = (i0 + 0) << 16;
-            if (i0 + 1 >= iend && i0 + 1 <= sym) v.y = (i0 + 1) << 16;
-            if (i0 + 2 >= iend && i0 + 2 <= sym) v.z = (i0 + 2) << 16;
-            if (i0 + 3 >= iend && i0 + 3 <= sym) v.w = (i0 + 3) << 16;
-            dirty |= __ballot(i0 + 3 >= iend && i0 <= sym);
-            iend = sym + 1;
-        }
-        const u32 mc = ((i0 + 0 < iend && (v.x >> 16) == sym) ? 1u : 0u) | ((i0 + 1 < iend && (v.y >> 16) == sym) ? 2u : 0u) |
-                       ((i0 + 2 < iend && (v.z >> 16) == sym) ? 4u : 0u) | ((i0 + 3 < iend && (v.w >> 16) == sym) ? 8u : 0u);
-        const u64 hit = __ballot(mc != 0);
-        const u32 hl = (u32)__ffsll((long long)hit) - 1u;                  // :98 (exactly one slot holds sym)
-        const u32 c = (u32)__ffs((int)rl(mc, hl)) - 1u;
-        const u32 i = 4 * hl + c;
-        const u32 part = ((i0 + 0 < i) ? (v.x & 0xffffu) : 0u) + ((i0 + 1 < i) ? (v.y & 0xffffu) : 0u) +
-                         ((i0 + 2 < i) ? (v.z & 0xffffu) : 0u) + ((i0 + 3 < i) ? (v.w & 0xffffu) : 0u);
-        const u32 sumf = i ? rl(wave_incl_scan(part), 63) : 0u;
-        u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
         u32 f = cur & 0xffffu;
-        Triple t; t.cum = sumf + i; t.freq = f + 1; t.tot = total + PW_NSYM;               // :100
         bool upd = true;
         if (f > (u32)((1 << 15) - 32 - 14)) {                              // update_freq :66-84
             if (i == 0 && f + 256u > total) upd = false;
@@ -131,6 +105,91 @@ struct WavePw {
             RowHdr nh; nh.total = total; nh.iend = (u16)iend; nh.count = (u8)count; nh.pad = 0; nh.epoch = epoch; nh.pad2 = 0;
             hdr[row] = nh;
         }
+    }
+    // PowerRanger::get (power_ranger.hpp:106-130): the slot whose cumulative range holds the coder's value -- every slot's
+    // freq + 1 summed four per lane, a wave scan, the first lane past the value, then its four slots; the slots between
+    // the old iend and the one found come into being on the way (:118-119).  Every lane runs the same (uniform) coder.
+    __device__ __forceinline__ u32 get(u32 row, RcDec& rc, ByteSrc1& src, u32 lane) {
+        u32* rs = slots + (size_t)row * PW_NSYM;
+        const RowHdr h = hdr[row];
+        const bool live = rl(h.epoch, 0) == epoch;
+        u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
+        const u32 prob = rc.get_freq(total + PW_NSYM);
+        const u32 i0 = 4 * lane;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);
+        if (i0 + 0 >= iend) v.x = (i0 + 0) << 16;                           // a slot not yet in the row: its own symbol, frequency 0
+        if (i0 + 1 >= iend) v.y = (i0 + 1) << 16;
+        if (i0 + 2 >= iend) v.z = (i0 + 2) << 16;
+        if (i0 + 3 >= iend) v.w = (i0 + 3) << 16;
+        const u32 f0 = (v.x & 0xffffu) + 1, f1 = (v.y & 0xffffu) + 1, f2 = (v.z & 0xffffu) + 1, f3 = (v.w & 0xffffu) + 1;
+        const u32 lsum = (f0 + f1) + (f2 + f3);
+        const u32 incl = wave_incl_scan(lsum);
+        const u64 past = __ballot(incl > prob);
+        u32 hl, c, sumf;
+        if (past) {
+            hl = (u32)__ffsll((long long)past) - 1u;
+            sumf = rl(incl - lsum, hl);
+            const u32 a0 = rl(f0, hl), a1 = rl(f1, hl), a2 = rl(f2, hl);
+            c = 0;
+            if (sumf + a0 <= prob) { sumf += a0; c = 1; if (sumf + a1 <= prob) { sumf += a1; c = 2; if (sumf + a2 <= prob) { sumf += a2; c = 3; } } }
+        } else {                                                            // the value lies beyond the row's total: a corrupt stream
+            rc.err = 1; hl = 63; c = 3; sumf = rl(incl, 63) - rl(f3, 63);
+        }
+        const u32 i = 4 * hl + c;
+        u64 dirty = 0;
+        if (i >= iend) { dirty |= __ballot(i0 + 3 >= iend && i0 <= i); iend = i + 1; }
+        const u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
+        rc.decode(src, sumf, (cur & 0xffffu) + 1);
+        update(rs, row, lane, i, hl, c, cur, total, iend, count, v, dirty);
+        return (cur >> 16) & 0xffu;
+    }
+    // PowerRangerU::get_u (power_ranger.hpp:165-190)
+    __device__ __forceinline__ u64 get_u(u32 row0, RcDec& rc, ByteSrc1& s, u32 lane) {
+        u64 num = get(row0, rc, s, lane);
+        if (num > 0x7f) {
+            num = (num << 8) | get(row0 + 1, rc, s, lane);
+            if (num < 0xfffe) num &= 0x7fff;
+            else if (num == 0xfffe) {
+                num = 0;
+                for (int sh = 0, k = 2; sh < 32; sh += 8, k++) num |= (u64)get(row0 + k, rc, s, lane) << sh;
+            } else {
+                num = 0;
+                for (int sh = 0, k = 6; sh < 64; sh += 8, k++) num |= (u64)get(row0 + k, rc, s, lane) << sh;
+            }
+        }
+        return num;
+    }
+    // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
+    __device__ __forceinline__ Triple model(u32 row, u32 sym, u32 lane) {
+        u32* rs = slots + (size_t)row * PW_NSYM;
+        const RowHdr h = hdr[row];
+        const bool live = rl(h.epoch, 0) == epoch;
+        u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
+        const u32 i0 = 4 * lane;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);       // only the lanes that hold live slots
+        u64 dirty = 0;                                                     // lanes to store back
+        if (iend <= sym) {                                                 // :94-96
+            if (i0 + 0 >= iend && i0 + 0 <= sym) v.x = (i0 + 0) << 16;
+            if (i0 + 1 >= iend && i0 + 1 <= sym) v.y = (i0 + 1) << 16;
+            if (i0 + 2 >= iend && i0 + 2 <= sym) v.z = (i0 + 2) << 16;
+            if (i0 + 3 >= iend && i0 + 3 <= sym) v.w = (i0 + 3) << 16;
+            dirty |= __ballot(i0 + 3 >= iend && i0 <= sym);
+            iend = sym + 1;
+        }
+        const u32 mc = ((i0 + 0 < iend && (v.x >> 16) == sym) ? 1u : 0u) | ((i0 + 1 < iend && (v.y >> 16) == sym) ? 2u : 0u) |
+                       ((i0 + 2 < iend && (v.z >> 16) == sym) ? 4u : 0u) | ((i0 + 3 < iend && (v.w >> 16) == sym) ? 8u : 0u);
+        const u64 hit = __ballot(mc != 0);
+        const u32 hl = (u32)__ffsll((long long)hit) - 1u;                  // :98 (exactly one slot holds sym)
+        const u32 c = (u32)__ffs((int)rl(mc, hl)) - 1u;
+        const u32 i = 4 * hl + c;
+        const u32 part = ((i0 + 0 < i) ? (v.x & 0xffffu) : 0u) + ((i0 + 1 < i) ? (v.y & 0xffffu) : 0u) +
+                         ((i0 + 2 < i) ? (v.z & 0xffffu) : 0u) + ((i0 + 3 < i) ? (v.w & 0xffffu) : 0u);
+        const u32 sumf = i ? rl(wave_incl_scan(part), 63) : 0u;
+        u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
+        Triple t; t.cum = sumf + i; t.freq = (cur & 0xffffu) + 1; t.tot = total + PW_NSYM;               // :100
+        update(rs, row, lane, i, hl, c, cur, total, iend, count, v, dirty);
         return t;
     }
     __device__ __forceinline__ void put(u32 row, RcEncU& rc, Sink0& s, u32 sym, u32 lane) {
@@ -256,6 +315,49 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
         }
     }
 }
+// The way back (decode_l.hip k_gen_exc_decode_l on one lane: every gap a walk of dependent reads through its row): a wave
+// per block, the row search across the lanes (WavePw::get).  gen.Ns lists the N positions whose quality is not '!' (-> the
+// N byte), gen.Nn the real bases under quality '!' (-> bit 7, which k_assemble reads as "keep this base"); gens.cpp:187-188.
+struct XfDecW {                // XFileLoad (xfile.cpp:76-99), wave-cooperative
+    RcDec rc; ByteSrc1 src; u32 row0, valid;
+    __device__ __forceinline__ void init(const u8* p, u32 n, u32 xf) {
+        src.init(p, n); row0 = PR_XF_BASE + xf * PR_XF_ROWS; valid = n > 0;
+        if (valid) rc.init(src); else { rc.low = rc.code = 0; rc.range = 0xFFFFFFFFu; rc.err = 0; }
+    }
+    __device__ __forceinline__ u64 get(WavePw& t, u32 lane) { return valid ? t.get_u(row0, rc, src, lane) : 0; }
+};
+__global__ __launch_bounds__(64) void k_gen_exc_decode_w(DecodeArgs a) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    const u32 b = a.m.batch0 + t;
+    BlockDesc* d = &a.m.blocks[b];
+    WavePw pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
+    XfDecW x_ns, x_nn;
+    x_ns.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_NS], d->size[SFQ_S_GEN_NS], XF_GEN_NS);
+    x_nn.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_NN], d->size[SFQ_S_GEN_NN], XF_GEN_NN);
+    const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
+    u8* const g = a.seq_stage + a.soff[d->rec0];
+    const u64 nb = a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
+    u32 bad = 0;
+    for (u64 at = x_ns.get(pw, lane); at; ) {                                               // gens.cpp:187
+        if (at > nb) { bad = 1; break; }
+        if (lane == 0) g[at - 1] = (u8)n_byte;
+        const u64 gap = x_ns.get(pw, lane);
+        if (!gap) break;
+        at += gap;
+    }
+    for (u64 at = x_nn.get(pw, lane); at; ) {                                               // gens.cpp:188
+        if (at > nb) { bad = 1; break; }
+        if (lane == 0) g[at - 1] |= 0x80u;
+        const u64 gap = x_nn.get(pw, lane);
+        if (!gap) break;
+        at += gap;
+    }
+    if (lane == 0 && (bad | x_ns.rc.err | x_nn.rc.err)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+}
+void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_gen_exc_decode_w, dim3(a.m.nbatch), dim3(64), 0, st, a);
+}
+
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, flags, ticket);
 }
