@@ -293,47 +293,58 @@ __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 n, u32 lan
     for (u32 i = lane; i < nd; i += 64) *reinterpret_cast<u32*>(dst + 4 * i) = *reinterpret_cast<const u32*>(src + 4 * i);
     if (lane < (n & 3u)) dst[4 * nd + lane] = src[4 * nd + lane];
 }
-// one wave per record; 4 records per 256-thread workgroup
-__global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const u64* roff, u8* out) {
+// one wave per record; 4 records per 256-thread workgroup.  A short read is five small copies: their first steps (64 dwords
+// each -- a whole 150-base line) are loaded together before anything is stored, so the record costs one memory round trip,
+// not five; what is longer goes through the loops behind.
+__device__ __forceinline__ u32 merge_n(u32 c, u32 q, u32 nb4) {         // four bases: bit 7 = "keep this base" (gen.Nn), else a quality '!' makes it the N byte
+    const u32 keep = ((c >> 7) & 0x01010101u) * 0xFFu;
+    const u32 x = q ^ 0x21212121u;
+    const u32 bang = ((~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;
+    return (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & nb4) | (~bang & c)));
+}
+__global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const u64* __restrict__ roff, u8* __restrict__ out) {
     const u32 lane = threadIdx.x & 63;
     u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nrec) return;
     const BlockDesc* d = &a.m.blocks[a.block_reads ? r / a.block_reads : 0];
-    const u32 h = a.hlen[r], s = d->solid, sl = a.slen[r], ql = a.qlen[r];
-    const u8* hp = a.hdr_stage + a.hoff[r];
-    u8* o = out + roff[r];
-    if (lane == 0) o[0] = '@';
-    wave_copy(o + 1, hp, h, lane);
-    o += 1 + h;
-    if (lane == 0) { o[0] = '\n'; if (s) o[1] = a.pfg[r]; }
-    o += 1 + s;
-    {   // bases, with the quality-'!'-means-N rule of normalize_gen (gens.cpp:206-208)
-        const u8* sp = a.seq_stage + a.soff[r]; const u8* qp = a.qual_stage + a.qoff[r];
-        const u32 n_byte = d->n_byte ? d->n_byte : 'N';
-        // four bases a lane and step: bit 7 = "keep this base" (gen.Nn), else a quality '!' makes it the N byte
-        const u32 nd = (sl < ql ? sl : ql) >> 2;
-        const u32 nb4 = n_byte * 0x01010101u;
-        for (u32 i = lane; i < nd; i += 64) {
-            const u32 c = *reinterpret_cast<const u32*>(sp + 4 * i), q = *reinterpret_cast<const u32*>(qp + 4 * i);
-            const u32 keep = ((c >> 7) & 0x01010101u) * 0xFFu;                                    // 0xFF in the bytes with bit 7
-            const u32 x = q ^ 0x21212121u;
-            const u32 bang = ((~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;   // 0xFF where the quality is '!'
-            *reinterpret_cast<u32*>(o + 4 * i) = (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & nb4) | (~bang & c)));
-        }
-        for (u32 i = 4 * nd + lane; i < sl; i += 64) {
-            const u32 c = sp[i];
-            o[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
-        }
+    const u32 h = a.hlen[r], s = d->solid, sl = a.slen[r], ql = a.qlen[r], two = d->two_id;
+    const u8* __restrict__ hp = a.hdr_stage + a.hoff[r];
+    const u8* __restrict__ sp = a.seq_stage + a.soff[r];
+    const u8* __restrict__ qp = a.qual_stage + a.qoff[r];
+    const u32 n_byte = d->n_byte ? d->n_byte : 'N';
+    const u32 nb4 = n_byte * 0x01010101u;
+    u8* const o_h = out + roff[r] + 1;                           // '@' hdr
+    u8* const o_s = o_h + h + 1 + s;                             // '\n' [pf] bases
+    u8* const o_2 = o_s + sl + 2;                                // '\n' '+' [hdr]
+    u8* const o_q = o_2 + (two ? h : 0) + 1 + s;                 // '\n' [pf] qualities
+    const u32 hd = h >> 2, md = (sl < ql ? sl : ql) >> 2, qd = ql >> 2;
+    // first steps, loads together
+    u32 vh = 0, vs = 0, vq = 0, vqq = 0;
+    if (lane < hd) vh = *reinterpret_cast<const u32*>(hp + 4 * lane);
+    if (lane < md) { vs = *reinterpret_cast<const u32*>(sp + 4 * lane); vq = *reinterpret_cast<const u32*>(qp + 4 * lane); }
+    if (lane < qd) vqq = lane < md ? vq : *reinterpret_cast<const u32*>(qp + 4 * lane);
+    if (lane < hd) { *reinterpret_cast<u32*>(o_h + 4 * lane) = vh; if (two) *reinterpret_cast<u32*>(o_2 + 4 * lane) = vh; }
+    if (lane < md) *reinterpret_cast<u32*>(o_s + 4 * lane) = merge_n(vs, vq, nb4);
+    if (lane < qd) *reinterpret_cast<u32*>(o_q + 4 * lane) = vqq;
+    // what is longer than 256 bytes
+    for (u32 i = lane + 64; i < hd; i += 64) { const u32 v = *reinterpret_cast<const u32*>(hp + 4 * i); *reinterpret_cast<u32*>(o_h + 4 * i) = v; if (two) *reinterpret_cast<u32*>(o_2 + 4 * i) = v; }
+    for (u32 i = lane + 64; i < md; i += 64) *reinterpret_cast<u32*>(o_s + 4 * i) = merge_n(*reinterpret_cast<const u32*>(sp + 4 * i), *reinterpret_cast<const u32*>(qp + 4 * i), nb4);
+    for (u32 i = lane + 64; i < qd; i += 64) *reinterpret_cast<u32*>(o_q + 4 * i) = *reinterpret_cast<const u32*>(qp + 4 * i);
+    // the ends: the last 0..3 bytes of each copy (the bases: whatever lies behind the shorter of the two lines), the fixed characters
+    if (lane < (h & 3u)) { const u8 c = hp[4 * hd + lane]; o_h[4 * hd + lane] = c; if (two) o_2[4 * hd + lane] = c; }
+    for (u32 i = 4 * md + lane; i < sl; i += 64) {
+        const u32 c = sp[i];
+        o_s[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
     }
-    o += sl;
-    if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
-    o += 2;
-    if (d->two_id) { wave_copy(o, hp, h, lane); o += h; }
-    if (lane == 0) { o[0] = '\n'; if (s) o[1] = a.pfq[r]; }
-    o += 1 + s;
-    wave_copy(o, a.qual_stage + a.qoff[r], ql, lane);
-    o += ql;
-    if (lane == 0) o[0] = '\n';
+    if (lane < (ql & 3u)) o_q[4 * qd + lane] = qp[4 * qd + lane];
+    if (lane == 0) {
+        o_h[-1] = '@';
+        o_h[h] = '\n'; if (s) o_h[h + 1] = a.pfg[r];
+        o_s[sl] = '\n'; o_s[sl + 1] = '+';
+        u8* e2 = o_2 + (two ? h : 0);
+        e2[0] = '\n'; if (s) e2[1] = a.pfq[r];
+        o_q[ql] = '\n';
+    }
 }
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st) {
     hipLaunchKernelGGL(k_assemble, dim3((u32)((nrec + 3) / 4)), dim3(256), 0, st, a, nrec, roff, out);
