@@ -44,11 +44,13 @@ static void tick(const char* what) {
     last = now;
 }
 
+static std::string g_partial;                // an archive being written as the slabs come back: a failed job removes it
 [[noreturn]] static void croak(const char* fmt, ...) {                 // config.cpp:54-68
     char msg[1024];
     va_list ap; va_start(ap, fmt);
     vsnprintf(msg, sizeof msg, fmt, ap);
     va_end(ap);
+    if (!g_partial.empty()) { unlink(g_partial.c_str()); g_partial.clear(); }
     if (g_batch) throw JobError{msg};
     fprintf(stderr, "slimfastq: %s %s: %s\n", g_encode ? "encoding" : "decoding", g_usr.empty() ? "<< stdin >>" : g_usr.c_str(), msg);
     exit(1);
@@ -209,6 +211,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         Bytes big_out;                                                  // only for a slab whose streams outgrow the pinned buffer
         std::string werr;
         if (!pw.open(fil, werr)) croak("%s", werr.c_str());
+        g_partial = fil;
         int sid[SFQ_NSTREAMS];
         for (int s2 = 0; s2 < SFQ_NSTREAMS; s2++) sid[s2] = -1;           // a stream gets its directory entry with its first bytes
         std::thread writer;                                             // appends the previous slab's streams to the archive
@@ -404,6 +407,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         }
         std::string werr;
         if (!pw.finish(a.info, werr)) croak("%s", werr.c_str());
+        g_partial.clear();
         tick("finish archive");
         return;
     }
@@ -602,6 +606,7 @@ int main(int argc, char** argv) {
                 printf("fail\t%s\t%s\n", src.c_str(), e.msg.c_str());
                 failed++;
             } catch (const std::exception& e) {                        // e.g. bad_alloc on a hostile archive: the job fails, the worker lives
+                if (!g_partial.empty()) { unlink(g_partial.c_str()); g_partial.clear(); }
                 printf("fail\t%s\t%s\n", src.c_str(), e.what());
                 failed++;
             }
