@@ -1666,9 +1666,15 @@ static size_t gen_bounds(size_t nblocks, size_t* bound) {   /* generation g = bl
     return n;
 }
 /* walk the bases of records [r0, r1): cb(ctx, code) per base; N is coded as 0, the context restarts per record */
+#define GEN_COUNT_CAP 524288ull      /* a generation of n records is counted through every ceil(n / cap)-th record (kernels.h) */
+static size_t gen_count_stride(size_t n) { size_t s = (n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP; return s ? s : 1; }
+static void gen_walk_s(const u8* base, const u64* goff, const u32* glen, size_t r0, size_t r1, size_t stride, u32 mask,
+                       void (*cb)(void*, u32, int), void* arg);
 static void gen_walk(const u8* base, const u64* goff, const u32* glen, size_t r0, size_t r1, u32 mask,
-                     void (*cb)(void*, u32, int), void* arg) {
-    for (size_t i = r0; i < r1; i++) {
+                     void (*cb)(void*, u32, int), void* arg) { gen_walk_s(base, goff, glen, r0, r1, 1, mask, cb, arg); }
+static void gen_walk_s(const u8* base, const u64* goff, const u32* glen, size_t r0, size_t r1, size_t stride, u32 mask,
+                       void (*cb)(void*, u32, int), void* arg) {
+    for (size_t i = r0; i < r1; i += stride) {
         u32 last = 0x007616c7u;                                                 /* gens.cpp:139 */
         for (u32 k = 0; k < glen[i]; k++) {
             int code = gencode_of(base[goff[i] + k]) & 3;
@@ -1711,17 +1717,18 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
 #define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
     if (ngen >= 3) {
         gcount gc = { cnt, NULL, 0, 0 };
-        gen_walk(base, goff, glen, REC_OF(bound[0]), REC_OF(bound[1]), mask, gcount_cb, &gc);
+#define GSTRIDE(g) gen_count_stride((bound[(g) + 1] - bound[g]) * block_reads)
+        gen_walk_s(base, goff, glen, REC_OF(bound[0]), REC_OF(bound[1]), GSTRIDE(0), mask, gcount_cb, &gc);
         u32* r1 = xmalloc(nctx * 4);
         for (size_t c = 0; c < nctx; c++) r1[c] = gen_row(cnt + c * 4, step);
         gc.rows = r1;
-        gen_walk(base, goff, glen, REC_OF(bound[1]), REC_OF(bound[2]), mask, gcount_cb, &gc);
+        gen_walk_s(base, goff, glen, REC_OF(bound[1]), REC_OF(bound[2]), GSTRIDE(1), mask, gcount_cb, &gc);
         free(r1);
         on = gc.nbases && gc.cost * 100 < gc.nbases * 2048 * 99;
         if (on) for (size_t g = 2; g < ngen; g++) {
             rows[g] = xmalloc(nctx * 4);
             for (size_t c = 0; c < nctx; c++) rows[g][c] = gen_row(cnt + c * 4, step);
-            if (g + 1 < ngen) { gcount g2 = { cnt, NULL, 0, 0 }; gen_walk(base, goff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), mask, gcount_cb, &g2); }
+            if (g + 1 < ngen) { gcount g2 = { cnt, NULL, 0, 0 }; gen_walk_s(base, goff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), GSTRIDE(g), mask, gcount_cb, &g2); }
         }
     }
     obuf o = { 0, 0, 0 };

@@ -465,11 +465,11 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
 
 // counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
 // cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
-__global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32* __restrict__ cnt, const u32* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32 stride, u32* __restrict__ cnt, const u32* __restrict__ rows,
                                                   const u16* __restrict__ log2fp, u64* cost) {
     const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
     u32 mybases = 0;
-    const u64 r = first + (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 r = first + ((u64)blockIdx.x * 256 + threadIdx.x) * stride;      // every stride-th record of the generation (gen_count_stride)
     const bool live = r < endr;
     u32 solid = 0, mask = 0;
     if (live) {
@@ -503,7 +503,9 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
 }
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
     if (!nrec_range) return;
-    hipLaunchKernelGGL(k_gen_count, dim3((u32)((nrec_range + 255) / 256)), dim3(256), 0, st, a, b0, b1, cnt, rows, log2fp, cost);
+    const u32 stride = gen_count_stride(nrec_range);
+    const u64 lanes = (nrec_range + stride - 1) / stride;
+    hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, cnt, rows, log2fp, cost);
 }
 // rows from counts
 __global__ __launch_bounds__(256) void k_gen_rows(const u32* __restrict__ cnt, u32* __restrict__ rows, u64 nctx, u32 step) {

@@ -89,6 +89,12 @@ void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int s
 void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);
 #define GEN_STEP 4u             // a counted base adds GEN_STEP to its row entry (chains.hip)
+// A generation of n records (its blocks x block_reads: the last block of a call may be short) is counted through every
+// s-th record, s = ceil(n / GEN_COUNT_CAP): half a million records tell a row's shape, and the counting -- a
+// scattered atomic per base into a table of 2^gen_bits x 16 bytes -- was most of the time of inputs whose bases can be
+// learned (half of a 10 M-read call: 50 ms).  The decoder counts the same records.
+#define GEN_COUNT_CAP 524288ull
+static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP ? (n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP : 1); }
 
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);

@@ -96,6 +96,30 @@ def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_frozen_big_generations_are_counted_through_every_nth_record(ctx):
+    """A generation of more than GEN_COUNT_CAP (524 288) records is counted through every ceil(n / cap)-th of them
+    (kernels.h gen_count_stride; the decoder counts the same records): 2.4 M reads sampled from a 10 Mbp genome put the
+    last counted generation at ~600 k records (stride 2).  The base chains against the oracle's restatement, then back."""
+    n = 2_400_000
+    fq = capi.synth_fastq(n, 100, seed=11, kind=3)
+    br, cr = 1024, 64
+    enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    ci = util.unpack_chains(enc.chains)
+    assert ci["flags"] & 1 and ci["chain_reads"] == cr
+    nblocks = -(-n // br)
+    bound = [0]; b = max(1, -(-nblocks // 64))
+    while b < nblocks and len(bound) + 1 < 40:
+        bound.append(b); b = max(b + 1, b * 2)
+    bound.append(nblocks)
+    assert max((bound[g + 1] - bound[g]) * br for g in range(len(bound) - 2)) > 524288        # a counted generation over the cap
+    starts, lens = util.line_table(fq)
+    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    assert on == 1
+    assert list(ci["gen"]) == list(sizes)
+    assert enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 @pytest.mark.parametrize("name", util.golden_names())
 def test_frozen_golden_samples(ctx, name):
     fq = util.golden_fastq(name)
