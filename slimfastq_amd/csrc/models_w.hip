@@ -1,21 +1,20 @@
-// models_w.hip -- wave-per-block throughput kernels.
+// models_w.hip -- wave-per-block kernels over ADAPTIVE tables (format 6, and format 7 with sfq_params.tables = 0), plus the
+// two wave-per-block kernels of the frozen-table mode whose rows stay adaptive: the N / quality-0 exception pass and its
+// decoder (k_gen_exc_w, k_gen_exc_decode_w).  The default coding kernels of block format 7 are in chains.hip.
 //
-// A 64-lane wavefront owns one record block (two, in the default quality kernel): its adaptive tables, its
-// range-coder state and its output cursor.  The work of a symbol is split in three stages so that only what is
-// inherently serial runs serially:
+// A 64-lane wavefront owns one record block (two, in the quality kernel): its adaptive tables, its range-coder state and
+// its output cursor.  The work of a symbol is split in three stages so that only what is inherently serial runs serially:
 //   (1) lane-parallel : 64 symbols are loaded coalesced, and their model contexts are computed across
 //                       lanes (the quality model's running `delta` is a wave prefix sum)
-//   (2) rows          : the adaptive row of each symbol is searched and updated.  Three forms live here:
-//                       k_qlt_encode_w   whole wave on ONE row, lane i = slot i (find by ballot, cumulative
-//                                        frequency by a DPP prefix sum) -- the first throughput kernel (kernel = 2)
-//                       k_qlt_encode_s   symbol-parallel: rows of different contexts in different lanes, one
-//                                        round per run of one symbol in one context (kernel = 4)
-//                       k_qlt_encode_k2  the same rows, two blocks per wave (the DEFAULT quality kernel)
-//                       k_rec_encode_w_* PowerRanger rows, four slots per lane (the default header kernel)
+//   (2) rows          : the adaptive row of each symbol is searched and updated:
+//                       k_qlt_encode_k2  symbol-parallel -- rows of different contexts in different lanes, one round per
+//                                        run of one symbol in one context; two blocks per wave
+//                       k_rec_encode_w_* PowerRanger rows, four slots per lane (WavePw: find by ballot, cumulative
+//                                        frequency by a DPP prefix sum)
 //   (3) coder         : the range coder consumes the (cum, freq, tot) triples; its one divide per symbol
 //                       (coder.hpp:68) is a multiply-high by a reciprocal computed for all 64 triples at once plus an
-//                       exact fix-up.  Scalar, one block (WaveCoder), or per lane group, two blocks (MultiCoder).
-// The default base kernel is models_k.hip.  The bytes produced are identical to models_l.hip (and so to the
+//                       exact fix-up.  Per lane group, two blocks (MultiCoder).
+// The adaptive base kernel is models_k.hip.  The bytes produced are identical to models_l.hip (and so to the
 // reference); tests compare all of them.
 #include "kernels.h"
 #include "dev_models.h"
