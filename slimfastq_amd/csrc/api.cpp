@@ -739,8 +739,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
         h_rows66 = (u32*)((u8*)ctx->pin + PIN_BYTES);
-        HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, st));
-        HIPC(hipEventRecord(ctx->ev[20], st));
+        // the 17 MB of rows go to the host for "qlt.pri"; with frozen tables on the framing stream, so that the copy does
+        // not sit between the sample and the quality chains on this one
+        hipStream_t cs = (frozen && !priors_only) ? mst[2] : st;
+        if (cs != st) { HIPC(hipEventRecord(ctx->ev[21], st)); HIPC(hipStreamWaitEvent(cs, ctx->ev[21], 0)); }
+        HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, cs));
+        HIPC(hipEventRecord(ctx->ev[20], cs));
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
