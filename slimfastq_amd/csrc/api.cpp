@@ -381,7 +381,7 @@ int rec_prior_finish(sfq_ctx* ctx, bool given, hipStream_t st) {
 // of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
 // Leaves ca.g_* describing which rows every generation codes with.
 struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; };
-int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits, hipStream_t st, GenPlan& gp) {
+int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits, u32 max_line, hipStream_t st, GenPlan& gp) {
     u32* bound = gp.bound;
     const u32 ngen = gp.ngen = gen_bounds(nblocks, bound);
     if (ngen < 3) return SFQ_OK;                                   // too few blocks to learn from
@@ -402,14 +402,14 @@ int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits,
     const u64 br = ca.block_reads;
     auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };          // an upper bound (the last block may be short): lanes past the end idle
     u32* rows = (u32*)ctx->grows.p;
-    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
+    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
     launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
-    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
+    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
     // the cost of generation 1 under generation 0's rows, and its bases (the initial row would cost 2 bits = 2048 units each)
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
     return SFQ_OK;
 }
-int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, hipStream_t st, const GenPlan& gp, u32* gen_on) {
+int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hipStream_t st, const GenPlan& gp, u32* gen_on) {
     *gen_on = 0;
     ca.g_ngen = 0;
     const u32 ngen = gp.ngen; const u32* bound = gp.bound;
@@ -430,7 +430,7 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, hipStream_t st, c
     for (u32 g = 2; g < ngen; g++) {
         launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * g, nctx, GEN_STEP, st);         // counts of generations < g
         ca.g_rows[g] = rows + nctx * g;
-        if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
+        if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
     }
     return SFQ_OK;
 }
@@ -608,11 +608,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
     if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 8 + (size_t)nblocks * 1024 + 4096))) return rc;
-    u32 h_status2[2] = {0, 0};
-    HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 8, hipMemcpyDeviceToHost, st));
+    u32 h_status2[3] = {0, 0, 0};
+    HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 12, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
-    const u32 h_status = h_status2[0], max_hdr = h_status2[1];
+    const u32 h_status = h_status2[0], max_hdr = h_status2[1], max_line = h_status2[2];
     if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
     if (h_status) return fail(ctx, -(int)h_status, "record over the line limits: headers up to 8190 bytes; base and quality lines up to 65534 in format 6 (-B 0; the reference would write oversize side streams, usrs.cpp:269-301, which this library does not), up to 1 Gi in the block format");
 
@@ -704,7 +704,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             ca.m = a;
             if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc; }
             if (models & SFQ_M_GEN) {
-                if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, mst[3], gplan))) return rc;
+                if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
                 if (!ca.exc_flag) launch_gen_exc_w(a, nullptr, tickets + 1, mst[2]);       // nobody marks the records: all of them, beside the chains
             }
             if (models & SFQ_M_USR)
@@ -817,7 +817,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
-            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, mst[3], gplan, &gen_on))) return rc;
+            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;
             HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3]); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
@@ -1246,6 +1246,13 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     u64 tot_s = 0, tot_q = 0;
+    u32 dec_max_line = 0;                              // the longest base line (how the base tables' counting passes split their work)
+    if (frozen) {
+        if ((rc = reserve(ctx, ctx->status, 256))) return rc;
+        HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
+        launch_max_u32(da.slen, nrec, (u32*)ctx->status.p, st);
+        HIPC(hipMemcpyAsync(&dec_max_line, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+    }
     HIPC(hipMemcpyAsync(&tot_s, (u64*)ctx->soff.p + nrec, 8, hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(&tot_q, (u64*)ctx->qoff.p + nrec, 8, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
@@ -1295,7 +1302,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 if (g >= 2) { launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * (g & 1), nctx, GEN_STEP, st_gen); ca.g_rows[g] = rows + nctx * (g & 1); }
                 else ca.g_rows[g] = nullptr;
                 launch_gen_decode_c(ca, da, bound[g], bound[g + 1], st_gen);
-                if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
+                if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, dec_max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
             }
         }
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_w(da, st_gen); }

@@ -119,13 +119,21 @@ struct LineWalk {
     const u8* buf; u64 nbytes;
     u64 r0; u32 nrec, k, line, solid;
     u64 pos, end, npos, nend;
+    u64 sub_lo, sub_len;         // a part of the line only: bytes [sub_lo, sub_lo + sub_len) of it (sub_len = 0: all of it)
     bool fresh;
     __device__ __forceinline__ void bounds(u32 kk, u64& b0, u64& b1) const {
         const u64 r = r0 + kk;
         if (st_off) { b0 = st_off[r]; b1 = b0 + st_len[r]; }
         else { b0 = line_off[4 * r + line] + solid; b1 = line_off[4 * r + line + 1] - 1; }
+        if (sub_len) {
+            if (b1 < b0) b1 = b0;
+            const u64 lo = b0 + sub_lo;
+            b0 = lo < b1 ? lo : b1;
+            b1 = b0 + sub_len < b1 ? b0 + sub_len : b1;
+        }
     }
-    __device__ __forceinline__ void init(const ChainArgs& a, u64 r0_, u32 nrec_, u32 line_, u32 solid_) {
+    __device__ __forceinline__ void init(const ChainArgs& a, u64 r0_, u32 nrec_, u32 line_, u32 solid_, u64 sub_lo_ = 0, u64 sub_len_ = 0) {
+        sub_lo = sub_lo_; sub_len = sub_len_;
         line_off = a.m.line_off; st_off = a.st_off; st_len = a.st_len;
         buf = st_off ? a.st_buf : a.m.fq; nbytes = st_off ? a.st_bytes : a.nbytes;
         r0 = r0_; nrec = nrec_; line = line_; solid = solid_; k = 0; pos = end = 0; npos = nend = 0; fresh = false;
@@ -394,33 +402,36 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 // per-lane walk over the base lines of records [r0, r0 + nrec): look(ctx) for every base of a piece first (so that a
 // caller can start its table lookups together), then code(j, code) for each base in order.  The bases come from the FASTQ
 // text or from the decoder's staged bases (ChainArgs::st_*).  N is coded as 0 (gens.cpp:116-136).
+// seg_len != 0: only the seg-th stretch of seg_len bases of the (one) record; the sixteen bases before it are run
+// through the context alone, so that the contexts of the stretch are what a walk from the line's start would give
 template <typename LOOK, typename CODE>
-__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, LOOK&& look, CODE&& code, u8* exc_flag = nullptr) {
-    LineWalk lw; lw.init(a, r0, nrec, 1, solid);
-    u32 last = 0;
+__device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, LOOK&& look, CODE&& code, u32 seg = 0, u32 seg_len = 0) {
+    const u32 warm = (seg_len && seg) ? 16u : 0u;                  // (seg_len is at least 16)
+    LineWalk lw;
+    if (seg_len) lw.init(a, r0, nrec, 1, solid, (u64)seg * seg_len - warm, (u64)seg_len + warm);
+    else lw.init(a, r0, nrec, 1, solid);
+    u32 last = 0, seen = 0;
     Piece pc = lw.next();
     uint4 w = lw.fetch(pc);
     while (__any(pc.valid)) {
         const Piece pn = lw.next();
         const uint4 wn = lw.fetch(pn);
-        if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139
+        if (pc.newline) last = 0x007616c7u;                        // gens.cpp:139 (a stretch behind the line's start overwrites it in its warm-up)
         u32 codes = 0;                                             // 2 bits per base of the piece
-        u32 odd = 0;
+        const u32 seen0 = seen;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             if (j >= pc.j0 && j < pc.j1) {
-                const u32 cd4 = gen_code_of(piece_byte(w, j));
-                const u32 cd = cd4 & 3u;
-                odd |= cd4;
-                look(j, last & mask);
+                const u32 cd = gen_code_of(piece_byte(w, j)) & 3u;
+                if (seen >= warm) look(j, last & mask);
+                seen++;
                 last = (last << 2) | cd;
                 codes |= cd << (2 * j);
             }
         }
-        // an N or an illegal character marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
-        if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
+        seen = seen0;
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) code(j, (codes >> (2 * j)) & 3u);
+        for (u32 j = 0; j < 16; j++) if (j >= pc.j0 && j < pc.j1) { if (seen >= warm) code(j, (codes >> (2 * j)) & 3u); seen++; }
         pc = pn; w = wn;
     }
 }
@@ -465,11 +476,15 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
 
 // counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
 // cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
-__global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32 stride, u32* __restrict__ cnt, const u32* __restrict__ rows,
+// Long lines (seg_len != 0): a lane takes one stretch of seg_len bases of a record, lane id = record x segs + stretch --
+// a lane per 30 kb read made this pass 95 ms of the long-read workload's 108.
+__global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32 stride, u32 seg_len, u32 segs, u32* __restrict__ cnt, const u32* __restrict__ rows,
                                                   const u16* __restrict__ log2fp, u64* cost) {
     const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
     u32 mybases = 0;
-    const u64 r = first + ((u64)blockIdx.x * 256 + threadIdx.x) * stride;      // every stride-th record of the generation (gen_count_stride)
+    const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 r = first + (id / segs) * stride;                    // every stride-th record of the generation (gen_count_stride)
+    const u32 seg = (u32)(id % segs);
     const bool live = r < endr;
     u32 solid = 0, mask = 0;
     if (live) {
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
                 const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
                 mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
             }
-        });
+        }, seg, seg_len);
     if (rows) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mycost += __shfl_xor(mycost, d, 64);
@@ -501,11 +516,14 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
         }
     }
 }
-void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
+void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
     if (!nrec_range) return;
     const u32 stride = gen_count_stride(nrec_range);
-    const u64 lanes = (nrec_range + stride - 1) / stride;
-    hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, cnt, rows, log2fp, cost);
+    // lines up to 1 KiB: a lane per record; longer: a lane per stretch of 512 bases (the lanes past a record's end idle)
+    const u32 seg_len = max_line > 1024u ? 512u : 0u;
+    const u32 segs = seg_len ? (max_line + seg_len - 1) / seg_len : 1u;
+    const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
+    hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost);
 }
 // rows from counts
 __global__ __launch_bounds__(256) void k_gen_rows(const u32* __restrict__ cnt, u32* __restrict__ rows, u64 nctx, u32 step) {

@@ -96,6 +96,18 @@ __global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, con
     }
 }
 
+// out[0] = max(out[0], max of v[0..n))
+__global__ __launch_bounds__(256) void k_max_u32(const u32* __restrict__ v, u64 n, u32* out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 m = i < n ? v[i] : 0u;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)m, dd, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m > out[0]) atomicMax(out, m);
+}
+void launch_max_u32(const u32* v, u64 n, u32* out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_max_u32, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, v, n, out);
+}
+
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st) {
     bool aligned = ((uintptr_t)fq & 15) == 0;
     hipLaunchKernelGGL(k_count_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_counts, aligned);
@@ -178,6 +190,11 @@ __global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u6
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)hl, dd, 64); hl = o > hl ? o : hl; }
     if ((threadIdx.x & 63) == 0 && hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
+    // status[2] = the longest base line (the base model's counting passes take long lines a stretch per lane)
+    u32 gl = (u32)(l2 - l1 - 1);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)gl, dd, 64); gl = o > gl ? o : gl; }
+    if ((threadIdx.x & 63) == 0 && gl > status[2]) atomicMax(status + 2, gl);
 }
 void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line, u32* status, hipStream_t st) {
     hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_line, status);

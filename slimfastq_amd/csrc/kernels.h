@@ -76,7 +76,8 @@ struct ChainArgs {
 void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
-void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
+void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,
+                      u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
@@ -98,6 +99,7 @@ static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1)
 
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
+void launch_max_u32(const u32* v, u64 n, u32* out /* raised to the largest of v */, hipStream_t st);
 void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
 void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line /* longest base / quality line taken */, u32* status, hipStream_t st);
 void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,

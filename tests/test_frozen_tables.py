@@ -120,6 +120,22 @@ def test_frozen_big_generations_are_counted_through_every_nth_record(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_frozen_counting_passes_take_long_lines_a_stretch_per_lane(ctx):
+    """Lines over 1 KiB: the base tables' counting passes give a lane a stretch of 512 bases (sixteen bases of warm-up in
+    front of it) instead of a whole record; the counts -- and so every chain's bytes -- must not depend on the split."""
+    fq = capi.synth_fastq(30000, 3000, seed=13, kind=3)          # 3 kb reads sampled from the 10 Mbp genome: the tables switch on
+    br, cr = 64, 8
+    enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    ci = util.unpack_chains(enc.chains)
+    starts, lens = util.line_table(fq)
+    assert int(lens[1::4].max()) > 1024
+    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    assert on == 1 and (ci["flags"] & 1)
+    assert list(ci["gen"]) == list(sizes)
+    assert enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 @pytest.mark.parametrize("name", util.golden_names())
 def test_frozen_golden_samples(ctx, name):
     fq = util.golden_fastq(name)
