@@ -146,6 +146,15 @@ class Encoded:
         self.res, self.blocks, self.first_hdrs, self.data, self.prior, self.chains = res, blocks, first_hdrs, data, prior, chains
         self.rec_prior = rec_prior
 
+    def clone(self):
+        """A deep copy (the tests damage copies)."""
+        blocks = (BlockInfo * len(self.blocks))()
+        C.memmove(blocks, self.blocks, C.sizeof(blocks))
+        res = Result()
+        C.memmove(C.byref(res), C.byref(self.res), C.sizeof(Result))
+        data = self.data.copy() if isinstance(self.data, np.ndarray) else bytes(self.data)
+        return Encoded(res, blocks, bytes(self.first_hdrs), data, bytes(self.prior), bytes(self.chains), bytes(self.rec_prior))
+
     def stream(self, s, block=None) -> bytes:
         """Bytes of stream s (an id or a name): the whole concatenation, or one block's part."""
         if isinstance(s, str):

@@ -1257,6 +1257,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipMemcpyAsync(&tot_q, (u64*)ctx->qoff.p + nrec, 8, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
+    // (a damaged usr stream can claim any lengths: what cannot fit the caller's buffer is refused before anything is decoded)
+    if (tot_s > out_cap || tot_q > out_cap) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
+                                                           (unsigned long long)tot_s, (unsigned long long)tot_q, (unsigned long long)out_cap);
     if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 16))) return rc;
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
@@ -1408,9 +1411,18 @@ int sfq_decode_blocks_host(sfq_ctx* ctx, const sfq_params* params, const sfq_blo
                            const uint8_t* h_first_hdrs, uint64_t first_hdr_bytes,
                            const uint8_t* h_streams, uint64_t streams_bytes, const uint64_t stream_offset[SFQ_NSTREAMS],
                            uint8_t* h_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* result) {
-    if (!ctx || !h_streams || !h_out) return fail(ctx, SFQ_E_ARG, "null argument");
+    if (!ctx || !h_streams || !h_out || !h_blocks || !stream_offset) return fail(ctx, SFQ_E_ARG, "null argument");
     HIPC(hipSetDevice(ctx->dev));
     int rc;
+    // the index is untrusted: every stream's blocks must lie inside the bytes handed over (the device entry point cannot
+    // know the size of the caller's buffer; there the caller vouches for stream_offset[s] + the blocks' sizes)
+    for (int sx = 0; sx < SFQ_NSTREAMS; sx++) {
+        u64 tot = 0;
+        for (u32 b = 0; b < n_blocks; b++) tot += h_blocks[b].size[sx];
+        if (stream_offset[sx] > streams_bytes || tot > streams_bytes - stream_offset[sx])
+            return fail(ctx, SFQ_E_CORRUPT, "block index: stream %s needs %llu bytes at offset %llu, %llu were given", sfq_stream_name(sx),
+                        (unsigned long long)tot, (unsigned long long)stream_offset[sx], (unsigned long long)streams_bytes);
+    }
     if ((rc = reserve(ctx, ctx->in_stage, (size_t)streams_bytes + 16))) return rc;
     if ((rc = reserve(ctx, ctx->out_stage, (size_t)out_cap + 16))) return rc;
     HIPC(hipMemcpyAsync(ctx->in_stage.p, h_streams, (size_t)streams_bytes, hipMemcpyHostToDevice, ctx->st));

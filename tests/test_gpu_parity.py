@@ -171,6 +171,53 @@ def test_reads_beyond_the_reference_line_limit(ctx):
     assert e.value.code == -7          # SFQ_E_UNSUPPORTED
 
 
+def test_corrupt_archives_fail_cleanly_or_decode_to_something(ctx):
+    """Untrusted input on the way back: flipped stream bytes, a lying block index, swapped chain sizes, damaged priors.
+    Every decode must end in an SfqError or in some bytes -- never in a device fault -- and the context must decode the
+    intact archive afterwards."""
+    import random
+    rnd = random.Random(11)
+    fq = capi.synth_fastq(3000, 120, seed=21)
+    for tables in (capi.TABLES_FROZEN, capi.TABLES_ADAPTIVE):
+        enc = ctx.encode_host(fq, level=3, block_reads=256, prior_step=capi.PRIOR_AUTO, tables=tables, chain_reads=32)
+        assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+        outcomes = {"error": 0, "bytes": 0}
+        for trial in range(60):
+            bad = enc.clone()
+            kind = trial % 6
+            if kind == 0:                                   # flipped bytes anywhere in the streams
+                data = bytearray(bad.data)
+                for _ in range(rnd.randint(1, 8)):
+                    data[rnd.randrange(len(data))] ^= 1 << rnd.randrange(8)
+                bad.data = bytes(data)
+            elif kind == 1:                                 # a block index that lies about lengths / flags
+                b = bad.blocks[rnd.randrange(len(bad.blocks))]
+                what = rnd.randrange(5)
+                if what == 0: b.llen = rnd.choice((0, 1, 119, 121, 5000))
+                elif what == 1: b.hdr_bytes = rnd.choice((0, 1, 7, 1 << 20))
+                elif what == 2: b.two_id ^= 1
+                elif what == 3: b.solid ^= 1
+                else: b.n_byte = rnd.randrange(256)
+            elif kind == 2 and bad.chains:                  # chain sizes moved between neighbours (the sums stay)
+                ch = bytearray(bad.chains)
+                i = rnd.randrange(4, max(5, len(ch) - 2))
+                if 1 < ch[i] < 0x7f and 1 < ch[i + 1] < 0x7f: ch[i] -= 1; ch[i + 1] += 1
+                bad.chains = bytes(ch)
+            elif kind == 3 and bad.prior:                   # a damaged quality prior
+                pr = bytearray(bad.prior); pr[rnd.randrange(len(pr))] ^= 0x55; bad.prior = bytes(pr)
+            elif kind == 4 and bad.rec_prior:               # a damaged header prior
+                pr = bytearray(bad.rec_prior); pr[rnd.randrange(len(pr))] ^= 0x33; bad.rec_prior = bytes(pr)
+            else:                                           # a truncated stream buffer
+                bad.data = bad.data[:rnd.randrange(len(bad.data) // 2, len(bad.data))]
+            try:
+                ctx.decode_host(bad, level=3, out_cap=2 * len(fq) + 4096)
+                outcomes["bytes"] += 1
+            except capi.SfqError:
+                outcomes["error"] += 1
+        assert outcomes["error"] > 0
+        assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 def test_ragged_and_error_inputs(ctx):
     one = b"@only 1\nACGT\n+\nIIII\n"
     enc = ctx.encode_host(one, level=3)
