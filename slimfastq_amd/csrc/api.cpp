@@ -50,6 +50,8 @@ struct sfq_ctx {
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf, cflags;
     u32 r_hot = 0;
+    bool blobs_from_encode = false;        // prior_blob / rec_prior_blob / chain_blob are what the last ENCODE left for sfq_get_*:
+                                           // a decode never reads those (only what sfq_set_* installed)
     bool unsettled = false;                // a call returned with an error: its side streams may still be running
     void* pin = nullptr; size_t pin_cap = 0;
     void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
@@ -537,6 +539,7 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     Settle settle(ctx);
     const int rc = encode_body(ctx, d_fastq, nbytes, pp, d_out, out_cap, res, force_models, priors_only);
     settle.ok = rc == SFQ_OK;
+    if (rc == SFQ_OK && !priors_only) ctx->blobs_from_encode = true;       // (sfq_build_priors leaves installed priors: SFQ_PRIOR_GIVEN reads them)
     return rc;
 }
 static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
@@ -1050,8 +1053,14 @@ int64_t sfq_get_qlt_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
     if (h_blob && cap >= ctx->prior_blob.size() && !ctx->prior_blob.empty()) memcpy(h_blob, ctx->prior_blob.data(), ctx->prior_blob.size());
     return (int64_t)ctx->prior_blob.size();
 }
+static void drop_encode_blobs(sfq_ctx* ctx) {
+    if (!ctx->blobs_from_encode) return;
+    ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); ctx->chain_blob.clear();
+    ctx->blobs_from_encode = false;
+}
 int sfq_set_qlt_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
     if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    drop_encode_blobs(ctx);
     ctx->prior_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
@@ -1062,6 +1071,7 @@ int64_t sfq_get_rec_prior(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
 }
 int sfq_set_rec_prior(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
     if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    drop_encode_blobs(ctx);
     ctx->rec_prior_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
@@ -1072,6 +1082,7 @@ int64_t sfq_get_chain_index(sfq_ctx* ctx, uint8_t* h_blob, uint64_t cap) {
 }
 int sfq_set_chain_index(sfq_ctx* ctx, const uint8_t* h_blob, uint64_t n) {
     if (!ctx || (n && !h_blob)) return SFQ_E_ARG;
+    drop_encode_blobs(ctx);
     ctx->chain_blob.assign(h_blob, h_blob + n);
     return SFQ_OK;
 }
@@ -1091,6 +1102,7 @@ int sfq_decode_blocks(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info* 
         return fail(ctx, SFQ_E_ARG, "null argument");
     HIPC(hipSetDevice(ctx->dev));
     Settle settle(ctx);
+    drop_encode_blobs(ctx);                             // whatever an encode left behind is not this archive's
     const int rc = decode_body(ctx, pp, h_blocks, nblocks, h_first_hdrs, first_hdr_bytes, d_streams, stream_offset, d_out, out_cap, out_bytes, res);
     settle.ok = rc == SFQ_OK;
     return rc;
