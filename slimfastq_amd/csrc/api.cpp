@@ -713,6 +713,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             if (models & SFQ_M_USR)
                 for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
+        } else if (models & SFQ_M_REC) {                    // sfq_build_priors: the header sample beside the quality sample
+            HIPC(hipStreamWaitEvent(mst[1], ctx->ev[13], 0));
+            if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc;
         }
     }
     u32* h_rows66 = nullptr;
@@ -787,12 +790,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     }
     if (!frozen) { if ((rc = setup_tables())) return rc; }
     if (priors_only) {
-        if (frozen && (models & SFQ_M_REC)) {
-            if ((rc = rec_prior_begin(ctx, a, nrec, given, st))) return rc;
-            if ((rc = rec_prior_finish(ctx, given, st))) return rc;
+        if (ctx->prior_on && !given) {                      // (packed while the header sample is still being counted)
+            HIPC(hipEventSynchronize(ctx->ev[20]));
+            ctx->prior_blob = pack_prior(h_rows66, q_rows);
         }
+        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc; }
+        HIPC(hipStreamSynchronize(mst[1]));
         HIPC(hipStreamSynchronize(st));
-        if (ctx->prior_on && !given) ctx->prior_blob = pack_prior(h_rows66, q_rows);
         ctx->prior_on = false;
         res->n_records = nrec; res->n_blocks = nblocks;
         return SFQ_OK;
