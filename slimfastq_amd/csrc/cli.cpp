@@ -506,6 +506,19 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     uint64_t spos[SFQ_NSTREAMS] = {0};
     std::vector<uint8_t> data;
     Bytes out;
+    // several segments of known size: the text of one is written (a thread) while the next is decoded, out of two
+    // page-locked buffers (kept for the life of the process, like the encoder's)
+    static uint8_t* opin[2] = { nullptr, nullptr }; static size_t opin_cap = 0;
+    size_t max_raw = 0; bool sized = segs.size() > 1;
+    for (const Segment& g : segs) { max_raw = std::max<size_t>(max_raw, (size_t)g.raw_bytes); if (!g.raw_bytes) sized = false; }
+    if (sized && opin_cap < max_raw + 64) {
+        for (auto& q : opin) { if (q) sfq_host_free(ctx, q); q = nullptr; }
+        opin[0] = (uint8_t*)sfq_host_alloc(ctx, max_raw + 64); opin[1] = (uint8_t*)sfq_host_alloc(ctx, max_raw + 64);
+        opin_cap = (opin[0] && opin[1]) ? max_raw + 64 : 0;
+        if (!opin_cap) sized = false;
+        tick("pinned buffers");
+    }
+    std::thread writer; std::atomic<int> wbad{0}; int ob = 0;
     for (const Segment& g : segs) {
         if (g.nblocks == 0 || g.nblocks > blocks.size() - b0) croak("bad segment index");
         if (pri ? g.prior_bytes > pri->size() - pri_off : g.prior_bytes != 0) croak("bad segment index");
@@ -536,20 +549,33 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         if (!cap) cap = data.size() * 8 + (1 << 20);
         sfq_result res;
         int rc = 0;
+        uint8_t* dst = nullptr;
         for (int attempt = 0; attempt < 2; attempt++) {
-            if (!out.reserve((size_t)cap + 16)) croak("out of memory");
-            out.touch((size_t)cap);
+            if (sized && cap + 16 <= opin_cap) dst = opin[ob];
+            else {
+                if (!out.reserve((size_t)cap + 16)) { if (writer.joinable()) writer.join(); croak("out of memory"); }
+                out.touch((size_t)cap);
+                dst = out.p;
+            }
             rc = sfq_decode_blocks_host(ctx, &p, sb.data(), (uint32_t)sb.size(), first.data() + h0, hbytes,
-                                        data.data(), data.size(), soff, out.p, cap, &got, &res);
+                                        data.data(), data.size(), soff, dst, cap, &got, &res);
             if (rc != SFQ_E_OVERFLOW || got <= cap) break;
             cap = got;                                                 // the call reports the size it needs
         }
-        if (rc) croak("%s", sfq_last_error(ctx));
+        if (rc) { if (writer.joinable()) writer.join(); croak("%s", sfq_last_error(ctx)); }
         tick("sfq_decode_blocks_host");
-        if (fwrite(out.p, 1, (size_t)got, of) != got) croak("USR: Error writing output");
+        if (writer.joinable()) writer.join();
+        if (wbad) croak("USR: Error writing output");
+        if (dst == out.p) { if (fwrite(dst, 1, (size_t)got, of) != got) croak("USR: Error writing output"); }
+        else {
+            writer = std::thread([dst, got, of, &wbad]() { if (fwrite(dst, 1, (size_t)got, of) != got) wbad = 1; });
+            ob ^= 1;
+        }
         tick("write output");
         b0 += g.nblocks; pri_off += g.prior_bytes; chn_off += g.chain_bytes; rpr_off += g.recpri_bytes;
     }
+    if (writer.joinable()) writer.join();
+    if (wbad) croak("USR: Error writing output");
     if (of != stdout) fclose(of); else fflush(stdout);
 }
 
