@@ -719,6 +719,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         }
     }
     u32* h_rows66 = nullptr;
+    bool rows66_copy_pending = false;
     // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
     // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
@@ -747,10 +748,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         h_rows66 = (u32*)((u8*)ctx->pin + PIN_BYTES);
         // the 17 MB of rows go to the host for "qlt.pri"; with frozen tables on the framing stream, so that the copy does
         // not sit between the sample and the quality chains on this one
-        hipStream_t cs = (frozen && !priors_only) ? mst[2] : st;
-        if (cs != st) { HIPC(hipEventRecord(ctx->ev[21], st)); HIPC(hipStreamWaitEvent(cs, ctx->ev[21], 0)); }
-        HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, cs));
-        HIPC(hipEventRecord(ctx->ev[20], cs));
+        // (with frozen tables the copy is queued later, behind the header chains on their stream: anywhere earlier it
+        //  holds up a model's kernels -- the streams share three hardware queues)
+        if (frozen && !priors_only && (models & SFQ_M_REC)) { HIPC(hipEventRecord(ctx->ev[21], st)); rows66_copy_pending = true; }
+        else {
+            HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipEventRecord(ctx->ev[20], st));
+        }
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
@@ -820,8 +824,14 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1])); launch_rec_encode_c(ca, (u32*)ctx->rflags.p, max_hdr, mst[1]); HIPC(hipEventRecord(ctx->ev[19], mst[1]));
-        }
-        HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
+            HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
+            if (rows66_copy_pending) {
+                HIPC(hipStreamWaitEvent(mst[1], ctx->ev[21], 0));
+                HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, mst[1]));
+                HIPC(hipEventRecord(ctx->ev[20], mst[1]));
+                rows66_copy_pending = false;
+            }
+        } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
             if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;

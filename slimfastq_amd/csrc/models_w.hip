@@ -358,7 +358,10 @@ void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st) {
 }
 
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
-    hipLaunchKernelGGL(k_gen_exc_w, dim3(a.nbatch), dim3(64), 0, st, a, flags, ticket);
+    // (persistent waves that take blocks off the ticket: not more of them than three quarters of the chip's wave slots --
+    //  the packing kernels run beside this pass and would otherwise wait for a slot until it is through)
+    const u32 grid = a.nbatch < 6144u ? a.nbatch : 6144u;
+    hipLaunchKernelGGL(k_gen_exc_w, dim3(grid), dim3(64), 0, st, a, flags, ticket);
 }
 
 
