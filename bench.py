@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode-and-compare leg after the timed steps")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 path (process group, shared prior, gather) with one rank")
     args = ap.parse_args()
     if args.reads <= 0:
         args.reads = 60_000 if args.kind == 1 else 10_000_000
@@ -119,9 +120,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        payload_group = dist.new_group(list(range(world)))          # the streams travel on a communicator of their own
     seed = 1
     prior_step = capi.PRIOR_AUTO if args.prior_step < 0 else args.prior_step
     models = 0 if args.workload == "full" else capi.M_QLT
@@ -144,12 +149,20 @@ def main():
     del fq
     ctx = capi.Context(local_rank)
     cap = capi.lib().sfq_encode_bound(nbytes)
-    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    # N > 1: the streams of step k travel to the writer rank while step k + 1 is coded -- two output buffers take turns
+    d_outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(2 if multi else 1)]
+    d_out = d_outs[0]
     torch.cuda.synchronize()
+    flight = {"n": 0, "gather": None}
+
+    def land():
+        if flight["gather"] is not None:
+            sdist.gather_bytes_finish(flight["gather"])
+            flight["gather"] = None
 
     def step(tables=args.tables):
         ps = prior_step
-        if world > 1 and prior_step == capi.PRIOR_AUTO:
+        if multi and prior_step == capi.PRIOR_AUTO:
             # one prior for the whole job: rank 0 builds it from its shard, broadcasts it (a few hundred KB),
             # every rank codes from it -- so a record block's bytes do not depend on how many GPUs shared the file
             from slimfastq_amd.dist_compress import bcast_bytes
@@ -159,16 +172,21 @@ def main():
             pri = bcast_bytes(pri, 0, d_in.device); rp = bcast_bytes(rp, 0, d_in.device)
             ctx.set_priors(pri, rp)
             ps = capi.PRIOR_GIVEN
-        res = ctx.encode_device(d_in.data_ptr(), nbytes, d_out.data_ptr(), cap, level=args.level,
+        buf = d_outs[flight["n"] % len(d_outs)]
+        flight["n"] += 1
+        res = ctx.encode_device(d_in.data_ptr(), nbytes, buf.data_ptr(), cap, level=args.level,
                                 block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=ps,
                                 tables=tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
-        if world > 1:
-            # the path's one exchange step: compressed streams to the writer rank, over RCCL/xGMI
-            sdist.gather_bytes(d_out[:res.total_bytes], dst=0)
+        if multi:
+            # the path's one exchange step: compressed streams to the writer rank, over RCCL/xGMI.  The previous step's
+            # streams have had this step's coding to arrive; this step's leave now (the last ones land inside the timed region)
+            land()
+            flight["gather"] = sdist.gather_bytes_start(buf[:res.total_bytes], dst=0, p2p_group=payload_group)
         return res
 
     for _ in range(args.warmup):
         res = step()
+    land()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -179,6 +197,7 @@ def main():
         res = step()
         phase += np.array(list(res.kernel_ms))
         coder += np.array(list(res.coder_ms))
+    land()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -251,7 +270,7 @@ def main():
                         "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
                         "device_total": round(phase[capi.T_TOTAL], 3)},
            "roofline": roofline, "synth_s": round(t_gen, 2)}
-    if world == 1 and args.workload == "full" and not args.models and not args.no_decode:
+    if not multi and args.workload == "full" and not args.models and not args.no_decode:
         # the way back ("decode MB/s secondarily"): the same blocks decoded in HBM and compared with the input;
         # outside the timed region, never part of `value`
         blocks = ctx.index(res.n_blocks)
@@ -270,7 +289,7 @@ def main():
         out["decode"] = {"value": round(nbytes / min(times) / 1e6, 2), "unit": "MB/s FASTQ restored", "ms": round(min(times) * 1e3, 3),
                          "round_trip_identical": same}
         del d_back, packed
-    if world == 1 and args.tables and args.workload == "full" and not args.models and not args.no_adaptive_leg:
+    if not multi and args.tables and args.workload == "full" and not args.models and not args.no_adaptive_leg:
         # secondary: the same call with ADAPTIVE tables (every block runs the reference's per-symbol row updates, a wavefront per
         # block) -- round 1's headline mode, kept beside the default so the two can be compared; never part of `value`
         step(0)
@@ -280,7 +299,7 @@ def main():
         torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / 3
         out["adaptive_tables"] = {"value": round(nbytes / ta / 1e6, 2), "unit": "MB/s", "ms_per_step": round(ta * 1e3, 3),
                                   "ratio": round(nbytes / ra.total_bytes, 4)}
-    if world == 1 and not args.no_cpu_baseline:
+    if not multi and not args.no_cpu_baseline:
         cb, sample, ref_payload = cpu_baseline(args, seed)
         out["cpu_baseline"] = cb
         # ratio vs the reference on the same sample: ours in blocks vs the reference's single adaptive stream

@@ -16,10 +16,14 @@ def shard_records(n_records: int, rank: int, world: int, block_reads: int):
     return min(b0 * block_reads, n_records), min(b1 * block_reads, n_records)
 
 
-def gather_bytes(payload: torch.Tensor, dst: int = 0, group=None):
+def gather_bytes_start(payload: torch.Tensor, dst: int = 0, group=None, p2p_group=None):
     """Variable-size gather of one uint8 tensor per rank to `dst` (there is no gatherv in RCCL: sizes via
-    all_gather, then point-to-point sends -- one hop on the fully connected xGMI mesh).
-    Returns the list of tensors (rank order) on dst, None elsewhere."""
+    all_gather, then point-to-point sends -- one hop on the fully connected xGMI mesh).  The payload is on its
+    way when this returns: gather_bytes_finish(handle) waits for it, so a caller can code its next batch of
+    blocks in between (`payload` and the returned buffers must stay untouched until then).  `p2p_group`: a second
+    group over the same ranks for the payload (its own communicator and stream), so that the small collectives of the
+    next batch (the shared prior's broadcast, the sizes) do not queue behind a payload still in flight."""
+    pg = p2p_group if p2p_group is not None else group
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
@@ -29,14 +33,26 @@ def gather_bytes(payload: torch.Tensor, dst: int = 0, group=None):
     hs = [int(x) for x in sizes.cpu().tolist()]
     if rank == dst:
         bufs = [payload if r == rank else torch.empty(hs[r], dtype=torch.uint8, device=dev) for r in range(world)]
-        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != rank and hs[r]]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, pg) for r in range(world) if r != rank and hs[r]]
     else:
         bufs = None
-        ops = [dist.P2POp(dist.isend, payload, dst, group)] if payload.numel() else []
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        ops = [dist.P2POp(dist.isend, payload, dst, pg)] if payload.numel() else []
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return works, bufs, dev
+
+
+def gather_bytes_finish(handle):
+    """Waits for a gather started by gather_bytes_start; returns the list of tensors (rank order) on dst, None elsewhere."""
+    works, bufs, dev = handle
+    for w in works:
+        w.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()       # (a "nccl" wait only orders the stream: the host must know too)
     return bufs
+
+
+def gather_bytes(payload: torch.Tensor, dst: int = 0, group=None):
+    return gather_bytes_finish(gather_bytes_start(payload, dst, group))
 
 
 def merge_indexes(per_rank_blocks, per_rank_first_hdrs):

@@ -89,3 +89,53 @@ def test_two_rank_shard_gather_merge_equals_single_process():
             off[r] += totals[r][s]
         assert merged == payload1[single_off:single_off + totals1[s]], s
         single_off += totals1[s]
+
+
+def _worker_pipelined(rank, world, port, q):
+    """bench.py's N > 1 loop: the payload of batch k travels (on a group of its own) while batch k + 1 is prepared and a
+    small collective of the next batch runs on the default group; two buffers take turns."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    payload_group = dist.new_group(list(range(world)))
+    sys.path.insert(0, ROOT)
+    from slimfastq_amd import dist as sdist
+    bufs = [torch.zeros(70000, dtype=torch.uint8) for _ in range(2)]
+    got, flight = [], None
+    for k in range(5):
+        buf = bufs[k % 2]
+        n = 1000 * (rank + 1) + 13000 * k                      # ragged: every rank and every batch its own size
+        note = torch.tensor([k if rank == 0 else -1])
+        dist.broadcast(note, 0)                                # (the shared prior's broadcast: default group, payload k - 1 in flight)
+        assert int(note) == k
+        buf[:n] = torch.arange(n, dtype=torch.int64).add(7 * k + rank).remainder(251).to(torch.uint8)
+        if flight is not None:
+            r = sdist.gather_bytes_finish(flight)
+            if rank == 0:
+                got.append([bytes(t.numpy()) for t in r])
+        flight = sdist.gather_bytes_start(buf[:n], dst=0, p2p_group=payload_group)
+    r = sdist.gather_bytes_finish(flight)
+    if rank == 0:
+        got.append([bytes(t.numpy()) for t in r])
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_payload_of_one_batch_travels_while_the_next_is_prepared():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(got) == 5
+    for k, parts in enumerate(got):
+        for rank, b in enumerate(parts):
+            n = 1000 * (rank + 1) + 13000 * k
+            want = bytes((torch.arange(n, dtype=torch.int64).add(7 * k + rank).remainder(251)).to(torch.uint8).numpy())
+            assert b == want, (k, rank)
