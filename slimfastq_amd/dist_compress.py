@@ -7,8 +7,8 @@ Rank 0 builds ONE set of priors (quality prior, header prior) from its shard and
 rank r compresses a contiguous, record-aligned byte range of the file on its GPU from that prior (the blocks are
 independent: no data-path collective), and ONE exchange follows: every rank's compressed streams -- as they lie in
 HBM -- plus its block index, first headers and chain index go to rank 0 (slimfastq_amd.dist.gather_bytes: RCCL over
-xGMI with the "nccl" backend), which writes the archive: one SEGMENT per rank, the priors
-stored once, decodable by `slimfastq-amd -d`.
+xGMI with the "nccl" backend), which writes the archive: a rank codes its range in slabs (-S, as the CLI does) and every
+slab is one SEGMENT, the priors stored once, decodable by `slimfastq-amd -d`.
 """
 import argparse
 import ctypes as C
@@ -182,6 +182,7 @@ def main(argv=None):
     ap.add_argument("-l", "--level", type=int, default=3)
     ap.add_argument("-B", "--block_reads", type=int, default=-1, help="records per block (default: automatic, about 376 KiB of text)")
     ap.add_argument("-A", "--adaptive", action="store_true", help="adaptive tables (a wavefront per block) instead of frozen tables")
+    ap.add_argument("-S", "--slab", type=int, default=2048, help="MiB of text per call and archive segment (default 2048)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL when every rank has its own GPU, else gloo)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,49 +195,75 @@ def main(argv=None):
                                 **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
     cdev = torch.device("cuda", dev)
     xdev = cdev if backend == "nccl" else torch.device("cpu")          # where the exchanged tensors live
-    with open(args.fastq, "rb") as f:
-        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-        lo, hi = shard_bytes(mm, rank, world)
-        text = mm[lo:hi]
-        mm.close()
+    # the rank's share of the file, cut into slabs at record boundaries: one archive segment per slab (as the CLI's -S),
+    # so that a rank's device memory is sized by the slab, not by its share of the file
+    slab_bytes = max(1, args.slab) << 20
+    f = open(args.fastq, "rb")
+    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if os.fstat(f.fileno()).st_size else b""
+    lo, hi = shard_bytes(mm, rank, world)
+    cuts = [lo]
+    while cuts[-1] < hi:
+        want = cuts[-1] + slab_bytes
+        nxt = hi if want >= hi else min(record_start(mm, want), hi)
+        cuts.append(nxt if nxt > cuts[-1] else hi)
+    spans = list(zip(cuts[:-1], cuts[1:]))
     per_gpu = (world + max(ngpu, 1) - 1) // max(ngpu, 1)            # ranks sharing one GPU share its memory
     budget = int(torch.cuda.get_device_properties(dev).total_memory * 0.6 / per_gpu) if per_gpu > 1 else None
     ctx = capi.Context(dev, table_budget=budget)
     tables = capi.TABLES_ADAPTIVE if args.adaptive else capi.TABLES_FROZEN
     br = capi.BLOCK_AUTO if args.block_reads < 0 else args.block_reads
     torch.cuda.set_device(dev)
-    d_in = torch.from_numpy(np.frombuffer(text, np.uint8).copy()).to(cdev) if text else torch.empty(0, dtype=torch.uint8, device=cdev)
-    # ONE prior for the whole file: rank 0 builds it from its shard, everybody codes from it
+
+    def to_device(text):
+        return torch.from_numpy(np.frombuffer(text, np.uint8).copy()).to(cdev)
+
+    # ONE prior for the whole file: rank 0 builds it from its first slab, everybody codes from it
     prior = rec_prior = b""
+    d_first = to_device(mm[spans[0][0]:spans[0][1]]) if spans else None
     if world > 1:
-        if rank == 0 and len(text):
-            prior, rec_prior = ctx.build_priors(d_in.data_ptr(), len(text), level=args.level, block_reads=br, tables=tables)
+        if rank == 0 and spans:
+            prior, rec_prior = ctx.build_priors(d_first.data_ptr(), d_first.numel(), level=args.level, block_reads=br, tables=tables)
         prior = bcast_bytes(prior, 0, xdev)
         rec_prior = bcast_bytes(rec_prior, 0, xdev)
     shared = bool(prior)
-    part_t = None
-    if len(text):
-        cap = capi.lib().sfq_encode_bound(len(text))
+    my_parts = []
+    for k, (a, b) in enumerate(spans):
+        d_in = d_first if k == 0 else to_device(mm[a:b])
+        nb = b - a
+        cap = capi.lib().sfq_encode_bound(nb)
         d_out = torch.empty(cap, dtype=torch.uint8, device=cdev)
         if shared:
             ctx.set_priors(prior, rec_prior)
-        res = ctx.encode_device(d_in.data_ptr(), len(text), d_out.data_ptr(), cap, level=args.level, block_reads=br,
+        res = ctx.encode_device(d_in.data_ptr(), nb, d_out.data_ptr(), cap, level=args.level, block_reads=br,
                                 prior_step=capi.PRIOR_GIVEN if shared else capi.PRIOR_AUTO, tables=tables)
         blocks = list(ctx.index(res.n_blocks))
-        # with a shared prior only rank 0's segment carries it
-        keep = (not shared) or rank == 0
-        part_t = pack_part(d_out, res, blocks, ctx.first_headers(res.first_hdr_bytes), ctx.prior() if keep else b"", ctx.chains(),
-                           ctx.rec_prior() if keep else b"", len(text))
-    else:
-        class _R:  # an empty shard
-            stream_bytes = [0] * capi.NSTREAMS; total_bytes = 0; n_records = 0
-        part_t = pack_part(torch.empty(0, dtype=torch.uint8, device=cdev), _R, [], b"", b"", b"", b"", 0)
+        # with a shared prior only the file's first segment carries it
+        keep = (not shared) or (rank == 0 and k == 0)
+        my_parts.append(pack_part(d_out, res, blocks, ctx.first_headers(res.first_hdr_bytes), ctx.prior() if keep else b"", ctx.chains(),
+                                  ctx.rec_prior() if keep else b"", nb))
+        del d_in, d_out
+        d_first = None
+    if len(mm):
+        mm.close()
+    f.close()
+    # a rank's segments travel as one tensor: the parts back to back, then their lengths and their count (int64)
+    trailer = np.array([int(t.numel()) for t in my_parts] + [len(my_parts)], np.int64)
+    part_t = torch.cat(my_parts + [torch.from_numpy(np.frombuffer(trailer.tobytes(), np.uint8).copy()).to(cdev)])
+
+    def split_parts(raw: bytes):
+        n = int(np.frombuffer(raw[-8:], np.int64)[0])
+        lens = [int(x) for x in np.frombuffer(raw[-8 * (n + 1):-8], np.int64)]
+        out, off = [], 0
+        for ln in lens:
+            out.append(unpack_part(raw[off:off + ln])); off += ln
+        return out
+
     if world > 1:
         # the one exchange: every rank's bytes to the writer, device to device (RCCL over xGMI) when each rank has a GPU
         got = sdist.gather_bytes(part_t.to(xdev), dst=0)
-        parts = [unpack_part(g.cpu().numpy().tobytes()) for g in got] if rank == 0 else None
+        parts = [p for g in got for p in split_parts(g.cpu().numpy().tobytes())] if rank == 0 else None
     else:
-        parts = [unpack_part(part_t.cpu().numpy().tobytes())]
+        parts = split_parts(part_t.cpu().numpy().tobytes())
     if rank == 0:
         first = [p for p in parts if p["records"]]
         info, streams = assemble(parts, args.level, int(first[0]["blocks"][0].n_records) if first else 0, args.fastq,

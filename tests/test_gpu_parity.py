@@ -565,6 +565,16 @@ def test_two_ranks_compress_one_file_into_one_archive(tmp_path):
     assert b"seg.count" in p.stderr and b"= 2" in p.stderr
     subprocess.check_call([_cli(), "-d", "-f", str(sfq), "-u", str(back), "-O"])
     assert back.read_bytes() == fq
+    # a rank's range in slabs of 1 MiB: every slab a segment, the file's one prior in the first
+    import re
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29534", "-m", "slimfastq_amd.dist_compress", str(src), str(sfq), "-B", "700", "-S", "1"],
+                   check=True, cwd=root, env=env, timeout=600)
+    p = subprocess.run([_cli(), "-s", "-f", str(sfq)], capture_output=True)
+    m = re.search(rb"seg\.count\s*=\s*(\d+)", p.stderr)
+    assert m and int(m.group(1)) == 4, p.stderr[-400:]
+    subprocess.check_call([_cli(), "-d", "-f", str(sfq), "-u", str(back), "-O"])
+    assert back.read_bytes() == fq
     # one rank: a plain one-segment archive
     subprocess.run([sys.executable, "-m", "slimfastq_amd.dist_compress", str(src), str(tmp_path / "one.sfq")], check=True, cwd=root, env=env, timeout=600)
     p = subprocess.run([_cli(), "-d", "-f", str(tmp_path / "one.sfq")], capture_output=True, check=True)
