@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qcoarse, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rcoarse, rmap, rflags, excf, cflags;
+    DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, excf, cflags;
     u32 r_hot = 0;
     bool blobs_from_encode = false;        // prior_blob / rec_prior_blob / chain_blob are what the last ENCODE left for sfq_get_*:
                                            // a decode never reads those (only what sfq_set_* installed)
@@ -295,9 +295,9 @@ int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
     }
     if ((rc = reserve(ctx, ctx->hfreq, f.size() * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rrows, f.size() * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->rcoarse, (size_t)PR_REC_ROWS * 16 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rdec, (size_t)PR_REC_ROWS * 272 * 2))) return rc;          // chains.hip RDEC_ROW
     HIPC(hipMemcpyAsync(ctx->hfreq.p, f.data(), f.size() * 4, hipMemcpyHostToDevice, st));
-    launch_rec_frozen_rows((const u32*)ctx->hfreq.p, PR_REC_ROWS, (u32*)ctx->rrows.p, (u32*)ctx->rcoarse.p, st);
+    launch_rec_frozen_rows((const u32*)ctx->hfreq.p, PR_REC_ROWS, (u32*)ctx->rrows.p, (u16*)ctx->rdec.p, st);
     HIPC(hipStreamSynchronize(st));            // `f` may be a local
     return SFQ_OK;
 }
@@ -483,7 +483,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rcoarse, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qcoarse, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
     for (DevBuf* b : all) release(*b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin2) (void)hipHostFree(ctx->pin2);
@@ -818,7 +818,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         HIPC(hipEventRecord(ctx->ev[3], st));
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
-            ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rcoarse = (const u32*)ctx->rcoarse.p;
+            ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rdec = (const u16*)ctx->rdec.p;
             ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
             if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
@@ -1303,9 +1303,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
         if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
         if ((rc = build_qesc(ctx, st))) return rc;
-        if ((rc = reserve(ctx, ctx->qcoarse, (size_t)q_rows * 8 * 4))) return rc;
-        launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u32*)ctx->qcoarse.p, st);
-        ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qcoarse = (const u32*)ctx->qcoarse.p;
+        if ((rc = reserve(ctx, ctx->qdec, (size_t)q_rows * 72 * 2))) return rc;                 // chains.hip QDEC_ROW
+        launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u16*)ctx->qdec.p, st);
+        ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qdec = (const u16*)ctx->qdec.p;
         ca.q_hot = 0;
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
@@ -1389,7 +1389,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; da.m.epoch_base = ctx->epoch_base; ctx->epoch_base += nblocks; }
         if (frozen_rec) {
             ChainArgs cr; memset(&cr, 0, sizeof cr);
-            cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rcoarse = (const u32*)ctx->rcoarse.p;
+            cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rdec = (const u16*)ctx->rdec.p;
             cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
             cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
             launch_rec_decode_c(cr, da, 64, st_rec);

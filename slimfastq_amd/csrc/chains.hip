@@ -23,8 +23,10 @@
 // 65536 - sum g goes to the largest g (the first of them).  Entry s = cum(g[0..s)) | g[s] << 16  (g <= 65473).
 // A context the sample never saw has the uniform row (g = 1024).  Rows are indexed by the context itself: q_rows x 256 B,
 // of which a file touches a few thousand rows (L2-resident).
-// qcoarse (decode only, may be null): [q_rows][8] the cum of every 8th symbol, so that a decoder finds a symbol in two steps
-__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows, u32* __restrict__ qcoarse) {
+// qdec (decode only, may be null): [q_rows][72] u16 -- the cum of every 8th symbol (8 of them), then the cum of all 64: a
+// decoder finds a symbol with two 16-byte fetches (the eighth of the row, then the symbol in it; QDEC_ROW below)
+#define QDEC_ROW 72u
+__global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows, u16* __restrict__ qdec) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
@@ -32,7 +34,10 @@ __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__
     const u32 slot = r[lane], iend = r[65];
     if (iend == 0) {
         qrows[(size_t)ctx * 64 + lane] = (lane << 10) | (1024u << 16);
-        if (qcoarse && (lane & 7) == 0) qcoarse[(size_t)ctx * 8 + (lane >> 3)] = lane << 10;
+        if (qdec) {
+            qdec[(size_t)ctx * QDEC_ROW + 8 + lane] = (u16)(lane << 10);
+            if ((lane & 7) == 0) qdec[(size_t)ctx * QDEC_ROW + (lane >> 3)] = (u16)(lane << 10);
+        }
         return;
     }
     // slot order -> symbol order: lane j sends its frequency to lane sym(j) (lanes >= iend hold no slot: they send 0 to themselves)
@@ -55,10 +60,13 @@ __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
     qrows[(size_t)ctx * 64 + lane] = (incl - g) | (g << 16);
-    if (qcoarse && (lane & 7) == 0) qcoarse[(size_t)ctx * 8 + (lane >> 3)] = incl - g;
+    if (qdec) {
+        qdec[(size_t)ctx * QDEC_ROW + 8 + lane] = (u16)(incl - g);
+        if ((lane & 7) == 0) qdec[(size_t)ctx * QDEC_ROW + (lane >> 3)] = (u16)(incl - g);
+    }
 }
-void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qcoarse);
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qdec);
 }
 
 // the sample's symbol count of every context: the host picks the rows worth staging in LDS from it
@@ -289,6 +297,10 @@ void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
 // =========================================================================================================
 // quality decode: one chain per lane; the symbol is found by a binary search over the row's cumulative entries
 // =========================================================================================================
+__device__ __forceinline__ void unpack8(const uint4& v, u32 (&o)[8]) {          // eight u16
+    o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16;
+    o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
+}
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArgs da) {
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
@@ -305,17 +317,24 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
         for (u32 i = 0; i < n; i++) {
             const u32 prob = rc.get_freq16();
             // largest s with cum[s] <= prob (cum is increasing: every g >= 1): the eighth of the row from the coarse
-            // entries, then the symbol among its eight -- two dependent fetches of 32 bytes each
-            const uint4* cq = reinterpret_cast<const uint4*>(a.qcoarse + (size_t)last * 8);
-            const uint4 c0 = cq[0], c1 = cq[1];
-            const u32 k8 = (c0.y <= prob) + (c0.z <= prob) + (c0.w <= prob) + (c1.x <= prob) + (c1.y <= prob) + (c1.z <= prob) + (c1.w <= prob);
-            const uint4* eq = reinterpret_cast<const uint4*>(a.qrows + (size_t)last * 64 + k8 * 8);
-            const uint4 e0 = eq[0], e1 = eq[1];
-            const u32 i8 = (FZ_CUM(e0.y) <= prob) + (FZ_CUM(e0.z) <= prob) + (FZ_CUM(e0.w) <= prob) + (FZ_CUM(e1.x) <= prob) +
-                           (FZ_CUM(e1.y) <= prob) + (FZ_CUM(e1.z) <= prob) + (FZ_CUM(e1.w) <= prob);
+            // entries, then the symbol among its eight -- two dependent fetches of 16 bytes each (what a lane fetches, and
+            // from how many places, is what this kernel's time is made of)
+            const u16* qd = a.qdec + (size_t)last * QDEC_ROW;
+            u32 cc[8], ff[8];
+            unpack8(*reinterpret_cast<const uint4*>(qd), cc);
+            u32 k8 = 0;
+#pragma unroll
+            for (u32 j = 1; j < 8; j++) k8 += cc[j] <= prob;
+            unpack8(*reinterpret_cast<const uint4*>(qd + 8 + k8 * 8), ff);
+            u32 i8 = 0, cum = ff[0], next = 65536u;
+#pragma unroll
+            for (u32 j = 7; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;       // the first entry past prob: in the coarse list ...
+#pragma unroll
+            for (u32 j = 7; j >= 1; j--) next = ff[j] > prob ? ff[j] : next;       // ... unless the symbol's own eighth has one
+#pragma unroll
+            for (u32 j = 1; j < 8; j++) { const bool le = ff[j] <= prob; i8 += le; cum = le ? ff[j] : cum; }
             const u32 s = k8 * 8 + i8;
-            const u32 e = i8 == 0 ? e0.x : i8 == 1 ? e0.y : i8 == 2 ? e0.z : i8 == 3 ? e0.w : i8 == 4 ? e1.x : i8 == 5 ? e1.y : i8 == 6 ? e1.z : e1.w;
-            rc.decode(FZ_CUM(e), FZ_FREQ(e));
+            rc.decode(cum, next - cum);
             u32 b = s;
             if (s == LAST_QLT) {                                            // qlts.cpp:168-171
                 const u32 pe = rc.get_freq16();
@@ -727,8 +746,10 @@ __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 str
     rec_encode_lane(a, r0, r0, n, cd, x_rec, none, hb, bad);
 }
 // frozen rows from the prior's scaled frequencies f[row][256]: x = f + 1, g = max(1, floor(x * 65536 / sum x)), the
-// remainder to the largest g (the first of them); entry = cum | g << 16; coarse[row][16] = cum at every 16th symbol
-__global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__ f, u32 nrows, u32* __restrict__ rrows, u32* __restrict__ coarse) {
+// remainder to the largest g (the first of them); entry = cum | g << 16.  rdec (may be null; the decoder's form):
+// [row][272] u16 -- the cum at every 16th symbol (16 of them), then the cum of all 256 (RDEC_ROW)
+#define RDEC_ROW 272u
+__global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__ f, u32 nrows, u32* __restrict__ rrows, u16* __restrict__ rdec) {
     const u32 lane = threadIdx.x & 63;
     const u32 row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -758,7 +779,12 @@ __global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
     u32 cum = incl - mine;
-    if ((lane & 3) == 0) coarse[(size_t)row * 16 + (lane >> 2)] = cum;
+    if (rdec) {
+        u16* rd = rdec + (size_t)row * RDEC_ROW;
+        if ((lane & 3) == 0) rd[lane >> 2] = (u16)cum;
+        const u32 c1 = cum + g[0], c2 = c1 + g[1], c3 = c2 + g[2];
+        *reinterpret_cast<uint2*>(rd + 16 + lane * 4) = make_uint2(cum | (c1 << 16), c2 | (c3 << 16));
+    }
     uint4 e;
     e.x = cum | (g[0] << 16); cum += g[0];
     e.y = cum | (g[1] << 16); cum += g[1];
@@ -766,8 +792,8 @@ __global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__
     e.w = cum | (g[3] << 16);
     *reinterpret_cast<uint4*>(rrows + (size_t)row * 256 + lane * 4) = e;
 }
-void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, coarse);
+void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, rdec);
 }
 
 // header encode, general path: one chain per lane; only the chains the fast kernel below has handed over (flags[c] != 0)
@@ -1035,20 +1061,29 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32 max_hdr, hipStream_
 // header decode: one chain per lane.  DecodeArgs::hdr_stage_off / hdr_stage_cap are per CHAIN here.
 struct RecFrozenDec {
     static constexpr bool inband = true;
-    const u32* rows; const u32* coarse; LaneDec rc;
+    const u16* rdec; LaneDec rc;
     __device__ __forceinline__ u32 get(u32 row) {
         const u32 prob = rc.get_freq16();
-        // the sixteenth of the row, then the symbol in it: largest s with cum[s] <= prob
-        const u32* cr = coarse + (size_t)row * 16;
+        // the sixteenth of the row, then the symbol in it: largest s with cum[s] <= prob.  Two round trips of 32 bytes (a
+        // search that fetched entry by entry was nine dependent fetches)
+        const u16* rd = rdec + (size_t)row * RDEC_ROW;
+        u32 cc[16], ff[16];
+        unpack8(*reinterpret_cast<const uint4*>(rd), *reinterpret_cast<u32 (*)[8]>(cc));
+        unpack8(*reinterpret_cast<const uint4*>(rd + 8), *reinterpret_cast<u32 (*)[8]>(cc + 8));
         u32 k = 0;
 #pragma unroll
-        for (u32 step = 8; step > 0; step >>= 1) { const u32 t = k + step; if (cr[t] <= prob) k = t; }
-        const u32* er = rows + (size_t)row * 256 + k * 16;
-        u32 s = 0;
+        for (u32 j = 1; j < 16; j++) k += cc[j] <= prob;
+        const u16* fr = rd + 16 + k * 16;
+        unpack8(*reinterpret_cast<const uint4*>(fr), *reinterpret_cast<u32 (*)[8]>(ff));
+        unpack8(*reinterpret_cast<const uint4*>(fr + 8), *reinterpret_cast<u32 (*)[8]>(ff + 8));
+        u32 s = 0, cum = ff[0], next = 65536u;
 #pragma unroll
-        for (u32 step = 8; step > 0; step >>= 1) { const u32 t = s + step; if (FZ_CUM(er[t]) <= prob) s = t; }
-        const u32 e = er[s];
-        rc.decode(FZ_CUM(e), FZ_FREQ(e));
+        for (u32 j = 15; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;
+#pragma unroll
+        for (u32 j = 15; j >= 1; j--) next = ff[j] > prob ? ff[j] : next;
+#pragma unroll
+        for (u32 j = 1; j < 16; j++) { const bool le = ff[j] <= prob; s += le; cum = le ? ff[j] : cum; }
+        rc.decode(cum, next - cum);
         return k * 16 + s;
     }
     __device__ __forceinline__ u64 get_u(u32 row0) { return get_u_rows(*this, row0); }
@@ -1059,7 +1094,7 @@ __global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da)
     if (c >= a.rgeo.nchains) return;
     const RecChainPos cp = rec_chain_pos(a, c);
     BlockDesc* d = &da.m.blocks[cp.b];
-    RecFrozenDec cd; cd.rows = a.rrows; cd.coarse = a.rcoarse;
+    RecFrozenDec cd; cd.rdec = a.rdec;
     cd.rc.init(da.streams + a.coff[c], a.csz[c]);
     XfDec x_rec; x_rec.init(nullptr, 0, XF_REC_X);
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;

@@ -55,14 +55,14 @@ struct ChainArgs {
     const u64* coff;            // decode: [nchains] absolute offsets of the chains' streams
     // quality: frozen rows, total 2^16 each
     const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
-    const u32* qcoarse;         // decode: [q_rows][8] cum of every 8th symbol
+    const u16* qdec;            // decode: [q_rows][72] u16: the cum of every 8th symbol, then of all 64 (chains.hip QDEC_ROW)
     u32 q_hot;                  // rows staged in LDS per workgroup (0 = none)
     const u32* qh_tab;          // [1024] direct-mapped context -> (context | LDS slot << 16), 0xFFFFFFFF = empty
     const u16* qh_ctx;          // [q_hot] the staged contexts
     const u32* qesc;            // escape row (256 entries), qlts.cpp:80-86
     // headers: frozen PowerRanger rows, total 2^16 each
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
-    const u32* rcoarse;         // [PR_REC_ROWS][16] cum at every 16th symbol (decode)
+    const u16* rdec;            // decode: [PR_REC_ROWS][272] u16: the cum at every 16th symbol, then of all 256 (chains.hip RDEC_ROW)
     const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> slot (0xFFFF = none), slot -> row, how many
     u8* exc_flag;               // encode: [records] set to 1 by the quality / base chains where a record holds a '!' / an N (null = not wanted)
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
@@ -74,7 +74,7 @@ struct ChainArgs {
     const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
 };
 void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
-void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u32* qcoarse /* decode; may be null */, hipStream_t st);
+void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,
                       u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
@@ -83,7 +83,7 @@ void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags /* [nruns], zeroed */, hipStream_t st);
-void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u32* coarse, hipStream_t st);
+void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec /* the decoder's form; may be null */, hipStream_t st);
 // one header chain per lane; a.csz / a.rhb per chain; max_hdr = the call's longest header (picks the LDS image of the fast kernel)
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32 max_hdr, hipStream_t st);
 void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb /* or null */, hipStream_t st);
