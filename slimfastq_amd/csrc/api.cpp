@@ -766,28 +766,17 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, nullptr, st);
             ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
             ca.q_hot = 0;
-            const u32 want_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : std::min<u32>(p.lds_rows, 240u);
+            // LDS staging of the rows the sample saw most (picked on the device, chains.hip k_hot_pick); without a sample of
+            // this call's own there is nothing to rank by
+            // (off unless asked for: measured, DESIGN.md 4.4 -- the rows' LDS keeps the header chains' workgroups off the CU)
+            const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE || given || !prior_step) ? 0u : std::min<u32>(p.lds_rows, 240u);
             if (want_hot) {
-                // LDS staging (measured, DESIGN.md section 5: off by default): the contexts the sample saw most
-                if ((rc = reserve(ctx, ctx->qw, (size_t)q_rows * 4 + 8192))) return rc;
-                launch_row_weights((const u32*)ctx->hist.p, q_rows, (u32*)ctx->qw.p, st);
-                std::vector<u32> w(q_rows);
-                HIPC(hipMemcpyAsync(w.data(), ctx->qw.p, (size_t)q_rows * 4, hipMemcpyDeviceToHost, st));
-                HIPC(hipStreamSynchronize(st));
-                std::vector<u32> order;
-                for (u32 c = 0; c < q_rows; c++) if (w[c]) order.push_back(c);
-                std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return w[x] > w[y]; });
-                std::vector<u32> tab(1024, 0xFFFFFFFFu); std::vector<u16> hot;
-                for (u32 c : order) {
-                    if (hot.size() >= want_hot) break;
-                    const u32 hsl = (c * 0x9E3Bu >> 4) & 1023u;                  // chains.hip qh_hash
-                    if (tab[hsl] != 0xFFFFFFFFu) continue;                       // direct-mapped: the hotter context keeps the slot
-                    tab[hsl] = c | ((u32)hot.size() << 16); hot.push_back((u16)c);
-                }
-                HIPC(hipMemcpyAsync((u8*)ctx->qw.p, tab.data(), 4096, hipMemcpyHostToDevice, st));
-                if (!hot.empty()) HIPC(hipMemcpyAsync((u8*)ctx->qw.p + 4096, hot.data(), hot.size() * 2, hipMemcpyHostToDevice, st));
-                HIPC(hipStreamSynchronize(st));
-                ca.q_hot = (u32)hot.size(); ca.qh_tab = (const u32*)ctx->qw.p; ca.qh_ctx = (const u16*)((u8*)ctx->qw.p + 4096);
+                if ((rc = reserve(ctx, ctx->qw, 8192 + 4096 + 512))) return rc;
+                HIPC(hipMemsetAsync(ctx->qw.p, 0, 8192 + 4096 + 512, st));
+                unsigned long long* best = (unsigned long long*)ctx->qw.p;
+                u32* tab = (u32*)((u8*)ctx->qw.p + 8192); u16* hot = (u16*)((u8*)ctx->qw.p + 8192 + 4096);
+                launch_hot_rows((const u32*)ctx->hist.p, q_rows, want_hot, best, tab, hot, st);
+                ca.q_hot = want_hot; ca.qh_tab = tab; ca.qh_ctx = hot;
             }
             HIPC(hipEventRecord(ctx->ev[1], st));
         }

@@ -69,18 +69,38 @@ void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec
     hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qdec);
 }
 
-// the sample's symbol count of every context: the host picks the rows worth staging in LDS from it
-__global__ __launch_bounds__(256) void k_row_weights(const u32* __restrict__ hist, u32 q_rows, u32* __restrict__ w) {
+// The rows a workgroup of the quality chains keeps in LDS, picked on the device (no host round trip between the sample and
+// the chains): every context competes for its slot of the direct-mapped table (qh_hash) with the number of symbols the
+// sample saw in it, and of the 1024 slot winners the `want` heaviest are staged.  tab[slot] = context | place << 16
+// (QH_EMPTY = none), hot[place] = context (zeroed by the caller: an unused place stages row 0, which nobody looks up there).
+#define QH_SLOTS 1024u
+#define QH_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ u32 qh_hash(u32 ctx) { return (ctx * 0x9E3Bu >> 4) & (QH_SLOTS - 1); }
+__global__ __launch_bounds__(256) void k_hot_slots(const u32* __restrict__ hist, u32 q_rows, unsigned long long* __restrict__ best) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
     u32 c = hist[(size_t)ctx * 64 + lane];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
-    if (lane == 0) w[ctx] = c;
+    if (lane == 0 && c) atomicMax(&best[qh_hash(ctx)], ((unsigned long long)c << 32) | (0xFFFFu - ctx));      // (of equals the lower context)
 }
-void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st) {
-    hipLaunchKernelGGL(k_row_weights, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, w);
+__global__ __launch_bounds__(1024) void k_hot_pick(const unsigned long long* __restrict__ best, u32 want, u32* __restrict__ tab, u16* __restrict__ hot) {
+    __shared__ unsigned long long k[QH_SLOTS];
+    const u32 t = threadIdx.x;
+    const unsigned long long key = best[t];
+    k[t] = key;
+    __syncthreads();
+    u32 place = 0;
+    for (u32 j = 0; j < QH_SLOTS; j++) place += k[j] > key;
+    const u32 ctx = 0xFFFFu - (u32)(key & 0xFFFFu);
+    const bool in = key != 0 && place < want;
+    tab[t] = in ? (ctx | (place << 16)) : QH_EMPTY;
+    if (in) hot[place] = (u16)ctx;
+}
+void launch_hot_rows(const u32* hist, u32 q_rows, u32 want, unsigned long long* best /* [1024], zeroed */, u32* tab /* [1024] */, u16* hot /* [want], zeroed */, hipStream_t st) {
+    hipLaunchKernelGGL(k_hot_slots, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, best);
+    hipLaunchKernelGGL(k_hot_pick, dim3(1), dim3(QH_SLOTS), 0, st, (const unsigned long long*)best, want, tab, hot);
 }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
@@ -181,9 +201,6 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 // LDS staging of the hottest rows (BASELINE north_star: "ranger probability tables are staged in LDS"): the workgroup
 // copies the q_hot most used rows into LDS once; a symbol's context is looked up in a direct-mapped LDS table
 // (QH_SLOTS entries: context | slot << 16), a hit reads the row entry from LDS, a miss from the L2-resident table.
-#define QH_SLOTS 1024u
-#define QH_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ u32 qh_hash(u32 ctx) { return (ctx * 0x9E3Bu >> 4) & (QH_SLOTS - 1); }
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {

@@ -96,16 +96,23 @@ __global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, con
     }
 }
 
-// out[0] = max(out[0], max of v[0..n))
+// out[0] = max(out[0], max of v[0..n)); a thread takes sixteen values, a wave one atomic
 __global__ __launch_bounds__(256) void k_max_u32(const u32* __restrict__ v, u64 n, u32* out) {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    u32 m = i < n ? v[i] : 0u;
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 16;
+    u32 m = 0;
+    if (i0 + 16 <= n) {
+        const uint4* q = reinterpret_cast<const uint4*>(v + i0);          // (v is a device allocation: 16-byte aligned at i0 % 4 == 0)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint4 w = q[j]; m = max(max(m, max(w.x, w.y)), max(w.z, w.w)); }
+    } else {
+        for (u64 i = i0; i < n; i++) m = max(m, v[i]);
+    }
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)m, dd, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m > out[0]) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 void launch_max_u32(const u32* v, u64 n, u32* out, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_max_u32, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, v, n, out);
+    if (n) hipLaunchKernelGGL(k_max_u32, dim3((u32)((n + 4095) / 4096)), dim3(256), 0, st, v, n, out);
 }
 
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st) {

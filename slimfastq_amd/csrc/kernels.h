@@ -73,7 +73,8 @@ struct ChainArgs {
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
     const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
 };
-void launch_row_weights(const u32* hist, u32 q_rows, u32* w, hipStream_t st);
+void launch_hot_rows(const u32* hist, u32 q_rows, u32 want, unsigned long long* best /* [1024], zeroed */, u32* tab /* [1024] */,
+                     u16* hot /* [want], zeroed */, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,

@@ -184,3 +184,17 @@ def test_given_prior_makes_block_bytes_independent_of_the_sharding(ctx):
         assert whole.stream(name) == parts[0].stream(name) + parts[1].stream(name), name
     assert ctx.decode_host(whole, level=3, out_cap=len(fq) + 4096) == fq
     ctx.set_priors(b"", b"")
+
+
+@pytest.mark.parametrize("level", (1, 3))
+def test_frozen_quality_rows_staged_in_lds_do_not_change_a_byte(ctx, level):
+    """sfq_params.lds_rows: every workgroup of the quality chains keeps the N rows the sample saw most in LDS (picked on the
+    device, chains.hip k_hot_pick) and reads the others from the table -- where a row comes from must not show in the stream."""
+    fq = capi.synth_fastq(20000, 150, seed=21)
+    kw = dict(level=level, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=25)
+    base = ctx.encode_host(fq, lds_rows=capi.LDS_ROWS_NONE, **kw)
+    for rows in (1, 64, 240, 5000):
+        enc = ctx.encode_host(fq, lds_rows=rows, **kw)
+        assert enc.stream("qlt") == base.stream("qlt"), rows
+        assert enc.chains == base.chains and enc.prior == base.prior, rows
+    assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
