@@ -49,7 +49,7 @@ struct sfq_ctx {
     DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, excf, cflags;
-    u32 r_hot = 0;
+    u32 r_hot = 0, r_hot_dec = 0;
     bool blobs_from_encode = false;        // prior_blob / rec_prior_blob / chain_blob are what the last ENCODE left for sfq_get_*:
                                            // a decode never reads those (only what sfq_set_* installed)
     bool unsettled = false;                // a call returned with an error: its side streams may still be running
@@ -285,13 +285,13 @@ int upload_rec_rows(sfq_ctx* ctx, const std::vector<u32>& f, hipStream_t st) {
         std::stable_sort(w.begin(), w.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
         u16 map[PR_REC_ROWS], hot[64];
         for (u32 r = 0; r < PR_REC_ROWS; r++) map[r] = 0xFFFFu;
-        const u32 nh = (u32)std::min<size_t>(w.size(), 8);        // REC_LDS_ROWS (chains.hip)
+        const u32 nh = (u32)std::min<size_t>(w.size(), RDEC_LDS_ROWS);        // the encoders stage the first 8 of them (REC_LDS_ROWS, chains.hip)
         for (u32 i = 0; i < nh; i++) { hot[i] = (u16)w[i].second; map[w[i].second] = (u16)i; }
         if ((rc = reserve(ctx, ctx->rmap, sizeof map + sizeof hot))) return rc;
         HIPC(hipMemcpyAsync(ctx->rmap.p, map, sizeof map, hipMemcpyHostToDevice, st));
         HIPC(hipMemcpyAsync((u8*)ctx->rmap.p + sizeof map, hot, sizeof hot, hipMemcpyHostToDevice, st));
         HIPC(hipStreamSynchronize(st));
-        ctx->r_hot = nh;
+        ctx->r_hot = std::min<u32>(nh, 8); ctx->r_hot_dec = nh;
     }
     if ((rc = reserve(ctx, ctx->hfreq, f.size() * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rrows, f.size() * 4))) return rc;
@@ -1381,7 +1381,14 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rdec = (const u16*)ctx->rdec.p;
             cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
             cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
-            launch_rec_decode_c(cr, da, 64, st_rec);
+            cr.rmap = (const u16*)ctx->rmap.p; cr.rhot = cr.rmap + PR_REC_ROWS; cr.r_hot = ctx->r_hot_dec;
+            u32* rflags = nullptr;
+            if (version >= 5) {                                        // (load_pre5 archives: the general path)
+                if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
+                HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, st_rec));
+                rflags = (u32*)ctx->rflags.p;
+            }
+            launch_rec_decode_c(cr, da, rflags, st_rec);
         } else
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
         HIPC(hipStreamSynchronize(st_rec));

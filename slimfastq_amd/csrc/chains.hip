@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* fla
     const u32 c = blockIdx.x * 64 + threadIdx.x;
     const bool mine = c < a.rgeo.nchains && flags[c] != 0;
     if (!__any(mine)) return;
-    for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) lmap[i] = a.rmap[i];
+    for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; lmap[i] = (u16)(sl < REC_LDS_ROWS ? sl : 0xFFFFu); }
     for (u32 i = threadIdx.x; i < a.r_hot * 256; i += 64) lrows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
     __syncthreads();
     if (!mine) return;
@@ -1076,39 +1076,46 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32 max_hdr, hipStream_
 }
 
 // header decode: one chain per lane.  DecodeArgs::hdr_stage_off / hdr_stage_cap are per CHAIN here.
+// largest s with cum[s] <= prob in a row of the decoder's form (RDEC_ROW): the sixteenth of the row, then the symbol in
+// it.  Two round trips of 32 bytes (a search that fetched entry by entry was nine dependent fetches).
+__device__ __forceinline__ u32 rdec_search(const u16* rd, u32 prob, u32& cum, u32& next) {
+    u32 cc[16], ff[16];
+    unpack8(*reinterpret_cast<const uint4*>(rd), *reinterpret_cast<u32 (*)[8]>(cc));
+    unpack8(*reinterpret_cast<const uint4*>(rd + 8), *reinterpret_cast<u32 (*)[8]>(cc + 8));
+    u32 k = 0;
+#pragma unroll
+    for (u32 j = 1; j < 16; j++) k += cc[j] <= prob;
+    const u16* fr = rd + 16 + k * 16;
+    unpack8(*reinterpret_cast<const uint4*>(fr), *reinterpret_cast<u32 (*)[8]>(ff));
+    unpack8(*reinterpret_cast<const uint4*>(fr + 8), *reinterpret_cast<u32 (*)[8]>(ff + 8));
+    u32 s = 0;
+    cum = ff[0]; next = 65536u;
+#pragma unroll
+    for (u32 j = 15; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;
+#pragma unroll
+    for (u32 j = 15; j >= 1; j--) next = ff[j] > prob ? ff[j] : next;
+#pragma unroll
+    for (u32 j = 1; j < 16; j++) { const bool le = ff[j] <= prob; s += le; cum = le ? ff[j] : cum; }
+    return k * 16 + s;
+}
 struct RecFrozenDec {
     static constexpr bool inband = true;
     const u16* rdec; LaneDec rc;
     __device__ __forceinline__ u32 get(u32 row) {
         const u32 prob = rc.get_freq16();
-        // the sixteenth of the row, then the symbol in it: largest s with cum[s] <= prob.  Two round trips of 32 bytes (a
-        // search that fetched entry by entry was nine dependent fetches)
-        const u16* rd = rdec + (size_t)row * RDEC_ROW;
-        u32 cc[16], ff[16];
-        unpack8(*reinterpret_cast<const uint4*>(rd), *reinterpret_cast<u32 (*)[8]>(cc));
-        unpack8(*reinterpret_cast<const uint4*>(rd + 8), *reinterpret_cast<u32 (*)[8]>(cc + 8));
-        u32 k = 0;
-#pragma unroll
-        for (u32 j = 1; j < 16; j++) k += cc[j] <= prob;
-        const u16* fr = rd + 16 + k * 16;
-        unpack8(*reinterpret_cast<const uint4*>(fr), *reinterpret_cast<u32 (*)[8]>(ff));
-        unpack8(*reinterpret_cast<const uint4*>(fr + 8), *reinterpret_cast<u32 (*)[8]>(ff + 8));
-        u32 s = 0, cum = ff[0], next = 65536u;
-#pragma unroll
-        for (u32 j = 15; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;
-#pragma unroll
-        for (u32 j = 15; j >= 1; j--) next = ff[j] > prob ? ff[j] : next;
-#pragma unroll
-        for (u32 j = 1; j < 16; j++) { const bool le = ff[j] <= prob; s += le; cum = le ? ff[j] : cum; }
+        u32 cum, next;
+        const u32 s = rdec_search(rdec + (size_t)row * RDEC_ROW, prob, cum, next);
         rc.decode(cum, next - cum);
-        return k * 16 + s;
+        return s;
     }
     __device__ __forceinline__ u64 get_u(u32 row0) { return get_u_rows(*this, row0); }
     __device__ __forceinline__ u32 err() const { return rc.err; }
 };
-__global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da) {
+// general path: one chain per lane; with `flags` only the chains the fast kernel below has handed over
+__global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da, const u32* flags) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.rgeo.nchains) return;
+    if (flags && !flags[c]) return;
     const RecChainPos cp = rec_chain_pos(a, c);
     BlockDesc* d = &da.m.blocks[cp.b];
     RecFrozenDec cd; cd.rdec = a.rdec;
@@ -1117,6 +1124,165 @@ __global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da)
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     rec_decode_lane(da, d, cp.r0, cp.nrec, c, cd, x_rec, none);
 }
-void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st) {
-    hipLaunchKernelGGL(k_rec_decode_c, dim3((a.rgeo.nchains + lanes - 1) / lanes), dim3(lanes), 0, st, a, da);
+
+// header decode, fast path (the decoder's side of k_rec_encode_f): RecLoad::load (recs.cpp:374-461) for chains whose
+// headers stay within RF_DML bytes and RF_NF fields, with the previous and the current header, the previous header's
+// field table, the field types / values and the hottest rows (in the decoder's form) in LDS, laid out [..][lane], and the
+// headers leaving through LaneOut (sixteen bytes a store).  The general path keeps these in per-lane scratch, re-reads
+// the previous header from the staging area byte by byte and stores single bytes: ~460 memory instructions per record
+// against ~10 here.  Anything unusual -- a longer header, more fields, a value that prints with a sign, a damaged
+// stream -- hands the chain over (flags[c] = 1): the general kernel starts it again and reports what it finds.
+#define RF_DML 127u
+struct RecFastDecLds {
+    u64 cnumb[RF_NF][64];
+    u16 drows[RDEC_LDS_ROWS][RDEC_ROW];
+    u8  text[2][RF_DML + 1][64];
+    u8  off[RF_NF][64], wln[RF_NF][64], sep[RF_NF][64];        // of the previous header
+    u8  ctype[RF_NF][64];
+    u8  map[PR_REC_ROWS];                                      // row -> LDS slot, 0xFF = not staged
+};
+struct RecFastDecSrc {
+    const u16* rdec; const RecFastDecLds* L; LaneDec rc;
+    __device__ __forceinline__ u32 get(u32 row) {
+        const u32 prob = rc.get_freq16();
+        const u32 slot = L->map[row];
+        u32 cum, next, s;
+        if (slot != 0xFFu) s = rdec_search(L->drows[slot], prob, cum, next);
+        else s = rdec_search(rdec + (size_t)row * RDEC_ROW, prob, cum, next);
+        rc.decode(cum, next - cum);
+        return s;
+    }
+    __device__ __forceinline__ u64 get_u(u32 row0) { return get_u_rows(*this, row0); }
+};
+// the header in text[buf][0 .. n) goes out (with its '\n') and is tokenised for the record after it (d_map_space,
+// recs.cpp:141-157); returns the number of fields
+__device__ __forceinline__ u32 rfd_emit(RecFastDecLds& L, u32 buf, u32 lane, u32 n, LaneOut* out) {
+    u32 nf = 0, start = 0; bool stop = false;
+    for (u32 pos = 0; pos <= n; pos++) {
+        const u32 c = pos < n ? L.text[buf][pos][lane] : '\n';
+        if (out) out->put(c);
+        if (!stop && !isword(c)) {
+            if (nf < RF_NF) { L.off[nf][lane] = (u8)start; L.wln[nf][lane] = (u8)(pos - start); L.sep[nf][lane] = (u8)c; }
+            nf++; start = pos + 1;
+            if (c == 0) stop = true;
+        }
+    }
+    return nf;
+}
+__device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const BlockDesc* d, RecFastDecLds& L, u32 lane, u64 r0, u32 nrec, u32 chain,
+                                                     RecFastDecSrc& cd) {
+    const u64 cap = a.hdr_stage_cap[chain], stage_off = a.hdr_stage_off[chain];
+    u32 n_prev = d->first_hdr_len;
+    if (n_prev > RF_DML) return false;
+    {                                                                          // the base: the block's first header (recs.cpp:113-119)
+        const u8* fh = a.first_hdrs + d->first_hdr_off;
+        for (u32 j = 0; j < n_prev; j++) L.text[0][j][lane] = fh[j];
+    }
+    u32 prv = 0, cur = 1;
+    u32 nf_prev = rfd_emit(L, prv, lane, n_prev, nullptr);
+    if (nf_prev > RF_NF) return false;
+    for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+    LaneOut out; out.begin(a.hdr_stage + stage_off);
+    u64 pos = 0;
+    for (u32 k = 0; k < nrec; k++) {
+        const u64 r = r0 + k;
+        if (pos + SFQ_MAX_ID_LLEN + 2 > cap) return false;                     // (the general path reports it)
+        u32 n;
+        if (r == d->rec0) {                                                    // the base itself
+            n = n_prev;
+            for (u32 j = 0; j < n; j++) out.put(L.text[prv][j][lane]);
+            out.put('\n');
+        } else {
+            if (cd.get(REC_FLAG_ROW) != 0) {                                   // a header of another shape, whole
+                const u64 len = cd.get_u(REC_FLAG_ROW + 2);
+                if (len > RF_DML) return false;
+                for (u32 j = 0; j < (u32)len; j++) L.text[cur][j][lane] = (u8)cd.get(REC_FLAG_ROW + 1);
+                n = (u32)len;
+                for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+            } else {
+                const u64 map = cd.get_u(0 * 16 + 2);
+                u32 b = 0;
+                for (u32 i = 0; i < nf_prev; i++) {
+                    const u32 wl = L.wln[i][lane], o = L.off[i][lane];
+                    if (b + wl + 24 > RF_DML) return false;                    // room for the field as it was or as a number (<= 21 bytes), and its separator
+                    const u32 rr = (i + 1) * 16;
+                    if (!((map >> i) & 1)) {
+                        for (u32 j = 0; j < wl; j++) L.text[cur][b + j][lane] = L.text[prv][o + j][lane];
+                        b += wl;
+                    } else {
+                        const u32 type = cd.get(rr + 0);
+                        if (type == ST_STR) {                                  // recs.cpp:421-428
+                            const u64 len = cd.get_u(rr + 2);
+                            if (len > RF_DML || b + len + 2 > RF_DML) return false;
+                            for (u32 j = 0; j < (u32)len; j++) L.text[cur][b + j][lane] = (u8)cd.get(rr + 1);
+                            b += (u32)len;
+                            L.ctype[i][lane] = 0;
+                        } else {                                               // recs.cpp:430-456
+                            if (type > ST_DLT_Z) return false;
+                            const u64 pval = L.ctype[i][lane] ? L.cnumb[i][lane] : 0;
+                            const u64 gap = cd.get_u(rr + 2);
+                            const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC ||
+                                              type == ST_HLTC_Z || type == ST_DLT_Z;
+                            const u64 val = less ? pval - gap : pval + gap;
+                            const bool deci = type < ST_STR || type >= ST_DGT_Z;
+                            const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z ||
+                                              type == ST_DGT_Z || type == ST_DLT_Z;
+                            const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
+                            L.ctype[i][lane] = deci ? 1 : 2;
+                            L.cnumb[i][lane] = val;
+                            if (val == 0) L.text[cur][b++][lane] = '0';        // recs.cpp:453-454
+                            else {
+                                if (lead) L.text[cur][b++][lane] = '0';
+                                if (deci) {                                    // "%lld"
+                                    if ((i64)val < 0) return false;            // (a sign changes the fields: the general path's business)
+                                    u32 nd = 0;
+                                    for (u64 t = val; t; t /= 10) nd++;
+                                    u64 t = val;
+                                    for (u32 j = nd; j-- > 0;) { L.text[cur][b + j][lane] = (u8)('0' + t % 10); t /= 10; }
+                                    b += nd;
+                                } else {                                       // "%llx" / "%llX"
+                                    int sh = 60;
+                                    while (sh > 0 && ((val >> sh) & 0xf) == 0) sh -= 4;
+                                    for (; sh >= 0; sh -= 4) {
+                                        const u32 dg = (u32)(val >> sh) & 0xf;
+                                        L.text[cur][b++][lane] = (u8)(dg < 10 ? '0' + dg : (upper ? 'A' : 'a') + dg - 10);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    L.text[cur][b++][lane] = L.sep[i][lane];
+                }
+                n = b - 1;                                                     // recs.cpp:460
+            }
+            if (cd.rc.err) return false;
+            nf_prev = rfd_emit(L, cur, lane, n, &out);
+            if (nf_prev > RF_NF) return false;
+            prv = cur; cur ^= 1u; n_prev = n;
+        }
+        a.hlen[r] = n; a.hoff[r] = stage_off + pos;
+        pos += (u64)n + 1;
+    }
+    out.end();
+    return true;
+}
+__global__ __launch_bounds__(64) void k_rec_decode_f(ChainArgs a, DecodeArgs da, u32* flags) {
+    __shared__ RecFastDecLds L;
+    const u32 lane = threadIdx.x;
+    for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < RDEC_LDS_ROWS ? sl : 0xFFu); }
+    for (u32 i = lane; i < a.r_hot * RDEC_ROW; i += 64) L.drows[i / RDEC_ROW][i % RDEC_ROW] = a.rdec[(size_t)a.rhot[i / RDEC_ROW] * RDEC_ROW + i % RDEC_ROW];
+    __syncthreads();
+    const u32 c = blockIdx.x * 64 + lane;
+    if (c >= a.rgeo.nchains) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    const BlockDesc* d = &da.m.blocks[cp.b];
+    RecFastDecSrc cd; cd.rdec = a.rdec; cd.L = &L;
+    cd.rc.init(da.streams + a.coff[c], a.csz[c]);
+    if (!rec_fast_decode_lane(da, d, L, lane, cp.r0, cp.nrec, c, cd)) flags[c] = 1;
+}
+// flags: one dword per header chain, zeroed by the caller (null: every chain on the general path -- archives before version 5)
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags, hipStream_t st) {
+    const dim3 grid((a.rgeo.nchains + 63) / 64);
+    if (flags) hipLaunchKernelGGL(k_rec_decode_f, grid, dim3(64), 0, st, a, da, flags);
+    hipLaunchKernelGGL(k_rec_decode_c, grid, dim3(64), 0, st, a, da, (const u32*)flags);
 }

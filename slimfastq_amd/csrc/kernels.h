@@ -43,6 +43,7 @@ struct DecodeArgs {
 
 // ---- lane-per-chain kernels with frozen tables (chains.hip, dev_chain.h) ----------------------------------------
 struct ChainGeoArgs { u32 chain_reads, cpb, nchains; };     // chain c = chain c % cpb of block c / cpb
+#define RDEC_LDS_ROWS 16u              // header rows (decoder's form) a workgroup of the fast header decoder stages in LDS
 #define GEN_MAX_GENERATIONS 40
 struct ChainArgs {
     ModelArgs m;
@@ -63,7 +64,7 @@ struct ChainArgs {
     // headers: frozen PowerRanger rows, total 2^16 each
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
     const u16* rdec;            // decode: [PR_REC_ROWS][272] u16: the cum at every 16th symbol, then of all 256 (chains.hip RDEC_ROW)
-    const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> slot (0xFFFF = none), slot -> row, how many
+    const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> place by weight (0xFFFF = none; a kernel stages the first few), place -> row, how many to stage
     u8* exc_flag;               // encode: [records] set to 1 by the quality / base chains where a record holds a '!' / an N (null = not wanted)
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
@@ -126,7 +127,7 @@ void launch_usr_encode_w(const ModelArgs& a, hipStream_t st);      // framing ex
 
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
-void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 lanes, hipStream_t st);
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags /* [rgeo.nchains], zeroed; null = general path only */, hipStream_t st);
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
 void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st);          // the same, a wave per block (models_w.hip); blocks [batch0, batch0 + nbatch), slot = workgroup
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
