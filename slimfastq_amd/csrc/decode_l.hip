@@ -6,6 +6,7 @@
 // buffers, and a last streaming kernel lays the 4-line records out (UsrLoad::save, usrs.cpp:512-535).
 // Order: usr (line lengths) -> scans -> qlt | gen | rec side by side on three streams -> record sizes -> scan ->
 // assemble (which applies the one rule that ties bases to qualities: quality '!' means N, gens.cpp:206-208).
+#include <algorithm>
 #include "kernels.h"
 #include "dev_models.h"
 #include "dev_rec_lane.h"
@@ -293,59 +294,88 @@ __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 n, u32 lan
     for (u32 i = lane; i < nd; i += 64) *reinterpret_cast<u32*>(dst + 4 * i) = *reinterpret_cast<const u32*>(src + 4 * i);
     if (lane < (n & 3u)) dst[4 * nd + lane] = src[4 * nd + lane];
 }
-// one wave per record; 4 records per 256-thread workgroup.  A short read is five small copies: their first steps (64 dwords
-// each -- a whole 150-base line) are loaded together before anything is stored, so the record costs one memory round trip,
-// not five; what is longer goes through the loops behind.
 __device__ __forceinline__ u32 merge_n(u32 c, u32 q, u32 nb4) {         // four bases: bit 7 = "keep this base" (gen.Nn), else a quality '!' makes it the N byte
     const u32 keep = ((c >> 7) & 0x01010101u) * 0xFFu;
     const u32 x = q ^ 0x21212121u;
     const u32 bang = ((~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;
     return (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & nb4) | (~bang & c)));
 }
-__global__ __launch_bounds__(256) void k_assemble(DecodeArgs a, u64 nrec, const u64* __restrict__ roff, u8* __restrict__ out) {
-    const u32 lane = threadIdx.x & 63;
-    u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nrec) return;
-    const BlockDesc* d = &a.m.blocks[a.block_reads ? r / a.block_reads : 0];
-    const u32 h = a.hlen[r], s = d->solid, sl = a.slen[r], ql = a.qlen[r], two = d->two_id;
-    const u8* __restrict__ hp = a.hdr_stage + a.hoff[r];
-    const u8* __restrict__ sp = a.seq_stage + a.soff[r];
-    const u8* __restrict__ qp = a.qual_stage + a.qoff[r];
-    const u32 n_byte = d->n_byte ? d->n_byte : 'N';
-    const u32 nb4 = n_byte * 0x01010101u;
-    u8* const o_h = out + roff[r] + 1;                           // '@' hdr
-    u8* const o_s = o_h + h + 1 + s;                             // '\n' [pf] bases
-    u8* const o_2 = o_s + sl + 2;                                // '\n' '+' [hdr]
-    u8* const o_q = o_2 + (two ? h : 0) + 1 + s;                 // '\n' [pf] qualities
-    const u32 hd = h >> 2, md = (sl < ql ? sl : ql) >> 2, qd = ql >> 2;
-    // first steps, loads together
-    u32 vh = 0, vs = 0, vq = 0, vqq = 0;
-    if (lane < hd) vh = *reinterpret_cast<const u32*>(hp + 4 * lane);
-    if (lane < md) { vs = *reinterpret_cast<const u32*>(sp + 4 * lane); vq = *reinterpret_cast<const u32*>(qp + 4 * lane); }
-    if (lane < qd) vqq = lane < md ? vq : *reinterpret_cast<const u32*>(qp + 4 * lane);
-    if (lane < hd) { *reinterpret_cast<u32*>(o_h + 4 * lane) = vh; if (two) *reinterpret_cast<u32*>(o_2 + 4 * lane) = vh; }
-    if (lane < md) *reinterpret_cast<u32*>(o_s + 4 * lane) = merge_n(vs, vq, nb4);
-    if (lane < qd) *reinterpret_cast<u32*>(o_q + 4 * lane) = vqq;
-    // what is longer than 256 bytes
-    for (u32 i = lane + 64; i < hd; i += 64) { const u32 v = *reinterpret_cast<const u32*>(hp + 4 * i); *reinterpret_cast<u32*>(o_h + 4 * i) = v; if (two) *reinterpret_cast<u32*>(o_2 + 4 * i) = v; }
-    for (u32 i = lane + 64; i < md; i += 64) *reinterpret_cast<u32*>(o_s + 4 * i) = merge_n(*reinterpret_cast<const u32*>(sp + 4 * i), *reinterpret_cast<const u32*>(qp + 4 * i), nb4);
-    for (u32 i = lane + 64; i < qd; i += 64) *reinterpret_cast<u32*>(o_q + 4 * i) = *reinterpret_cast<const u32*>(qp + 4 * i);
-    // the ends: the last 0..3 bytes of each copy (the bases: whatever lies behind the shorter of the two lines), the fixed characters
-    if (lane < (h & 3u)) { const u8 c = hp[4 * hd + lane]; o_h[4 * hd + lane] = c; if (two) o_2[4 * hd + lane] = c; }
-    for (u32 i = 4 * md + lane; i < sl; i += 64) {
-        const u32 c = sp[i];
-        o_s[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
-    }
-    if (lane < (ql & 3u)) o_q[4 * qd + lane] = qp[4 * qd + lane];
-    if (lane == 0) {
-        o_h[-1] = '@';
-        o_h[h] = '\n'; if (s) o_h[h + 1] = a.pfg[r];
-        o_s[sl] = '\n'; o_s[sl + 1] = '+';
-        u8* e2 = o_2 + (two ? h : 0);
-        e2[0] = '\n'; if (s) e2[1] = a.pfq[r];
-        o_q[ql] = '\n';
+// A wave lays out `rpw` consecutive records (64 where there are millions of them, one where they are few and long: the host
+// keeps the grid at tens of thousands of waves).  Their bounds are fetched a record per lane (coalesced) and handed round with
+// readlane, so a record costs no round trip of its own for them; and a record is five small copies whose first steps (64
+// dwords each -- a whole 150-base line) are loaded together, for the NEXT record before the current one is stored: the
+// memory round trips of consecutive records overlap.  What is longer than 256 bytes goes through the loops behind.
+struct AsmRec { u32 h, sl, ql, s, two, nb, pfg, pfq; const u8* hp; const u8* sp; const u8* qp; u8* o; };
+struct AsmFirst { u32 vh, vs, vq, vqq; };
+__device__ __forceinline__ u32 bc32(u32 v, u32 k) { return (u32)__builtin_amdgcn_readlane((int)v, (int)k); }
+__device__ __forceinline__ u64 bc64(u64 v, u32 k) { return (u64)bc32((u32)v, k) | ((u64)bc32((u32)(v >> 32), k) << 32); }
+__device__ __forceinline__ AsmFirst asm_first(const AsmRec& r, u32 lane) {
+    const u32 hd = r.h >> 2, md = (r.sl < r.ql ? r.sl : r.ql) >> 2, qd = r.ql >> 2;
+    AsmFirst f; f.vh = f.vs = f.vq = f.vqq = 0;
+    if (lane < hd) f.vh = *reinterpret_cast<const u32*>(r.hp + 4 * lane);
+    if (lane < md) { f.vs = *reinterpret_cast<const u32*>(r.sp + 4 * lane); f.vq = *reinterpret_cast<const u32*>(r.qp + 4 * lane); }
+    if (lane < qd) f.vqq = lane < md ? f.vq : *reinterpret_cast<const u32*>(r.qp + 4 * lane);
+    return f;
+}
+__global__ __launch_bounds__(64) void k_assemble(DecodeArgs a, u64 nrec, u32 rpw, const u64* __restrict__ roff, u8* __restrict__ out) {
+    const u32 lane = threadIdx.x;
+    const u64 r0 = (u64)blockIdx.x * rpw;
+    if (r0 >= nrec) return;
+    const u32 cnt = (u32)(nrec - r0 < rpw ? nrec - r0 : rpw);
+    // the bounds of record r0 + lane
+    const u64 rl = r0 + (lane < cnt ? lane : cnt - 1);
+    const BlockDesc* d = &a.m.blocks[a.block_reads ? rl / a.block_reads : 0];
+    const u32 m_h = a.hlen[rl], m_sl = a.slen[rl], m_ql = a.qlen[rl];
+    const u64 m_ho = a.hoff[rl], m_so = a.soff[rl], m_qo = a.qoff[rl], m_ro = roff[rl];
+    const u32 m_s = d->solid, m_two = d->two_id, m_nb = d->n_byte ? d->n_byte : 'N';
+    const u32 m_pf = m_s ? ((u32)a.pfg[rl] | ((u32)a.pfq[rl] << 8)) : 0u;
+    auto rec = [&](u32 k) {
+        AsmRec r;
+        r.h = bc32(m_h, k); r.sl = bc32(m_sl, k); r.ql = bc32(m_ql, k); r.s = bc32(m_s, k); r.two = bc32(m_two, k); r.nb = bc32(m_nb, k);
+        const u32 pf = bc32(m_pf, k); r.pfg = pf & 0xffu; r.pfq = pf >> 8;
+        r.hp = a.hdr_stage + bc64(m_ho, k); r.sp = a.seq_stage + bc64(m_so, k); r.qp = a.qual_stage + bc64(m_qo, k);
+        r.o = out + bc64(m_ro, k);
+        return r;
+    };
+    AsmRec r = rec(0);
+    AsmFirst f = asm_first(r, lane);
+    for (u32 k = 0; k < cnt; k++) {
+        AsmRec rn = r; AsmFirst fn = f;
+        if (k + 1 < cnt) { rn = rec(k + 1); fn = asm_first(rn, lane); }          // the next record's loads, before this one's stores
+        const u32 h = r.h, s = r.s, sl = r.sl, ql = r.ql, two = r.two, n_byte = r.nb;
+        const u8* __restrict__ hp = r.hp; const u8* __restrict__ sp = r.sp; const u8* __restrict__ qp = r.qp;
+        const u32 nb4 = n_byte * 0x01010101u;
+        u8* const o_h = r.o + 1;                                     // '@' hdr
+        u8* const o_s = o_h + h + 1 + s;                             // '\n' [pf] bases
+        u8* const o_2 = o_s + sl + 2;                                // '\n' '+' [hdr]
+        u8* const o_q = o_2 + (two ? h : 0) + 1 + s;                 // '\n' [pf] qualities
+        const u32 hd = h >> 2, md = (sl < ql ? sl : ql) >> 2, qd = ql >> 2;
+        if (lane < hd) { *reinterpret_cast<u32*>(o_h + 4 * lane) = f.vh; if (two) *reinterpret_cast<u32*>(o_2 + 4 * lane) = f.vh; }
+        if (lane < md) *reinterpret_cast<u32*>(o_s + 4 * lane) = merge_n(f.vs, f.vq, nb4);
+        if (lane < qd) *reinterpret_cast<u32*>(o_q + 4 * lane) = f.vqq;
+        // what is longer than 256 bytes
+        for (u32 i = lane + 64; i < hd; i += 64) { const u32 v = *reinterpret_cast<const u32*>(hp + 4 * i); *reinterpret_cast<u32*>(o_h + 4 * i) = v; if (two) *reinterpret_cast<u32*>(o_2 + 4 * i) = v; }
+        for (u32 i = lane + 64; i < md; i += 64) *reinterpret_cast<u32*>(o_s + 4 * i) = merge_n(*reinterpret_cast<const u32*>(sp + 4 * i), *reinterpret_cast<const u32*>(qp + 4 * i), nb4);
+        for (u32 i = lane + 64; i < qd; i += 64) *reinterpret_cast<u32*>(o_q + 4 * i) = *reinterpret_cast<const u32*>(qp + 4 * i);
+        // the ends: the last 0..3 bytes of each copy (the bases: whatever lies behind the shorter of the two lines), the fixed characters
+        if (lane < (h & 3u)) { const u8 c = hp[4 * hd + lane]; o_h[4 * hd + lane] = c; if (two) o_2[4 * hd + lane] = c; }
+        for (u32 i = 4 * md + lane; i < sl; i += 64) {
+            const u32 c = sp[i];
+            o_s[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
+        }
+        if (lane < (ql & 3u)) o_q[4 * qd + lane] = qp[4 * qd + lane];
+        if (lane == 0) {
+            o_h[-1] = '@';
+            o_h[h] = '\n'; if (s) o_h[h + 1] = (u8)r.pfg;
+            o_s[sl] = '\n'; o_s[sl + 1] = '+';
+            u8* e2 = o_2 + (two ? h : 0);
+            e2[0] = '\n'; if (s) e2[1] = (u8)r.pfq;
+            o_q[ql] = '\n';
+        }
+        r = rn; f = fn;
     }
 }
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_assemble, dim3((u32)((nrec + 3) / 4)), dim3(256), 0, st, a, nrec, roff, out);
+    const u32 rpw = (u32)std::max<u64>(1, std::min<u64>(64, nrec / 32768));
+    hipLaunchKernelGGL(k_assemble, dim3((u32)((nrec + rpw - 1) / rpw)), dim3(64), 0, st, a, nrec, rpw, roff, out);
 }
