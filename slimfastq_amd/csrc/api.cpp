@@ -46,7 +46,7 @@ struct sfq_ctx {
     // decode scratch
     DevBuf slen, qlen, pfg, pfq, soff, qoff, seq_stage, qual_stage, hdr_stage, hlen, hoff, hso, hsc, rsize, roff, d_first;
     // quality warm start
-    DevBuf hist, rows66, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
+    DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, excf, cflags;
     u32 r_hot = 0, r_hot_dec = 0;
@@ -190,18 +190,22 @@ std::vector<u8> pack_prior(const u32* rows66, u32 q_rows) {
     put_v(o, 0);
     return o;
 }
-bool unpack_prior(const u8* b, size_t n, u32 q_rows, std::vector<u32>& rows66) {
+// "qlt.pri" -> the rows it lists, back to back (66 words each: 64 slots freq | sym << 16, total, iend), and their contexts
+bool unpack_prior(const u8* b, size_t n, u32 q_rows, std::vector<u32>& ctxs, std::vector<u32>& rows) {
     size_t p = 0; u64 v;
     if (!get_v(b, n, p, v) || v != q_rows) return false;
-    rows66.assign((size_t)q_rows * 66, 0);
+    ctxs.clear(); rows.clear();
     u64 c = 0; bool first = true;
     for (;;) {
         if (!get_v(b, n, p, v)) return false;
         if (v == 0) break;
-        c = first ? v - 1 : c + v - 1; first = false;
         // deltas are stored +1 so that 0 terminates; each is relative to the previous context (the first to 0)
+        if (!first && v == 1) return false;                 // (the same context twice)
+        c = first ? v - 1 : c + v - 1; first = false;
         if (c >= q_rows || p + 2 > n) return false;
-        u32* r = rows66.data() + (size_t)c * 66;
+        ctxs.push_back((u32)c);
+        rows.resize(rows.size() + 66, 0);
+        u32* r = rows.data() + rows.size() - 66;
         const u32 iend = b[p++], nnz = b[p++];
         if (iend > 64 || nnz > iend) return false;
         bool used[64] = {false};
@@ -226,6 +230,26 @@ int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
     if ((rc = reserve(ctx, ctx->prior_wovf, (size_t)q_rows * 4 * 4))) return rc;
     if ((rc = reserve(ctx, ctx->prior_ls, (size_t)q_rows * 64 * 4))) return rc;
     if ((rc = reserve(ctx, ctx->prior_lh, (size_t)q_rows * sizeof(RowHdr)))) return rc;
+    return SFQ_OK;
+}
+
+// the quality prior of a call that was handed one ("qlt.pri"): rows66 on the device = zeros + the listed rows, scattered by
+// a kernel (the dense form is 17 MB, of which a file lists a few thousand rows), and the adaptive kernels' spread of it
+int upload_prior(sfq_ctx* ctx, u32 q_rows, hipStream_t st) {
+    std::vector<u32> ctxs, rows;
+    if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, ctxs, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
+    int rc;
+    if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
+    HIPC(hipMemsetAsync(ctx->rows66.p, 0, (size_t)q_rows * 66 * 4, st));
+    if (!ctxs.empty()) {
+        if ((rc = reserve(ctx, ctx->ptmp, (ctxs.size() + rows.size()) * 4))) return rc;
+        u32* d_ctx = (u32*)ctx->ptmp.p; u32* d_rows = d_ctx + ctxs.size();
+        HIPC(hipMemcpyAsync(d_ctx, ctxs.data(), ctxs.size() * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        launch_prior_scatter(d_ctx, d_rows, (u32)ctxs.size(), (u32*)ctx->rows66.p, st);
+    }
+    launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
+    HIPC(hipStreamSynchronize(st));            // the vectors are locals
     return SFQ_OK;
 }
 
@@ -437,6 +461,11 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
     return SFQ_OK;
 }
 
+// pieces of a page-locked buffer, handed out front to back
+struct Bump {
+    u8* p; size_t off, cap;
+    template <typename T> T* take(size_t n) { off = (off + 15) & ~(size_t)15; T* r = reinterpret_cast<T*>(p + off); off += n * sizeof(T); return off <= cap ? r : nullptr; }
+};
 float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 }  // namespace
@@ -483,7 +512,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
     for (DevBuf* b : all) release(*b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin2) (void)hipHostFree(ctx->pin2);
@@ -729,13 +758,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 60000000ull), 0x7FFFFFFFull);
     }
     if (given && (models & SFQ_M_QLT)) {
-        std::vector<u32> rows;
-        if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
-        HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
-        launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
-        HIPC(hipStreamSynchronize(st));            // `rows` is a local
+        if ((rc = upload_prior(ctx, q_rows, st))) return rc;
         HIPC(hipEventRecord(ctx->ev[1], st));
         ctx->prior_on = true;
     } else if (prior_step && (models & SFQ_M_QLT)) {
@@ -1125,9 +1150,21 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     res->abi_version = SFQ_ABI_VERSION;
     HIPC(hipEventRecord(ctx->ev[0], st));
 
+    // What the host builds for the device -- block descriptors, stream offsets, the chains' sizes and offsets, the header
+    // staging slices -- is built in page-locked memory (the encoder's end-of-call scratch): a copy out of pageable memory goes
+    // through the driver's bounce buffer at a few GB/s, and these are megabytes per call.
+    Bump bump;
+    {
+        const size_t cn = ctx->chain_blob.size();              // (a chain takes at least a byte of "chn.idx")
+        const size_t need = (size_t)nblocks * (sizeof(BlockDesc) + 8 * SFQ_NSTREAMS + 12) + (cn + 64) * 24 + 4096;
+        if ((rc = reserve_pinned_buf(ctx, ctx->pin2, ctx->pin2_cap, need))) return rc;
+        bump.p = (u8*)ctx->pin2; bump.off = 0; bump.cap = need;
+    }
     // device block descriptors + per-block stream offsets
-    std::vector<BlockDesc> hb(nblocks);
-    std::vector<u64> bso((size_t)nblocks * SFQ_NSTREAMS);
+    BlockDesc* hb = bump.take<BlockDesc>(nblocks);
+    const size_t nbso = (size_t)nblocks * SFQ_NSTREAMS;
+    u64* bso = bump.take<u64>(nbso);
+    if (!hb || !bso) return fail(ctx, SFQ_E_NOMEM, "decode: host scratch");
     u64 run[SFQ_NSTREAMS];
     for (int s = 0; s < SFQ_NSTREAMS; s++) run[s] = stream_offset[s];
     u64 nrec = 0; u32 block_reads = h_blocks[0].n_records; int g_bits = 0;
@@ -1165,8 +1202,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         const u64 want = (u64)(nblocks - 1) * cpb + (last_nrec + chain_reads - 1) / chain_reads;
         if (v != want || want > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu chains, the blocks have %llu", (unsigned long long)v, (unsigned long long)want);
         nchains = (u32)want;
-        std::vector<u32> h_csz((size_t)nchains * 2);
-        std::vector<u64> h_coff((size_t)nchains * 2);
+        u32* h_csz = bump.take<u32>(cn + 16);
+        u64* h_coff = bump.take<u64>(cn + 16);
+        if (!h_csz || !h_coff || (size_t)nchains * 2 > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        size_t ncs = (size_t)nchains * 2;
         auto parse_rec_chains = [&]() -> bool {
             if (!get_v(cb, cn, cp, v) || v == 0 || v > block_reads) return false;
             rchain_reads = (u32)v;
@@ -1200,20 +1239,20 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (rec_chains) {
             if (!parse_rec_chains()) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
             u64 at = stream_offset[SFQ_S_REC];
-            for (u32 c = 0; c < nsub; c++) { h_csz.push_back(h_rsz[c]); h_coff.push_back(at); at += h_rsz[c]; }
+            if (ncs + nsub > cn + 16) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
+            for (u32 c = 0; c < nsub; c++) { h_csz[ncs] = h_rsz[c]; h_coff[ncs] = at; ncs++; at += h_rsz[c]; }
         }
-        if ((rc = reserve(ctx, ctx->csz, h_csz.size() * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->coff, h_coff.size() * 8))) return rc;
-        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz.data(), h_csz.size() * 4, hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff.data(), h_coff.size() * 8, hipMemcpyHostToDevice, st));
-        HIPC(hipStreamSynchronize(st));            // locals
+        if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
+        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, ncs * 8, hipMemcpyHostToDevice, st));
         if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
     }
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
-    if ((rc = reserve(ctx, ctx->blk_stream_off, bso.size() * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->blk_stream_off, nbso * 8))) return rc;
     if ((rc = reserve(ctx, ctx->d_first, (size_t)first_hdr_bytes + 16))) return rc;
-    HIPC(hipMemcpyAsync(ctx->blocks.p, hb.data(), (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(ctx->blk_stream_off.p, bso.data(), bso.size() * 8, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->blocks.p, hb, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->blk_stream_off.p, bso, nbso * 8, hipMemcpyHostToDevice, st));
     if (first_hdr_bytes) HIPC(hipMemcpyAsync(ctx->d_first.p, h_first_hdrs, (size_t)first_hdr_bytes, hipMemcpyHostToDevice, st));
 
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);
@@ -1234,14 +1273,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
 
     ctx->prior_on = false;
-    std::vector<u32> prior_rows;
     if (!ctx->prior_blob.empty()) {
-        std::vector<u32>& rows = prior_rows;
-        if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
-        if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
-        HIPC(hipMemcpyAsync(ctx->rows66.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
-        launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
-        HIPC(hipStreamSynchronize(st));            // `rows` is a local
+        if ((rc = upload_prior(ctx, q_rows, st))) return rc;
         ctx->prior_on = true;
     }
     DecodeArgs da;
@@ -1346,8 +1379,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if ((rc = upload_rec_rows(ctx, hf, ctx->st_aux[0]))) return rc;
     }
     const u32 nstage = frozen_rec ? nsub : nblocks;            // staging slices: one per header chain / per block
-    std::vector<u64> hso((size_t)nstage + 1);
-    std::vector<u32> hsc(nstage);
+    u64* hso = bump.take<u64>((size_t)nstage + 1);
+    u32* hsc = bump.take<u32>(nstage);
+    if (!hso || !hsc) return fail(ctx, SFQ_E_NOMEM, "decode: host scratch");
     if ((rc = reserve(ctx, ctx->hso, ((size_t)nstage + 1) * 8))) return rc;
     if ((rc = reserve(ctx, ctx->hsc, (size_t)nstage * 4))) return rc;
     for (int attempt = 0; ; attempt++) {
@@ -1370,8 +1404,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         }
         hso[nstage] = o;
         if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
-        HIPC(hipMemcpyAsync(ctx->hso.p, hso.data(), ((size_t)nstage + 1) * 8, hipMemcpyHostToDevice, st_rec));
-        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc.data(), (size_t)nstage * 4, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemcpyAsync(ctx->hso.p, hso, ((size_t)nstage + 1) * 8, hipMemcpyHostToDevice, st_rec));
+        HIPC(hipMemcpyAsync(ctx->hsc.p, hsc, (size_t)nstage * 4, hipMemcpyHostToDevice, st_rec));
         HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
         HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
@@ -1393,7 +1427,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
         HIPC(hipStreamSynchronize(st_rec));
         HIPC(hipStreamSynchronize(st));
-        HIPC(hipMemcpyAsync(hb.data(), ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         bool overflow = false; int worst = 0;
         for (u32 b = 0; b < nblocks; b++) {
@@ -1404,7 +1438,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (!overflow) break;
         if (attempt >= 8) return fail(ctx, SFQ_E_OVERFLOW, "decode: header staging overflow");
         for (u32 b = 0; b < nblocks; b++) hb[b].status = 0;
-        HIPC(hipMemcpyAsync(ctx->blocks.p, hb.data(), (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->blocks.p, hb, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
     }
     HIPC(hipEventRecord(ctx->ev[5], st));
 

@@ -149,4 +149,5 @@ void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockD
                      int level, u32 cap /* symbols counted per sampled record */, u32* hist, hipStream_t st);
 #define PRIOR_SYMBOLS 4096u
 void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);
+void launch_prior_scatter(const u32* ctxs, const u32* rows /* [n][66] */, u32 n, u32* rows66 /* zeroed */, hipStream_t st);
 void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);

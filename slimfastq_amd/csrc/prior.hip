@@ -165,6 +165,18 @@ __global__ __launch_bounds__(256) void k_prior_spread(const u32* rows66, u32 q_r
     if (lane < 60) w[4 + lane] = slot; else w_ovf[(size_t)ctx * 4 + (lane - 60)] = slot;
     if (lane == 0) { w[0] = tot; w[1] = iend; w[2] = 0; w[3] = 0; }
 }
+// rows66[ctxs[i]] = rows[i] (66 words each): the rows a "qlt.pri" lists, into the zeroed dense table
+__global__ __launch_bounds__(256) void k_prior_scatter(const u32* __restrict__ ctxs, const u32* __restrict__ rows, u32 n, u32* __restrict__ rows66) {
+    const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    u32* dst = rows66 + (size_t)ctxs[i] * 66;
+    const u32* src = rows + (size_t)i * 66;
+    dst[lane] = src[lane];
+    if (lane < 2) dst[64 + lane] = src[64 + lane];
+}
+void launch_prior_scatter(const u32* ctxs, const u32* rows, u32 n, u32* rows66, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_prior_scatter, dim3((n + 3) / 4), dim3(256), 0, st, ctxs, rows, n, rows66);
+}
 void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st) {
     hipLaunchKernelGGL(k_prior_spread, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, w_rows, w_ovf, l_slots, l_hdr);
 }
