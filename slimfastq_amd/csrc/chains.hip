@@ -742,10 +742,10 @@ struct RecFrozenEnc {
 };
 struct RecCountEnc {
     static constexpr bool inband = true;
-    u32* cnt; bool on;
-    __device__ __forceinline__ void record(u32 k) { on = k >= 1; }       // the run's first coded record only warms the field types up
+    u32* cnt; u32 kc;
+    __device__ __forceinline__ void record(u32 k) { kc = k; }
     __device__ __forceinline__ const u8* stage(const u8* g, u32, u32) { return g; }
-    __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
+    __device__ __forceinline__ void put(u32 row, u32 sym) { atomicAdd(&cnt[(size_t)row * 256 + sym], kc >= 1u ? 1u : 0u); }    // (see RecFastCount::put)
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
 // counting pass: lane i walks records [i * stride, i * stride + run): the first is the run's base
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 str
     const u64 r0 = (u64)i * stride;
     if (r0 >= nrec) return;
     const u32 n = (u32)(nrec - r0 < run ? nrec - r0 : run);
-    RecCountEnc cd; cd.cnt = cnt; cd.on = false;
+    RecCountEnc cd; cd.cnt = cnt; cd.kc = 0;
     XfEnc x_rec; x_rec.init(nullptr, 0, XF_REC_X);
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     u32 hb; int bad;
@@ -1037,9 +1037,12 @@ __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
 // the counting pass on the fast path: a run whose headers all fit (looked at first: counts cannot be taken back) is
 // counted here, the others are marked for k_rec_count
 struct RecFastCount {
-    u32* cnt; bool on;
-    __device__ __forceinline__ void record(u32 k) { on = k >= 1; }       // the run's first coded record only warms the field types up
-    __device__ __forceinline__ void put(u32 row, u32 sym) { if (on) atomicAdd(&cnt[(size_t)row * 256 + sym], 1u); }
+    u32* cnt; u32 kc;                                                     // kc: which coded record of the run this is
+    __device__ __forceinline__ void record(u32 k) { kc = k; }
+    // the run's first coded record only warms the field types up: it adds 0.  (Not `if (counted) atomicAdd(.., 1)`: the
+    // compiler branched on that as a wave-uniform condition whose mask held zeros for the lanes that were inactive where it
+    // was computed -- a lane coding a field alone counted its warm-up record.  tests: ..._outside_the_fast_kernels_envelope)
+    __device__ __forceinline__ void put(u32 row, u32 sym) { atomicAdd(&cnt[(size_t)row * 256 + sym], kc >= 1u ? 1u : 0u); }
     __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
 };
 __global__ __launch_bounds__(64) void k_rec_count_f(ModelArgs a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags) {
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(64) void k_rec_count_f(ModelArgs a, u64 nrec, u64 s
         fits = len <= 127u && rf_stage(L, 0, lane, a.fq + h0, len) <= RF_NF;
     }
     if (!fits) { flags[i] = 1; return; }
-    RecFastCount cd; cd.cnt = cnt; cd.on = false;
+    RecFastCount cd; cd.cnt = cnt; cd.kc = 0;
     u32 hb = 0;
     rec_fast_lane(a, L, lane, r0, r0, n, cd, hb);
 }

@@ -198,3 +198,50 @@ def test_frozen_quality_rows_staged_in_lds_do_not_change_a_byte(ctx, level):
         assert enc.stream("qlt") == base.stream("qlt"), rows
         assert enc.chains == base.chains and enc.prior == base.prior, rows
     assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+
+
+def _odd_headers_fastq(n, seed):
+    """Headers that leave the fast header kernels' envelope now and then: longer than 127 bytes, more than 16 fields, a
+    number of twenty digits (prints with a sign through "%lld": the reference is lossy there), a field that turns
+    hexadecimal, a leading zero, an empty field -- between runs of ordinary ones."""
+    rng = np.random.default_rng(seed)
+    out = []
+    x = 1000
+    for i in range(n):
+        x += int(rng.integers(0, 50))
+        k = rng.random()
+        if k < 0.02:
+            hdr = "@long.%d %s:%d" % (i, "Z" * int(rng.integers(120, 300)), x)
+        elif k < 0.04:
+            hdr = "@many.%d " % i + ":".join(str(int(v)) for v in rng.integers(0, 99, int(rng.integers(17, 40))))
+        elif k < 0.06:
+            hdr = "@big.%d run:%d:%d" % (i, 18446744073709551000 + int(rng.integers(0, 600)), x)
+        elif k < 0.08:
+            hdr = "@hex.%d run:%x:%d" % (i, 0xabc000 + i, x)
+        elif k < 0.10:
+            hdr = "@zero.%d run:0%d::%d" % (i, i, x)
+        else:
+            hdr = "@SIM.%d M7:12:FC9:%d:%d:%d:%d 1:N:0:ACGT" % (i, 1 + i // 2000, 1100 + i // 500, x, int(rng.integers(1000, 30000)))
+        ln = 60
+        seq = "".join("ACGT"[int(v)] for v in rng.integers(0, 4, ln))
+        q = "".join(chr(33 + int(v)) for v in rng.integers(2, 41, ln))
+        out += [hdr, seq, "+", q]
+    return ("\n".join(out) + "\n").encode()
+
+
+def test_frozen_headers_outside_the_fast_kernels_envelope(ctx):
+    """The fast header kernels (k_rec_encode_f / k_rec_decode_f: 127 bytes, 16 fields, no signs) hand a chain with anything
+    else to the general kernels; the bytes must be the oracle's either way, and the text must come back as the reference
+    restores it block by block (it is lossy on the twenty-digit numbers: SURVEY H7)."""
+    fq = _odd_headers_fastq(6000, 5)
+    br, cr = 400, 50
+    want = b"".join(O.decompress(O.compress(c, 3).image) for c in util.split_records(fq, br))
+    assert want != fq                                                 # (the lossy case is in there)
+    enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="odd headers")
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == want
+    # and with the ordinary headers only: everything on the fast path, exact
+    lines = fq.split(b"\n")[:-1]
+    keep = [lines[i:i + 4] for i in range(0, len(lines), 4) if lines[i].startswith(b"@SIM.")]
+    fq2 = b"\n".join(b"\n".join(r) for r in keep) + b"\n"
+    enc = check_against_oracle(ctx, fq2, 3, br=br, cr=cr, step=1, what="plain headers")
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq2) + 4096) == fq2
