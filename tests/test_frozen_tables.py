@@ -245,3 +245,22 @@ def test_frozen_headers_outside_the_fast_kernels_envelope(ctx):
     fq2 = b"\n".join(b"\n".join(r) for r in keep) + b"\n"
     enc = check_against_oracle(ctx, fq2, 3, br=br, cr=cr, step=1, what="plain headers")
     assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq2) + 4096) == fq2
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_frozen_fuzz_structurally_hostile_inputs(ctx, seed):
+    """The hostile little FASTQs of test_gpu_parity (ragged lengths, header shapes that change, hex / leading-zero / shrinking
+    fields, escapes, N with and without '!', short quality lines, a second id) through the frozen-table chains: every prior,
+    every chain and every side stream against the oracle's restatement, and back to what the reference restores."""
+    from test_gpu_parity import _fuzz_fastq
+    rng = np.random.default_rng(4000 + seed)
+    for rep in range(3):
+        nrec = int(rng.integers(150, 2500))
+        fq = _fuzz_fastq(rng, nrec)
+        level = int(rng.integers(1, 5))
+        br = int(rng.integers(40, min(700, nrec) + 1))
+        cr = int(rng.integers(1, br + 1))
+        what = "fuzz seed %d rep %d: %d records, level %d, blocks of %d, chains of %d" % (seed, rep, nrec, level, br, cr)
+        want = b"".join(O.decompress(O.compress(c, level).image) for c in util.split_records(fq, br))
+        enc = check_against_oracle(ctx, fq, level, br=br, cr=cr, step=1, what=what)
+        assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == want, what
