@@ -141,9 +141,9 @@ def test_frozen_golden_samples(ctx, name):
     fq = util.golden_fastq(name)
     nrec = fq.count(b"\n") // 4
     br = max(2, nrec // 7)
-    # what the reference restores block by block (it is lossy on a few inputs: SURVEY H7)
-    want = b"".join(O.decompress(O.compress(c, 3).image) for c in util.split_records(fq, br))
+    # what the reference restores block by block, header chain by header chain (it is lossy on a few inputs: SURVEY H7)
     enc = check_against_oracle(ctx, fq, 3, br=br, cr=max(1, br // 3), step=1, what=name)
+    want = util.reference_restoration(fq, br, 3, util.unpack_chains(enc.chains)["rec_chain_reads"])
     assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == want, name
 
 
@@ -235,9 +235,9 @@ def test_frozen_headers_outside_the_fast_kernels_envelope(ctx):
     restores it block by block (it is lossy on the twenty-digit numbers: SURVEY H7)."""
     fq = _odd_headers_fastq(6000, 5)
     br, cr = 400, 50
-    want = b"".join(O.decompress(O.compress(c, 3).image) for c in util.split_records(fq, br))
-    assert want != fq                                                 # (the lossy case is in there)
     enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="odd headers")
+    want = util.reference_restoration(fq, br, 3, util.unpack_chains(enc.chains)["rec_chain_reads"])
+    assert want != fq                                                 # (the lossy case is in there)
     assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == want
     # and with the ordinary headers only: everything on the fast path, exact
     lines = fq.split(b"\n")[:-1]
@@ -261,6 +261,6 @@ def test_frozen_fuzz_structurally_hostile_inputs(ctx, seed):
         br = int(rng.integers(40, min(700, nrec) + 1))
         cr = int(rng.integers(1, br + 1))
         what = "fuzz seed %d rep %d: %d records, level %d, blocks of %d, chains of %d" % (seed, rep, nrec, level, br, cr)
-        want = b"".join(O.decompress(O.compress(c, level).image) for c in util.split_records(fq, br))
         enc = check_against_oracle(ctx, fq, level, br=br, cr=cr, step=1, what=what)
+        want = util.reference_restoration(fq, br, level, util.unpack_chains(enc.chains)["rec_chain_reads"])
         assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == want, what
