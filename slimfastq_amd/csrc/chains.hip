@@ -637,7 +637,26 @@ void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_encode_c<T>, dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
 }
 
-// decode the chains of blocks [b0, b1): GenLoad::load_x (gens.cpp:215-249) without the N rules (k_gen_exc_decode)
+// One base: the row's four frequencies -> the symbol under prob, its cum and freq (base2_ranger.hpp:86-104)
+__device__ __forceinline__ u32 b2_pick(u32 v, LaneDec& rc, const u32* rcp) {
+    const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
+    const u32 tot = (f0 + f1) + (f2 + f3);
+    const u32 prob = rc.get_freq(tot, rcp[tot]);
+    u32 b, cum, f;
+    if (f0 > prob)                { b = 0; cum = 0;            f = f0; }
+    else if (f0 + f1 > prob)      { b = 1; cum = f0;           f = f1; }
+    else if (f0 + f1 + f2 > prob) { b = 2; cum = f0 + f1;      f = f2; }
+    else                          { b = 3; cum = f0 + f1 + f2; f = f3; if (prob >= tot) rc.err = 1; }
+    rc.decode(cum, f);
+    return b;
+}
+// decode the chains of blocks [b0, b1): GenLoad::load_x (gens.cpp:215-249) without the N rules (k_gen_exc_decode).
+// With rows, a base's row is a fetch from a table far larger than the caches whose address the base before it decides:
+// the walk of a chain is a chain of memory round trips.  The NEXT context's four candidate rows are one aligned 16-byte
+// piece, fetched while this base is decoded (fetching the sixteen candidates two bases ahead was measured: four times the
+// vector memory instructions cost more than the round trip they hide -- 158 ms against 95 per 10 M genome-sampled reads).
+// (Also measured: the generation's counting pass folded into this kernel -- the atomics share the vector memory path
+// with the row fetch every base waits for: 109 ms against 95.)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArgs da, u32 b0, u32 b1) {
     __shared__ u32 rcp[1024];
@@ -651,24 +670,27 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     const u32* rows = gen_rows_of(a, cp.b);
     const u32 alphabet = d->solid ? 0x33323130u /* "0123" */ : 0x54474341u /* "ACGT" */;    // gens.cpp:173-178
     const u32 mask = (1u << d->gen_bits) - 1u;
+    const u32 INIT = 0x007616c7u;                                                           // gens.cpp:139
     for (u32 k = 0; k < cp.nrec; k++) {
         const u64 r = cp.r0 + k;
         const u32 llen = da.slen[r];
         LaneOut out; out.begin(da.seq_stage + da.soff[r]);
-        u32 last = 0x007616c7u;
-        for (u32 i = 0; i < llen; i++) {
-            const u32 v = rows ? rows[last & mask] : B2_INIT;
-            const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-            const u32 tot = (f0 + f1) + (f2 + f3);
-            const u32 prob = rc.get_freq(tot, rcp[tot]);
-            u32 b, cum, f;                                                              // base2_ranger.hpp:86-104
-            if (f0 > prob)                { b = 0; cum = 0;            f = f0; }
-            else if (f0 + f1 > prob)      { b = 1; cum = f0;           f = f1; }
-            else if (f0 + f1 + f2 > prob) { b = 2; cum = f0 + f1;      f = f2; }
-            else                          { b = 3; cum = f0 + f1 + f2; f = f3; if (prob >= tot) rc.err = 1; }
-            rc.decode(cum, f);
-            out.put((alphabet >> (8 * b)) & 0xff);
-            last = (last << 2) | b;
+        u32 last = INIT;
+        if (rows) {                                                                         // (gen_bits >= 2: the four candidates are in bounds)
+            u32 v = rows[last & mask];
+            for (u32 i = 0; i < llen; i++) {
+                const uint4 cand = *reinterpret_cast<const uint4*>(rows + ((last << 2) & mask));
+                const u32 b = b2_pick(v, rc, rcp);
+                out.put((alphabet >> (8 * b)) & 0xff);
+                last = (last << 2) | b;
+                v = b == 0 ? cand.x : b == 1 ? cand.y : b == 2 ? cand.z : cand.w;
+            }
+        } else {
+            for (u32 i = 0; i < llen; i++) {
+                const u32 b = b2_pick(B2_INIT, rc, rcp);
+                out.put((alphabet >> (8 * b)) & 0xff);
+                last = (last << 2) | b;
+            }
         }
         out.end();
     }
