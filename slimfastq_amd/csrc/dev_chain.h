@@ -217,10 +217,10 @@ struct LaneOut {
 struct LaneDec {
     u64 low, code; u32 range;
     const u8* p; u32 pos, n;
-    u64 cur, nxt;       // stream bytes fetched ahead: `have` of them in cur (next one in its low byte), eight more in nxt
-    u32 have, fpos;     // fpos = stream position of nxt's first byte
+    u64 cur, a0, a1;    // stream bytes fetched ahead: `have` of them in cur (next one in its low byte), then a0 and -- while `ahead` is 2 -- a1
+    u32 have, ahead, fpos;      // fpos = stream position of the first byte not fetched yet
     u32 err;
-    // eight stream bytes from position at, zeros past the end (FilerLoad::get returns 0 there, filer.hpp:94-97); nothing
+    // stream bytes from position at, zeros past the end (FilerLoad::get returns 0 there, filer.hpp:94-97); nothing
     // outside [p, p + n) is touched
     __device__ __forceinline__ u64 fetch8(u32 at) const {
         if (at + 8 <= n) { const u32* q = reinterpret_cast<const u32*>(p + at); return (u64)q[0] | ((u64)q[1] << 32); }   // (no alignment needed on gfx9)
@@ -228,15 +228,24 @@ struct LaneDec {
         for (u32 i = 0; i < 8; i++) if (at + i < n) v |= (u64)p[at + i] << (8 * i);
         return v;
     }
+    __device__ __forceinline__ void fetch16(u32 at) {                  // sixteen bytes a load: a lane's refills are what the decoders' vector memory path is busy with
+        if (at + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + at);
+            a0 = (u64)v.x | ((u64)v.y << 32); a1 = (u64)v.z | ((u64)v.w << 32);
+        } else { a0 = fetch8(at); a1 = fetch8(at + 8); }
+    }
     __device__ __forceinline__ u32 get() {
-        if (have == 0) { cur = nxt; have = 8; fpos += 8; nxt = fetch8(fpos); }     // the load issued here is used eight bytes later
+        if (have == 0) {
+            cur = a0; a0 = a1; have = 8;
+            if (--ahead == 0) { fetch16(fpos); fpos += 16; ahead = 2; }     // the load issued here is used eight bytes later
+        }
         const u32 b = (u32)cur & 0xffu;
         cur >>= 8; have--; pos++;
         return b;
     }
     __device__ __forceinline__ void init(const u8* ptr, u32 len) {
         p = ptr; pos = 0; n = len; low = 0; range = 0xFFFFFFFFu; err = 0;
-        cur = fetch8(0); nxt = fetch8(8); have = 8; fpos = 8;
+        cur = fetch8(0); fetch16(8); have = 8; ahead = 2; fpos = 24;
         code = 0;
         for (int i = 0; i < 4; i++) code = (code << 8) | get();          // the four elided zero bytes, then four real ones
     }
