@@ -1,6 +1,10 @@
 // container.cpp -- see container.h.  Host-side file plumbing only; no entropy coding here.
 #include "container.h"
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <fcntl.h>
 #include <unistd.h>
 #include <algorithm>
 
@@ -97,16 +101,40 @@ bool parse_image(const uint8_t* img, size_t n, Archive& a, std::string& err) {
 }
 
 bool read_file(const std::string& path, Archive& a, std::string& err) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) { err = "Can't read file '" + path + "'"; return false; }
-    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> img((size_t)n);
-    size_t got = n ? fread(img.data(), 1, (size_t)n, f) : 0;
-    fclose(f);
-    if (got != (size_t)n) { err = "short read on '" + path + "'"; return false; }
-    if (!parse_image(img.data(), img.size(), a, err)) return false;
+    // a regular file is mapped and its page chains copied out of the mapping (reading it into a zero-filled buffer first
+    // cost as much again as the copy); anything else is read
+    unsigned long long n = 0;
+    {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) { err = "Can't read file '" + path + "'"; return false; }
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+                n = (unsigned long long)sb.st_size;
+                const bool ok = parse_image((const uint8_t*)m, (size_t)n, a, err);
+                munmap(m, (size_t)sb.st_size);
+                close(fd);
+                if (!ok) return false;
+                goto check;
+            }
+        }
+        close(fd);
+    }
+    {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) { err = "Can't read file '" + path + "'"; return false; }
+        std::vector<uint8_t> img;
+        uint8_t buf[1 << 16];
+        for (size_t got; (got = fread(buf, 1, sizeof buf, f)) > 0; ) img.insert(img.end(), buf, buf + got);
+        fclose(f);
+        n = img.size();
+        if (!parse_image(img.data(), img.size(), a, err)) return false;
+    }
+check:
     long long cs = a.get_long("comp.size", 0);                         // config.cpp:366-371
-    if (cs > 0 && (unsigned long long)cs != (unsigned long long)n) { err = "expected compressed file size to be " + std::to_string(cs); return false; }
+    if (cs > 0 && (unsigned long long)cs != n) { err = "expected compressed file size to be " + std::to_string(cs); return false; }
     return true;
 }
 
