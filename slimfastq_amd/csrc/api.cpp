@@ -700,6 +700,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
         ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
         ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
+        // the automatic choice: the block's chains of equal length (1024 records in chains of 50 would leave a last chain of
+        // 24 -- a lane that idles half of its wave's time)
+        if (!p.chain_reads) ca.geo.chain_reads = std::max<u32>(1u, (u32)((std::min<u64>(block_reads, nrec) + ca.geo.cpb - 1) / ca.geo.cpb));
         const u32 last_nrec = (u32)(nrec - (u64)(nblocks - 1) * block_reads);
         const u64 nc = (u64)(nblocks - 1) * ca.geo.cpb + (last_nrec + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
         if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
