@@ -250,27 +250,48 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
           const u32 kk = k0 + lane;
           const bool have = kk < nrec;
           const u64 rr = rec0 + (have ? kk : 0);
+          // every lane its own record's line bounds (the marked ones are handed round with readlane: no round trip of their own)
           const u64 lg0 = a.line_off[4 * rr + 1] + solid, lg1 = a.line_off[4 * rr + 2] - 1;
+          const u64 lq0 = a.line_off[4 * rr + 3] + solid, lq1 = a.line_off[4 * rr + 4] - 1;
           const u32 my_llen = have && lg1 > lg0 ? (u32)(lg1 - lg0) : 0u;
+          const u32 my_qlen = have && lq1 > lq0 ? (u32)(lq1 - lq0) : 0u;
           const u32 incl = wave_incl_scan(my_llen);
           const u32 excl = incl - my_llen;
           u64 todo = __ballot(have && (flags ? flags[rr] != 0 : true));
           const u64 genofs0 = genofs;
+          // the first 256 bases / qualities of a marked record are fetched while the one before it is coded
+          auto first = [&](u32 pk, u32 (&gch)[4], u32 (&qch)[4]) {
+              const u8* gp = a.fq + (((u64)rl((u32)(lg0 >> 32), pk) << 32) | rl((u32)lg0, pk));
+              const u8* qp = a.fq + (((u64)rl((u32)(lq0 >> 32), pk) << 32) | rl((u32)lq0, pk));
+              const u32 llen = rl(my_llen, pk), qlen = rl(my_qlen, pk);
+#pragma unroll
+              for (u32 u = 0; u < 4; u++) {
+                  const u32 idx = 64 * u + lane;
+                  gch[u] = idx < llen ? gp[idx] : 'A';
+                  qch[u] = (idx < llen && idx < qlen) ? qp[idx] : 40u;                  // gens.cpp:153
+              }
+          };
+          u32 ng[4], nq[4];
+          if (todo) first((u32)__ffsll((long long)todo) - 1u, ng, nq);
           while (todo) {
             const u32 pick = (u32)__ffsll((long long)todo) - 1u;
             todo &= todo - 1;
-            const u64 r = rec0 + k0 + pick;
             genofs = genofs0 + rl(excl, pick);
-            const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1, q0 = a.line_off[4 * r + 3] + solid, q1 = a.line_off[4 * r + 4] - 1;
-            const u32 llen = g1 > g0 ? (u32)(g1 - g0) : 0, qlen = q1 > q0 ? (u32)(q1 - q0) : 0;
-            const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
-            for (u32 base0 = 0; base0 < llen; base0 += 256) {
-                u32 gch[4], qch[4];
+            const u8* gp = a.fq + (((u64)rl((u32)(lg0 >> 32), pick) << 32) | rl((u32)lg0, pick));
+            const u8* qp = a.fq + (((u64)rl((u32)(lq0 >> 32), pick) << 32) | rl((u32)lq0, pick));
+            const u32 llen = rl(my_llen, pick), qlen = rl(my_qlen, pick);
+            u32 gch[4], qch[4];
 #pragma unroll
-                for (u32 u = 0; u < 4; u++) {
-                    const u32 idx = base0 + 64 * u + lane;
-                    gch[u] = idx < llen ? gp[idx] : 'A';
-                    qch[u] = (idx < llen && idx < qlen) ? qp[idx] : 40u;                  // gens.cpp:153
+            for (u32 u = 0; u < 4; u++) { gch[u] = ng[u]; qch[u] = nq[u]; }
+            if (todo) first((u32)__ffsll((long long)todo) - 1u, ng, nq);
+            for (u32 base0 = 0; base0 < llen; base0 += 256) {
+                if (base0) {
+#pragma unroll
+                    for (u32 u = 0; u < 4; u++) {
+                        const u32 idx = base0 + 64 * u + lane;
+                        gch[u] = idx < llen ? gp[idx] : 'A';
+                        qch[u] = (idx < llen && idx < qlen) ? qp[idx] : 40u;                  // gens.cpp:153
+                    }
                 }
 #pragma unroll
                 for (u32 u = 0; u < 4; u++) {
