@@ -59,6 +59,11 @@ struct RcEncU {                // RCoder (coder.hpp) on uniform values, one symb
 // A block slot's PowerRanger rows with lane l holding slots 4l..4l+3 (power_ranger.hpp:36-131).
 struct WavePw {
     u32* slots; RowHdr* hdr; u32 epoch;
+    // rows [hrow0, hrow0 + hn) live in the wave's LDS instead (k_gen_exc_w: the two rows nearly every gap goes through --
+    // a gap's row is read, updated and written back, and the next gap reads it again: round trips through L2 otherwise)
+    u32* hslots = nullptr; RowHdr* hhdr = nullptr; u32 hrow0 = 0, hn = 0;
+    __device__ __forceinline__ u32* row_slots(u32 row) const { const u32 k = row - hrow0; return k < hn ? hslots + (size_t)k * PW_NSYM : slots + (size_t)row * PW_NSYM; }
+    __device__ __forceinline__ RowHdr* row_hdr(u32 row) const { const u32 k = row - hrow0; return k < hn ? hhdr + k : hdr + row; }
     __device__ __forceinline__ u32 comp(const uint4& v, u32 c) const { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
     // update_freq (power_ranger.hpp:66-84) of slot i = 4 hl + c (value cur), then the row and its header back to HBM
     __device__ __forceinline__ void update(u32* rs, u32 row, u32 lane, u32 i, u32 hl, u32 c, u32 cur, u32 total, u32 iend, u32 count, uint4 v, u64 dirty) {
@@ -102,15 +107,15 @@ struct WavePw {
         if ((dirty >> lane) & 1) *reinterpret_cast<uint4*>(rs + i0) = v;
         if (lane == 0) {
             RowHdr nh; nh.total = total; nh.iend = (u16)iend; nh.count = (u8)count; nh.pad = 0; nh.epoch = epoch; nh.pad2 = 0;
-            hdr[row] = nh;
+            *row_hdr(row) = nh;
         }
     }
     // PowerRanger::get (power_ranger.hpp:106-130): the slot whose cumulative range holds the coder's value -- every slot's
     // freq + 1 summed four per lane, a wave scan, the first lane past the value, then its four slots; the slots between
     // the old iend and the one found come into being on the way (:118-119).  Every lane runs the same (uniform) coder.
     __device__ __forceinline__ u32 get(u32 row, RcDec& rc, ByteSrc1& src, u32 lane) {
-        u32* rs = slots + (size_t)row * PW_NSYM;
-        const RowHdr h = hdr[row];
+        u32* rs = row_slots(row);
+        const RowHdr h = *row_hdr(row);
         const bool live = rl(h.epoch, 0) == epoch;
         u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
         const u32 prob = rc.get_freq(total + PW_NSYM);
@@ -161,8 +166,8 @@ struct WavePw {
     }
     // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
     __device__ __forceinline__ Triple model(u32 row, u32 sym, u32 lane) {
-        u32* rs = slots + (size_t)row * PW_NSYM;
-        const RowHdr h = hdr[row];
+        u32* rs = row_slots(row);
+        const RowHdr h = *row_hdr(row);
         const bool live = rl(h.epoch, 0) == epoch;
         u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
         const u32 i0 = 4 * lane;
@@ -233,10 +238,14 @@ struct XfEncW {                // XFileSave (xfile.cpp:40-74), wave-cooperative
 // flags (from the quality and base chains, which have read every byte anyway): the records that may hold an N or a '!';
 // the others only move the base offset on, 64 records a step.  Null: every record is looked at.
 __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restrict__ flags, u32* ticket) {
+    __shared__ u32 hot_slots[2 * PW_NSYM];
+    __shared__ RowHdr hot_hdr[2];
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
         WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
+        pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = PR_XF_BASE + XF_GEN_NS * PR_XF_ROWS; pw.hn = 2;
+        if (lane < 2) hot_hdr[lane].epoch = 0;             // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
         XfEncW x_ns, x_nn;                                 // the whole wave codes a gap: lane = four slots of the PowerRanger row
         x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
         x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
