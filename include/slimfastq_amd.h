@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SFQ_ABI_VERSION 2
+#define SFQ_ABI_VERSION 3
 
 /* status codes */
 #define SFQ_OK              0
@@ -34,7 +34,8 @@ extern "C" {
 #define SFQ_E_FORMAT       -4   /* input is not 4-line FASTQ (reference: croak, usrs.cpp:162-172) */
 #define SFQ_E_OVERFLOW     -5   /* an output arena was too small                             */
 #define SFQ_E_CORRUPT      -6   /* compressed stream inconsistent                            */
-#define SFQ_E_UNSUPPORTED  -7   /* e.g. format 6 and a record over the reference's line limits (usrs.hpp:34-36), whose oversize side streams are not written */
+#define SFQ_E_UNSUPPORTED  -7   /* e.g. the block format and a '+' line that is neither empty nor the record's header (the reference
+                                   would silently replace it, usrs.cpp:236-239 / 518-523)                                       */
 #define SFQ_E_GENCHAR      -8   /* unexpected genome char (gens.cpp:125-126) / switched N byte (gens.cpp:107-108) */
 
 /* Stream ids: the reference's stream names (FilerSave(name) call sites). */
@@ -49,7 +50,12 @@ enum sfq_stream {
     SFQ_S_USR_XQ = 7,   /* "usr.x.q" usrs.cpp:49      */
     SFQ_S_USR_PFG = 8,  /* "usr.pfg" usrs.cpp:50      */
     SFQ_S_USR_PFQ = 9,  /* "usr.pfq" usrs.cpp:51      */
-    SFQ_NSTREAMS = 10
+    SFQ_S_GEN_LC = 10,  /* "gen.lc"  block format only: positions of the lowercase bases (the reference accepts them,
+                           gens.cpp:73-77, and gives them back uppercase, gens.cpp:171-178), gap-coded like "gen.Ns"     */
+    SFQ_S_USR_LREC = 11,/* "usr.lrec" usrs.cpp:55: oversize records -- gap, header line, '+' line, raw            */
+    SFQ_S_USR_LGEN = 12,/* "usr.lgen" usrs.cpp:53: their base lines                                              */
+    SFQ_S_USR_LQLT = 13,/* "usr.lqlt" usrs.cpp:54: their quality lines                                           */
+    SFQ_NSTREAMS = 14
 };
 const char* sfq_stream_name(int stream);
 
@@ -65,8 +71,12 @@ typedef struct sfq_ctx sfq_ctx;
 typedef struct sfq_params {
     int32_t  level;        /* 1..4 : conf.level (config.cpp:260-263, clamped like config.cpp:232-237) */
     uint32_t block_reads;  /* records per independent block; 0 = a single block, i.e. streams that are
-                              byte-identical to the reference's own (format 6); SFQ_BLOCK_AUTO = about 376 KiB of
-                              text per block (1024 records of 150 bp, a handful of long reads)            */
+                              byte-identical to the reference's own (format 6), its quirks included: lowercase bases
+                              come back uppercase, an emptied header field comes back "0" (SURVEY H7);
+                              SFQ_BLOCK_AUTO = about 376 KiB of text per block (1024 records of 150 bp, a handful of
+                              long reads).  The block format is LOSSLESS: where the reference would alter the text,
+                              its blocks depart from the reference's bytes (a header field that would not print back
+                              is coded as a string, lowercase bases are listed in "gen.lc") or refuse the input    */
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (the reference loop on one lane:
@@ -107,7 +117,8 @@ typedef struct sfq_block_info {
     uint32_t extra_hi;                     /* "qlt.extra.hi" (qlts.cpp:57-61)                     */
     uint32_t first_hdr_len;                /* "rec.first" length (recs.cpp:68-75)                 */
     uint64_t first_hdr_off;                /* its offset in the first-header blob                 */
-    uint32_t size[SFQ_NSTREAMS];           /* bytes of each stream of this block (0 = absent)     */
+    uint64_t size[SFQ_NSTREAMS];           /* bytes of each stream of this block (0 = absent); 64 bit: a format-6
+                                              archive is ONE block, and the reference writes streams over 4 GiB  */
     uint32_t status;                       /* 0 or -SFQ_E_* for this block                        */
     uint32_t hdr_bytes;                    /* sum of header-line lengths (sizes the decoder's staging; 0 = unknown) */
 } sfq_block_info;

@@ -28,7 +28,7 @@ def ref_binary():
 
 class Opts(C.Structure):
     _fields_ = [("level", C.c_int), ("quiet", C.c_int), ("gen_bits", C.c_int),
-                ("orig_filename", C.c_char_p), ("orig_size", C.c_longlong)]
+                ("orig_filename", C.c_char_p), ("orig_size", C.c_longlong), ("lossless", C.c_int)]
 
 
 class GenSide(C.Structure):
@@ -106,9 +106,10 @@ class Archive:
         return sum(len(v) for v in self.streams.values())
 
 
-def compress(fastq: bytes, level=3, quiet=True, gen_bits=0, orig_filename=None, orig_size=-1) -> Archive:
+def compress(fastq: bytes, level=3, quiet=True, gen_bits=0, orig_filename=None, orig_size=-1, lossless=False) -> Archive:
+    """lossless: the rules of this project's block format (sfq_oracle.h sfqo_opts.lossless) instead of the reference's quirks."""
     L = lib()
-    o = Opts(level, int(quiet), gen_bits, orig_filename, orig_size)
+    o = Opts(level, int(quiet), gen_bits, orig_filename, orig_size, int(lossless))
     h = L.sfqo_compress(fastq, len(fastq), C.byref(o))
     if not h:
         raise _err()

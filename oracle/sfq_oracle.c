@@ -681,12 +681,13 @@ typedef struct {
     u64 genofs;                 /* g_genofs_count, config.cpp:44 */
     u64 ns_index, nn_index;     /* gens.hpp:59-63 */
     u8  n_byte;
+    int lossless; u64 lc_index; /* block format: lowercase bases listed in "gen.lc" (not reference behaviour) */
     /* save side */
-    xsave *x_ns, *x_nn;
+    xsave *x_ns, *x_nn, *x_lc;
     u64 *ns_list, *nn_list; size_t n_ns, n_nn, cap_ns, cap_nn; int keep_lists;
     sfqo_archive* a; wr* info;  /* for set_info("gen.N_byte") gens.cpp:104 */
     /* load side */
-    xload *l_ns, *l_nn;
+    xload *l_ns, *l_nn, *l_lc;
     const char* gencode;
 } genm;
 
@@ -734,6 +735,11 @@ static void gen_bad(genm* g, u8 gen, int bad_n, int bad_q) {                  /*
 }
 static inline u8 gen_normalize_save(genm* g, u8 gen, u8 qlt) {                /* gens.cpp:116-136 */
     int bad_n; const int bad_q = qlt == '!';
+    if (g->lossless && (gen == 'a' || gen == 'c' || gen == 'g' || gen == 't' || gen == 'n')) {   /* block format only */
+        xs_put(g->x_lc, g->genofs + 1 - g->lc_index);
+        g->lc_index = g->genofs + 1;
+        if (gen == 'n') gen = 'N';
+    }
     int n = gencode_of(gen);
     if (n <= 3) bad_n = 0;
     else {
@@ -767,6 +773,7 @@ static void gen_load(genm* g, u8* gen, const u8* qlt, u64 llen, u64 qlen) {   /*
         gen[i] = (u8)g->gencode[b];
         last = (last << 2) + b;
         gen_normalize_load(g, &gen[i], (llen == qlen || i < qlen) ? qlt[i] : 40);
+        if (g->l_lc && g->lc_index == g->genofs) { gen[i] |= 0x20; g->lc_index += xl_get(g->l_lc); }   /* block format: "gen.lc" */
     }
 }
 
@@ -790,6 +797,7 @@ typedef struct {
     /* frozen-table mode (this project's format 7, not reference behaviour): when set, the symbols of the "rec" stream
        go to hook(arg, row, byte) instead of the adaptive PowerRanger rows; row = field * 16 + {0 type, 1 str, 2.. num} */
     void (*hook)(void* arg, int row, u8 sym); void* hook_arg; int no_x;
+    int lossless;               /* block format (not reference behaviour): string fallback for numbers that would not print back */
 } recm;
 
 enum {  /* recs.cpp:159-190 */
@@ -890,7 +898,8 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
     map_space(r, buf, imap);
     if (g_failed) return;
     space_map *mi = &r->smap[imap], *mp = &r->smap[pmap];
-    const int shape = mi->len != mp->len || memcmp(mi->str, mp->str, (size_t)mi->len);
+    int shape = mi->len != mp->len || memcmp(mi->str, mp->str, (size_t)mi->len);
+    if (r->lossless && mi->len && mi->str[mi->len - 1] == 0) shape = 1;       /* a NUL inside: the fields behind it would be lost */
     if (r->hook) r->hook(r->hook_arg, 65 * 16, (u8)(shape ? 1 : 0));          /* frozen mode: every record starts with a flag symbol */
     if (shape) {
         if (r->hook) {                                                        /* ... and a header whose shape changed is coded in the chain itself */
@@ -915,6 +924,10 @@ static void rec_save(recm* r, u64 record_count, const u8* buf, const u8* end, co
             const u8* b = buf + mi->off[i];
             u64 bnum;
             u8 type = numberwang(b, mi->wln[i], &bnum, r->ctype[pmap][i]);
+            if (r->lossless && type != ST_STR) {                               /* would RecLoad::load (recs.cpp:430-456) print the same bytes back? */
+                const int len = mi->wln[i], deci = type < ST_STR || type >= ST_DGT_Z;
+                if (len == 0 || (deci && len - (b[0] == '0') > 18)) type = ST_STR;
+            }
             if (type == ST_STR) {
                 rec_sym(r, i + 1, 0, type);
                 rec_num(r, i + 1, (u64)mi->wln[i]);                            /* put_str recs.cpp:77-81 */
@@ -1059,6 +1072,7 @@ typedef struct {
     u64 i_llen, i_qlen, i_sgen, i_sqlt, i_long; u8 solid_pf_gen, solid_pf_qlt;   /* usrs.hpp:53-63 */
     xsave *x_llen, *x_qlen, *x_sgen, *x_sqlt, *x_lgen, *x_lqlt, *x_lrec;
     const u8 *rec, *rec_end, *prev_rec, *prev_rec_end, *gen, *qlt;
+    int lossless, two_id;                   /* block format: an irregular '+' line is refused (not reference behaviour) */
 } usrs;
 
 static u8 us_at(const usrs* u, size_t i) { return i < u->end ? u->buf[i] : 0; }
@@ -1123,6 +1137,7 @@ static void us_determine_record(usrs* u, sfqo_archive* a, wr* info) {         /*
     if (u->solid) { set_info_ll(a, info, "usr.solid", u->solid); u->llen--; }
     set_info_ll(a, info, "llen", u->llen);
     set_info_ll(a, info, "usr.2id", has_2nd_id);
+    u->two_id = has_2nd_id;
 }
 static int us_get_record(usrs* u) {                                           /* usrs.cpp:303-390 */
 #define CHECK_OVERFLOW if (u->cur >= u->end) { fail("fastq file: record seems truncated  after record %llu", (unsigned long long)u->record_count); return 0; }
@@ -1150,9 +1165,16 @@ static int us_get_record(usrs* u) {                                           /*
     if ((size_t)u->llen != u->cur - gi) us_update(u, 0, (u16)(u->cur - gi));
     if (!us_expect(u, '\n')) return 0;
     if (!us_expect(u, '+')) return 0;
+    const size_t plus0 = u->cur;
     for (sanity = MAX_ID_LLEN; --sanity && us_at(u, u->cur) != '\n'; u->cur++);
     CHECK_OVERFLOW;
     if (!sanity) { fail("wierd second id at record %llu", (unsigned long long)u->record_count); return 0; }
+    if (u->lossless) {
+        const size_t pl = u->cur - plus0, hl = (size_t)(rec_end - (u->buf + currec + 1));
+        if (u->two_id ? (pl != hl || memcmp(u->buf + plus0, u->buf + currec + 1, hl)) : pl != 0) {
+            fail("record %llu: a '+' line that is neither empty nor the record's header", (unsigned long long)u->record_count); return 0;
+        }
+    }
     if (!us_expect(u, '\n')) return 0;
     if (u->solid) {
         if (u->solid_pf_qlt != us_at(u, u->cur)) us_update(u, 3, us_at(u, u->cur));
@@ -1195,14 +1217,17 @@ sfqo_archive* sfqo_compress(const u8* fastq, size_t n, const sfqo_opts* opts) {
     u.x_llen = xs_new(a, "usr.x");   u.x_qlen = xs_new(a, "usr.x.q");
     u.x_sgen = xs_new(a, "usr.pfg"); u.x_sqlt = xs_new(a, "usr.pfq");
     u.x_lgen = xs_new(a, "usr.lgen"); u.x_lqlt = xs_new(a, "usr.lqlt"); u.x_lrec = xs_new(a, "usr.lrec");
+    u.lossless = opts->lossless;
     if (u.valid) us_determine_record(&u, a, info);
 
     recm rec; rec_alloc(&rec);                                                /* UsrSave::encode usrs.cpp:392-407 */
+    rec.lossless = opts->lossless;
     wr* f_rec = wr_new_named(a, "rec"); rc_init_save(&rec.rc, f_rec);
     rec.x_file = xs_new(a, "rec.x");
     genm gen; gen_alloc(&gen, opts->gen_bits ? opts->gen_bits : gen_bits_for_level(level));
     wr* f_gen = wr_new_named(a, "gen"); rc_init_save(&gen.rc, f_gen);
     gen.x_ns = xs_new(a, "gen.Ns"); gen.x_nn = xs_new(a, "gen.Nn");
+    gen.lossless = opts->lossless; gen.x_lc = opts->lossless ? xs_new(a, "gen.lc") : NULL;
     gen.a = a; gen.info = info;
     qltm qlt; qlt_alloc(&qlt, level);
     wr* f_qlt = wr_new_named(a, "qlt"); rc_init_save(&qlt.rc, f_qlt);
@@ -1221,6 +1246,7 @@ sfqo_archive* sfqo_compress(const u8* fastq, size_t n, const sfqo_opts* opts) {
     rc_done(&gen.rc);                                                         /* gens.cpp:80-89 */
     free(gen.ranger); wr_close(f_gen);
     xs_close(gen.x_ns, NULL, NULL); xs_close(gen.x_nn, NULL, NULL);
+    if (gen.x_lc) xs_close(gen.x_lc, NULL, NULL);
     rc_done(&rec.rc);                                                         /* recs.cpp:50-57 */
     wr_close(f_rec); xs_close(rec.x_file, NULL, NULL);
     free(rec.ranger);
@@ -1294,6 +1320,7 @@ int sfqo_decompress(const sfqo_archive* a, u8** out, size_t* out_len) {      /* 
     rd r_gen = rd_open(a, "gen"); rc_init_load(&gen.rc, &r_gen);
     gen.l_ns = xl_new(a, "gen.Ns"); gen.l_nn = xl_new(a, "gen.Nn");
     gen.ns_index = xl_get(gen.l_ns); gen.nn_index = xl_get(gen.l_nn);
+    if (sfqo_stream_find(a, "gen.lc") >= 0) { gen.l_lc = xl_new(a, "gen.lc"); gen.lc_index = xl_get(gen.l_lc); }   /* block format only */
     qltm qlt; qlt_alloc(&qlt, level);                                         /* QltLoad::QltLoad qlts.cpp:142-148 */
     rd r_qlt = rd_open(a, "qlt"); rc_init_load(&qlt.rc, &r_qlt);
 
@@ -1345,7 +1372,7 @@ int sfqo_decompress(const sfqo_archive* a, u8** out, size_t* out_len) {      /* 
     }
     free(rec.ranger); free(gen.ranger); free(qlt.ranger);
     rd_close(&r_rec); rd_close(&r_gen); rd_close(&r_qlt);
-    xl_close(rec.l_file); xl_close(gen.l_ns); xl_close(gen.l_nn);
+    xl_close(rec.l_file); xl_close(gen.l_ns); xl_close(gen.l_nn); xl_close(gen.l_lc);
     xl_close(x_llen); xl_close(x_qlen); xl_close(x_sgen); xl_close(x_sqlt);
     xl_close(x_lrec); xl_close(x_lgen); xl_close(x_lqlt);
     if (g_failed) { free(o.p); return -1; }
@@ -1768,7 +1795,7 @@ int sfqo_rec_count(const u8* base, const u64* off, const u32* len, size_t nrec, 
         const size_t n = nrec - r0 < run ? nrec - r0 : run;
         recm r; rec_alloc(&r);
         void* arg[2] = { counts, NULL };
-        r.hook = hcount_hook; r.hook_arg = arg; r.no_x = 1;
+        r.hook = hcount_hook; r.hook_arg = arg; r.no_x = 1; r.lossless = 1;
         const u8* prev = NULL;
         for (size_t k = 0; k < n && !g_failed; k++) {
             arg[1] = k >= 2 ? (void*)counts : NULL;
@@ -1819,7 +1846,7 @@ long long sfqo_rec_encode_chains_frozen(const u8* base, const u64* off, const u3
             chenc c; ch_init(&c);
             hfz h = { &c, frozen_rows };
             recm r; rec_alloc(&r);
-            r.hook = hfz_hook; r.hook_arg = &h;
+            r.hook = hfz_hook; r.hook_arg = &h; r.lossless = 1;
             rec_save(&r, 1, base + off[b0], base + off[b0] + len[b0], NULL, NULL, NULL);      /* the base */
             const u8* prev = base + off[b0];
             u32 hb = 0;

@@ -31,6 +31,9 @@ typedef struct sfqo_opts {
     int gen_bits;       /* 0 = by level (gens.hpp:43-53: 18/22/24/26); else context bits        */
     const char* orig_filename;   /* NULL -> "<< stdin >>" (config.cpp:346)                      */
     long long   orig_size;       /* <0 -> key omitted (stdin mode)                              */
+    int lossless;       /* this project's block format (NOT reference behaviour; slimfastq_amd/csrc/dev_common.h): a header
+                           field the reference would not print back is coded as a string, a header with a NUL inside goes
+                           whole, lowercase bases are listed in a "gen.lc" stream, an irregular '+' line is an error  */
 } sfqo_opts;
 
 /* Whole-file compress: restates main.cpp:51-60 -> UsrSave::encode (usrs.cpp:392-407).

@@ -7,8 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimfastq_amd.so")
 
-NSTREAMS = 10
-STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"]
+NSTREAMS = 14
+STREAM_NAMES = ["rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq",
+                "gen.lc", "usr.lrec", "usr.lgen", "usr.lqlt"]
 M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
 PRIOR_AUTO = 0xFFFFFFFF
@@ -37,7 +38,7 @@ class BlockInfo(C.Structure):
     _fields_ = [("first_record", C.c_uint64), ("n_records", C.c_uint32), ("llen", C.c_uint32),
                 ("solid", C.c_uint8), ("two_id", C.c_uint8), ("n_byte", C.c_uint8), ("gen_bits", C.c_uint8),
                 ("extra_hi", C.c_uint32), ("first_hdr_len", C.c_uint32), ("first_hdr_off", C.c_uint64),
-                ("size", C.c_uint32 * NSTREAMS), ("status", C.c_uint32), ("hdr_bytes", C.c_uint32)]
+                ("size", C.c_uint64 * NSTREAMS), ("status", C.c_uint32), ("hdr_bytes", C.c_uint32)]
 
 
 class Result(C.Structure):

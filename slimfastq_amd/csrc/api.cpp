@@ -133,7 +133,7 @@ int ensure_tables(sfq_ctx* ctx, u32 want, u32 q_rows, u32 g_bits, u32 models, u3
     return SFQ_OK;
 }
 
-void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_bits) {
+void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_bits, bool lossless) {
     memset(&a, 0, sizeof a);
     Tables& t = ctx->tab;
     a.line_off = (const u64*)ctx->line_off.p;
@@ -141,6 +141,7 @@ void fill_model_args(sfq_ctx* ctx, ModelArgs& a, u32 nblocks, int level, u32 g_b
     a.nblocks = nblocks;
     a.arena = (u8*)ctx->arena.p;
     a.level = level;
+    a.lossless = lossless ? 1u : 0u;
     a.epoch_base = ctx->epoch_base;
     ctx->epoch_base += nblocks;            // taken now: a call that fails half-way has used them all the same
     a.q_slots = (u32*)t.q_slots.p; a.q_hdr = (RowHdr*)t.q_hdr.p; a.q_rows = t.q_rows;
@@ -475,7 +476,8 @@ float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTim
 extern "C" {
 
 const char* sfq_stream_name(int s) {
-    static const char* names[SFQ_NSTREAMS] = { "rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq" };
+    static const char* names[SFQ_NSTREAMS] = { "rec", "gen", "qlt", "gen.Ns", "gen.Nn", "rec.x", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq",
+                                               "gen.lc", "usr.lrec", "usr.lgen", "usr.lqlt" };
     return (s >= 0 && s < SFQ_NSTREAMS) ? names[s] : "";
 }
 int sfq_abi_version(void) { return SFQ_ABI_VERSION; }
@@ -641,14 +643,14 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (g_bits < 2 || g_bits > 26 ) return fail(ctx, SFQ_E_ARG, "gen_bits %d out of range", g_bits);
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
-    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 8 + (size_t)nblocks * 1024 + 4096))) return rc;
+    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 17 / 2 + (size_t)nblocks * 1024 + 4096))) return rc;      // frame.hip k_block_prepare
     u32 h_status2[3] = {0, 0, 0};
     HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 12, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
     const u32 h_status = h_status2[0], max_hdr = h_status2[1], max_line = h_status2[2];
     if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
-    if (h_status) return fail(ctx, -(int)h_status, "record over the line limits: headers up to 8190 bytes; base and quality lines up to 65534 in format 6 (-B 0; the reference would write oversize side streams, usrs.cpp:269-301, which this library does not), up to 1 Gi in the block format");
+    if (h_status) return fail(ctx, -(int)h_status, "record over the line limits: headers up to 8190 bytes; base and quality lines up to 65534 in format 6 (-B 0; the reference would write oversize side streams, usrs.cpp:269-301, which this library does not), up to 1 Gi in the block format; or an empty base line");
 
     // ---- models --------------------------------------------------------------------------------
     const u32 q_rows = p.level == 1 ? (1u << 12) : (1u << 16);       // qlts.hpp:36-40
@@ -676,7 +678,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
             slots &= ~(KR - 1);
         }
         if ((rc = advance_epoch(ctx, nblocks))) return rc;
-        fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits);
+        fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits, p.block_reads != 0);          // the block format is lossless (dev_common.h)
         a.fq = d_fastq;
         // Default kernels are persistent: one workgroup per pair of table slots, blocks handed out through ticket counters.
         if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
@@ -979,7 +981,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     int worst = 0;
     for (u32 b = 0; b < nblocks; b++) if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
     if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
-                           -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" : "see status codes");
+                           -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" :
+                           -worst == SFQ_E_UNSUPPORTED ? "a '+' line that is neither empty nor its record's header: the block format refuses what it could not give back (usrs.cpp:236-239)" : "see status codes");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
     HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
     launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
@@ -1186,13 +1189,20 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         d.rec0 = nrec; d.nrec = bi.n_records; d.llen = bi.llen; d.solid = bi.solid; d.two_id = bi.two_id;
         d.gen_bits = bi.gen_bits; d.n_byte = bi.n_byte; d.first_hdr_off = bi.first_hdr_off; d.first_hdr_len = bi.first_hdr_len;
         g_bits = std::max<int>(g_bits, bi.gen_bits);
-        for (int s = 0; s < SFQ_NSTREAMS; s++) { d.size[s] = bi.size[s]; bso[(size_t)b * SFQ_NSTREAMS + s] = run[s]; run[s] += bi.size[s]; }
+        for (int s = 0; s < SFQ_NSTREAMS; s++) {
+            if (bi.size[s] > 0xFFFFFFFFull) return fail(ctx, SFQ_E_UNSUPPORTED, "block %u: stream %s has %llu bytes (the kernels take streams below 4 GiB)", b, sfq_stream_name(s), (unsigned long long)bi.size[s]);
+            d.size[s] = (u32)bi.size[s]; bso[(size_t)b * SFQ_NSTREAMS + s] = run[s]; run[s] += bi.size[s];
+        }
         nrec += bi.n_records;
     }
+    for (u32 b = 0; b < nblocks; b++)
+        if (h_blocks[b].size[SFQ_S_USR_LREC] | h_blocks[b].size[SFQ_S_USR_LGEN] | h_blocks[b].size[SFQ_S_USR_LQLT])
+            return fail(ctx, SFQ_E_UNSUPPORTED, "block %u holds oversize records (usr.lrec, usrs.cpp:269-301): not decoded yet", b);
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
-    std::vector<u32> h_rsz, h_rhb;
+    std::vector<u32> h_rsz, h_rhb, rec_prior_f;
+    u32* h_csz = nullptr; u64* h_coff = nullptr; size_t ncs = 0;
     if (frozen) {
         const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
         size_t cp = 0; u64 v = 0;
@@ -1207,10 +1217,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         const u64 want = (u64)(nblocks - 1) * cpb + (last_nrec + chain_reads - 1) / chain_reads;
         if (v != want || want > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu chains, the blocks have %llu", (unsigned long long)v, (unsigned long long)want);
         nchains = (u32)want;
-        u32* h_csz = bump.take<u32>(cn + 16);
-        u64* h_coff = bump.take<u64>(cn + 16);
+        h_csz = bump.take<u32>(cn + 16);
+        h_coff = bump.take<u64>(cn + 16);
         if (!h_csz || !h_coff || (size_t)nchains * 2 > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
-        size_t ncs = (size_t)nchains * 2;
+        ncs = (size_t)nchains * 2;
         auto parse_rec_chains = [&]() -> bool {
             if (!get_v(cb, cn, cp, v) || v == 0 || v > block_reads) return false;
             rchain_reads = (u32)v;
@@ -1247,11 +1257,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if (ncs + nsub > cn + 16) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
             for (u32 c = 0; c < nsub; c++) { h_csz[ncs] = h_rsz[c]; h_coff[ncs] = at; ncs++; at += h_rsz[c]; }
         }
+        // what the call needs besides the streams is checked here, on host state alone, before any device work is queued
+        if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
+        if (rec_chains) {
+            if (ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "header chains need the header prior (rec.pri)");
+            if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), rec_prior_f)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
+        }
         if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
         if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
         HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
         HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, ncs * 8, hipMemcpyHostToDevice, st));
-        if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
     }
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     if ((rc = reserve(ctx, ctx->blk_stream_off, nbso * 8))) return rc;
@@ -1284,7 +1299,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     }
     DecodeArgs da;
     memset(&da, 0, sizeof da);
-    fill_model_args(ctx, da.m, nblocks, p.level, (u32)g_bits);
+    fill_model_args(ctx, da.m, nblocks, p.level, (u32)g_bits, false);                      // (a decoder follows what the streams say)
     ctx->prior_on = false;
     da.streams = d_streams;
     da.blk_stream_off = (const u64*)ctx->blk_stream_off.p;
@@ -1377,12 +1392,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
 
     // 3. headers; the staging size comes from the index when known, else grows on overflow
     const bool frozen_rec = frozen && rec_chains != 0;
-    if (frozen_rec && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "header chains need the header prior (rec.pri)");
-    if (frozen_rec) {
-        std::vector<u32> hf;
-        if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
-        if ((rc = upload_rec_rows(ctx, hf, ctx->st_aux[0]))) return rc;
-    }
+    if (frozen_rec) { if ((rc = upload_rec_rows(ctx, rec_prior_f, ctx->st_aux[0]))) return rc; }
     const u32 nstage = frozen_rec ? nsub : nblocks;            // staging slices: one per header chain / per block
     u64* hso = bump.take<u64>((size_t)nstage + 1);
     u32* hsc = bump.take<u32>(nstage);

@@ -478,7 +478,7 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
 }
 
 // The encoder's walk, without branches inside a piece: the codes come from a 256-entry table in LDS (code | 4 for an
-// N-like character | 0x10 for an illegal one), look(j, ctx) runs for all 16 positions (a position outside the lane's
+// N-like character | 0x10 for an illegal one | 0x20 for a lowercase one), look(j, ctx) runs for all 16 positions (a position outside the lane's
 // bytes repeats the context before it, so its lookup is harmless), code(j, code, valid) likewise with a flag, and
 // piece_end() once per piece.
 template <typename LOOK, typename CODE, typename PEND>
@@ -504,8 +504,8 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
             codes |= (cd4[j] & 3u) << (2 * j);
             odd |= cd4[j] & (j < len ? ~0u : 0u);
         }
-        // an N or an illegal character marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
-        if (exc_flag && (odd & 0x14u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
+        // an N, a lowercase base or an illegal character marks the record for the pass over the N / quality-0 / case exceptions (k_gen_exc_w)
+        if (exc_flag && (odd & 0x34u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             code(j, (codes >> (2 * j)) & 3u, j < len ? ~0u : 0u);
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
     __shared__ u32 ring[LaneEncB<THREADS, GEN_RING>::LDS_DWORDS];
     for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
-    for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)gen_code_of(i);
+    for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)(gen_code_of(i) | (is_lower_base(i) ? 0x20u : 0u));    // 0x20: a lowercase base ("gen.lc")
     __syncthreads();
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < a.geo.nchains;
@@ -935,7 +935,8 @@ struct RecFastEnc {
 };
 // a header line into LDS, tokenised on the way (map_space, recs.cpp:141-157): a separator closes a field; the byte behind
 // the text is the line's '\n', the last separator; a NUL ends the scan.  Eight dwords are fetched at a time, so a header
-// costs a memory round trip or two, not one per dword.  Returns the number of fields (more than RF_NF: not all recorded).
+// costs a memory round trip or two, not one per dword.  Returns the number of fields (more than RF_NF: not all recorded;
+// 0xFFFF: a NUL inside).
 template <typename LT>
 __device__ __forceinline__ u32 rf_stage(LT& L, u32 buf, u32 lane, const u8* text, u32 n) {
     const u32* g = reinterpret_cast<const u32*>(text);             // (global loads need no alignment on gfx9; the text goes on behind the line)
@@ -961,7 +962,7 @@ __device__ __forceinline__ u32 rf_stage(LT& L, u32 buf, u32 lane, const u8* text
             }
         }
     }
-    return nf;
+    return stop ? 0xFFFFu : nf;             // a NUL inside the header: not for the fast path (the general one sends it whole)
 }
 // one chain (or one run of the counting pass) on the fast path; returns false where a header is too long / has too many
 // fields for it (the coder has then seen part of the chain: an encoder starts over on the general path, the counting
@@ -1018,6 +1019,7 @@ __device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lan
             const u32 o = L.off[cur][f][lane], wl = L.wln[cur][f][lane], pct = L.ctype[f][lane];
             u64 bnum;
             u32 type = nw_lds(L, cur, lane, o, (int)wl, bnum, pct);
+            if (type != ST_STR && !rec_number_prints_back(type, wl, L.text[cur][o][lane])) type = ST_STR;      // (chains are block format only: lossless)
             const u32 rr = (f + 1) * 16;
             if (type == ST_STR) {                                             // recs.cpp:324-331
                 cd.put(rr + 0, type);

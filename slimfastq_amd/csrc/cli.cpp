@@ -22,7 +22,8 @@
 #include "container.h"
 
 static const int   kInternalVersion = 6;      // config.cpp:41
-static const int   kBlockVersion = 7;
+static const int   kBlockVersion = 8;          // 7: block format, the reference's quirks kept; 8: lossless ("gen.lc", 14 stream sizes per index entry)
+static const int   kBlockVersionMin = 7;
 static const char* kUserVersion = "2.04-amd";
 
 static bool g_encode = true;
@@ -51,10 +52,18 @@ static std::string g_partial;                // an archive being written as the 
     vsnprintf(msg, sizeof msg, fmt, ap);
     va_end(ap);
     if (!g_partial.empty()) { unlink(g_partial.c_str()); g_partial.clear(); }
-    if (g_batch) throw JobError{msg};
-    fprintf(stderr, "slimfastq: %s %s: %s\n", g_encode ? "encoding" : "decoding", g_usr.empty() ? "<< stdin >>" : g_usr.c_str(), msg);
-    exit(1);
+    // (thrown in one-shot mode too: the stack unwinds through the guards below, which join the reader / writer threads
+    //  before main() prints the message and exits -- exit() from here would race a thread still inside pwrite / fwrite)
+    throw JobError{msg};
 }
+// a thread that is joined wherever its scope ends, croak()'s unwinding included (a joinable std::thread that goes out of
+// scope calls std::terminate)
+struct Joiner {
+    std::thread t;
+    ~Joiner() { join(); }
+    void join() { if (t.joinable()) t.join(); }
+    template <typename F> void start(F&& f) { join(); t = std::thread(std::forward<F>(f)); }
+};
 
 static void usage() {
     printf("Usage: \n"
@@ -185,8 +194,27 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     // A regular file in the block format: slabs are read AHEAD -- several threads pread the next slab into one of two
     // page-locked buffers while the GPU codes the current one -- and the streams come back into a page-locked buffer too.
     // (File to file the time is the host's: one thread fread()s at ~5 GB/s, pageable H2D/D2H copies crawl.)
-    const bool ahead = !legacy && in != stdin && file_left != SIZE_MAX;
-    const size_t slab = (size_t)(o.slab_bytes ? o.slab_bytes : ahead ? (512ull << 20) : (2048ull << 20));
+    bool ahead = !legacy && in != stdin && file_left != SIZE_MAX;
+    size_t slab = (size_t)(o.slab_bytes ? o.slab_bytes : ahead ? (512ull << 20) : (2048ull << 20));
+    // (a small file: buffers of its size, not of the slab's -- page-locking 1.5 GiB for a 1 MB file costs hundreds of
+    //  milliseconds and may not fit a small memlock limit)
+    if (ahead) slab = std::min(slab, std::max<size_t>(file_left, (size_t)1 << 20));
+    // kept for the life of the process: a -b worker reuses them, a one-shot run exits without the 0.2 s of unpinning
+    static uint8_t* pinned[4] = { nullptr, nullptr, nullptr, nullptr }; static size_t pinned_cap = 0;
+    if (ahead) {
+        const size_t cap = slab + (64u << 20), out_pin = cap / 3 + (16u << 20);
+        if (pinned_cap < cap) {
+            for (auto& q : pinned) { if (q) sfq_host_free(ctx, q); q = nullptr; }
+            pinned[0] = (uint8_t*)sfq_host_alloc(ctx, cap); pinned[1] = (uint8_t*)sfq_host_alloc(ctx, cap);
+            pinned[2] = (uint8_t*)sfq_host_alloc(ctx, out_pin); pinned[3] = (uint8_t*)sfq_host_alloc(ctx, out_pin);
+            pinned_cap = (pinned[0] && pinned[1] && pinned[2] && pinned[3]) ? cap : 0;
+            if (!pinned_cap) {                                             // no page-locked memory to be had: the plain path below
+                for (auto& q : pinned) { if (q) sfq_host_free(ctx, q); q = nullptr; }
+                ahead = false;
+                slab = (size_t)(o.slab_bytes ? o.slab_bytes : (2048ull << 20));
+            }
+        }
+    }
     Bytes fq, out;
     bool eof = false;
     sfqc::PagedWriter pw; bool streamed = false;                       // the archive written as the slabs come back
@@ -195,30 +223,24 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         const size_t fsize = file_left;
         const size_t cap = slab + (64u << 20);                          // room for the carried-over partial record
         const size_t out_cap = (size_t)sfq_encode_bound(cap);
-        // (kept for the life of the process: a -b worker reuses them, a one-shot run exits without the 0.2 s of unpinning)
-        static uint8_t* pinned[4] = { nullptr, nullptr, nullptr, nullptr }; static size_t pinned_cap = 0;
         // the streams of a slab are rarely a third of its text: that much is page-locked, twice (one buffer is written to
         // the archive while the next slab's streams arrive in the other); a slab that needs more goes through a plain buffer
         const size_t out_pin = cap / 3 + (16u << 20);
-        if (pinned_cap < cap) {
-            for (auto& q : pinned) { if (q) sfq_host_free(ctx, q); q = nullptr; }
-            pinned[0] = (uint8_t*)sfq_host_alloc(ctx, cap); pinned[1] = (uint8_t*)sfq_host_alloc(ctx, cap);
-            pinned[2] = (uint8_t*)sfq_host_alloc(ctx, out_pin); pinned[3] = (uint8_t*)sfq_host_alloc(ctx, out_pin);
-            pinned_cap = (pinned[0] && pinned[1] && pinned[2] && pinned[3]) ? cap : 0;
-        }
         uint8_t* buf[2] = { pinned[0], pinned[1] };
-        if (!pinned_cap) croak("out of page-locked memory (-S sets the slab size)");
         Bytes big_out;                                                  // only for a slab whose streams outgrow the pinned buffer
         std::string werr;
         if (!pw.open(fil, werr)) croak("%s", werr.c_str());
         g_partial = fil;
         int sid[SFQ_NSTREAMS];
         for (int s2 = 0; s2 < SFQ_NSTREAMS; s2++) sid[s2] = -1;           // a stream gets its directory entry with its first bytes
-        std::thread writer;                                             // appends the previous slab's streams to the archive
+        Joiner writer;                                                  // appends the previous slab's streams to the archive
         int ob = 0;
         tick("pinned buffers");
         // read file bytes [off, off + len) to dst with o.io_threads threads; newlines counted on the way
-        struct Read { std::vector<std::thread> th; std::atomic<uint64_t> nl{0}; std::atomic<int> bad{0}; };
+        struct Read {
+            std::vector<std::thread> th; std::atomic<uint64_t> nl{0}; std::atomic<int> bad{0};
+            ~Read() { for (auto& t : th) if (t.joinable()) t.join(); }
+        };
         auto start_read = [&](Read& r, uint8_t* dst, size_t off, size_t len) {
             r.nl = 0; r.bad = 0;
             const int nt = std::max(1, o.io_threads);
@@ -272,12 +294,12 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             uint8_t* outp = pinned[2 + ob];
             int rc = sfq_encode_blocks_host(ctx, text, use, &p, outp, out_pin, &res);
             if (rc == SFQ_E_OVERFLOW) {
-                if (!big_out.reserve(out_cap)) { join_read(r); croak("out of memory"); }
-                if (writer.joinable()) writer.join();
+                if (!big_out.reserve(out_cap)) croak("out of memory");
+                writer.join();
                 outp = big_out.p;
                 rc = sfq_encode_blocks_host(ctx, text, use, &p, outp, out_cap, &res);
             }
-            if (rc) { join_read(r); if (writer.joinable()) writer.join(); croak("%s", sfq_last_error(ctx)); }
+            if (rc) croak("%s", sfq_last_error(ctx));
             tick("sfq_encode_blocks_host");
             const size_t b0 = blocks_all.size();
             blocks_all.resize(b0 + res.n_blocks);
@@ -287,10 +309,10 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             first_all.resize(f0 + (size_t)res.first_hdr_bytes + 1);
             sfq_get_first_headers(ctx, first_all.data() + f0, res.first_hdr_bytes);
             first_all.resize(f0 + (size_t)res.first_hdr_bytes);
-            if (writer.joinable()) writer.join();
+            writer.join();
             {
                 const sfq_result rr = res; sfqc::PagedWriter* w = &pw; int* ids = sid; const uint8_t* src = outp;
-                writer = std::thread([rr, w, ids, src]() {
+                writer.start([rr, w, ids, src]() {
                     for (int s2 = 0; s2 < SFQ_NSTREAMS; s2++) if (rr.stream_bytes[s2]) {
                         if (ids[s2] < 0) ids[s2] = w->stream(sfq_stream_name(s2));
                         w->append(ids[s2], src + rr.stream_offset[s2], (size_t)rr.stream_bytes[s2]);
@@ -313,7 +335,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             have[nxt] = carry + len; nls[nxt] = carry_nl + r.nl; off += len;
             cur = nxt;
         }
-        if (writer.joinable()) writer.join();
+        writer.join();
         streamed = true;
         eof = true;                                                     // nothing left for the loop below
     }
@@ -442,7 +464,6 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     tick("read archive");
     const int version = (int)a.get_long("version", 0);
     if (version > kBlockVersion) croak("%s was compressed with slimfastq version %d. My version is %d. Please upgrade me before decoing", fil.c_str(), version, kBlockVersion);
-    if (a.find("usr.lrec")) croak("archive holds oversize records (usr.lrec): not supported by the GPU decoder yet");
     const int level = clamp_level((int)a.get_long("config.level", 2));       // config.cpp:359
     std::vector<sfq_block_info> blocks;
     std::vector<uint8_t> first;
@@ -450,12 +471,15 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     const std::vector<uint8_t>* pri = a.find("qlt.pri");
     const std::vector<uint8_t>* chn = a.find("chn.idx");
     const std::vector<uint8_t>* rpr = a.find("rec.pri");
-    const bool frozen = a.get_long("blk.tables", 0) == 1;
+    const long long blk_tables = a.get_long("blk.tables", 0);
+    if (blk_tables != 0 && blk_tables != 1) croak("%s: blk.tables = %lld is not a table mode this version knows. Please upgrade me before decoing", fil.c_str(), blk_tables);
+    const bool frozen = blk_tables == 1;
+    if (!frozen && chn) croak("archive holds a chain index (chn.idx) but does not say frozen tables (blk.tables)");
     const bool shared_prior = a.get_long("seg.shared_prior", 0) == 1;
     if (frozen && !chn) croak("archive says frozen tables but holds no chain index (chn.idx)");
-    if (version >= kBlockVersion) {
+    if (version >= kBlockVersionMin) {
         const std::vector<uint8_t>* idx = a.find("blk.idx");
-        if (!idx || !sfqc::unpack_block_index(*idx, blocks)) croak("bad block index");
+        if (!idx || !sfqc::unpack_block_index(*idx, blocks, version >= 8 ? SFQ_NSTREAMS : 10)) croak("bad block index");
         if (const std::vector<uint8_t>* h = a.find("blk.hdr")) first = *h;
         if (const std::vector<uint8_t>* si = a.find("seg.idx")) {
             size_t q = 0; uint64_t n = 0;
@@ -482,7 +506,7 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         if (a.get_long("num_records") > 0xFFFFFFFFll) croak("archive too large for the single-block GPU path (more than 2^32 - 1 records)");
         for (int s = 0; s < SFQ_NSTREAMS; s++) if (auto* v = a.find(sfq_stream_name(s))) {
             if (v->size() > 0xFFFFFFFFull) croak("archive too large for the single-block GPU path (stream %s has %zu bytes)", sfq_stream_name(s), v->size());
-            b.size[s] = (uint32_t)v->size();
+            b.size[s] = v->size();
         }
         blocks.push_back(b);
         segs.push_back(Segment{1, 0, (uint64_t)a.get_long("orig.size", 0), 0, 0});
@@ -500,7 +524,7 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         }
     }
     sfq_params p; memset(&p, 0, sizeof p);
-    p.level = level; p.version = version >= kBlockVersion ? kInternalVersion : (uint32_t)version;
+    p.level = level; p.version = version >= kBlockVersionMin ? kInternalVersion : (uint32_t)version;
     // walk the segments: each one's blocks, its slice of every stream (streams are segment-major), its prior
     size_t b0 = 0, pri_off = 0, chn_off = 0, rpr_off = 0;
     uint64_t spos[SFQ_NSTREAMS] = {0};
@@ -518,7 +542,8 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         if (!opin_cap) sized = false;
         tick("pinned buffers");
     }
-    std::thread writer; std::atomic<int> wbad{0}; int ob = 0;
+    std::atomic<int> wbad{0}; int ob = 0;
+    Joiner writer;                                                      // (declared after what its thread uses: joined first when the scope unwinds)
     for (const Segment& g : segs) {
         if (g.nblocks == 0 || g.nblocks > blocks.size() - b0) croak("bad segment index");
         if (pri ? g.prior_bytes > pri->size() - pri_off : g.prior_bytes != 0) croak("bad segment index");
@@ -553,7 +578,7 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         for (int attempt = 0; attempt < 2; attempt++) {
             if (sized && cap + 16 <= opin_cap) dst = opin[ob];
             else {
-                if (!out.reserve((size_t)cap + 16)) { if (writer.joinable()) writer.join(); croak("out of memory"); }
+                if (!out.reserve((size_t)cap + 16)) croak("out of memory");
                 out.touch((size_t)cap);
                 dst = out.p;
             }
@@ -562,19 +587,19 @@ static void decode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
             if (rc != SFQ_E_OVERFLOW || got <= cap) break;
             cap = got;                                                 // the call reports the size it needs
         }
-        if (rc) { if (writer.joinable()) writer.join(); croak("%s", sfq_last_error(ctx)); }
+        if (rc) croak("%s", sfq_last_error(ctx));
         tick("sfq_decode_blocks_host");
-        if (writer.joinable()) writer.join();
+        writer.join();
         if (wbad) croak("USR: Error writing output");
         if (dst == out.p) { if (fwrite(dst, 1, (size_t)got, of) != got) croak("USR: Error writing output"); }
         else {
-            writer = std::thread([dst, got, of, &wbad]() { if (fwrite(dst, 1, (size_t)got, of) != got) wbad = 1; });
+            writer.start([dst, got, of, &wbad]() { if (fwrite(dst, 1, (size_t)got, of) != got) wbad = 1; });
             ob ^= 1;
         }
         tick("write output");
         b0 += g.nblocks; pri_off += g.prior_bytes; chn_off += g.chain_bytes; rpr_off += g.recpri_bytes;
     }
-    if (writer.joinable()) writer.join();
+    writer.join();
     if (wbad) croak("USR: Error writing output");
     if (of != stdout) fclose(of); else fflush(stdout);
 }
@@ -657,6 +682,7 @@ int main(int argc, char** argv) {
     }
     if (fil.empty()) { fprintf(stderr, "Missing essential argument: -f\n"); exit(1); }
 
+    try {
     std::string err;
     if (statistics) {                                                  // config.cpp:76-85
         sfqc::Archive a;
@@ -677,6 +703,11 @@ int main(int argc, char** argv) {
     if (o.table_pct) sfq_ctx_set_table_budget(ctx, sfq_ctx_device_memory(ctx) / 100 * (uint64_t)o.table_pct);
     if (g_encode) encode_file(ctx, o, g_usr, fil); else decode_file(ctx, o, g_usr, fil);
     tick("done");
+    } catch (const JobError& e) {                                      // croak(): config.cpp:54-68
+        fprintf(stderr, "slimfastq: %s %s: %s\n", g_encode ? "encoding" : "decoding", g_usr.empty() ? "<< stdin >>" : g_usr.c_str(), e.msg.c_str());
+        fflush(nullptr);
+        _exit(1);
+    }
     // a one-shot process: the driver reclaims the context's 10s of GB faster than freeing them one by one
     fflush(nullptr);
     _exit(0);

@@ -4,8 +4,6 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
-#include <fcntl.h>
-#include <unistd.h>
 #include <algorithm>
 
 #include <cstdio>
@@ -305,7 +303,9 @@ std::vector<uint8_t> pack_block_index(const std::vector<sfq_block_info>& blocks)
     }
     return o;
 }
-bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks) {
+// nstreams: stream sizes per entry -- 10 in archives of block format 7, SFQ_NSTREAMS (14) since format 8
+bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks, int nstreams) {
+    if (nstreams < 1 || nstreams > SFQ_NSTREAMS) return false;
     size_t p = 0; uint64_t n, v;
     if (!get_v(bytes, p, n) || n > (1u << 24)) return false;
     blocks.assign((size_t)n, sfq_block_info());
@@ -321,7 +321,7 @@ bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block
         if (!get_v(bytes, p, v)) return false; b.extra_hi = (uint32_t)v;
         if (!get_v(bytes, p, v)) return false; b.first_hdr_len = (uint32_t)v; b.first_hdr_off = hoff; hoff += v;
         if (!get_v(bytes, p, v)) return false; b.hdr_bytes = (uint32_t)v;
-        for (int s = 0; s < SFQ_NSTREAMS; s++) { if (!get_v(bytes, p, v)) return false; b.size[s] = (uint32_t)v; }
+        for (int s = 0; s < nstreams; s++) { if (!get_v(bytes, p, v)) return false; b.size[s] = v; }
     }
     return true;
 }

@@ -7,7 +7,8 @@
 // from `node` pages of 2047 ids + 1 next-node id.  (filer.hpp:34-42, filer.cpp:41-53, 88-97, 121-128,
 // 217-242, 273-303.)
 //
-// Format 7 (this project's block format) keeps the same container and stream names; every stream is the
+// Formats 7 and 8 (this project's block format; 8 = lossless, with the "gen.lc" stream and 14 stream sizes per index
+// entry) keep the same container and stream names; every stream is the
 // concatenation of its per-block parts, and two extra streams describe the blocks:
 //   "blk.idx" : varint-coded sfq_block_info fields, one entry per block
 //   "blk.hdr" : the blocks' first headers (the reference keeps one in info key "rec.first")
@@ -63,6 +64,6 @@ private:
 
 // block index <-> "blk.idx"
 std::vector<uint8_t> pack_block_index(const std::vector<sfq_block_info>& blocks);
-bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks);
+bool unpack_block_index(const std::vector<uint8_t>& bytes, std::vector<sfq_block_info>& blocks, int nstreams = SFQ_NSTREAMS);
 
 }  // namespace sfqc

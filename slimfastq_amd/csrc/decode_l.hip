@@ -182,10 +182,12 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
     BlockDesc* d = &a.m.blocks[sl.b];
     ByteSrc src = stream_src(a, d, sl.b, SFQ_S_GEN);
     RcDec rc; rc.init(src);
-    XfDec x_ns, x_nn;
+    XfDec x_ns, x_nn, x_lc;
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NS); x_ns.init(s.p, s.n, XF_GEN_NS); }
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NN); x_nn.init(s.p, s.n, XF_GEN_NN); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_LC); x_lc.init(s.p, s.n, XF_GEN_LC); }
     u64 ns_index = x_ns.get(sl.pw), nn_index = x_nn.get(sl.pw);                             // gens.cpp:187-188
+    u64 lc_index = x_lc.get(sl.pw);                                                         // "gen.lc" (block format): absent = 0 = never
     const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
     const u32 code = d->solid ? 0x33323130u /* "0123" */ : 0x54474341u /* "ACGT" */;        // gens.cpp:173-178
     const u32 mask = (1u << d->gen_bits) - 1u;
@@ -216,10 +218,11 @@ __global__ __launch_bounds__(64) void k_gen_decode_l(DecodeArgs a) {
             genofs++;
             if (nn_index == genofs) { nn_index += x_nn.get(sl.pw); ch |= 0x80u; }
             else if (ns_index == genofs) { ch = n_byte; ns_index += x_ns.get(sl.pw); }
+            if (lc_index == genofs) { ch |= 0x20u; lc_index += x_lc.get(sl.pw); }               // a lowercase base (k_assemble carries the bit over to an N made by a quality '!')
             g[i] = (u8)ch;
         }
     }
-    if (rc.err | x_ns.rc.err | x_nn.rc.err) dset_status(d, SFQ_E_CORRUPT);
+    if (rc.err | x_ns.rc.err | x_nn.rc.err | x_lc.rc.err) dset_status(d, SFQ_E_CORRUPT);
 }
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st) {
     const u32 L = decode_lanes();
@@ -249,9 +252,10 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_l(DecodeArgs a) {
     DSlot sl;
     if (!dslot_init(a.m, sl)) return;
     BlockDesc* d = &a.m.blocks[sl.b];
-    XfDec x_ns, x_nn;
+    XfDec x_ns, x_nn, x_lc;
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NS); x_ns.init(s.p, s.n, XF_GEN_NS); }
     { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_NN); x_nn.init(s.p, s.n, XF_GEN_NN); }
+    { ByteSrc s = stream_src(a, d, sl.b, SFQ_S_GEN_LC); x_lc.init(s.p, s.n, XF_GEN_LC); }
     const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
     u8* const g = a.seq_stage + a.soff[d->rec0];
     const u64 nb = a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
@@ -270,7 +274,14 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_l(DecodeArgs a) {
         if (!gap) break;
         at += gap;
     }
-    if (bad | x_ns.rc.err | x_nn.rc.err) dset_status(d, SFQ_E_CORRUPT);
+    for (u64 at = x_lc.get(sl.pw); at; ) {                                                  // "gen.lc": lowercase bases
+        if (at > nb) { bad = 1; break; }
+        g[at - 1] |= 0x20u;
+        const u64 gap = x_lc.get(sl.pw);
+        if (!gap) break;
+        at += gap;
+    }
+    if (bad | x_ns.rc.err | x_nn.rc.err | x_lc.rc.err) dset_status(d, SFQ_E_CORRUPT);
 }
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st) {
     const u32 L = decode_lanes();
@@ -298,7 +309,8 @@ __device__ __forceinline__ u32 merge_n(u32 c, u32 q, u32 nb4) {         // four 
     const u32 keep = ((c >> 7) & 0x01010101u) * 0xFFu;
     const u32 x = q ^ 0x21212121u;
     const u32 bang = ((~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) >> 7) * 0xFFu;
-    return (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & nb4) | (~bang & c)));
+    const u32 low = c & 0x20202020u & ((c & 0x40404040u) >> 1);          // a lowercase letter ("gen.lc"): the N byte it turns into is lowercase too
+    return (c & 0x7F7F7F7Fu & keep) | (~keep & ((bang & (nb4 | low)) | (~bang & c)));
 }
 // A wave lays out `rpw` consecutive records (64 where there are millions of them, one where they are few and long: the host
 // keeps the grid at tens of thousands of waves).  Their bounds are fetched a record per lane (coalesced) and handed round with
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(64) void k_assemble(DecodeArgs a, u64 nrec, u32 rpw
         if (lane < (h & 3u)) { const u8 c = hp[4 * hd + lane]; o_h[4 * hd + lane] = c; if (two) o_2[4 * hd + lane] = c; }
         for (u32 i = 4 * md + lane; i < sl; i += 64) {
             const u32 c = sp[i];
-            o_s[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? n_byte : c);
+            o_s[i] = (u8)((c & 0x80u) ? (c & 0x7fu) : (i < ql && qp[i] == '!') ? (n_byte | (c & 0x20u & ((c & 0x40u) >> 1))) : c);
         }
         if (lane < (ql & 3u)) o_q[4 * qd + lane] = qp[4 * qd + lane];
         if (lane == 0) {

@@ -46,11 +46,12 @@ struct RowHdr {
 #define PR_REC_ROWS   (66 * 16)
 #define PR_XF_BASE    PR_REC_ROWS
 #define PR_XF_ROWS    16
-#define PR_XF_COUNT   8          // gen.Ns gen.Nn rec.x usr.x usr.x.q usr.pfg usr.pfq (+1 spare)
+#define PR_XF_COUNT   12         // gen.Ns gen.Nn rec.x usr.x usr.x.q usr.pfg usr.pfq gen.lc usr.lrec usr.lgen usr.lqlt (+1 spare)
 #define PR_EXQ_ROW    (PR_XF_BASE + PR_XF_ROWS * PR_XF_COUNT)
 #define PR_ROWS       (PR_EXQ_ROW + 8)   // padded
 
-enum { XF_GEN_NS = 0, XF_GEN_NN = 1, XF_REC_X = 2, XF_USR_X = 3, XF_USR_XQ = 4, XF_USR_PFG = 5, XF_USR_PFQ = 6 };
+enum { XF_GEN_NS = 0, XF_GEN_NN = 1, XF_REC_X = 2, XF_USR_X = 3, XF_USR_XQ = 4, XF_USR_PFG = 5, XF_USR_PFQ = 6,
+       XF_GEN_LC = 7, XF_USR_LREC = 8, XF_USR_LGEN = 9, XF_USR_LQLT = 10 };
 
 // ---- per-block descriptor (device) ---------------------------------------------------------------
 struct BlockDesc {
@@ -68,6 +69,34 @@ struct BlockDesc {
     u32 out_cap[SFQ_NSTREAMS];
     u32 hdr_bytes;      // sum of header lengths in the block
 };
+
+// ---- the block format is lossless --------------------------------------------------------------------
+// Where the reference would give back something else than it was given, the block format (sfq_params.block_reads != 0;
+// ModelArgs::lossless) departs from the reference's bytes:
+//  * a header field that numberwang (recs.cpp:192-262) types as a number although RecLoad::load (recs.cpp:430-456) would not
+//    print the same bytes back -- an empty field (prints "0"), a decimal of more than 18 digits ("%lld" wraps or signs it) --
+//    is coded as a string (ST_STR) instead; a header with a NUL inside (map_space stops there, recs.cpp:148) goes whole;
+//  * lowercase bases (accepted gens.cpp:73-77, restored uppercase gens.cpp:171-178) are listed in the side stream "gen.lc";
+//  * a '+' line that is neither empty nor the record's own header (usrs.cpp:236-239 keeps one flag per file) is refused.
+// Format 6 (one block) keeps the reference's behaviour byte for byte.
+// rec_number_prints_back: does a field of `len` bytes (first byte `c0`) typed as the number type `type` print back?
+__device__ __forceinline__ bool rec_number_prints_back(u32 type, u32 len, u32 c0) {
+    if (len == 0) return false;                                  // recs.cpp:209-210 types it decimal 0; recs.cpp:453-454 prints "0"
+    const bool deci = type < 2u /* ST_STR */ || type >= 11u /* ST_DGT_Z */;
+    const u32 digits = len - (c0 == '0' ? 1u : 0u);
+    return !(deci && digits > 18u);                              // 10^18 < 2^63: no wrap in numberwang's loop, no sign from "%lld"
+}
+// the '+' line of record r: empty (two_id == 0) or the record's header again (two_id != 0); anything else the reference
+// would replace by one of the two (usrs.cpp:236-239, 518-523)
+__device__ __forceinline__ bool plus_line_is_regular(const u8* fq, const u64* line_off, u64 r, u32 two_id) {
+    const u64 h0 = line_off[4 * r] + 1, h1 = line_off[4 * r + 1] - 1;
+    const u64 p0 = line_off[4 * r + 2] + 1, p1 = line_off[4 * r + 3] - 1;
+    if (!two_id) return p1 == p0;
+    if (p1 - p0 != h1 - h0) return false;
+    for (u64 i = 0; i < h1 - h0; i++) if (fq[h0 + i] != fq[p0 + i]) return false;
+    return true;
+}
+__device__ __forceinline__ bool is_lower_base(u32 c) { return c == 'a' || c == 'c' || c == 'g' || c == 't' || c == 'n'; }
 
 // character of a base line -> code (gens.cpp:72-77): 0..3, N-like -> 4, illegal -> 0x10
 __device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0..3, N-like -> 4, illegal -> 0x10

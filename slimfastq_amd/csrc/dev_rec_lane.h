@@ -48,6 +48,7 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
         SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
         bool shape = mi.len != mp.len;
         if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
+        if (a.lossless && mi.str[mi.len - 1] == 0) shape = true;              // a NUL inside: the fields behind it would be lost (dev_common.h)
         if constexpr (C::inband) cd.put(REC_FLAG_ROW, shape ? 1u : 0u);
         if (shape) {                                                          // recs.cpp:292-305
             if constexpr (C::inband) {
@@ -71,6 +72,7 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
                 const u8* bp = buf + mi.off[i];
                 u64 bnum;
                 u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                if (a.lossless && type != ST_STR && !rec_number_prints_back(type, mi.wln[i], bp[0])) type = ST_STR;
                 const u32 rr = (i + 1) * 16;
                 if (type == ST_STR) {                                         // recs.cpp:324-331
                     cd.put(rr + 0, type);

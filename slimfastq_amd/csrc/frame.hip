@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void k_block_prepare(const u8* fq, const u64* l
     // scratch-arena regions: sized from the block's text bytes (overflow is detected, never silent)
     const u64 t0 = l0, t1 = line_off[4 * rend];
     const u64 bb = t1 - t0;
-    u64 off = (t0 * 8 + (u64)b * 1024 + 15) & ~15ull;          // the ten caps below add up to 7.75 bb + 640, 16-byte rounding included < 8 bb + 1024
+    u64 off = (t0 * 17 / 2 + (u64)b * 1024 + 15) & ~15ull;     // the caps below add up to 8.25 bb + 704, 16-byte rounding included < 8.5 bb + 1024 (api.cpp sizes the arena)
     const u32 caps[SFQ_NSTREAMS] = {
         (u32)(bb + bb / 2 + 64),   // rec
         (u32)(bb * 3 / 4 + 64),    // gen
@@ -246,7 +246,9 @@ __global__ __launch_bounds__(64) void k_block_prepare(const u8* fq, const u64* l
         (u32)(bb / 2 + 64),        // usr.x
         (u32)(bb / 2 + 64),        // usr.x.q
         (u32)(bb / 4 + 64),        // usr.pfg
-        (u32)(bb / 4 + 64) };      // usr.pfq
+        (u32)(bb / 4 + 64),        // usr.pfq
+        (u32)(bb / 2 + 64),        // gen.lc
+        0, 0, 0 };                 // usr.lrec / usr.lgen / usr.lqlt: the oversize pass has regions of its own (api.cpp)
     for (int s = 0; s < SFQ_NSTREAMS; s++) {
         d.size[s] = 0; d.out_off[s] = off; d.out_cap[s] = caps[s];
         off += (caps[s] + 15u) & ~15u;

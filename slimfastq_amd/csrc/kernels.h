@@ -12,6 +12,7 @@ struct ModelArgs {
     u32 batch0, nbatch;     // this launch covers blocks [batch0, batch0+nbatch)
     u8* arena;              // per-block stream regions (BlockDesc::out_off/out_cap)
     i32 level;
+    u32 lossless;           // the block format's rules (dev_common.h): string fallback for header numbers, "gen.lc", the '+' line check
     u32 epoch_base;         // block b runs with epoch epoch_base + b + 1
     // tables
     u32* q_slots; RowHdr* q_hdr; u32 q_rows;     // Log64 rows per slot: 4096 (level 1) or 65536

@@ -18,6 +18,7 @@
 struct GenChains {                    // per-chain state, lane j = chain j
     u32 act, b, k, nrec, rec0l, rec0h, base, carry, mask, solid;
     u32 gl, gh, nsl, nsh, nnl, nnh;   // g_genofs_count, m_last.{Ns,Nn}_index (block-relative), 64 bit each
+    u32 lcl, lch;                     // the last lowercase base listed in "gen.lc" (block format only)
     u32 nbyte, bad;
 };
 
@@ -32,6 +33,7 @@ __device__ __forceinline__ u32 gen_window(const ModelArgs& a, GenChains& g, u32 
     const u32 carry = base ? CGET(g.carry, j) : 0x007616c7u;                          // gens.cpp:139
     u64 genofs = ((u64)CGET(g.gh, j) << 32) | CGET(g.gl, j);
     u64 ns_index = ((u64)CGET(g.nsh, j) << 32) | CGET(g.nsl, j), nn_index = ((u64)CGET(g.nnh, j) << 32) | CGET(g.nnl, j);
+    u64 lc_index = ((u64)CGET(g.lch, j) << 32) | CGET(g.lcl, j);
     u32 n_byte = CGET(g.nbyte, j), bad = CGET(g.bad, j);
 
     const u32 m = llen - base < 64 ? llen - base : 64;
@@ -54,10 +56,21 @@ __device__ __forceinline__ u32 gen_window(const ModelArgs& a, GenChains& g, u32 
             if (lane == 0) xf[1].put(pw, pos - nn_index);
             nn_index = pos;
         } else {
-            const u32 ch = rl(gch, bit);
+            u32 ch = rl(gch, bit);
+            if (a.lossless && ch == 'n') ch = 'N';                                    // its case travels in "gen.lc"
             if (!n_byte) n_byte = ch;
             if (ch != n_byte) bad = (u32)(-SFQ_E_GENCHAR);
             if (!is_q) { if (lane == 0) xf[0].put(pw, pos - ns_index); ns_index = pos; }
+        }
+    }
+    if (a.lossless) {                                                                 // lowercase bases: "gen.lc" (dev_common.h)
+        u64 ml = __ballot(in && is_lower_base(gch));
+        while (ml) {
+            const u32 bit = (u32)__ffsll((long long)ml) - 1u;
+            ml &= ml - 1;
+            const u64 pos = genofs + bit + 1;
+            if (lane == 0) xf[2].put(pw, pos - lc_index);
+            lc_index = pos;
         }
     }
     genofs += m;
@@ -97,6 +110,7 @@ __device__ __forceinline__ u32 gen_window(const ModelArgs& a, GenChains& g, u32 
     CSET(g.gl, j, (u32)genofs); CSET(g.gh, j, (u32)(genofs >> 32));
     CSET(g.nsl, j, (u32)ns_index); CSET(g.nsh, j, (u32)(ns_index >> 32));
     CSET(g.nnl, j, (u32)nn_index); CSET(g.nnh, j, (u32)(nn_index >> 32));
+    CSET(g.lcl, j, (u32)lc_index); CSET(g.lch, j, (u32)(lc_index >> 32));
     CSET(g.nbyte, j, n_byte); CSET(g.bad, j, bad);
     return m;
 }
@@ -105,12 +119,12 @@ template <int K>
 __global__ __launch_bounds__(64) void k_gen_encode_k(ModelArgs a, u32* ticket) {
     constexpr u32 LPC = 64 / K;                        // lanes per chain
     __shared__ uint4 trip[K][64];
-    __shared__ XfEnc xfs[K][2];                        // [chain][0 = gen.Ns, 1 = gen.Nn]: side-stream coders, used by lane 0
+    __shared__ XfEnc xfs[K][3];                        // [chain][0 = gen.Ns, 1 = gen.Nn, 2 = gen.lc]: side-stream coders, used by lane 0
     const u32 lane = threadIdx.x, h = lane / LPC;
     const bool lead = (lane % LPC) == 0;
     MultiCoder dc; dc.lo = 0; dc.vr = 0xFFFFFFFFu; dc.acc = 0; dc.pos = 0; dc.cap = 0; dc.outp = nullptr; dc.err = 0;
     GenChains g; g.act = 0; g.b = g.k = g.nrec = g.rec0l = g.rec0h = g.base = g.carry = g.mask = g.solid = 0;
-    g.gl = g.gh = g.nsl = g.nsh = g.nnl = g.nnh = g.nbyte = g.bad = 0;
+    g.gl = g.gh = g.nsl = g.nsh = g.nnl = g.nnh = g.lcl = g.lch = g.nbyte = g.bad = 0;
     bool drained = false;                              // the ticket counter ran out
     for (;;) {
         // (re)fill idle chains with new blocks
@@ -125,6 +139,7 @@ __global__ __launch_bounds__(64) void k_gen_encode_k(ModelArgs a, u32* ticket) {
             CSET(g.rec0l, j, (u32)rec0); CSET(g.rec0h, j, (u32)(rec0 >> 32));
             CSET(g.base, j, 0u); CSET(g.solid, j, (u32)d->solid); CSET(g.mask, j, (1u << d->gen_bits) - 1u);
             CSET(g.gl, j, 0u); CSET(g.gh, j, 0u); CSET(g.nsl, j, 0u); CSET(g.nsh, j, 0u); CSET(g.nnl, j, 0u); CSET(g.nnh, j, 0u);
+            CSET(g.lcl, j, 0u); CSET(g.lch, j, 0u);
             CSET(g.nbyte, j, 0u); CSET(g.bad, j, 0u);
             // Base2Ranger rows start at 3,3,3,3 (base2_ranger.hpp:68-71)
             u32* tab = a.g_tab + (((size_t)blockIdx.x * K + j) << a.g_bits);
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(64) void k_gen_encode_k(ModelArgs a, u32* ticket) {
             if (lane == 0) {
                 xfs[j][0].init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
                 xfs[j][1].init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+                xfs[j][2].init(a.arena + d->out_off[SFQ_S_GEN_LC], d->out_cap[SFQ_S_GEN_LC], XF_GEN_LC);
             }
             dc.reset(h == j, a.arena + d->out_off[SFQ_S_GEN], d->out_cap[SFQ_S_GEN]);
         }
@@ -169,8 +185,10 @@ __global__ __launch_bounds__(64) void k_gen_encode_k(ModelArgs a, u32* ticket) {
                 d->size[SFQ_S_GEN] = size;
                 d->size[SFQ_S_GEN_NS] = xfs[j][0].finish(pw);
                 d->size[SFQ_S_GEN_NN] = xfs[j][1].finish(pw);
-                if (size > cap || xfs[j][0].sink.pos > xfs[j][0].sink.cap || xfs[j][1].sink.pos > xfs[j][1].sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-                if (cerr | xfs[j][0].rc.err | xfs[j][1].rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+                d->size[SFQ_S_GEN_LC] = xfs[j][2].finish(pw);
+                if (size > cap || xfs[j][0].sink.pos > xfs[j][0].sink.cap || xfs[j][1].sink.pos > xfs[j][1].sink.cap || xfs[j][2].sink.pos > xfs[j][2].sink.cap)
+                    atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+                if (cerr | xfs[j][0].rc.err | xfs[j][1].rc.err | xfs[j][2].rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
                 if (bad) atomicMax(&d->status, bad);
             }
             if (h == j) dc.err = 0;
@@ -204,6 +222,8 @@ __global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
         const u32 solid = d->solid;
         u32 c_llen = d->llen, c_pfg = 0, c_pfq = 0;            // the running values carried from window to window
         u64 i_llen = 0, i_qlen = 0, i_sgen = 0, i_sqlt = 0;
+        const u32 two_id = d->two_id;
+        u32 odd_plus = 0;                                      // block format: a '+' line the reference would not give back (dev_common.h)
         for (u32 k0 = 0; k0 < d->nrec; k0 += 64) {
             const u32 m = d->nrec - k0 < 64 ? d->nrec - k0 : 64;
             const bool in = lane < m;
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
             const u32 sl_len = (u32)(g1 - g0) - solid;
             const u32 ql = (q1 - q0) >= solid ? (u32)(q1 - q0) - solid : 0;
             const u32 cg = solid ? (u32)a.fq[g0] : 0u, cq = solid ? (u32)a.fq[q0] : 0u;
+            if (a.lossless && in && !plus_line_is_regular(a.fq, a.line_off, r, two_id)) odd_plus = 1;
             const u32 p_len = wave_shr1(sl_len, c_llen), p_cg = wave_shr1(cg, c_pfg), p_cq = wave_shr1(cq, c_pfq);
             const u64 mL = __ballot(in && sl_len != p_len), mQ = __ballot(in && ql != sl_len);
             const u64 mG = __ballot(in && solid && cg != p_cg), mS = __ballot(in && solid && cq != p_cq);
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
                 x_sgen.sink.pos > x_sgen.sink.cap || x_sqlt.sink.pos > x_sqlt.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
             if (x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
         }
+        if (odd_plus) atomicMax(&d->status, (u32)(-SFQ_E_UNSUPPORTED));
     }
 }
 void launch_usr_encode_w(const ModelArgs& a, hipStream_t st) {

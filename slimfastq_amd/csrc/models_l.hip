@@ -1,8 +1,7 @@
 // models_l.hip -- lane-per-block kernels: every lane owns one record block and runs that block's
 // serial model + range-coder chains exactly as the reference does on a CPU thread, with the model
 // tables in HBM.  These are the bit-exactness anchor on the device (selected with
-// sfq_params.kernel = 1) and the only decode path so far; the throughput kernels (models_w.hip) must
-// reproduce their bytes.
+// sfq_params.kernel = 1); the throughput kernels (models_w.hip, models_k.hip) must reproduce their bytes.
 //
 //   quality  : QltSave::save_1/2/3, QltLoad::load_1/2/3      qlts.cpp:74-136, 163-234
 //   bases    : GenSave::save_x / normalize_gen, GenLoad      gens.cpp:91-159, 200-249
@@ -110,12 +109,13 @@ __global__ __launch_bounds__(64) void k_gen_encode_l(ModelArgs a) {
     BlockDesc* d = &a.blocks[sl.b];
     ByteSink snk = { a.arena + d->out_off[SFQ_S_GEN], 0, d->out_cap[SFQ_S_GEN] };
     RcEnc rc; rc.init();
-    XfEnc x_ns, x_nn;
+    XfEnc x_ns, x_nn, x_lc;
     x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
     x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+    x_lc.init(a.arena + d->out_off[SFQ_S_GEN_LC], d->out_cap[SFQ_S_GEN_LC], XF_GEN_LC);
     const u32 solid = d->solid;
     const u32 mask = (1u << d->gen_bits) - 1u;
-    u64 genofs = 0, ns_index = 0, nn_index = 0;       // g_genofs_count, m_last.{Ns,Nn}_index (block-relative)
+    u64 genofs = 0, ns_index = 0, nn_index = 0, lc_index = 0;       // g_genofs_count, m_last.{Ns,Nn}_index (block-relative); the last "gen.lc" entry
     u32 n_byte = 0; int bad = 0;
     for (u64 r = d->rec0; r < d->rec0 + d->nrec; r++) {
         const u64 g0 = a.line_off[4 * r + 1] + solid, g1 = a.line_off[4 * r + 2] - 1;
@@ -124,8 +124,12 @@ __global__ __launch_bounds__(64) void k_gen_encode_l(ModelArgs a) {
         const u8* gp = a.fq + g0; const u8* qp = a.fq + q0;
         u32 last = 0x007616c7u;                                                   // gens.cpp:139
         for (u32 i = 0; i < llen; i++) {
-            const u32 gch = gp[i];
+            u32 gch = gp[i];
             const u32 qch = (i < qlen) ? qp[i] : 40u;                             // gens.cpp:153
+            if (a.lossless && is_lower_base(gch)) {                               // block format: the case goes to "gen.lc" (dev_common.h)
+                x_lc.put(sl.pw, genofs + 1 - lc_index); lc_index = genofs + 1;
+                if (gch == 'n') gch = 'N';
+            }
             u32 n = gencode(gch);                                                 // normalize_gen gens.cpp:116-136
             const bool bad_q = qch == '!';
             bool bad_n = false;
@@ -149,8 +153,9 @@ __global__ __launch_bounds__(64) void k_gen_encode_l(ModelArgs a) {
     finish_stream(d, SFQ_S_GEN, snk, rc.err);
     d->size[SFQ_S_GEN_NS] = x_ns.finish(sl.pw);
     d->size[SFQ_S_GEN_NN] = x_nn.finish(sl.pw);
-    if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) set_status(d, SFQ_E_OVERFLOW);
-    if (x_ns.rc.err | x_nn.rc.err) set_status(d, SFQ_E_CORRUPT);
+    d->size[SFQ_S_GEN_LC] = x_lc.finish(sl.pw);
+    if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap || x_lc.sink.pos > x_lc.sink.cap) set_status(d, SFQ_E_OVERFLOW);
+    if (x_ns.rc.err | x_nn.rc.err | x_lc.rc.err) set_status(d, SFQ_E_CORRUPT);
     if (bad) set_status(d, bad);
 }
 void launch_gen_encode_l(const ModelArgs& a, hipStream_t st) {
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(64) void k_usr_encode_l(ModelArgs a) {
         }
         const u32 ql = (q1 - q0) >= solid ? (u32)(q1 - q0) - solid : 0;
         if (ql != llen) { x_qlen.put(sl.pw, rcnt - i_qlen); x_qlen.put(sl.pw, ql); i_qlen = rcnt; }   // usrs.cpp:371-372
+        if (a.lossless && !plus_line_is_regular(a.fq, a.line_off, r, d->two_id)) set_status(d, SFQ_E_UNSUPPORTED);   // dev_common.h
     }
     d->size[SFQ_S_USR_X]   = x_llen.finish(sl.pw);
     d->size[SFQ_S_USR_XQ]  = x_qlen.finish(sl.pw);

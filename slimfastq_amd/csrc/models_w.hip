@@ -246,12 +246,13 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
         WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
         pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = PR_XF_BASE + XF_GEN_NS * PR_XF_ROWS; pw.hn = 2;
         if (lane < 2) hot_hdr[lane].epoch = 0;             // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
-        XfEncW x_ns, x_nn;                                 // the whole wave codes a gap: lane = four slots of the PowerRanger row
+        XfEncW x_ns, x_nn, x_lc;                           // the whole wave codes a gap: lane = four slots of the PowerRanger row
         x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
         x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+        x_lc.init(a.arena + d->out_off[SFQ_S_GEN_LC], d->out_cap[SFQ_S_GEN_LC], XF_GEN_LC);
         const u32 solid = d->solid;
         const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
-        u64 genofs = 0, ns_index = 0, nn_index = 0;
+        u64 genofs = 0, ns_index = 0, nn_index = 0, lc_index = 0;
         u32 n_byte = 0; int bad = 0;
         // 64 records a step: lane = record; the base offsets of the marked ones come from a wave scan over the line lengths.
         // A marked record is taken 256 bases at a time (four loads per lane in flight).
@@ -321,10 +322,21 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
                             x_nn.put(pw, pos - nn_index, lane);
                             nn_index = pos;
                         } else {
-                            const u32 ch = rl(gch[u], bit);
+                            u32 ch = rl(gch[u], bit);
+                            if (a.lossless && ch == 'n') ch = 'N';                    // its case travels in "gen.lc"
                             if (!n_byte) n_byte = ch;
                             if (ch != n_byte) bad = SFQ_E_GENCHAR;
                             if (!is_q) { x_ns.put(pw, pos - ns_index, lane); ns_index = pos; }
+                        }
+                    }
+                    if (a.lossless) {                                                 // lowercase bases: "gen.lc" (dev_common.h)
+                        u64 ml = __ballot(in && is_lower_base(gch[u]));
+                        while (ml) {
+                            const u32 bit = (u32)__ffsll((long long)ml) - 1u;
+                            ml &= ml - 1;
+                            const u64 pos = genofs + bit + 1;
+                            x_lc.put(pw, pos - lc_index, lane);
+                            lc_index = pos;
                         }
                     }
                     genofs += m;
@@ -333,13 +345,14 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
           }
           genofs = genofs0 + rl(incl, 63);
         }
-        const u32 sz_ns = x_ns.finish(pw, lane), sz_nn = x_nn.finish(pw, lane);
+        const u32 sz_ns = x_ns.finish(pw, lane), sz_nn = x_nn.finish(pw, lane), sz_lc = x_lc.finish(pw, lane);
         if (lane == 0) {
             d->n_byte = n_byte;
             d->size[SFQ_S_GEN_NS] = sz_ns;
             d->size[SFQ_S_GEN_NN] = sz_nn;
-            if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
-            if (x_ns.rc.err | x_nn.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+            d->size[SFQ_S_GEN_LC] = sz_lc;
+            if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap || x_lc.sink.pos > x_lc.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (x_ns.rc.err | x_nn.rc.err | x_lc.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
             if (bad) atomicMax(&d->status, (u32)(-bad));
         }
     }
@@ -360,9 +373,10 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_w(DecodeArgs a) {
     const u32 b = a.m.batch0 + t;
     BlockDesc* d = &a.m.blocks[b];
     WavePw pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
-    XfDecW x_ns, x_nn;
+    XfDecW x_ns, x_nn, x_lc;
     x_ns.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_NS], d->size[SFQ_S_GEN_NS], XF_GEN_NS);
     x_nn.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_NN], d->size[SFQ_S_GEN_NN], XF_GEN_NN);
+    x_lc.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_LC], d->size[SFQ_S_GEN_LC], XF_GEN_LC);
     const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
     u8* const g = a.seq_stage + a.soff[d->rec0];
     const u64 nb = a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
@@ -381,7 +395,15 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_w(DecodeArgs a) {
         if (!gap) break;
         at += gap;
     }
-    if (lane == 0 && (bad | x_ns.rc.err | x_nn.rc.err)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    // "gen.lc": the lowercase bases (bit 5; k_assemble carries it over to an N that a quality '!' makes, decode_l.hip merge_n)
+    for (u64 at = x_lc.get(pw, lane); at; ) {
+        if (at > nb) { bad = 1; break; }
+        if (lane == 0) g[at - 1] |= 0x20u;
+        const u64 gap = x_lc.get(pw, lane);
+        if (!gap) break;
+        at += gap;
+    }
+    if (lane == 0 && (bad | x_ns.rc.err | x_nn.rc.err | x_lc.rc.err)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_exc_decode_w, dim3(a.m.nbatch), dim3(64), 0, st, a);
@@ -429,6 +451,7 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
         SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
         bool shape = mi.len != mp.len;
         if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
+        if (a.lossless && mi.str[mi.len - 1] == 0) shape = true;              // a NUL inside (dev_common.h)
         if (shape) {                                                          // recs.cpp:292-305
             x_rec.put(pw, record_count - last_index, lane);
             last_index = record_count;
@@ -446,6 +469,7 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
                 const u8* bp = buf + mi.off[i];
                 u64 bnum;
                 u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                if (a.lossless && type != ST_STR && !rec_number_prints_back(type, mi.wln[i], bp[0])) type = ST_STR;
                 const u32 rr = (i + 1) * 16;
                 if (type == ST_STR) {                                         // recs.cpp:324-331
                     pw.put(rr + 0, rc, snk, type, lane);
@@ -584,7 +608,7 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
             pb = cb; psep = sepc; pspos = spos; pnf = nf;
             continue;
         }
-        const bool shape = nf != pnf || __ballot(lane < nf && sepc != psep) != 0;
+        const bool shape = nf != pnf || __ballot(lane < nf && sepc != psep) != 0 || (a.lossless && (nul0 | nul1) != 0);
         if (shape) {                                      // recs.cpp:292-305
             x_rec.put(pw, record_count - last_index, lane);
             last_index = record_count;
@@ -621,6 +645,7 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
             const u32 off = rl(offv, i), wln = rl(wlnv, i), pct = rl(ct, i);
             u64 bnum;
             u32 type = nw_lanes(cb, off, (int)wln, bnum, pct);
+            if (a.lossless && type != ST_STR && !rec_number_prints_back(type, wln, cb.at(off))) type = ST_STR;
             const u32 rr = (i + 1) * 16;
             if (type == ST_STR) {                         // recs.cpp:324-331
                 pw.put(rr + 0, rc, snk, type, lane);

@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(capi.EXPORTS) == syms
-    assert L.sfq_abi_version() == 2
+    assert L.sfq_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Params) == 40
-    assert ctypes.sizeof(capi.BlockInfo) == 88
-    assert ctypes.sizeof(capi.Result) == 8 + 4 + 4 + 80 + 80 + 8 + 8 + 4 + 4 + 64 + 32
+    assert ctypes.sizeof(capi.BlockInfo) == 8 + 4 + 4 + 4 + 4 + 4 + 4 + 8 + 8 * 14 + 4 + 4
+    assert ctypes.sizeof(capi.Result) == 8 + 4 + 4 + 112 + 112 + 8 + 8 + 4 + 4 + 64 + 32
     assert [capi.lib().sfq_stream_name(i).decode() for i in range(capi.NSTREAMS)] == capi.STREAM_NAMES
 
 

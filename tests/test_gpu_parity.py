@@ -52,14 +52,15 @@ def test_single_block_equals_reference_golden(ctx, name, kernel):
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_blocks_equal_reference_run_per_chunk(ctx, kernel):
     """The block format's definition: block b's streams == the reference's streams for a FASTQ holding
-    only that block's records (counters restart per block)."""
+    only that block's records (counters restart per block) -- with the lossless rules where the reference would alter
+    the text (util.block_reference; none of them applies to this input)."""
     fq = capi.synth_fastq(5300, 150, seed=21)
     for level, br in ((3, 1000), (1, 2500), (4, 700)):
         enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel)
         chunks = util.split_records(fq, br)
         assert enc.res.n_blocks == len(chunks)
         for b, chunk in enumerate(chunks):
-            want = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            want = util.block_reference(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, want, block=b, ctxmsg="level %d block %d" % (level, b))
             assert enc.blocks[b].n_records == chunk.count(b"\n") // 4
 
@@ -71,7 +72,7 @@ def test_blocks_on_real_samples(ctx, name):
     br = max(2, nrec // 7)
     enc = ctx.encode_host(fq, level=3, block_reads=br)
     for b, chunk in enumerate(util.split_records(fq, br)):
-        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        want = util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
         assert_streams_equal(enc, want, block=b, ctxmsg="%s block %d" % (name, b))
 
 
@@ -169,6 +170,87 @@ def test_reads_beyond_the_reference_line_limit(ctx):
     with pytest.raises(capi.SfqError) as e:
         ctx.encode_host(fq, level=3, block_reads=0)
     assert e.value.code == -7          # SFQ_E_UNSUPPORTED
+
+
+def _quirk_fastq(n, seed, mixed_n=True):
+    """Everything the reference gives back altered: lowercase bases (soft-masked stretches, single ones, 'n' with
+    and without quality '!'), a header field that becomes empty, numbers of 19 and 20 digits, a field of value 0 after a
+    larger one, a NUL inside a header.  mixed_n: both 'n' and 'N' occur (the reference aborts on that: "switched N_byte",
+    gens.cpp:107-108; the block format lists the lowercase ones in "gen.lc")."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(40, 180))
+        seq = rng.choice(list("ACGT"), ln)
+        qual = rng.integers(2, 41, ln)
+        k = rng.random()
+        if k < 0.3:                                                   # a soft-masked stretch
+            a = int(rng.integers(0, ln)); b = int(rng.integers(a, ln + 1))
+            seq[a:b] = np.char.lower(seq[a:b])
+        elif k < 0.5:
+            seq = np.where(rng.random(ln) < 0.1, np.char.lower(seq), seq)
+        nmask = rng.random(ln) < 0.04
+        seq = np.where(nmask, np.where((rng.random(ln) < 0.5) & mixed_n, "n", "N"), seq)
+        qual = np.where(nmask & (rng.random(ln) < 0.6), 0, qual)
+        qual = np.where(~nmask & (rng.random(ln) < 0.02), 0, qual)       # a real (maybe lowercase) base under quality '!'
+        h = rng.random()
+        if h < 0.05: hdr = "q%d::%d" % (i, i * 3)                     # an empty field
+        elif h < 0.10: hdr = "q%d:%d:%d" % (i, 9223372036854775800 + int(rng.integers(0, 9)), i)      # 19 digits, >= 2^63 - 8
+        elif h < 0.15: hdr = "q%d:%d:%d" % (i, 18446744073709551000 + i, i)                            # 20 digits
+        elif h < 0.20: hdr = "q%d:0:%d" % (i, i)
+        elif h < 0.22: hdr = "q%d:a\0b:%d" % (i, i)                   # a NUL inside
+        else: hdr = "q%d:%d:%d" % (i, 1000 + (i * 7) % 50, i)
+        out += ["@" + hdr, "".join(seq), "+", "".join(chr(33 + int(q)) for q in qual)]
+    return ("\n".join(out) + "\n").encode("latin1")
+
+
+@pytest.mark.parametrize("tables", (capi.TABLES_FROZEN, capi.TABLES_ADAPTIVE))
+def test_block_format_is_lossless_where_the_reference_is_not(ctx, tables):
+    """SURVEY H7 / VERDICT r02 item 1: decode(encode(x)) == x in the block format for the inputs the reference mangles; every
+    block's side streams (and, with adaptive tables, all of its streams) are the oracle's lossless restatement; format 6
+    (-B 0) keeps the reference's bytes AND its restoration."""
+    fq = _quirk_fastq(3000, 9)
+    with pytest.raises(O.OracleError):                                    # 'n' and 'N' in one file: the reference gives up
+        O.compress(fq, 3)
+    br = 256
+    for kernel in ((0,) if tables == capi.TABLES_FROZEN else (0, 1)):
+        enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=tables, chain_reads=40, kernel=kernel)
+        assert enc.res.stream_bytes[capi.STREAM_NAMES.index("gen.lc")] > 0
+        for b, chunk in enumerate(util.split_records(fq, br)):
+            want = util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+            names = ("gen.Ns", "gen.Nn", "gen.lc", "usr.x", "usr.x.q") if tables == capi.TABLES_FROZEN else [n for n in capi.STREAM_NAMES if n != "qlt"]
+            for name in names:                                              # (the quality rows start from the prior: not the cold reference's)
+                assert enc.stream(name, b) == want.get(name, b""), (kernel, b, name)
+        assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq, kernel
+    # format 6: the reference's streams, the reference's restoration (and its refusal of 'n' beside 'N')
+    with pytest.raises(capi.SfqError) as e:
+        ctx.encode_host(fq, level=3, block_reads=0)
+    assert e.value.code == -8
+    fq = _quirk_fastq(3000, 9, mixed_n=False)
+    ref = O.compress(fq, 3)
+    assert O.decompress(ref.image) != fq                                  # the reference is lossy on this input
+    leg = ctx.encode_host(fq, level=3, block_reads=0)
+    assert_streams_equal(leg, ref.streams, ctxmsg="quirks, one block")
+    assert ctx.decode_host(leg, level=3, out_cap=2 * len(fq) + 4096) == O.decompress(ref.image)
+
+
+def test_block_format_refuses_a_plus_line_it_could_not_give_back(ctx):
+    """The reference keeps ONE flag for the '+' line (usrs.cpp:236-239): a second id that differs from the first comes back
+    as the first, a '+' line of blanks comes back empty.  The block format refuses such a record (SFQ_E_UNSUPPORTED) instead
+    of altering it; a second id that repeats the header round-trips."""
+    ok = b"@a 1\nACGT\n+a 1\nIIII\n@b 2\nACGT\n+b 2\nIIII\n"
+    for tables in (capi.TABLES_FROZEN, capi.TABLES_ADAPTIVE):
+        enc = ctx.encode_host(ok, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=tables)
+        assert enc.blocks[0].two_id == 1 and ctx.decode_host(enc, level=3, out_cap=4096) == ok
+        for bad in (b"@a 1\nACGT\n+a 1\nIIII\n@b 2\nACGT\n+b 3\nIIII\n", b"@a 1\nACGT\n+a 1\nIIII\n@b 2\nACGT\n+\nIIII\n",
+                    b"@a 1\nACGT\n+\nIIII\n@b 2\nACGT\n+b 2\nIIII\n", b"@a 1\nACGT\n+ \nIIII\n"):
+            with pytest.raises(capi.SfqError) as e:
+                ctx.encode_host(bad, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=tables)
+            assert e.value.code == -7, bad
+    # format 6 takes them, the reference's way
+    bad = b"@a 1\nACGT\n+a 1\nIIII\n@b 2\nACGT\n+b 3\nIIII\n"
+    leg = ctx.encode_host(bad, level=3, block_reads=0)
+    assert ctx.decode_host(leg, level=3, out_cap=4096) == O.decompress(O.compress(bad, 3).image) != bad
 
 
 def test_corrupt_archives_fail_cleanly_or_decode_to_something(ctx):
@@ -275,7 +357,7 @@ def test_low_complexity_bases_same_context_in_one_window(ctx, kernel):
     for level, br in ((1, 0), (3, 0), (4, 0), (3, 64)):
         enc = ctx.encode_host(fq, level=level, block_reads=br, kernel=kernel)
         for b, chunk in enumerate(util.split_records(fq, br) if br else [fq]):
-            want = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            want = util.block_reference(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, want, block=b, ctxmsg="lowcomplexity l%d b%d" % (level, b))
         assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
 
@@ -344,7 +426,7 @@ def test_warm_start_prior_matches_oracle_rule(ctx, level, kernel):
     # the other streams are untouched by the prior: still the reference's per-chunk result
     chunks = util.split_records(fq, br)
     for b in (0, len(chunks) - 1):
-        ref = O.compress(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
+        ref = util.block_reference(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
         assert enc.stream("gen", b) == ref["gen"] and enc.stream("rec", b) == ref["rec"]
     assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
     # and it pays: within a fraction of a percent of the whole-file (reference) quality stream
@@ -382,7 +464,7 @@ def test_headers_longer_than_one_wave_of_bytes(ctx, kernel):
     fq2 = b"\n".join(lines)
     enc = ctx.encode_host(fq2, level=3, block_reads=600, kernel=kernel)
     for b, chunk in enumerate(util.split_records(fq2, 600)):
-        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        want = util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
         assert_streams_equal(enc, want, block=b, ctxmsg="mixed headers block %d" % b)
     assert ctx.decode_host(enc, level=3, out_cap=len(fq2) + 4096) == fq2
 
@@ -411,7 +493,7 @@ def test_small_table_budget_forces_batches():
             enc = c.encode_host(fq, level=3, block_reads=400, kernel=kernel, prior_step=2)       # 10 blocks, 3-4 batches
             cold = c.encode_host(fq, level=3, block_reads=400, kernel=kernel)
             for b, chunk in enumerate(util.split_records(fq, 400)):
-                want = O.compress(chunk, 3, gen_bits=cold.blocks[b].gen_bits).streams
+                want = util.block_reference(chunk, 3, gen_bits=cold.blocks[b].gen_bits).streams
                 assert_streams_equal(cold, want, block=b, ctxmsg="batched kernel %d block %d" % (kernel, b))
             assert c.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
             assert c.decode_host(cold, level=3, out_cap=len(fq) + 4096) == fq
@@ -430,7 +512,7 @@ def test_escape_heavy_qualities(ctx, kernel):
     assert sum(c >= 96 for c in lines[3]) > 50
     enc = ctx.encode_host(fq, level=3, block_reads=1000, kernel=kernel)
     for b, chunk in enumerate(util.split_records(fq, 1000)):
-        want = O.compress(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+        want = util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
         assert_streams_equal(enc, want, block=b, ctxmsg="escape-heavy block %d" % b)
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
@@ -466,6 +548,39 @@ def test_cli_slabs_make_segments_and_batch_mode(tmp_path):
     assert [l.split("\t")[0] for l in lines] == ["ok", "fail", "ok"] and p.returncode == 2
     p = subprocess.run([cli, "-b", "-d", "-O"], input=("%s\t%s\n" % (tmp_path / "b3.sfq", tmp_path / "b3.out")).encode(), capture_output=True)
     assert p.returncode == 0 and (tmp_path / "b3.out").read_bytes() == fq
+
+
+def test_cli_batch_worker_survives_a_damaged_second_segment(tmp_path):
+    """A -b worker decodes a multi-segment archive one segment at a time, the text of a segment written by a thread while
+    the next is decoded.  A segment index that lies about its SECOND segment makes the job croak while that thread is still
+    running: the worker must answer 'fail' for the job (the stack unwinds through guards that join the thread; an unjoined
+    std::thread would call std::terminate) and go on to the next job."""
+    import subprocess
+    from slimfastq_amd import dist_compress as dc
+    cli = _cli()
+    fq = capi.synth_fastq(12000, 150, seed=23)
+    src = tmp_path / "big.fq"; src.write_bytes(fq)
+    good = tmp_path / "good.sfq"
+    subprocess.check_call([cli, "-u", str(src), "-f", str(good), "-O", "-S", "1", "-B", "500"])
+    a = O.parse(good.read_bytes())
+    v = util._vints(a.streams["seg.idx"])
+    assert v[0] >= 3 and len(v) == 1 + 5 * v[0]                 # nblocks, prior, raw, chain, rec.pri bytes per segment
+    v[1 + 5 + 4] += 1 << 20                                      # the second segment claims a megabyte more of "rec.pri" than there is
+    si = bytearray()
+    for x in v:
+        dc.put_v(si, x)
+    info = "".join(l + "\n" for l in a.streams["<info>"].decode("latin1").split("\n") if l and not l.startswith("comp.size="))
+    bad = tmp_path / "bad.sfq"
+    dc.write_archive(str(bad), info, [(k, bytes(si) if k == "seg.idx" else d) for k, d in a.streams.items() if k != "<info>"])
+    jobs = "%s\t%s\n%s\t%s\n" % (bad, tmp_path / "bad.out", good, tmp_path / "good.out")
+    p = subprocess.run([cli, "-b", "-d", "-O"], input=jobs.encode(), capture_output=True)
+    lines = p.stdout.decode().splitlines()
+    assert [l.split("\t")[0] for l in lines] == ["fail", "ok"] and p.returncode == 2, (p.stdout, p.stderr)
+    assert "segment index" in lines[0]
+    assert (tmp_path / "good.out").read_bytes() == fq
+    # one-shot mode: the same archive ends the process with the reference's wording and exit code, not a crash
+    p = subprocess.run([cli, "-d", "-f", str(bad), "-u", str(tmp_path / "bad2.out"), "-O"], capture_output=True)
+    assert p.returncode == 1 and b"slimfastq: decoding" in p.stderr and b"segment index" in p.stderr
 
 
 def test_multi_file_driver(tmp_path):
@@ -632,10 +747,9 @@ def test_fuzz_small_structurally_hostile_inputs(ctx, seed):
         br = int(rng.integers(1, max(2, nrec // 2 + 1)))
         enc = ctx.encode_host(fq, level=level, block_reads=br)
         for b, chunk in enumerate(util.split_records(fq, br)):
-            wantb = O.compress(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
+            wantb = util.block_reference(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, wantb, block=b, ctxmsg="fuzz seed %d rep %d block %d of %d" % (seed, rep, b, br))
-        back = ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096)
-        assert back == b"".join(O.decompress(O.compress(c, level).image) for c in util.split_records(fq, br))
+        assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == fq          # the block format is lossless
 
 
 @pytest.mark.parametrize("kernel", (1,))

@@ -98,3 +98,27 @@ def test_oracle_vs_compiled_reference_synthetic_and_chunks():
         assert O.compress(chunk, 3).image == O.ref_compress(chunk, 3)
     lr = capi.synth_fastq(6, 0, seed=3, kind=1)
     assert O.compress(lr, 3).image == O.ref_compress(lr, 3)
+
+
+@pytest.mark.skipif(O.ref_binary() is None, reason="compiled reference only exists in the build container")
+def test_pre5_header_stream_is_what_the_reference_decodes():
+    """The oracle's pre-version-5 "rec" encoder (sfqo_rec_encode_pre5) is derived from RecLoad::load_pre5 (recs.cpp:463-510),
+    the only statement of that layout the reference still has.  Pin it: an archive that says version=4 and holds that stream
+    beside the reference's other streams must decode, with the COMPILED REFERENCE, to the text."""
+    from slimfastq_amd import capi, dist_compress as dc
+    import tempfile
+    fq = capi.synth_fastq(1200, 100, seed=44)
+    starts, lens = util.line_table(fq)
+    ref = O.compress(fq, 3)
+    rec4 = O.rec_encode_pre5(fq, starts[0::4] + 1, lens[0::4] - 1)
+    assert rec4 != ref.streams["rec"]
+    info = ref.streams["<info>"].decode("latin1").replace("version=6", "version=4")
+    info = "".join(l + "\n" for l in info.split("\n") if l and not l.startswith("comp.size="))
+    streams = [(k, rec4 if k == "rec" else v) for k, v in ref.streams.items() if k != "<info>"]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "v4.sfq")
+        dc.write_archive(path, info, streams)
+        img = open(path, "rb").read()
+    assert O.parse(img).info["version"] == "4"
+    assert O.ref_decompress(img) == fq                       # the reference itself, through load_pre5
+    assert O.decompress(img) == fq                           # and the oracle's restatement of it

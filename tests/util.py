@@ -147,27 +147,9 @@ def unpack_rec_prior(blob: bytes):
     return f
 
 
-def reference_restoration(fastq: bytes, block_reads: int, level: int, rec_chain_reads: int = 0) -> bytes:
-    """What a decoder of block format 7 must give back: the reference's own restoration of every block coded alone (it is
-    lossy on a few inputs -- lowercase bases, numbers that print with a sign: SURVEY H7).  With header CHAINS
-    (rec_chain_reads != 0) a chain's first header is coded against the block's first header, not against its neighbour, so
-    its restoration is the reference's for the sequence base, chain: the headers are taken from such runs."""
+def block_reference(chunk: bytes, level: int, gen_bits: int = 0):
+    """The oracle's archive for ONE block of the block format: the reference run on a FASTQ holding only that block's
+    records, with the block format's lossless rules (oracle sfqo_opts.lossless: where the reference would alter the text
+    the block format departs from its bytes -- SURVEY H7; everywhere else the two are byte-identical)."""
     from oracle import oracle as O
-    out = []
-    for chunk in split_records(fastq, block_reads):
-        back = O.decompress(O.compress(chunk, level).image)
-        if rec_chain_reads:
-            src = chunk.split(b"\n")[:-1]
-            lines = back.split(b"\n")[:-1]
-            two_id = len(lines[2]) > 1
-            nrec = len(src) // 4
-            for c0 in range(rec_chain_reads, nrec, rec_chain_reads):          # (the block's first chain is the block-wise run's start)
-                recs = src[0:4] + src[4 * c0:4 * min(c0 + rec_chain_reads, nrec)]
-                sub = O.decompress(O.compress(b"\n".join(recs) + b"\n", level).image).split(b"\n")[:-1]
-                for k in range(1, len(sub) // 4):
-                    lines[4 * (c0 + k - 1)] = sub[4 * k]
-                    if two_id:
-                        lines[4 * (c0 + k - 1) + 2] = b"+" + sub[4 * k][1:]
-            back = b"\n".join(lines) + b"\n"
-        out.append(back)
-    return b"".join(out)
+    return O.compress(chunk, level, gen_bits=gen_bits, lossless=True)
