@@ -49,6 +49,9 @@ struct sfq_ctx {
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, excf, cflags;
+    // format 6's oversize records (frame.hip): flags, kept bytes, their scans, the text without them, kept record -> file number, the list;
+    // the file's own line index; decode: numbers, pieces, raw text of the three streams, sizes / offsets in file order
+    DevBuf oflags, okbytes, ofpos, okoff, ofilt, orecmap, olist, line_off_o, ono, opiece, otxt[3], osize_all, oroff_all, oroff_k, ocnt;
     u32 r_hot = 0, r_hot_dec = 0;
     bool blobs_from_encode = false;        // prior_blob / rec_prior_blob / chain_blob are what the last ENCODE left for sfq_get_*:
                                            // a decode never reads those (only what sfq_set_* installed)
@@ -516,7 +519,9 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags };
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags,
+        &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
+        &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin2) (void)hipHostFree(ctx->pin2);
@@ -575,8 +580,9 @@ static int encode_impl(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (rc == SFQ_OK && !priors_only) ctx->blobs_from_encode = true;       // (sfq_build_priors leaves installed priors: SFQ_PRIOR_GIVEN reads them)
     return rc;
 }
-static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_params* pp, u8* d_out, u64 out_cap,
+static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const sfq_params* pp, u8* d_out, u64 out_cap,
                        sfq_result* res, u32 force_models, bool priors_only) {
+    const u8* d_fastq = d_fastq_in; u64 nbytes = nbytes_in;       // (format 6 with oversize records: the text without them, below)
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
@@ -588,12 +594,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
 
     // ---- framing -------------------------------------------------------------------------------
     HIPC(hipEventRecord(ctx->ev[0], st));
-    const u32 nchunks = (u32)((nbytes + FRAME_CHUNK - 1) / FRAME_CHUNK);
-    if ((rc = reserve(ctx, ctx->chunk_counts, (size_t)nchunks * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->chunk_base, ((size_t)nchunks + 1) * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nchunks / 1024 + 4) * 8 + 65536))) return rc;
     if ((rc = reserve(ctx, ctx->status, 256))) return rc;
-    HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
     // the quality sample's counters (16 MiB) are cleared here, ahead of the framing kernels: behind them the memset sat on
     // the quality model's critical path for a millisecond (it shares the chip with the counting passes by then)
     const u32 q_rows0 = p.level == 1 ? (1u << 12) : (1u << 16);
@@ -603,21 +604,88 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows0 * 64 * 4, st));
         hist_cleared = true;
     }
-    launch_count_newlines(d_fastq, nbytes, (u32*)ctx->chunk_counts.p, nchunks, st);
-    launch_scan_u32((const u32*)ctx->chunk_counts.p, (u64*)ctx->chunk_base.p, nchunks, (u64*)ctx->scan_tmp.p, st);
-    u64 nlines = 0; u8 last_byte = 0;
-    HIPC(hipMemcpyAsync(&nlines, (u64*)ctx->chunk_base.p + nchunks, 8, hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(&last_byte, d_fastq + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    if (last_byte != '\n') return fail(ctx, SFQ_E_FORMAT, "fastq file: record seems truncated (no final newline)");   // usrs.cpp:169-172
-    if (nlines == 0 || (nlines & 3)) return fail(ctx, SFQ_E_FORMAT, "fastq file: %llu lines is not a multiple of 4", (unsigned long long)nlines);
-    const u64 nrec = nlines / 4;
-    if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
-    if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
-    launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
-    // format 6 (one block, the reference's own): its line limits, beyond which it writes "oversize" side streams this
-    // library does not; the block format has no such limit on base / quality lines (a block's regions are sized by its text)
-    launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, p.block_reads ? 0x3ffffffeu : 0xfffeu, (u32*)ctx->status.p, st);
+    const bool legacy = p.block_reads == 0;
+    u64 nrec = 0;
+    // the line index of the current text (d_fastq, nbytes) and the per-record checks
+    auto frame = [&]() -> int {
+        int rc;
+        const u32 nchunks = (u32)((nbytes + FRAME_CHUNK - 1) / FRAME_CHUNK);
+        if ((rc = reserve(ctx, ctx->chunk_counts, (size_t)nchunks * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->chunk_base, ((size_t)nchunks + 1) * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nchunks / 1024 + 4) * 8 + 65536))) return rc;
+        HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
+        launch_count_newlines(d_fastq, nbytes, (u32*)ctx->chunk_counts.p, nchunks, st);
+        launch_scan_u32((const u32*)ctx->chunk_counts.p, (u64*)ctx->chunk_base.p, nchunks, (u64*)ctx->scan_tmp.p, st);
+        u64 nlines = 0; u8 last_byte = 0;
+        HIPC(hipMemcpyAsync(&nlines, (u64*)ctx->chunk_base.p + nchunks, 8, hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(&last_byte, d_fastq + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        if (last_byte != '\n') return fail(ctx, SFQ_E_FORMAT, "fastq file: record seems truncated (no final newline)");   // usrs.cpp:169-172
+        if (nlines == 0 || (nlines & 3)) return fail(ctx, SFQ_E_FORMAT, "fastq file: %llu lines is not a multiple of 4", (unsigned long long)nlines);
+        nrec = nlines / 4;
+        if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
+        if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
+        launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
+        // headers up to 8190 bytes (usrs.hpp:34; format 6 sends longer ones to its oversize streams, below), base / quality lines
+        // of any length: the block format codes them the usual way (a block's regions are sized by its text), format 6 has its
+        // oversize streams
+        launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, st);
+        return SFQ_OK;
+    };
+    if ((rc = frame())) return rc;
+    // ---- format 6: the reference's oversize records (usrs.cpp:269-301; frame.hip) ---------------------------------------
+    u64 nrec_file = nrec;                       // records of the file, the oversize ones included ("num_records", usrs.cpp:405)
+    u32 n_over = 0;
+    const u8* d_file = d_fastq;                 // the whole text and its line index (ctx->line_off_o once the text is split)
+    if (legacy) {
+        u32 h4[4] = {0, 0, 0, 0};
+        HIPC(hipMemcpyAsync(h4, ctx->status.p, 16, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        if (h4[0] == 0 && h4[3] != 0) {         // (a format error is reported below, from the same status words)
+            if (nrec > 0xFFFFFFF0ull) return fail(ctx, SFQ_E_UNSUPPORTED, "oversize records in a file of more than 2^32 records");
+            u32* d_first = (u32*)ctx->status.p + 8; u32* d_solid = d_first + 1; u32* d_bad = d_first + 2;
+            u32 init3[3] = { 0xFFFFFFFFu, 0, 0 };
+            HIPC(hipMemcpyAsync(d_first, init3, 12, hipMemcpyHostToDevice, st));
+            launch_over_first((const u64*)ctx->line_off.p, nrec, d_first, st);
+            u32 first = 0;
+            HIPC(hipMemcpyAsync(&first, d_first, 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (first == 0xFFFFFFFFu) return fail(ctx, SFQ_E_UNSUPPORTED, "every record is over the reference's line limits (usrs.cpp:190-197: \"all records were oversized\")");
+            launch_over_solid(d_fastq, (const u64*)ctx->line_off.p, first, d_solid, st);
+            u32 solid = 0;
+            HIPC(hipMemcpyAsync(&solid, d_solid, 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if ((rc = reserve(ctx, ctx->oflags, (size_t)nrec * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->okbytes, (size_t)nrec * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->ofpos, ((size_t)nrec + 1) * 8))) return rc;
+            if ((rc = reserve(ctx, ctx->okoff, ((size_t)nrec + 1) * 8))) return rc;
+            if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
+            launch_over_flags((const u64*)ctx->line_off.p, nrec, solid, (u32*)ctx->oflags.p, (u32*)ctx->okbytes.p, d_bad, st);
+            launch_scan_u32((const u32*)ctx->oflags.p, (u64*)ctx->ofpos.p, nrec, (u64*)ctx->scan_tmp.p, st);
+            launch_scan_u32((const u32*)ctx->okbytes.p, (u64*)ctx->okoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+            u64 h_nover = 0, h_kbytes = 0; u32 h_bad = 0, first_flag = 0;
+            HIPC(hipMemcpyAsync(&h_nover, (u64*)ctx->ofpos.p + nrec, 8, hipMemcpyDeviceToHost, st));
+            HIPC(hipMemcpyAsync(&h_kbytes, (u64*)ctx->okoff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+            HIPC(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipMemcpyAsync(&first_flag, (u32*)ctx->oflags.p + first, 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (h_bad) return fail(ctx, SFQ_E_UNSUPPORTED, "a quality line over 65534 bytes beside a base line within the limit: the reference's own archive of such a record does not decode (usrs.cpp:340-345 run before 372-373)");
+            if (first_flag) return fail(ctx, SFQ_E_UNSUPPORTED, "the first record within determine_record's limits (usrs.cpp:218-229) is oversize for get_record (usrs.cpp:333-338): a base line of exactly 65535 bytes");
+            if (h_nover == nrec) return fail(ctx, SFQ_E_UNSUPPORTED, "every record is over the reference's line limits");
+            if (h_nover) {
+                n_over = (u32)h_nover;
+                if ((rc = reserve(ctx, ctx->ofilt, (size_t)h_kbytes + 16))) return rc;
+                if ((rc = reserve(ctx, ctx->orecmap, (size_t)(nrec - h_nover) * 4 + 16))) return rc;
+                if ((rc = reserve(ctx, ctx->olist, (size_t)h_nover * 4 + 16))) return rc;
+                launch_over_split(d_fastq, (const u64*)ctx->line_off.p, nrec, (const u32*)ctx->oflags.p, (const u64*)ctx->ofpos.p, (const u64*)ctx->okoff.p,
+                                  (u8*)ctx->ofilt.p, (u32*)ctx->orecmap.p, (u32*)ctx->olist.p, st);
+                std::swap(ctx->line_off, ctx->line_off_o);               // the file's line index stays for the oversize pass
+                d_fastq = (const u8*)ctx->ofilt.p; nbytes = h_kbytes;
+                if ((rc = frame())) return rc;                           // the text the models see
+                if (nrec + h_nover != nrec_file) return fail(ctx, SFQ_E_HIP, "oversize split: %llu + %llu records of %llu", (unsigned long long)nrec, (unsigned long long)h_nover, (unsigned long long)nrec_file);
+            }
+        }
+    }
 
     // SFQ_BLOCK_AUTO: blocks of about 376 KiB of text (1024 records of 150 bp; ~6 records of 60 kb): the unit of
     // parallelism is the block, and a fixed record count would leave long-read inputs with a handful of huge blocks
@@ -643,7 +711,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
     if (g_bits < 2 || g_bits > 26 ) return fail(ctx, SFQ_E_ARG, "gen_bits %d out of range", g_bits);
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     launch_block_prepare(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, nblocks, nbytes, p.level, g_bits, st);
-    if ((rc = reserve(ctx, ctx->arena, (size_t)nbytes * 17 / 2 + (size_t)nblocks * 1024 + 4096))) return rc;      // frame.hip k_block_prepare
+    // (format 6 with oversize records: three more regions behind the block's, for "usr.lrec" / "usr.lgen" / "usr.lqlt")
+    const u64 arena_main = (((u64)nbytes * 17 / 2 + (u64)nblocks * 1024 + 4096) + 15) & ~15ull;      // frame.hip k_block_prepare
+    const u64 over_bytes = n_over ? nbytes_in - nbytes : 0;
+    const u64 over_cap = n_over ? ((over_bytes + over_bytes / 4 + 4096 + 15) & ~15ull) : 0;
+    if (over_cap > 0xFFFFFFF0ull) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3.4 GB of oversize records");
+    if ((rc = reserve(ctx, ctx->arena, (size_t)(arena_main + 3 * over_cap)))) return rc;
     u32 h_status2[3] = {0, 0, 0};
     HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 12, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[1], st));
@@ -680,6 +753,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         if ((rc = advance_epoch(ctx, nblocks))) return rc;
         fill_model_args(ctx, a, nblocks, p.level, (u32)g_bits, p.block_reads != 0);          // the block format is lossless (dev_common.h)
         a.fq = d_fastq;
+        a.rec_map = n_over ? (const u32*)ctx->orecmap.p : nullptr;
         // Default kernels are persistent: one workgroup per pair of table slots, blocks handed out through ticket counters.
         if ((rc = reserve(ctx, ctx->tickets, 64))) return rc;
         HIPC(hipMemsetAsync(ctx->tickets.p, 0, 64, st));
@@ -908,6 +982,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
                 }
             }
         }
+        if (order[m] == SFQ_M_USR && n_over) {                     // the oversize records' raw lines: three waves beside everything else
+            const u64 ooff[3] = { arena_main, arena_main + over_cap, arena_main + 2 * over_cap };
+            const u32 ocap[3] = { (u32)over_cap, (u32)over_cap, (u32)over_cap };
+            launch_over_encode_w(a, d_file, (const u64*)ctx->line_off_o.p, (const u32*)ctx->olist.p, n_over, ooff, ocap, mst[m]);
+        }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * m], mst[m]));
         if (m) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
     }
@@ -1021,13 +1100,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq, u64 nbytes, const sfq_pa
         sfq_block_info& bi = ctx->index[b];
         const BlockDesc& d = hb[b];
         memset(&bi, 0, sizeof bi);
-        bi.first_record = d.rec0; bi.n_records = d.nrec; bi.llen = d.llen;
+        bi.first_record = d.rec0; bi.n_records = n_over ? (u32)nrec_file : d.nrec; bi.llen = d.llen;      // (num_records counts the oversize records too, usrs.cpp:405)
         bi.solid = d.solid; bi.two_id = d.two_id; bi.n_byte = (u8)d.n_byte; bi.gen_bits = d.gen_bits;
         bi.extra_hi = d.extra_hi; bi.first_hdr_len = d.first_hdr_len; bi.first_hdr_off = hboff[b];
         for (int s = 0; s < SFQ_NSTREAMS; s++) bi.size[s] = d.size[s];
         bi.status = 0; bi.hdr_bytes = d.hdr_bytes;
     }
-    res->n_records = nrec; res->n_blocks = nblocks; res->first_hdr_bytes = hboff[nblocks];
+    res->n_records = nrec_file; res->n_blocks = nblocks; res->first_hdr_bytes = hboff[nblocks];
     res->kernel_ms[SFQ_T_FRAME] = ev_ms(ctx->ev[0], ctx->ev[1]);
     for (int m = 0; m < 4; m++) res->kernel_ms[tslot[m]] = ev_ms(ctx->ev[2 + 2 * m], ctx->ev[3 + 2 * m]);     // the models overlap: these do not add up
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
@@ -1195,9 +1274,12 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         }
         nrec += bi.n_records;
     }
-    for (u32 b = 0; b < nblocks; b++)
+    // format 6's oversize records (usrs.cpp:269-301): one block, its "usr.lrec" / "usr.lgen" / "usr.lqlt" streams
+    const bool has_over = h_blocks[0].size[SFQ_S_USR_LREC] != 0;
+    for (u32 b = has_over ? 1u : 0u; b < nblocks; b++)
         if (h_blocks[b].size[SFQ_S_USR_LREC] | h_blocks[b].size[SFQ_S_USR_LGEN] | h_blocks[b].size[SFQ_S_USR_LQLT])
-            return fail(ctx, SFQ_E_UNSUPPORTED, "block %u holds oversize records (usr.lrec, usrs.cpp:269-301): not decoded yet", b);
+            return fail(ctx, SFQ_E_UNSUPPORTED, "block %u holds oversize records (usr.lrec): only a one-block (format 6) archive does", b);
+    if (has_over && nblocks != 1) return fail(ctx, SFQ_E_UNSUPPORTED, "oversize records (usr.lrec) in an archive of %u blocks: only a one-block (format 6) archive has them", nblocks);
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
@@ -1309,6 +1391,50 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     da.hlen = (u32*)ctx->hlen.p; da.hoff = (u64*)ctx->hoff.p;
     da.block_reads = block_reads; da.version = version; da.max_line = (u32)std::min<u64>(out_cap, 0x3ffffffeull);
 
+    // 0. format 6's oversize records (UsrLoad::update, usrs.cpp:473-485): their numbers and raw lines first -- the other
+    //    streams count records in file numbers, the models never saw them
+    const u64 nrec_file = nrec; u32 n_over = 0;
+    if (has_over) {
+        ctx->epoch_base += 2;                              // (the passes below run under epochs of their own: models_w.hip k_over_decode_w)
+        const sfq_block_info& bi = h_blocks[0];
+        const u8* s_l[3] = { d_streams + stream_offset[SFQ_S_USR_LREC], d_streams + stream_offset[SFQ_S_USR_LGEN], d_streams + stream_offset[SFQ_S_USR_LQLT] };
+        if ((rc = reserve(ctx, ctx->ocnt, 64))) return rc;
+        HIPC(hipMemsetAsync(ctx->ocnt.p, 0, 64, st));
+        da.m.batch0 = 0; da.m.nbatch = 1;
+        launch_over_decode_w(da.m, s_l[0], (u32)bi.size[SFQ_S_USR_LREC], 0, 0, 0, (u64*)ctx->ocnt.p, nullptr, nullptr, nullptr, out_cap, st);
+        u64 h_cnt[2] = {0, 0}; u32 h_st = 0;
+        u32* d_status0 = &((BlockDesc*)ctx->blocks.p)[0].status;
+        HIPC(hipMemcpyAsync(h_cnt, ctx->ocnt.p, 16, hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(&h_st, d_status0, 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        if (h_st || h_cnt[0] == 0 || h_cnt[0] >= nrec_file || h_cnt[1] > out_cap) return fail(ctx, SFQ_E_CORRUPT, "damaged oversize stream (usr.lrec)");
+        n_over = (u32)h_cnt[0];
+        if ((rc = reserve(ctx, ctx->ono, (size_t)n_over * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->opiece, (size_t)n_over * 64))) return rc;
+        if ((rc = reserve(ctx, ctx->otxt[0], (size_t)h_cnt[1] + 16))) return rc;
+        if ((rc = reserve(ctx, ctx->otxt[1], (size_t)out_cap + 16))) return rc;
+        if ((rc = reserve(ctx, ctx->otxt[2], (size_t)out_cap + 16))) return rc;
+        HIPC(hipMemsetAsync(ctx->opiece.p, 0, (size_t)n_over * 64, st));
+        HIPC(hipEventRecord(ctx->ev[8], st));
+        launch_over_decode_w(da.m, s_l[0], (u32)bi.size[SFQ_S_USR_LREC], 0, 1, n_over, nullptr, (u64*)ctx->ono.p, (u64*)ctx->opiece.p, (u8*)ctx->otxt[0].p, h_cnt[1], st);
+        // the base and quality lines: a wave each, beside everything else (joined before the records are laid out)
+        HIPC(hipStreamWaitEvent(ctx->st_aux[2], ctx->ev[8], 0));
+        launch_over_decode_w(da.m, s_l[1], (u32)bi.size[SFQ_S_USR_LGEN], 1, 1, n_over, nullptr, nullptr, (u64*)ctx->opiece.p, (u8*)ctx->otxt[1].p, out_cap, ctx->st_aux[2]);
+        launch_over_decode_w(da.m, s_l[2], (u32)bi.size[SFQ_S_USR_LQLT], 2, 1, n_over, nullptr, nullptr, (u64*)ctx->opiece.p, (u8*)ctx->otxt[2].p, out_cap, ctx->st_aux[2]);
+        HIPC(hipEventRecord(ctx->ev[9], ctx->st_aux[2]));
+        // kept record -> file number
+        if ((rc = reserve(ctx, ctx->oflags, (size_t)nrec_file * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->ofpos, ((size_t)nrec_file + 1) * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->orecmap, (size_t)nrec_file * 4 + 16))) return rc;
+        HIPC(hipMemsetAsync(ctx->oflags.p, 0, (size_t)nrec_file * 4, st));
+        launch_over_mark((const u64*)ctx->ono.p, n_over, nrec_file, (u32*)ctx->oflags.p, d_status0, st);
+        launch_scan_u32((const u32*)ctx->oflags.p, (u64*)ctx->ofpos.p, nrec_file, (u64*)ctx->scan_tmp.p, st);
+        launch_over_map((const u32*)ctx->oflags.p, (const u64*)ctx->ofpos.p, nrec_file, (u32*)ctx->orecmap.p, st);
+        nrec = nrec_file - n_over;
+        hb[0].nrec = (u32)nrec;
+        HIPC(hipMemcpyAsync(&((BlockDesc*)ctx->blocks.p)[0].nrec, &hb[0].nrec, 4, hipMemcpyHostToDevice, st));
+        da.m.rec_map = (const u32*)ctx->orecmap.p;
+    }
     // 1. framing exceptions -> per-record line lengths
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_usr_decode_l(da, st); }
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
@@ -1412,12 +1538,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         } else
         for (u32 b = 0; b < nblocks; b++) {
             const sfq_block_info& bi = h_blocks[b];
-            u64 cap = bi.hdr_bytes ? (u64)bi.hdr_bytes + bi.n_records + SFQ_MAX_ID_LLEN + 64
+            // (hdr_bytes is what the ENCODER saw: where the reference's restoration differs from the text -- an emptied field
+            //  comes back "0", SURVEY H7 -- the headers of a format-6 block come back longer, so an overflow is retried with more)
+            u64 cap = bi.hdr_bytes ? (((u64)bi.hdr_bytes + bi.n_records) << attempt) + SFQ_MAX_ID_LLEN + 64
                                    : ((u64)bi.n_records * 96 << attempt) + 2 * SFQ_MAX_ID_LLEN + 64;
             if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
             hso[b] = o; hsc[b] = (u32)cap; o += (cap + 15) & ~15ull;
         }
         hso[nstage] = o;
+        // (all the headers together cannot outgrow the caller's buffer for the text: a damaged stream that keeps asking for more ends here)
+        if (attempt && o > 2 * out_cap + (u64)nstage * (SFQ_MAX_ID_LLEN + 96)) return fail(ctx, SFQ_E_CORRUPT, "decode: the headers do not fit the output buffer (corrupt stream)");
         if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
         HIPC(hipMemcpyAsync(ctx->hso.p, hso, ((size_t)nstage + 1) * 8, hipMemcpyHostToDevice, st_rec));
         HIPC(hipMemcpyAsync(ctx->hsc.p, hsc, (size_t)nstage * 4, hipMemcpyHostToDevice, st_rec));
@@ -1446,7 +1576,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         HIPC(hipStreamSynchronize(st));
         bool overflow = false; int worst = 0;
         for (u32 b = 0; b < nblocks; b++) {
-            if (hb[b].status == (u32)(-SFQ_E_OVERFLOW) && !h_blocks[b].hdr_bytes) overflow = true;
+            if (hb[b].status == (u32)(-SFQ_E_OVERFLOW) && !frozen_rec) overflow = true;
             else if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
         }
         if (worst) return fail(ctx, -worst, "decode: block kernel reported error %d (corrupt or truncated stream)", -worst);
@@ -1459,16 +1589,34 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
 
     // 4. lay the records out
     launch_record_sizes(da, nrec, (u32*)ctx->rsize.p, st);
-    launch_scan_u32((const u32*)ctx->rsize.p, (u64*)ctx->roff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     u64 total = 0;
-    HIPC(hipMemcpyAsync(&total, (u64*)ctx->roff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+    const u64* d_roff = (const u64*)ctx->roff.p;
+    if (!n_over) {
+        launch_scan_u32((const u32*)ctx->rsize.p, (u64*)ctx->roff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+        HIPC(hipMemcpyAsync(&total, (u64*)ctx->roff.p + nrec, 8, hipMemcpyDeviceToHost, st));
+    } else {                                               // every record of the file in file order: the kept ones' sizes, the oversize ones' raw lines
+        HIPC(hipStreamWaitEvent(st, ctx->ev[9], 0));
+        if ((rc = reserve(ctx, ctx->osize_all, (size_t)nrec_file * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->oroff_all, ((size_t)nrec_file + 1) * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->oroff_k, (size_t)nrec * 8 + 16))) return rc;
+        launch_over_sizes((const u32*)ctx->orecmap.p, (const u32*)ctx->rsize.p, nrec, (const u64*)ctx->ono.p, (const u64*)ctx->opiece.p, n_over, (u32*)ctx->osize_all.p, st);
+        launch_scan_u32((const u32*)ctx->osize_all.p, (u64*)ctx->oroff_all.p, nrec_file, (u64*)ctx->scan_tmp.p, st);
+        launch_gather_u64((const u64*)ctx->oroff_all.p, (const u32*)ctx->orecmap.p, nrec, (u64*)ctx->oroff_k.p, st);
+        HIPC(hipMemcpyAsync(&total, (u64*)ctx->oroff_all.p + nrec_file, 8, hipMemcpyDeviceToHost, st));
+        d_roff = (const u64*)ctx->oroff_k.p;
+    }
+    u32 h_st_end = 0;
+    if (n_over) HIPC(hipMemcpyAsync(&h_st_end, &((BlockDesc*)ctx->blocks.p)[0].status, 4, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
+    if (h_st_end) return fail(ctx, SFQ_E_CORRUPT, "damaged oversize streams (usr.lgen / usr.lqlt)");
     *out_bytes = total;
     if (total > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "decoded text needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)out_cap);
-    launch_assemble(da, nrec, (const u64*)ctx->roff.p, d_out, st);
+    launch_assemble(da, nrec, d_roff, d_out, st);
+    if (n_over) launch_over_place(n_over, (const u64*)ctx->ono.p, (const u64*)ctx->opiece.p, (const u8*)ctx->otxt[0].p, (const u8*)ctx->otxt[1].p, (const u8*)ctx->otxt[2].p,
+                                  (const u64*)ctx->oroff_all.p, d_out, st);
     HIPC(hipEventRecord(ctx->ev[6], st));
     HIPC(hipStreamSynchronize(st));
-    res->n_records = nrec; res->n_blocks = nblocks; res->total_bytes = total;
+    res->n_records = nrec_file; res->n_blocks = nblocks; res->total_bytes = total;
     res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[0], ctx->ev[1]);
     res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
     res->kernel_ms[SFQ_T_GEN] = ev_ms(ctx->ev[7], ctx->ev[4]);

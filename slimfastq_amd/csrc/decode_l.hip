@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_usr_decode_l(DecodeArgs a) {
     const u32 solid = d->solid;
     u32 llen = d->llen, qlen = llen, pfg = 0, pfq = 0, bad = 0;
     for (u32 k = 0; k < d->nrec; k++) {
-        const u64 r = d->rec0 + k, rcnt = (u64)k + 1;
+        const u64 r = d->rec0 + k, rcnt = rec_count_of(a.m, r, d->rec0);
         if (i_llen == rcnt) { llen = (u32)x_llen.get(sl.pw); qlen = llen; i_llen += x_llen.get(sl.pw); }
         if (i_qlen == rcnt) { qlen = (u32)x_qlen.get(sl.pw); i_qlen += x_qlen.get(sl.pw); }
         else if (qlen != llen) qlen = llen;
@@ -386,6 +386,28 @@ __global__ __launch_bounds__(64) void k_assemble(DecodeArgs a, u64 nrec, u32 rpw
         }
         r = rn; f = fn;
     }
+}
+// format 6 with oversize records: the size of every record of the file in file order -- a kept record's from rsize (through
+// rec_map), an oversize one's from its four raw lines and its '@'
+__global__ __launch_bounds__(256) void k_over_sizes(const u32* __restrict__ rec_map, const u32* __restrict__ rsize, u64 n_kept, const u64* __restrict__ no,
+                                                    const u64* __restrict__ piece, u32 n_over, u32* __restrict__ size_all) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_kept) size_all[rec_map[i]] = rsize[i];
+    else if (i - n_kept < n_over) {
+        const u64 j = i - n_kept;
+        size_all[no[j] - 1] = (u32)(1 + piece[(j * 4 + 0) * 2 + 1] + piece[(j * 4 + 1) * 2 + 1] + piece[(j * 4 + 2) * 2 + 1] + piece[(j * 4 + 3) * 2 + 1]);
+    }
+}
+void launch_over_sizes(const u32* rec_map, const u32* rsize, u64 n_kept, const u64* no, const u64* piece, u32 n_over, u32* size_all, hipStream_t st) {
+    const u64 n = n_kept + n_over;
+    if (n) hipLaunchKernelGGL(k_over_sizes, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, rec_map, rsize, n_kept, no, piece, n_over, size_all);
+}
+__global__ __launch_bounds__(256) void k_gather_u64(const u64* __restrict__ src, const u32* __restrict__ idx, u64 n, u64* __restrict__ dst) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+void launch_gather_u64(const u64* src, const u32* idx, u64 n, u64* dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_gather_u64, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, src, idx, n, dst);
 }
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st) {
     const u32 rpw = (u32)std::max<u64>(1, std::min<u64>(64, nrec / 32768));

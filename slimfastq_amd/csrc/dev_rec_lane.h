@@ -35,7 +35,7 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
     }
     for (u32 k = 0; k < nrec && !bad; k++) {
         const u64 r = rec0 + k;
-        const u64 record_count = r - base_rec + 1;   // g_record_count, block-relative
+        const u64 record_count = rec_count_of(a, r, base_rec);   // g_record_count, block-relative
         const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
         hdr_bytes += n;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
     for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
     if (prev_n > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; nrec = 0; }                        // (also refused by sfq_decode_blocks)
     for (u32 k = 0; k < nrec; k++) {
-        const u64 r = rec0 + k, rcnt = r - d->rec0 + 1;
+        const u64 r = rec0 + k, rcnt = rec_count_of(a.m, r, d->rec0);
         // worst case for one header: every field regenerated at its longest (MAX_ID_LLEN) -> bounded check
         if (pos + SFQ_MAX_ID_LLEN + 2 > cap) { bad = SFQ_E_OVERFLOW; break; }
         u8* buf = stage + pos;

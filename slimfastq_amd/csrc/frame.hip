@@ -180,7 +180,7 @@ void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
 }
 
 // ---- record validation ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line, u32* status) {
+__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
     u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrec) return;
     const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u6
     if (fq[l0] != '@' || fq[l2] != '+') bad = (u32)(-SFQ_E_FORMAT);           // usrs.cpp:311, 346
     // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367): max_line = 0xfffe
     // where its format is written; the block format codes base / quality lines of any length the usual way
-    else if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line)
+    else if ((l1 - l0 - 2) > max_hdr || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line)
         bad = (u32)(-SFQ_E_UNSUPPORTED);
     else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);               // empty base line: usrs.cpp:217-222 mis-frames it
     if (bad) atomicMax(status, bad);
@@ -202,9 +202,98 @@ __global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u6
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)gl, dd, 64); gl = o > gl ? o : gl; }
     if ((threadIdx.x & 63) == 0 && gl > status[2]) atomicMax(status + 2, gl);
+    // status[3] != 0: some record may be over format 6's line limits (usrs.hpp:34-36; a SOLiD line may be one longer -- the
+    // oversize pass below decides exactly)
+    if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l4 - l3 - 1) > 0xfffe) status[3] = 1;
 }
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line, u32* status, hipStream_t st) {
-    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_line, status);
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_hdr, max_line, status);
+}
+
+// ---- format 6: the reference's OVERSIZE records (usrs.cpp:269-301) -----------------------------------------------------
+// A record whose header has more than 8190 bytes or whose base line (less a SOLiD prefix) more than 65534 never reaches
+// the reference's models: UsrSave::get_record (usrs.cpp:313-318, 333-338) sends its four lines raw to "usr.lrec" /
+// "usr.lgen" / "usr.lqlt" and goes on to the next record; the record still counts (g_record_count).  Here: flags per
+// record, the text WITHOUT those records (what the model kernels code, through the usual framing), the map from a kept
+// record to its number in the file (the exception streams count in those), and the list of the oversize ones.
+// first[0] = the first record that passes determine_record's test (usrs.cpp:203-229: header within 8190 bytes, raw base line
+// of 1..65535): the file's llen / usr.solid / usr.2id come from it
+__global__ __launch_bounds__(256) void k_over_first(const u64* __restrict__ line_off, u64 nrec, u32* first) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2];
+    if ((l1 - l0 - 2) <= 0x1ffe && (l2 - l1 - 1) >= 1 && (l2 - l1 - 1) <= 0xffff) atomicMin(first, (u32)r);
+}
+// usrs.cpp:241-259 on that record: a digit 0..3 before any of a, c, g, t means SOLiD colour space
+__global__ void k_over_solid(const u8* __restrict__ fq, const u64* __restrict__ line_off, u64 r, u32* out) {
+    const u64 l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2];
+    const u32 llen = (u32)(l2 - l1 - 1);
+    u32 solid = 0;
+    for (u32 i = 1; i < llen; i++) {
+        const u32 c = fq[l1 + i] | 0x20;
+        if (c >= '0' && c <= '3') { solid = 1; break; }
+        if (c == 'a' || c == 'c' || c == 'g' || c == 't') break;
+    }
+    *out = solid;
+}
+// flags[r] = 1: record r is oversize; kbytes[r] = the bytes of a kept record.  A quality line over the limit beside a base
+// line within it is refused: the reference has by then written the record's "usr.x" / "usr.pfg" exceptions under a number
+// its decoder never looks them up at (usrs.cpp:340-345 run before 372-373) -- its own archive of such a file does not decode.
+__global__ __launch_bounds__(256) void k_over_flags(const u64* __restrict__ line_off, u64 nrec, u32 solid, u32* __restrict__ flags,
+                                                    u32* __restrict__ kbytes, u32* status) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
+    const u64 hl = l1 - l0 - 2, gl = l2 - l1 - 1, ql = l4 - l3 - 1;
+    const bool over = hl > 0x1ffe || gl > 0xfffeull + solid;
+    if (!over && ql > 0xfffeull + solid) atomicMax(status, (u32)(-SFQ_E_UNSUPPORTED));
+    flags[r] = over ? 1u : 0u;
+    kbytes[r] = over ? 0u : (u32)(l4 - l0);
+}
+// a wave per record: a kept record's text goes to its place in the filtered text, its file number to rec_map; an oversize
+// record's number to over_list
+__global__ __launch_bounds__(256) void k_over_split(const u8* __restrict__ fq, const u64* __restrict__ line_off, u64 nrec, const u32* __restrict__ flags,
+                                                    const u64* __restrict__ fpos, const u64* __restrict__ koff, u8* __restrict__ filt,
+                                                    u32* __restrict__ rec_map, u32* __restrict__ over_list) {
+    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u32 lane = threadIdx.x & 63;
+    if (r >= nrec) return;
+    if (flags[r]) { if (lane == 0) over_list[fpos[r]] = (u32)r; return; }
+    if (lane == 0) rec_map[r - fpos[r]] = (u32)r;
+    const u64 l0 = line_off[4 * r], n = line_off[4 * r + 4] - l0;
+    const u8* src = fq + l0; u8* dst = filt + koff[r];
+    for (u64 i = lane; i < n; i += 64) dst[i] = src[i];
+}
+void launch_over_first(const u64* line_off, u64 nrec, u32* first, hipStream_t st) {
+    hipLaunchKernelGGL(k_over_first, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, line_off, nrec, first);
+}
+void launch_over_solid(const u8* fq, const u64* line_off, u64 r, u32* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_over_solid, dim3(1), dim3(1), 0, st, fq, line_off, r, out);
+}
+void launch_over_flags(const u64* line_off, u64 nrec, u32 solid, u32* flags, u32* kbytes, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_over_flags, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, line_off, nrec, solid, flags, kbytes, status);
+}
+void launch_over_split(const u8* fq, const u64* line_off, u64 nrec, const u32* flags, const u64* fpos, const u64* koff, u8* filt, u32* rec_map, u32* over_list, hipStream_t st) {
+    hipLaunchKernelGGL(k_over_split, dim3((u32)((nrec + 3) / 4)), dim3(256), 0, st, fq, line_off, nrec, flags, fpos, koff, filt, rec_map, over_list);
+}
+// decode side: flags[number - 1] = 1 for the oversize records' 1-based numbers; rec_map[k] = the file number (0-based) of the k-th kept record
+__global__ __launch_bounds__(256) void k_over_mark(const u64* __restrict__ over_no, u32 n_over, u64 total, u32* __restrict__ flags, u32* status) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_over) return;
+    const u64 no = over_no[i];
+    if (no == 0 || no > total || (i && over_no[i - 1] >= no)) { atomicMax(status, (u32)(-SFQ_E_CORRUPT)); return; }
+    flags[no - 1] = 1u;
+}
+__global__ __launch_bounds__(256) void k_over_map(const u32* __restrict__ flags, const u64* __restrict__ fpos, u64 total, u32* __restrict__ rec_map) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= total || flags[r]) return;
+    rec_map[r - fpos[r]] = (u32)r;
+}
+void launch_over_mark(const u64* over_no, u32 n_over, u64 total, u32* flags, u32* status, hipStream_t st) {
+    if (n_over) hipLaunchKernelGGL(k_over_mark, dim3((n_over + 255) / 256), dim3(256), 0, st, over_no, n_over, total, flags, status);
+}
+void launch_over_map(const u32* flags, const u64* fpos, u64 total, u32* rec_map, hipStream_t st) {
+    hipLaunchKernelGGL(k_over_map, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, flags, fpos, total, rec_map);
 }
 
 // ---- block descriptors: UsrSave::determine_record (usrs.cpp:186-267) on each block's first record ----

@@ -21,7 +21,12 @@ struct ModelArgs {
     // quality warm start (prior.hip); all null = cold rows, the reference's behaviour
     const u32* prior_w; const u32* prior_wovf;   // wave layout [q_rows][64] + overflow [q_rows][4]
     const u32* prior_ls; const RowHdr* prior_lh; // lane-per-block layout
+    // format 6 with oversize records (frame.hip): the model kernels see the text without them; rec_map[k] = the file number
+    // (0-based) of the k-th record they see -- the exception streams count records in file numbers (g_record_count).  Null: k itself.
+    const u32* rec_map;
 };
+// g_record_count (config.cpp:43) of record r of a block that starts at base: block-relative, 1-based
+__device__ __forceinline__ u64 rec_count_of(const ModelArgs& a, u64 r, u64 base) { return a.rec_map ? (u64)a.rec_map[r] + 1 : r - base + 1; }
 
 // Decode-side extras.
 struct DecodeArgs {
@@ -104,7 +109,19 @@ static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1)
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
 void launch_max_u32(const u32* v, u64 n, u32* out /* raised to the largest of v */, hipStream_t st);
 void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_line /* longest base / quality line taken */, u32* status, hipStream_t st);
+void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line /* longest header / base or quality line taken */, u32* status, hipStream_t st);
+// format 6's oversize records (frame.hip, models_w.hip)
+void launch_over_first(const u64* line_off, u64 nrec, u32* first /* 0xFFFFFFFF */, hipStream_t st);
+void launch_over_solid(const u8* fq, const u64* line_off, u64 r, u32* out, hipStream_t st);
+void launch_over_flags(const u64* line_off, u64 nrec, u32 solid, u32* flags, u32* kbytes, u32* status, hipStream_t st);
+void launch_over_split(const u8* fq, const u64* line_off, u64 nrec, const u32* flags, const u64* fpos, const u64* koff, u8* filt, u32* rec_map, u32* over_list, hipStream_t st);
+void launch_over_encode_w(const ModelArgs& a, const u8* fq, const u64* line_off, const u32* over_list, u32 n_over, const u64 out_off[3], const u32 out_cap[3], hipStream_t st);
+void launch_over_mark(const u64* over_no, u32 n_over, u64 total, u32* flags /* zeroed */, u32* status, hipStream_t st);
+void launch_over_map(const u32* flags, const u64* fpos, u64 total, u32* rec_map, hipStream_t st);
+void launch_over_decode_w(const ModelArgs& a, const u8* stream, u32 size, u32 which, u32 store, u32 n_over, u64* cnt, u64* no, u64* piece, u8* txt, u64 cap, hipStream_t st);
+void launch_over_place(u32 n_over, const u64* no, const u64* piece, const u8* lrec_txt, const u8* lgen_txt, const u8* lqlt_txt, const u64* roff_all, u8* out, hipStream_t st);
+void launch_over_sizes(const u32* rec_map, const u32* rsize, u64 n_kept, const u64* no, const u64* piece, u32 n_over, u32* size_all, hipStream_t st);
+void launch_gather_u64(const u64* src, const u32* idx, u64 n, u64* dst, hipStream_t st);
 void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
                           u64 nbytes, i32 level, i32 gen_bits_req, hipStream_t st);
 #define FRAME_CHUNK 16384u

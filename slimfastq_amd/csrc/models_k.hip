@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_usr_encode_w(ModelArgs a) {
             while (mx) {
                 const u32 bit = (u32)__ffsll((long long)mx) - 1u;
                 mx &= mx - 1;
-                const u64 rcnt = (u64)k0 + bit + 1;
+                const u64 rcnt = rec_count_of(a, d->rec0 + k0 + bit, d->rec0);
                 if ((mG >> bit) & 1) { const u32 c = rl(cg, bit); if (lane == 0) { x_sgen.put(pw, rcnt - i_sgen); x_sgen.put_chr(pw, c); } i_sgen = rcnt; }   // usrs.cpp:323-327
                 if ((mL >> bit) & 1) { const u32 v = rl(sl_len, bit); if (lane == 0) { x_llen.put(pw, rcnt - i_llen); x_llen.put(pw, v); } i_llen = rcnt; }   // usrs.cpp:342-343
                 if ((mS >> bit) & 1) { const u32 c = rl(cq, bit); if (lane == 0) { x_sqlt.put(pw, rcnt - i_sqlt); x_sqlt.put_chr(pw, c); } i_sqlt = rcnt; }   // usrs.cpp:356-360

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_usr_encode_l(ModelArgs a) {
     u32 pf_gen = 0, pf_qlt = 0;
     for (u32 k = 0; k < d->nrec; k++) {
         const u64 r = d->rec0 + k;
-        const u64 rcnt = (u64)k + 1;
+        const u64 rcnt = rec_count_of(a, r, d->rec0);
         const u64 g0 = a.line_off[4 * r + 1], g1 = a.line_off[4 * r + 2] - 1;
         const u64 q0 = a.line_off[4 * r + 3], q1 = a.line_off[4 * r + 4] - 1;
         if (solid) {

@@ -409,6 +409,126 @@ void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_gen_exc_decode_w, dim3(a.m.nbatch), dim3(64), 0, st, a);
 }
 
+// =========================================================================================================
+// format 6: the reference's oversize records (usrs.cpp:269-301, 471-510; frame.hip picks them).  Three XFile streams, each
+// its own coder and rows, a wave each: "usr.lrec" = for every such record the gap to the one before (in file numbers),
+// the header line behind its '@' and the whole '+' line; "usr.lgen" / "usr.lqlt" = its base / quality line; every line
+// with its newline, character by character through the stream's string row (XFileSave::put_chr, xfile.cpp:71-74) -- which
+// lives in the wave's LDS: every character reads, updates and writes that one row.
+// =========================================================================================================
+struct OverArgs {
+    const u8* fq; const u64* line_off;      // the ORIGINAL text and its line index
+    const u32* over_list; u32 n_over;       // the oversize records (0-based file numbers), ascending
+    u64 out_off[3]; u32 out_cap[3];         // regions in the arena: lrec, lgen, lqlt
+};
+__global__ __launch_bounds__(64) void k_over_encode_w(ModelArgs a, OverArgs o) {
+    __shared__ u32 hot_slots[PW_NSYM];
+    __shared__ RowHdr hot_hdr[1];
+    const u32 lane = threadIdx.x, which = blockIdx.x;                    // 0 lrec, 1 lgen, 2 lqlt
+    BlockDesc* d = &a.blocks[0];
+    WavePw pw; pw.slots = a.p_slots; pw.hdr = a.p_hdr; pw.epoch = EPOCH_L(a.epoch_base + 1);      // block 0's rows (every XFile has rows of its own)
+    XfEncW x; x.init(a.arena + o.out_off[which], o.out_cap[which], XF_USR_LREC + which);
+    pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = x.row0 + 14; pw.hn = 1;
+    if (lane == 0) hot_hdr[0].epoch = 0;
+    u64 i_long = 0;                                                     // m_last.i_long usrs.cpp:271-272
+    for (u32 i = 0; i < o.n_over; i++) {
+        const u64 r = o.over_list[i];
+        if (which == 0) { x.put(pw, r + 1 - i_long, lane); i_long = r + 1; }
+        for (u32 part = 0; part < (which == 0 ? 2u : 1u); part++) {
+            // lrec: the header line behind its '@', then the '+' line whole; lgen / lqlt: the line; each with its '\n'
+            const u32 ln = which == 0 ? (part ? 2u : 0u) : which == 1 ? 1u : 3u;
+            const u64 b0 = o.line_off[4 * r + ln] + ((which == 0 && part == 0) ? 1u : 0u), b1 = o.line_off[4 * r + ln + 1];
+            for (u64 at = b0; at < b1; at += 64) {
+                const u32 m = (u32)(b1 - at < 64 ? b1 - at : 64);
+                const u32 ch = lane < m ? o.fq[at + lane] : 0u;
+                for (u32 j = 0; j < m; j++) pw.put(x.row0 + 14, x.rc, x.sink, rl(ch, j), lane);
+            }
+            x.opened = 1;
+        }
+    }
+    const u32 sz = x.finish(pw, lane);
+    if (lane == 0) {
+        const int sid = SFQ_S_USR_LREC + (int)which;
+        d->size[sid] = sz; d->out_off[sid] = o.out_off[which]; d->out_cap[sid] = o.out_cap[which];
+        if (x.sink.pos > x.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+        if (x.rc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+    }
+}
+void launch_over_encode_w(const ModelArgs& a, const u8* fq, const u64* line_off, const u32* over_list, u32 n_over, const u64 out_off[3], const u32 out_cap[3], hipStream_t st) {
+    OverArgs o; o.fq = fq; o.line_off = line_off; o.over_list = over_list; o.n_over = n_over;
+    for (int k = 0; k < 3; k++) { o.out_off[k] = out_off[k]; o.out_cap[k] = out_cap[k]; }
+    hipLaunchKernelGGL(k_over_encode_w, dim3(3), dim3(64), 0, st, a, o);
+}
+// The way back (UsrLoad::update, usrs.cpp:473-485).  which = 0 ("usr.lrec"): with store == 0 only counts -- cnt[0] = records,
+// cnt[1] = bytes of their header and '+' lines -- so that the host can size the buffers; with store != 0 fills no[i] (1-based file
+// number) and piece[i][0..1] = {offset, length} of the header line (behind '@') and the '+' line in txt.  which = 1 / 2
+// ("usr.lgen" / "usr.lqlt"): n_over lines into txt, piece[i][2] / piece[i][3].  Lengths include the newline.
+struct OverDecArgs {
+    const u8* stream; u32 size; u32 which, store, n_over;
+    u64* cnt; u64* no; u64* piece;           // piece: [n_over][4][2]
+    u8* txt; u64 cap;
+};
+__global__ __launch_bounds__(64) void k_over_decode_w(ModelArgs a, OverDecArgs o) {
+    __shared__ u32 hot_slots[PW_NSYM];
+    __shared__ RowHdr hot_hdr[1];
+    const u32 lane = threadIdx.x, which = o.which;
+    BlockDesc* d = &a.blocks[0];
+    // (rows of the call's first table slot under an epoch of their own per pass: the counting pass and the storing pass both start fresh)
+    WavePw pw; pw.slots = a.p_slots; pw.hdr = a.p_hdr; pw.epoch = EPOCH_L(a.epoch_base + 1 + o.store);
+    XfDecW x; x.init(o.stream, o.size, XF_USR_LREC + which);
+    pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = x.row0 + 14; pw.hn = 1;
+    if (lane == 0) hot_hdr[0].epoch = 0;
+    u64 pos = 0, nrecs = 0, number = 0; u32 bad = 0;
+    // one line: characters up to and including the newline (a line that does not end within the buffer is a damaged stream)
+    auto line = [&](u32 slot, u64 i) {
+        const u64 p0 = pos;
+        for (;;) {
+            const u32 c = x.valid ? pw.get(x.row0 + 14, x.rc, x.src, lane) : (u32)'\n';
+            if (o.store && pos < o.cap && lane == 0) o.txt[pos] = (u8)c;
+            pos++;
+            if (c == '\n') break;
+            if (pos >= o.cap || x.rc.err) { bad = 1; break; }              // (cap: the caller's room for the text, in the counting pass too)
+        }
+        if (o.store && lane == 0) { o.piece[(i * 4 + slot) * 2] = p0; o.piece[(i * 4 + slot) * 2 + 1] = pos - p0; }
+    };
+    if (which == 0) {
+        for (u64 gap = x.get(pw, lane); gap && !bad; gap = x.get(pw, lane)) {           // usrs.cpp:449, 482
+            number += gap;
+            if (o.store) { if (nrecs >= o.n_over) { bad = 1; break; } if (lane == 0) o.no[nrecs] = number; }
+            line(0, nrecs); if (bad) break;
+            line(1, nrecs);
+            nrecs++;
+            if (nrecs > (1ull << 32)) bad = 1;
+        }
+        if (lane == 0 && o.cnt) { o.cnt[0] = nrecs; o.cnt[1] = pos; }
+    } else {
+        for (u64 i = 0; i < o.n_over && !bad; i++) line(which + 1, i);
+    }
+    if (lane == 0 && (bad | x.rc.err)) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
+}
+void launch_over_decode_w(const ModelArgs& a, const u8* stream, u32 size, u32 which, u32 store, u32 n_over, u64* cnt, u64* no, u64* piece, u8* txt, u64 cap, hipStream_t st) {
+    OverDecArgs o; o.stream = stream; o.size = size; o.which = which; o.store = store; o.n_over = n_over; o.cnt = cnt; o.no = no; o.piece = piece; o.txt = txt; o.cap = cap;
+    hipLaunchKernelGGL(k_over_decode_w, dim3(1), dim3(64), 0, st, a, o);
+}
+// a wave per oversize record: '@', the header line, the base line, the '+' line, the quality line (usrs.cpp:474-481) to its place
+__global__ __launch_bounds__(64) void k_over_place(const u64* __restrict__ no, const u64* __restrict__ piece, const u8* lrec_txt, const u8* lgen_txt, const u8* lqlt_txt,
+                                                   const u64* __restrict__ roff_all, u8* __restrict__ out) {
+    const u32 i = blockIdx.x, lane = threadIdx.x;
+    u8* dst = out + roff_all[no[i] - 1];
+    if (lane == 0) dst[0] = '@';
+    dst++;
+    const u8* src[4] = { lrec_txt, lgen_txt, lrec_txt, lqlt_txt };
+    const u32 slot[4] = { 0, 2, 1, 3 };
+    for (int k = 0; k < 4; k++) {
+        const u64 p0 = piece[((u64)i * 4 + slot[k]) * 2], n = piece[((u64)i * 4 + slot[k]) * 2 + 1];
+        for (u64 j = lane; j < n; j += 64) dst[j] = src[k][p0 + j];
+        dst += n;
+    }
+}
+void launch_over_place(u32 n_over, const u64* no, const u64* piece, const u8* lrec_txt, const u8* lgen_txt, const u8* lqlt_txt, const u64* roff_all, u8* out, hipStream_t st) {
+    if (n_over) hipLaunchKernelGGL(k_over_place, dim3(n_over), dim3(64), 0, st, no, piece, lrec_txt, lgen_txt, lqlt_txt, roff_all, out);
+}
+
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
     // (persistent waves that take blocks off the ticket: not more of them than three quarters of the chip's wave slots --
     //  the packing kernels run beside this pass and would otherwise wait for a slot until it is through)
@@ -433,7 +553,7 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
     const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
     for (u32 k = 0; k < nrec; k++) {
         const u64 r = rec0 + k;
-        const u64 record_count = (u64)k + 1;
+        const u64 record_count = rec_count_of(a, r, rec0);
         const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
         const u8* buf = a.fq + h0;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
@@ -572,7 +692,7 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
     int bad = 0;
     for (u32 k = 0; k < nrec; k++) {
         const u64 r = rec0 + k;
-        const u64 record_count = (u64)k + 1;
+        const u64 record_count = rec_count_of(a, r, rec0);
         const u64 h0 = a.line_off[4 * r] + 1, h1 = a.line_off[4 * r + 1] - 1;
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
         hdr_bytes += n;

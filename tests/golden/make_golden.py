@@ -7,7 +7,7 @@ page and the reference's own decode of that archive are stored.  Fixtures are da
   * a few of the reference's sample inputs (samples/*.fq, the data files its `make test` uses),
   * edge-case FASTQs written here (cases the samples miss: SURVEY.md section 4 / 8c).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [name ...]
 """
 import gzip
 import hashlib
@@ -49,6 +49,19 @@ def edge_cases():
                        b"@v.5 x\nACGTACGTACGT\n+v.5 x\nIIIIIIIIIIII\n")
     # a single record
     out["edge_one"] = b"@only 1\nACGT\n+\nIIII\n"
+    # oversize records (usrs.cpp:269-301): base lines of 70 kb and 300 kb, a header of 9000 bytes, one right at the limit
+    # (65534: still on the model path) and one just over it (65535), between ordinary records of changing length; the first
+    # record of the file is oversize too (determine_record's own branch, usrs.cpp:206-229).  Skewed bases and few quality
+    # values keep the raw streams small.
+    rng = np.random.default_rng(20261004)
+
+    def rec(i, n, hdr=None):
+        seq = "".join(rng.choice(list("ACGTN"), n, p=[0.94, 0.02, 0.02, 0.015, 0.005]))
+        q = "".join(rng.choice(list("IH5#!"), n, p=[0.95, 0.02, 0.01, 0.01, 0.01]))
+        return "@%s\n%s\n+\n%s\n" % (hdr or "ov.%d len=%d" % (i, n), seq, q)
+    recs = [rec(0, 66000), rec(1, 150), rec(2, 70000), rec(3, 200), rec(4, 200), rec(5, 300001), rec(6, 65534), rec(7, 65535),
+            rec(8, 120, hdr="long " + "h" * 9000 + " 8"), rec(9, 120), rec(10, 131072), rec(11, 90)]
+    out["edge_oversize"] = "".join(recs).encode()
     return out
 
 
@@ -59,6 +72,10 @@ def main():
     for s in SAMPLES:
         fixtures[s] = open("/root/reference/samples/%s.fq" % s, "rb").read()
     fixtures.update(edge_cases())
+    only = set(sys.argv[1:])                        # names on the command line: (re)generate those only
+    if only:
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        fixtures = {k: v for k, v in fixtures.items() if k in only}
     for name, fq in sorted(fixtures.items()):
         with gzip.GzipFile(os.path.join(HERE, name + ".fq.gz"), "wb", mtime=0) as f:
             f.write(fq)

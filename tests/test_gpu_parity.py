@@ -150,7 +150,7 @@ def test_roundtrip_long_reads_and_samples(ctx):
 
 def test_reads_beyond_the_reference_line_limit(ctx):
     """Base / quality lines over 65 534 bytes: the reference diverts such records to its raw usr.lrec / usr.lgen / usr.lqlt
-    streams (usrs.cpp:269-301); format 6 (-B 0) therefore refuses them here, the block format codes them like any other."""
+    streams (usrs.cpp:269-301), and so does format 6 (-B 0) here, stream for stream; the block format codes them like any other."""
     import random
     rnd = random.Random(5)
     recs = []
@@ -167,9 +167,38 @@ def test_reads_beyond_the_reference_line_limit(ctx):
         for br in (capi.BLOCK_AUTO, 2, 4):
             enc = ctx.encode_host(fq, level=3, block_reads=br, tables=tables)
             assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq, (tables, br)
+    for kernel in KERNELS:
+        leg = ctx.encode_host(fq, level=3, block_reads=0, kernel=kernel)
+        assert_streams_equal(leg, O.compress(fq, 3).streams, ctxmsg="oversize records, one block, kernel %d" % kernel)
+        assert leg.blocks[0].n_records == 9 and leg.res.n_records == 9
+        assert ctx.decode_host(leg, level=3, out_cap=len(fq) + 4096) == fq
+    # what the reference's framing cannot express is refused, not mangled: a quality line over the limit beside a base line within it
+    odd = b"@q 1\nACGT\n+\nIIII\n@q 2\n" + b"A" * 100 + b"\n+\n" + b"I" * 70000 + b"\n"
     with pytest.raises(capi.SfqError) as e:
-        ctx.encode_host(fq, level=3, block_reads=0)
+        ctx.encode_host(odd, level=3, block_reads=0)
     assert e.value.code == -7          # SFQ_E_UNSUPPORTED
+
+
+def test_oversize_records_through_the_cli_and_the_reference(tmp_path):
+    """usr.lrec / usr.lgen / usr.lqlt both ways through the container: `slimfastq-amd -B 0` writes the archive the reference
+    writes (streams identical, the oracle and -- where it travelled -- the compiled reference decode it), and decodes the
+    reference's archive of the golden fixture."""
+    import subprocess
+    cli = _cli()
+    fq = util.golden_fastq("edge_oversize")
+    src = tmp_path / "ov.fq"; src.write_bytes(fq)
+    leg = tmp_path / "ov.sfq"
+    subprocess.check_call([cli, "-u", str(src), "-f", str(leg), "-O", "-l", "3", "-B", "0", "-q"])
+    img = leg.read_bytes()
+    got, want = O.parse(img), O.compress(fq, 3)
+    assert {k: v for k, v in got.streams.items() if k != "<info>"} == {k: v for k, v in want.streams.items() if k != "<info>"}
+    assert got.info["num_records"] == "12" and got.info["rec.first"] == want.info["rec.first"]
+    assert O.decompress(img) == fq
+    if O.ref_binary():
+        assert O.ref_decompress(img) == fq
+    refimg = tmp_path / "ov.ref.sfq"; refimg.write_bytes(want.image)
+    p = subprocess.run([cli, "-d", "-f", str(refimg)], capture_output=True, check=True)
+    assert p.stdout == fq
 
 
 def _quirk_fastq(n, seed, mixed_n=True):
@@ -309,7 +338,8 @@ def test_ragged_and_error_inputs(ctx):
         with pytest.raises(capi.SfqError) as e:
             ctx.encode_host(bad, level=3)
         assert e.value.code == code, bad
-    # a record over the model path's 65535-base limit is refused, not mangled
+    # a file whose EVERY record is over the model path's line limits is refused (the reference writes an archive without a
+    # first record for it: "all records were oversized", usrs.cpp:190-197)
     big = b"@big\n" + b"A" * 70000 + b"\n+\n" + b"I" * 70000 + b"\n"
     with pytest.raises(capi.SfqError) as e:
         ctx.encode_host(big, level=3)
