@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode-and-compare leg after the timed steps")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 path (process group, shared prior, gather) with one rank")
+    ap.add_argument("--no-format6-leg", action="store_true", help="skip the format-6 (one block, the reference's own streams) encode / decode timing")
+    ap.add_argument("--format6-reads", type=int, default=60_000, help="records of the format-6 leg (a single serial chain per stream: MB/s, not GB/s)")
+    ap.add_argument("--no-genome-leg", action="store_true", help="skip the genome-sampled secondary workload (the honest stress of the base model, SURVEY 8d)")
+    ap.add_argument("--genome-reads", type=int, default=10_000_000)
+    ap.add_argument("--genome-ratio-reads", type=int, default=2_000_000, help="records the reference itself codes for the genome leg's ratio (30x coverage of the 10 Mbp genome)")
     args = ap.parse_args()
     if args.reads <= 0:
         args.reads = 60_000 if args.kind == 1 else 10_000_000
@@ -96,6 +101,10 @@ def cpu_baseline(args, seed):
     t_port = time.perf_counter() - t0
     ref_payload = a.payload_bytes() - len(a.streams["<info>"])
     out.update(kind="port", value=round(len(fq) / 1e6 / t_port, 2), port_MBps=round(len(fq) / 1e6 / t_port, 2))
+    t0 = time.perf_counter()
+    back = O.decompress(a.image)
+    out["decode_value"] = round(len(fq) / 1e6 / (time.perf_counter() - t0), 2)      # the way back, same sample (UsrLoad::decode, usrs.cpp:539-574)
+    assert back == fq
     if O.ref_binary():
         try:
             t0 = time.perf_counter()
@@ -103,9 +112,27 @@ def cpu_baseline(args, seed):
             t_ref = time.perf_counter() - t0
             assert O.parse(img).streams == a.streams
             out.update(kind="reference", value=round(len(fq) / 1e6 / t_ref, 2))
+            t0 = time.perf_counter()
+            back = O.ref_decompress(img)
+            out["decode_value"] = round(len(fq) / 1e6 / (time.perf_counter() - t0), 2)
+            assert back == fq
         except Exception as e:  # the binary may not run on this host; keep the port number
             out["reference_error"] = str(e)[:100]
     return out, fq, ref_payload
+
+
+def _varints(blob: bytes, n: int):
+    """the first n varints of a blob ("chn.idx": records per chain, flags -- bit 0: the base tables are in use)"""
+    out, p = [], 0
+    while len(out) < n and p < len(blob):
+        v = sh = 0
+        while True:
+            c = blob[p]; p += 1
+            v |= (c & 0x7f) << sh; sh += 7
+            if not c & 0x80:
+                break
+        out.append(v)
+    return out + [0] * (n - len(out))
 
 
 def main():
@@ -309,6 +336,74 @@ def main():
         if args.workload == "full":
             out["ratio_vs_reference"] = {"sample_raw": len(sample), "reference_stream_bytes": int(ref_payload),
                                          "ours_stream_bytes": int(ours), "ours_over_reference": round(ours / ref_payload, 4)}
+    if not multi and args.workload == "full" and not args.models and not args.no_format6_leg and args.kind != 1:
+        # format 6 (block_reads = 0): ONE adaptive chain per stream, byte-identical to the reference's -- the drop-in mode.
+        # A serial chain does not parallelise: this is MB/s next to the reference's own MB/s on one core, not GB/s
+        f6 = capi.synth_fastq(args.format6_reads, args.read_len, seed=seed, kind=args.kind)
+        t6 = torch.from_numpy(np.frombuffer(f6, np.uint8).copy()).cuda()
+        o6 = torch.empty(capi.lib().sfq_encode_bound(len(f6)), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r6 = ctx.encode_device(t6.data_ptr(), len(f6), o6.data_ptr(), o6.numel(), level=args.level, block_reads=0)
+        torch.cuda.synchronize(); te = time.perf_counter() - t0
+        b6 = ctx.index(1); h6 = ctx.first_headers(r6.first_hdr_bytes)
+        back6 = torch.empty(len(f6) + 4096, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        got6, _r = ctx.decode_device(b6, h6, o6.data_ptr(), list(r6.stream_offset), back6.data_ptr(), back6.numel(), level=args.level)
+        torch.cuda.synchronize(); td = time.perf_counter() - t0
+        out["format6"] = {"sample": "%d x %d bp reads (%.1f MB), one block = the reference's own streams" % (args.format6_reads, args.read_len, len(f6) / 1e6),
+                          "encode_MBps": round(len(f6) / 1e6 / te, 2), "decode_MBps": round(len(f6) / 1e6 / td, 2),
+                          "round_trip_identical": bool(got6 == len(f6) and torch.equal(back6[:len(f6)], t6)),
+                          "reference_encode_MBps": out.get("cpu_baseline", {}).get("value"), "reference_decode_MBps": out.get("cpu_baseline", {}).get("decode_value")}
+        del t6, o6, back6
+    if not multi and args.workload == "full" and not args.models and not args.no_genome_leg and args.kind == 0 and args.tables:
+        # the genome-sampled workload ("the honest stress of the base model"; iid bases switch the base tables off):
+        # the same call over reads sampled from a 10 Mbp genome -- encode, decode, and the ratio against the reference itself on
+        # the first --genome-ratio-reads records (30x coverage at 2 M reads of 150 bp)
+        del d_in
+        torch.cuda.empty_cache()
+        gq = capi.synth_fastq(args.genome_reads, args.read_len, seed=seed, kind=3)
+        gn = len(gq)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g_in = torch.from_numpy(np.frombuffer(gq, np.uint8)).cuda()
+        gcap = capi.lib().sfq_encode_bound(gn)
+        g_out = d_out if d_out.numel() >= gcap else torch.empty(gcap, dtype=torch.uint8, device="cuda")
+        kw = dict(level=args.level, block_reads=args.block_reads, prior_step=prior_step, tables=args.tables, chain_reads=args.chain_reads)
+        ctx.encode_device(g_in.data_ptr(), gn, g_out.data_ptr(), gcap, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            rg = ctx.encode_device(g_in.data_ptr(), gn, g_out.data_ptr(), gcap, **kw)
+        torch.cuda.synchronize(); tg = (time.perf_counter() - t0) / 3
+        leg = {"workload": "synthetic %d x %d bp reads sampled from a 10 Mbp genome, -l %d" % (args.genome_reads, args.read_len, args.level),
+               "value": round(gn / tg / 1e6, 2), "unit": "MB/s", "ms_per_step": round(tg * 1e3, 3), "ratio": round(gn / rg.total_bytes, 4),
+               "base_tables_on": bool(_varints(ctx.chains(), 2)[1] & 1)}
+        if not args.no_decode:
+            gb, gh = ctx.index(rg.n_blocks), ctx.first_headers(rg.first_hdr_bytes)
+            gp, gc, grp = ctx.prior(), ctx.chains(), ctx.rec_prior()
+            g_back = torch.empty(gn + 4096, dtype=torch.uint8, device="cuda")
+            times = []
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                got, _r = ctx.decode_device(gb, gh, g_out.data_ptr(), list(rg.stream_offset), g_back.data_ptr(), g_back.numel(), prior=gp, level=args.level, chains=gc, rec_prior=grp)
+                torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+            leg["decode"] = {"value": round(gn / min(times) / 1e6, 2), "unit": "MB/s FASTQ restored", "ms": round(min(times) * 1e3, 3),
+                             "round_trip_identical": bool(got == gn and torch.equal(g_back[:gn], g_in))}
+            del g_back
+        if not args.no_cpu_baseline and args.genome_ratio_reads:
+            from oracle import oracle as O
+            lines = 4 * min(args.genome_ratio_reads, args.genome_reads)
+            cut = 0
+            for _ in range(lines):
+                cut = gq.index(b"\n", cut) + 1
+            sample = gq[:cut]
+            t0 = time.perf_counter()
+            ra = O.compress(sample, args.level)
+            t_ref = time.perf_counter() - t0
+            ref_payload = ra.payload_bytes() - len(ra.streams["<info>"])
+            enc = ctx.encode_host(sample, **kw)
+            leg["ratio_vs_reference"] = {"sample_reads": lines // 4, "sample_raw": len(sample), "reference_stream_bytes": int(ref_payload), "ours_stream_bytes": int(enc.archive_bytes),
+                                         "ours_over_reference": round(enc.archive_bytes / ref_payload, 4), "cpu_port_MBps": round(len(sample) / 1e6 / t_ref, 2)}
+        out["genome_sampled"] = leg
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
