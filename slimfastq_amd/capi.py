@@ -276,13 +276,13 @@ class Context:
         return res
 
     def decode_device(self, blocks, first_hdrs: bytes, d_streams, stream_offset, d_out, out_cap, prior=b"", level=3, version=0,
-                      chains=b"", lds_rows=0, rec_prior=b""):
+                      chains=b"", lds_rows=0, rec_prior=b"", kernel=0):
         """Device-pointer decode (ints from torch .data_ptr()): returns (bytes written, Result)."""
         L = lib()
         self._check(L.sfq_set_qlt_prior(self._h, prior if prior else None, len(prior)))
         self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
         self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
-        p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, lds_rows)
+        p = Params(level, 0, 0, 0, kernel, version, 0, 0, 0, lds_rows)
         res = Result()
         n = C.c_uint64()
         fb = np.frombuffer(first_hdrs if len(first_hdrs) else b"\0", np.uint8)
@@ -291,7 +291,7 @@ class Context:
                                         C.c_void_p(d_streams), soff, C.c_void_p(d_out), out_cap, C.byref(n), C.byref(res)))
         return n.value, res
 
-    def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None) -> bytes:
+    def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None, kernel=0) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()
         prior = chains = rec_prior = b""
@@ -312,7 +312,7 @@ class Context:
         self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
         self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
-        p = Params(level, 0, 0, 0, 0, version, 0, 0, 0, 0)
+        p = Params(level, 0, 0, 0, kernel, version, 0, 0, 0, 0)
         res = Result()
         if out_cap is None:
             out_cap = 64 * len(data) + (1 << 20)

@@ -1229,6 +1229,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     const u32 version = p.version ? p.version : 6;
+    if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
     if (version > 6) return fail(ctx, SFQ_E_UNSUPPORTED, "archive version %u is newer than 6 (config.cpp:373-377)", version);
     hipStream_t st = ctx->st;
     int rc;
@@ -1504,13 +1505,18 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         }
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_w(da, st_gen); }
     } else {
-    for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_qlt_decode_l(da, st); }
+    // adaptive tables: a wavefront per block (decode_w.hip); sfq_params.kernel = 1: the lane-per-block cross-check kernels
+    const bool wave_dec = p.kernel == 0;
+    for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+        da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
+        if (wave_dec) launch_qlt_decode_w(da, st); else launch_qlt_decode_l(da, st);
+    }
     HIPC(hipEventRecord(ctx->ev[3], st));
     HIPC(hipEventRecord(ctx->ev[7], st_gen));
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st_gen);
-        launch_gen_decode_l(da, st_gen);
+        if (wave_dec && g_bits >= 6) launch_gen_decode_w(da, st_gen); else launch_gen_decode_l(da, st_gen);
     }
     }
     HIPC(hipEventRecord(ctx->ev[4], st_gen));
@@ -1569,7 +1575,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             }
             launch_rec_decode_c(cr, da, rflags, st_rec);
         } else
-        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_rec_decode_l(da, st_rec); }
+        for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+            da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
+            if (p.kernel == 0) launch_rec_decode_w(da, st_rec); else launch_rec_decode_l(da, st_rec);
+        }
         HIPC(hipStreamSynchronize(st_rec));
         HIPC(hipStreamSynchronize(st));
         HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));

@@ -24,7 +24,8 @@ __device__ __forceinline__ u32 b2_put(u32 v, RcEnc& rc, ByteSink& s, u32 sym) { 
     rc.encode(s, cum, f, total);
     return b2_update(v, sym);
 }
-__device__ __forceinline__ u32 b2_get(u32 v, RcDec& rc, ByteSrc& s, u32& sym_out) {   // base2_ranger.hpp:86-104
+template <typename SRC>
+__device__ __forceinline__ u32 b2_get(u32 v, RcDec& rc, SRC& s, u32& sym_out) {   // base2_ranger.hpp:86-104
     u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
     u32 total = (f0 + f1) + (f2 + f3);
     u32 prob = rc.get_freq(total);

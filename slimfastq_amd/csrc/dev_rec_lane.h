@@ -187,8 +187,8 @@ __device__ bool d_is_number(const u8* p, int len, i64& num) {          // recs.c
     return true;
 }
 
-template <typename C>
-__device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* d, u64 rec0, u32 nrec, u32 blk, C& cd, XfDec& x_rec, const PwTab& xpw) {
+template <typename C, typename X>
+__device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* d, u64 rec0, u32 nrec, u32 blk, C& cd, X& x_rec, const PwTab& xpw) {
     u64 index = 0;
     if constexpr (!C::inband) index = x_rec.get(xpw);                                       // recs.cpp:104
     u8* const stage = a.hdr_stage + a.hdr_stage_off[blk];

@@ -91,3 +91,26 @@ __device__ __forceinline__ u32 b2_model(u32 v, u32 sym, u32& cum, u32& freq, u32
     return b2_update(v, sym);
 }
 
+
+// A stream's bytes for wave-UNIFORM code (every lane the same stream position): 256 bytes at a time, a dword per lane, the
+// 256 behind them fetched while these are used -- no memory round trip sits on the coder's renormalisation.  Zeros past the
+// end (FilerLoad::get, filer.hpp:94-97); nothing outside [p, p + n) is touched.
+struct WaveSrc {
+    const u8* p; u32 n, pos, lane;
+    u32 cur, nxt;                                          // per lane: dword `lane` of the window at pos & ~255, and of the next one
+    __device__ __forceinline__ u32 fetch(u32 base) const {
+        const u32 at = base + 4u * lane;
+        if (at + 4u <= n) return *reinterpret_cast<const u32*>(p + at);       // (vector loads need no alignment on gfx9)
+        u32 v = 0;
+        for (u32 k = 0; k < 4; k++) if (at + k < n) v |= (u32)p[at + k] << (8 * k);
+        return v;
+    }
+    __device__ __forceinline__ void init(const u8* ptr, u32 len) { p = ptr; n = len; pos = 0; lane = threadIdx.x & 63u; cur = fetch(0); nxt = fetch(256); }
+    __device__ __forceinline__ u32 get() {
+        const u32 w = rl(cur, (pos >> 2) & 63u);
+        const u32 b = (w >> ((pos & 3u) * 8u)) & 0xffu;
+        pos++;
+        if ((pos & 255u) == 0) { cur = nxt; nxt = fetch(pos + 256u); }
+        return b;
+    }
+};

@@ -152,6 +152,10 @@ void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_rec_decode_l(const DecodeArgs& a, hipStream_t st);
+// the same chains, a wavefront per block (decode_w.hip): blocks [batch0, batch0 + nbatch), slot = workgroup
+void launch_qlt_decode_w(const DecodeArgs& a, hipStream_t st);
+void launch_gen_decode_w(const DecodeArgs& a, hipStream_t st);          // (gen_bits >= 6)
+void launch_rec_decode_w(const DecodeArgs& a, hipStream_t st);
 
 // packing
 void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, u32 s0, u32 s1 /* streams [s0, s1) */, hipStream_t st);

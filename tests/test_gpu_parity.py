@@ -94,8 +94,9 @@ def test_decode_reference_written_streams(ctx, name):
         for i, s in enumerate(capi.STREAM_NAMES):
             soff.append(len(data)); data += gold.get(s, b""); bi.size[i] = len(gold.get(s, b""))
         blocks = (capi.BlockInfo * 1)(bi)
-        out = ctx.decode_host((blocks, first, data, soff), level=level, version=int(info["version"]), out_cap=len(fq) * 2 + 4096)
-        assert out == gold.get("<decoded>", fq), (name, level)
+        for kernel in KERNELS:               # a wavefront per stream (decode_w.hip) / the lane-per-block cross-check kernels
+            out = ctx.decode_host((blocks, first, data, soff), level=level, version=int(info["version"]), out_cap=len(fq) * 2 + 4096, kernel=kernel)
+            assert out == gold.get("<decoded>", fq), (name, level, kernel)
 
 
 def test_decode_pre5_header_stream(ctx):
@@ -133,7 +134,8 @@ def test_roundtrip_blocks(ctx, level):
     fq = capi.synth_fastq(4100, 150, seed=30 + level)
     for br in (0, 512):
         enc = ctx.encode_host(fq, level=level, block_reads=br)
-        assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+        for kernel in KERNELS:
+            assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096, kernel=kernel) == fq, (br, kernel)
 
 
 def test_roundtrip_long_reads_and_samples(ctx):
@@ -389,7 +391,8 @@ def test_low_complexity_bases_same_context_in_one_window(ctx, kernel):
         for b, chunk in enumerate(util.split_records(fq, br) if br else [fq]):
             want = util.block_reference(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, want, block=b, ctxmsg="lowcomplexity l%d b%d" % (level, b))
-        assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+        for dk in KERNELS:                     # (homopolymers: the wave decoder forwards the rows it has just written)
+            assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096, kernel=dk) == fq, (level, br, dk)
 
 
 def _cli():
@@ -773,13 +776,15 @@ def test_fuzz_small_structurally_hostile_inputs(ctx, seed):
             continue
         enc = ctx.encode_host(fq, level=level, block_reads=0)
         assert_streams_equal(enc, want.streams, ctxmsg="fuzz seed %d rep %d one block" % (seed, rep))
-        assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == O.decompress(want.image)
+        for kernel in KERNELS:
+            assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096, kernel=kernel) == O.decompress(want.image), kernel
         br = int(rng.integers(1, max(2, nrec // 2 + 1)))
         enc = ctx.encode_host(fq, level=level, block_reads=br)
         for b, chunk in enumerate(util.split_records(fq, br)):
             wantb = util.block_reference(chunk, level, gen_bits=enc.blocks[b].gen_bits).streams
             assert_streams_equal(enc, wantb, block=b, ctxmsg="fuzz seed %d rep %d block %d of %d" % (seed, rep, b, br))
-        assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == fq          # the block format is lossless
+        for kernel in KERNELS:
+            assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096, kernel=kernel) == fq, kernel     # the block format is lossless
 
 
 @pytest.mark.parametrize("kernel", (1,))
