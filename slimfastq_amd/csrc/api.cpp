@@ -379,18 +379,22 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
 // of records spread over the call -- or the installed one (SFQ_PRIOR_GIVEN); leaves the frozen rows on the device.
 // Two halves, so that the launching thread can queue other streams' work while the counting pass runs: _begin queues the
 // pass and the copy of its counts to pinned host memory (PIN_REC_OFF), _finish waits for them and builds the rows.
+#define REC_PRIOR_RUN 6u          // records per run of the header prior's counting pass: the base, one that warms the field types up, four counted
+#define REC_PRIOR_RUNS 32768u
 #define PIN_GEN_OFF 0u
 #define PIN_REC_OFF 64u
 #define PIN_BYTES (PIN_REC_OFF + (size_t)PR_REC_ROWS * 256 * 4)
 int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipStream_t st) {
     if (given) return SFQ_OK;
     int rc;
-    if ((rc = reserve(ctx, ctx->hcnt, (size_t)PR_REC_ROWS * 256 * 4))) return rc;
-    HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)PR_REC_ROWS * 256 * 4, st));
-    const u32 run = 18;
-    const u32 nruns = (u32)std::min<u64>(8192, std::max<u64>(1, nrec / run));
+    if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
+    HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4, st));
+    // (short runs, many of them: the pass's time is one lane's walk through its run -- 8192 runs of 18 records took 2.9 ms of
+    //  every call on 128 wavefronts; the sample is the same 131 k counted records)
+    const u32 run = REC_PRIOR_RUN;
+    const u32 nruns = (u32)std::min<u64>(REC_PRIOR_RUNS, std::max<u64>(1, nrec / run));
     const u64 stride = std::max<u64>(run, nrec / nruns);
-    if ((rc = reserve(ctx, ctx->cflags, (size_t)8192 * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->cflags, (size_t)REC_PRIOR_RUNS * 4))) return rc;
     HIPC(hipMemsetAsync(ctx->cflags.p, 0, (size_t)nruns * 4, st));
     launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, (u32*)ctx->cflags.p, st);
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
@@ -495,10 +499,19 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     sfq_ctx* ctx = new sfq_ctx();
     ctx->dev = hip_device;
     // one stream per model (quality, bases, headers, framing)
-    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    // (the context's stream carries the call's critical path -- framing, the quality sample, the quality chains -- and the
+    //  framing-exception stream the pass over the N / quality-0 / case exceptions: both at the higher priority, so that their
+    //  workgroups are placed first and they have hardware queues of their own)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if ((prio_hi != prio_lo ? hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking)) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     // (the runtime maps streams of one priority onto three hardware queues: the framing stream shares one with the base
     //  model's, and two streams that share a queue run one after the other -- keep long kernels off the framing stream)
-    for (int i = 0; i < 3; i++) if (hipStreamCreateWithFlags(&ctx->st_aux[i], hipStreamNonBlocking) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    for (int i = 0; i < 3; i++) {
+        const hipError_t e = (i == 1 && prio_hi != prio_lo) ? hipStreamCreateWithPriority(&ctx->st_aux[i], hipStreamNonBlocking, prio_hi)
+                                                              : hipStreamCreateWithFlags(&ctx->st_aux[i], hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return SFQ_E_HIP; }
+    }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
@@ -605,6 +618,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         hist_cleared = true;
     }
     const bool legacy = p.block_reads == 0;
+    // frozen tables: the framing marks the records the pass over the N / quality-0 / case exceptions has to look at
+    const bool want_marks = p.tables == SFQ_TABLES_FROZEN && p.block_reads != 0 && p.kernel == 0 && (models & SFQ_M_GEN) && !priors_only;
     u64 nrec = 0;
     // the line index of the current text (d_fastq, nbytes) and the per-record checks
     auto frame = [&]() -> int {
@@ -625,7 +640,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         nrec = nlines / 4;
         if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
         if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
-        launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, st);
+        if (want_marks) {
+            if ((rc = reserve(ctx, ctx->excf, (size_t)nrec))) return rc;
+            HIPC(hipMemsetAsync(ctx->excf.p, 0, (size_t)nrec, st));
+        }
+        launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, want_marks ? (u8*)ctx->excf.p : nullptr, st);
         // headers up to 8190 bytes (usrs.hpp:34; format 6 sends longer ones to its oversize streams, below), base / quality lines
         // of any length: the block format codes them the usual way (a block's regions are sized by its text), format 6 has its
         // oversize streams
@@ -800,16 +819,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
         if ((rc = setup_tables())) return rc;
-        // the pass over the N / quality-0 exceptions looks only at the records k_exc_mark marks
-        // the pass over the N / quality-0 exceptions looks only at the records the quality and base chains mark
-        // (marking them ahead -- a pass of its own over the text, then the exception pass while the counting passes run
-        //  -- was measured: the extra pass costs more chip time than the 2 ms the exception pass takes behind the chains)
-        const bool exc_marks = (models & SFQ_M_QLT) && (models & SFQ_M_GEN);
-        if (exc_marks) {
-            if ((rc = reserve(ctx, ctx->excf, (size_t)nrec))) return rc;
-            HIPC(hipMemsetAsync(ctx->excf.p, 0, (size_t)nrec, st));
-            ca.exc_flag = (u8*)ctx->excf.p;
-        }
+        // the pass over the N / quality-0 / case exceptions looks only at the records the framing has marked (frame.hip
+        // k_write_newlines: the text is in registers there anyway) and runs beside the counting passes, while the chip is
+        // mostly idle.  (Round 2 had the quality and base chains mark them -- the pass then ran BEHIND the chains, 2.5 ms at
+        // the call's tail; a marking pass of its own over the text was measured too: it costs more than those 2.5 ms.)
         HIPC(hipEventRecord(ctx->ev[13], st));
         if (!priors_only) {
             for (int m = 1; m < 4; m++) { HIPC(hipStreamWaitEvent(mst[m], ctx->ev[13], 0)); HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m])); }
@@ -818,7 +831,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc; }
             if (models & SFQ_M_GEN) {
                 if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
-                if (!ca.exc_flag) launch_gen_exc_w(a, nullptr, tickets + 1, mst[2]);       // nobody marks the records: all of them, beside the chains
+                launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
             }
             if (models & SFQ_M_USR)
                 for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
@@ -830,13 +843,17 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     }
     u32* h_rows66 = nullptr;
     bool rows66_copy_pending = false;
-    // auto: sample about 60 M quality symbols (~400 k records of 150 bp; for long reads far fewer records --
+    // auto: sample about 24 M quality symbols (~160 k records of 150 bp: one per lane of the histogram kernel, all of them on
+    // the chip at once; 60 M symbols coded 0.01 % smaller; for long reads far fewer records --
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
     // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
     //  the longest walk)
     if (prior_step == SFQ_PRIOR_AUTO) {
         const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
-        prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 60000000ull), 0x7FFFFFFFull);
+        prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 24000000ull), 0x7FFFFFFFull);
+        // (short records: not more of them than the histogram kernel's workgroups hold on the chip at once -- 512 of 256 lanes, a
+        //  record per lane: a second round of workgroups waits for the first while the other models' kernels take the chip)
+        if (nbytes / nrec <= 4000) prior_step = (u32)std::max<u64>(prior_step, (nrec + 131071) / 131072);
     }
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
@@ -934,12 +951,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         side_late = false;
-        if ((models & SFQ_M_GEN) && ca.exc_flag) {                  // the marks are complete once both chain kernels are through
-            HIPC(hipStreamWaitEvent(mst[3], ctx->ev[3], 0));
-            launch_gen_exc_w(a, ca.exc_flag, tickets + 1, mst[3]);
-            HIPC(hipEventRecord(ctx->ev[12], mst[3]));
-            side_late = true;                                       // joined in the second half of the packing (below)
-        }
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 1], 0));        // header chains
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 3], 0));        // base chains
         if (!side_late) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 2], 0));

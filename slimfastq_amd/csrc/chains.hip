@@ -482,9 +482,9 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
 // bytes repeats the context before it, so its lookup is harmless), code(j, code, valid) likewise with a flag, and
 // piece_end() once per piece.
 template <typename LOOK, typename CODE, typename PEND>
-__device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, const u8* lut, LOOK&& look, CODE&& code, PEND&& piece_end, u8* exc_flag) {
+__device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, const u8* lut, LOOK&& look, CODE&& code, PEND&& piece_end, u8* exc_flag) {
     LineWalk lw; lw.init(a, r0, nrec, 1, solid);
-    u32 last = 0;
+    u32 last = 0, illegal = 0;
     Piece pc = lw.next();
     uint4 w = lw.fetch(pc);
     while (__any(pc.valid)) {
@@ -506,6 +506,7 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
         }
         // an N, a lowercase base or an illegal character marks the record for the pass over the N / quality-0 / case exceptions (k_gen_exc_w)
         if (exc_flag && (odd & 0x34u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
+        illegal |= odd & 0x10u;                                    // (unexpected genome char, gens.cpp:125-126: reported by the chain itself)
 #pragma unroll
         for (u32 j = 0; j < 16; j++) {
             code(j, (codes >> (2 * j)) & 3u, j < len ? ~0u : 0u);
@@ -513,6 +514,7 @@ __device__ __forceinline__ void walk_bases_b(const ChainArgs& a, u64 r0, u32 nre
         }
         pc = pn; w = wn;
     }
+    return illegal;
 }
 
 // counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
@@ -560,8 +562,16 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
     if (!nrec_range) return;
     const u32 stride = gen_count_stride(nrec_range);
-    // lines up to 1 KiB: a lane per record; longer: a lane per stretch of 512 bases (the lanes past a record's end idle)
-    const u32 seg_len = max_line > 1024u ? 512u : 0u;
+    // lines up to 1 KiB: a lane per record; longer: a lane per stretch of 512 bases (the lanes past a record's end idle).
+    // A SMALL generation (the first ones: 1/64 of the call each, whose passes every base chain waits for) is latency, not
+    // throughput: its time is one lane's walk through its record, so the records are cut into the shortest stretches (of 32
+    // bases or more, sixteen bases of warm-up before each) that still fit the chip's 524 288 lanes at once
+    u32 seg_len = max_line > 1024u ? 512u : 0u;
+    if (!seg_len && max_line >= 64u) {
+        const u64 nsel = (nrec_range + stride - 1) / stride;
+        for (u32 sl = 32u; sl < max_line; sl *= 2u)
+            if (nsel * ((max_line + sl - 1) / sl) <= 524288ull) { seg_len = sl; break; }
+    }
     const u32 segs = seg_len ? (max_line + seg_len - 1) / seg_len : 1u;
     const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
     hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost);
@@ -607,10 +617,11 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
     rc.init(ring, threadIdx.x, outp, cap);
     const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
+    u32 illegal = 0;
     if (!__any(rows != nullptr)) {
         // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
         const u32 r12 = fz_recip(12u);
-        walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
+        illegal = walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
             [&](u32, u32 code, u32 vm) { rc.encode_if(vm, 3u * code, 3u, 12u, r12); },
             [&]() { rc.drain(); }, a.exc_flag);
     } else {
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
         const u32* rp = rows ? rows : a.g_init;
         const u32 mask = (live && rows) ? (1u << d->gen_bits) - 1u : 0u;
         u32 rv[16];
-        walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, mask, lut,
+        illegal = walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, mask, lut,
             [&](u32 j, u32 ctx) { rv[j] = rp[ctx]; },
             [&](u32 j, u32 code, u32 vm) {
                 const u32 v = rv[j];
@@ -635,6 +646,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
         a.csz[c] = rc.finish();
         if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));
         else if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
+        if (illegal) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_GENCHAR));
     }
 }
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
@@ -783,11 +795,22 @@ __global__ __launch_bounds__(64) void k_rec_count(ModelArgs a, u64 nrec, u64 str
     const u64 r0 = (u64)i * stride;
     if (r0 >= nrec) return;
     const u32 n = (u32)(nrec - r0 < run ? nrec - r0 : run);
-    RecCountEnc cd; cd.cnt = cnt; cd.kc = 0;
+    RecCountEnc cd; cd.cnt = cnt + (size_t)(blockIdx.x % REC_COUNT_COPIES) * PR_REC_ROWS * 256; cd.kc = 0;
     XfEnc x_rec; x_rec.init(nullptr, 0, XF_REC_X);
     PwTab none; none.slots = nullptr; none.hdr = nullptr; none.epoch = 0;
     u32 hb; int bad;
     rec_encode_lane(a, r0, r0, n, cd, x_rec, none, hb, bad);
+}
+// the counting pass counts into REC_COUNT_COPIES copies of the table (a workgroup takes copy blockIdx % copies): nearly every
+// header puts its symbols on the same few dozen counters, and atomics on ONE address run one after the other in the L2
+// (1.6 M of them on ~50 addresses were most of the pass's 2.5 ms).  cnt[0] += the other copies.
+__global__ __launch_bounds__(256) void k_rec_count_sum(u32* __restrict__ cnt) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= PR_REC_ROWS * 256u) return;
+    u32 s = 0;
+#pragma unroll 8
+    for (u32 k = 1; k < REC_COUNT_COPIES; k++) s += cnt[(size_t)k * PR_REC_ROWS * 256 + i];
+    if (s) cnt[i] += s;
 }
 // frozen rows from the prior's scaled frequencies f[row][256]: x = f + 1, g = max(1, floor(x * 65536 / sum x)), the
 // remainder to the largest g (the first of them); entry = cum | g << 16.  rdec (may be null; the decoder's form):
@@ -1089,7 +1112,7 @@ __global__ __launch_bounds__(64) void k_rec_count_f(ModelArgs a, u64 nrec, u64 s
         fits = len <= 127u && rf_stage(L, 0, lane, a.fq + h0, len) <= RF_NF;
     }
     if (!fits) { flags[i] = 1; return; }
-    RecFastCount cd; cd.cnt = cnt; cd.kc = 0;
+    RecFastCount cd; cd.cnt = cnt + (size_t)(blockIdx.x % REC_COUNT_COPIES) * PR_REC_ROWS * 256; cd.kc = 0;
     u32 hb = 0;
     rec_fast_lane(a, L, lane, r0, r0, n, cd, hb);
 }
@@ -1097,6 +1120,7 @@ __global__ __launch_bounds__(64) void k_rec_count_f(ModelArgs a, u64 nrec, u64 s
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_count_f, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt, flags);
     hipLaunchKernelGGL(k_rec_count, dim3((nruns + 63) / 64), dim3(64), 0, st, a, nrec, stride, run, nruns, cnt, (const u32*)flags);
+    hipLaunchKernelGGL(k_rec_count_sum, dim3((PR_REC_ROWS * 256u + 255) / 256), dim3(256), 0, st, cnt);
 }
 // flags: one dword per header chain, zeroed by the caller
 void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32 max_hdr, hipStream_t st) {

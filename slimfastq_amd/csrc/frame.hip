@@ -66,7 +66,18 @@ __global__ __launch_bounds__(256) void k_count_newlines(const u8* fq, u64 n, u32
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, bool aligned) {
+// 0x80 in every byte of x that equals the byte repeated in c
+__device__ __forceinline__ u32 eq_mask(u32 x, u32 c) {
+    const u32 y = x ^ c;
+    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+}
+// the four 0x80 flags of a byte mask as four bits
+__device__ __forceinline__ u32 pack4(u32 m) { return ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; }
+// exc_flag (may be null): [records] set to 1 where a record's quality line holds a '!' or its base line an N-like or lowercase
+// character -- the records the pass over the N / quality-0 / case exceptions (models_w.hip k_gen_exc_w) has to look at.  The
+// text is in registers here anyway and such bytes are rare: a test per dword, the byte-by-byte attribution to lines only
+// where it fires.  (Marking a record too many costs that pass a look at it, nothing else.)
+__global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, bool aligned, u8* exc_flag) {
     __shared__ u32 lds[8];
     const u64 cbase = (u64)blockIdx.x * FRAME_CHUNK;
     u64 run = chunk_base[blockIdx.x];          // newlines before this chunk
@@ -82,6 +93,40 @@ __global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, con
         u32 total;
         u32 ex = block_excl_scan_256(cnt, lds, &total);
         u64 k = run + ex;
+        if (exc_flag && pos < n) {
+            // '!' in a quality line; 'N', '.' or a byte of 0x60..0x7f (the lowercase letters) in a base line.  A piece without a
+            // newline lies in ONE line (k & 3 says which): a test per dword of the kind its line asks for, none in a header or
+            // '+' line.  A piece that holds a line's end: the matches and the newlines as sixteen-bit masks, and a look at the
+            // matching bytes only (a loop over the piece's bytes had every wave walk all sixteen: 0.9 -> 2.3 ms for the kernel)
+            u32 bang = 0, oddb = 0;
+            const u32 type0 = (u32)k & 3u;
+            if (cnt == 0) {
+                if (type0 == 3u) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) bang |= eq_mask(w[q], 0x21212121u);
+                } else if (type0 == 1u) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) oddb |= eq_mask(w[q], 0x4e4e4e4eu) | eq_mask(w[q], 0x2e2e2e2eu) | ((w[q] << 1) & (w[q] << 2) & 0x80808080u);
+                }
+                if (bang | oddb) exc_flag[k >> 2] = 1;
+            } else {
+                u32 nl16 = 0, b16 = 0, o16 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    nl16 |= pack4(nl_mask(w[q])) << (4 * q);
+                    b16 |= pack4(eq_mask(w[q], 0x21212121u)) << (4 * q);
+                    o16 |= pack4(eq_mask(w[q], 0x4e4e4e4eu) | eq_mask(w[q], 0x2e2e2e2eu) | ((w[q] << 1) & (w[q] << 2) & 0x80808080u)) << (4 * q);
+                }
+                u32 cand = b16 | o16;
+                while (cand) {
+                    const u32 i = (u32)__ffs((int)cand) - 1u;
+                    cand &= cand - 1u;
+                    const u64 line = k + (u32)__popc(nl16 & ((1u << i) - 1u));
+                    const u32 type = (u32)line & 3u;
+                    if ((type == 3u && ((b16 >> i) & 1u)) || (type == 1u && ((o16 >> i) & 1u))) exc_flag[line >> 2] = 1;
+                }
+            }
+        }
         if (cnt) {
             for (int q = 0; q < 4; q++) {
                 u32 m = nl_mask(w[q]);
@@ -119,9 +164,9 @@ void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, 
     bool aligned = ((uintptr_t)fq & 15) == 0;
     hipLaunchKernelGGL(k_count_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_counts, aligned);
 }
-void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st) {
+void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, u8* exc_flag, hipStream_t st) {
     bool aligned = ((uintptr_t)fq & 15) == 0;
-    hipLaunchKernelGGL(k_write_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_base, line_off, aligned);
+    hipLaunchKernelGGL(k_write_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_base, line_off, aligned, exc_flag);
 }
 
 // ---- generic exclusive scan u32 -> u64 -------------------------------------------------------------

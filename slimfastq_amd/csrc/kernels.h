@@ -90,7 +90,9 @@ void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t 
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
-void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt, u32* flags /* [nruns], zeroed */, hipStream_t st);
+#define REC_COUNT_COPIES 32u        // the header prior's counting pass counts into this many copies of the table (chains.hip k_rec_count_sum)
+void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt /* [REC_COUNT_COPIES][PR_REC_ROWS][256], zeroed; the sums end up in copy 0 */,
+                      u32* flags /* [nruns], zeroed */, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec /* the decoder's form; may be null */, hipStream_t st);
 // one header chain per lane; a.csz / a.rhb per chain; max_hdr = the call's longest header (picks the LDS image of the fast kernel)
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32 max_hdr, hipStream_t st);
@@ -108,7 +110,8 @@ static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1)
 // framing
 void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
 void launch_max_u32(const u32* v, u64 n, u32* out /* raised to the largest of v */, hipStream_t st);
-void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, hipStream_t st);
+void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks,
+                           u8* exc_flag /* [records], zeroed, or null: marks the records with a '!' / N / lowercase base */, hipStream_t st);
 void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line /* longest header / base or quality line taken */, u32* status, hipStream_t st);
 // format 6's oversize records (frame.hip, models_w.hip)
 void launch_over_first(const u64* line_off, u64 nrec, u32* first /* 0xFFFFFFFF */, hipStream_t st);

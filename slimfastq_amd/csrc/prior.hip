@@ -22,11 +22,14 @@ __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 
 // (ctx, symbol).  Plain global atomics serialise on the few very hot counters (memory-side atomics:
 // ~30 ns each on one address), so every workgroup first aggregates in an LDS hash table and flushes each
 // distinct key once.
-#define HIST_SLOTS 8192u            // 64 KiB of LDS: keys + counts
+#define HIST_SLOTS 8192u            // 64 KiB of LDS: keys + counts (half of that was measured: the table overflows onto the hot
+                                    // global counters and the kernel takes 34 ms instead of 4)
 #define HIST_EMPTY 0xFFFFFFFFu
 __device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 key) {
     u32 slot = (key * 2654435761u) >> 19;                 // 13 bits
-    for (int probe = 0; probe < 8; probe++) {
+    // (as many probes as it takes while the table has room: a key that gives up after a few in a crowded neighbourhood goes to
+    //  the global counters, and the ones that are hot there are hot in every workgroup -- those atomics were most of the kernel's time)
+    for (int probe = 0; probe < 256; probe++) {
         const u32 old = atomicCAS(&keys[slot], HIST_EMPTY, key);
         if (old == HIST_EMPTY || old == key) { atomicAdd(&cnts[slot], 1u); return; }
         slot = (slot + 1) & (HIST_SLOTS - 1);
@@ -90,8 +93,10 @@ void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockD
         const u64 per_wg = 64;
         hipLaunchKernelGGL((k_qlt_hist<64, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(64), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     } else {
-        const u64 per_wg = 256ull * 4;
-        hipLaunchKernelGGL((k_qlt_hist<256, 4>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
+        // (a record per lane: the kernel's time is one lane's walk -- with four records per lane and a 64 KiB table, two workgroups
+        //  per CU, it took 4.6 ms of every call whatever the sample's size)
+        const u64 per_wg = 256ull;
+        hipLaunchKernelGGL((k_qlt_hist<256, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     }
 }
 

@@ -14,8 +14,8 @@ GEN_STEP = 4
 
 
 def rec_sample(nrec):
-    run = 18
-    nruns = min(8192, max(1, nrec // run))
+    run = 6                                       # api.cpp REC_PRIOR_RUN / REC_PRIOR_RUNS
+    nruns = min(32768, max(1, nrec // run))
     return max(run, nrec // nruns), run, nruns
 
 
