@@ -190,15 +190,11 @@ def main():
     def step(tables=args.tables):
         ps = prior_step
         if multi and prior_step == capi.PRIOR_AUTO:
-            # one prior for the whole job: rank 0 builds it from its shard, broadcasts it (a few hundred KB),
-            # every rank codes from it -- so a record block's bytes do not depend on how many GPUs shared the file
-            from slimfastq_amd.dist_compress import bcast_bytes
-            pri = rp = b""
-            if rank == 0:
-                pri, rp = ctx.build_priors(d_in.data_ptr(), nbytes, level=args.level, block_reads=args.block_reads, tables=tables)
-            pri = bcast_bytes(pri, 0, d_in.device); rp = bcast_bytes(rp, 0, d_in.device)
-            ctx.set_priors(pri, rp)
-            ps = capi.PRIOR_GIVEN
+            # one prior for the whole job and no rank the others wait for: every rank counts a 1 / world share of the
+            # sample over its own shard, the count tables are summed over the ranks (all_reduce: 17 MiB), every rank builds the
+            # same priors from the sums -- so a record block's bytes do not depend on how many GPUs shared the file
+            sdist.allreduce_prior_counts(ctx, d_in.data_ptr(), nbytes, d_in.device, level=args.level, block_reads=args.block_reads, tables=tables)
+            ps = capi.PRIOR_COUNTS
         buf = d_outs[flight["n"] % len(d_outs)]
         flight["n"] += 1
         res = ctx.encode_device(d_in.data_ptr(), nbytes, buf.data_ptr(), cap, level=args.level,

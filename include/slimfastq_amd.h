@@ -101,6 +101,7 @@ typedef struct sfq_params {
 #define SFQ_LDS_ROWS_NONE  0xFFFFFFFFu
 #define SFQ_PRIOR_AUTO  0xFFFFFFFFu
 #define SFQ_PRIOR_GIVEN 0xFFFFFFFEu  /* prior_step: the priors installed with sfq_set_qlt_prior / sfq_set_rec_prior */
+#define SFQ_PRIOR_COUNTS 0xFFFFFFFDu /* prior_step: the sample COUNTS installed with sfq_set_prior_counts stand for this call's own sample */
 #define SFQ_BLOCK_AUTO 0xFFFFFFFFu
 
 /* One entry per block: what a decoder needs besides the stream bytes (the "block index").
@@ -184,6 +185,15 @@ int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes,
  * an sfq_encode_blocks call with the same parameters would have built.  For several contexts / GPUs that compress parts
  * of one file from ONE prior: build it once, install it everywhere (sfq_set_*_prior), encode with prior_step = SFQ_PRIOR_GIVEN. */
 int sfq_build_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params);
+/* Several GPUs, one file, NO serial head: every rank counts the sample of ITS share of the file (sfq_count_priors: every
+ * sample_scale-th record of what one call alone would sample -- sample_scale = the number of ranks keeps the job's sample the size
+ * of one call's), the ranks add their counts up (an all-reduce of two u32 arrays: sfq_get_prior_counts -> the caller's device
+ * buffers -> sfq_set_prior_counts), and every rank codes with prior_step = SFQ_PRIOR_COUNTS: identical priors everywhere, nobody
+ * waits for a rank that builds them.  Array sizes in u32 words: sfq_prior_counts_words. */
+int  sfq_count_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params, uint32_t sample_scale);
+void sfq_prior_counts_words(int level, uint64_t* qlt_words, uint64_t* rec_words);
+int  sfq_get_prior_counts(sfq_ctx* ctx, int level, uint32_t* d_qlt, uint32_t* d_rec);
+int  sfq_set_prior_counts(sfq_ctx* ctx, int level, const uint32_t* d_qlt, const uint32_t* d_rec);
 /* Same with host buffers (stages through the context's device memory; PCIe-inclusive). */
 int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
                            uint8_t* h_out, uint64_t out_cap, sfq_result* result);

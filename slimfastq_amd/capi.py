@@ -14,6 +14,7 @@ M_REC, M_GEN, M_QLT, M_USR, M_ALL = 1, 2, 4, 8, 15
 T_FRAME, T_QLT, T_GEN, T_REC, T_USR, T_PACK, T_TOTAL = range(7)
 PRIOR_AUTO = 0xFFFFFFFF
 PRIOR_GIVEN = 0xFFFFFFFE
+PRIOR_COUNTS = 0xFFFFFFFD
 BLOCK_AUTO = 0xFFFFFFFF
 TABLES_ADAPTIVE, TABLES_FROZEN = 0, 1
 LDS_ROWS_NONE = 0xFFFFFFFF
@@ -24,7 +25,7 @@ EXPORTS = [
     "sfq_encode_blocks_host", "sfq_get_block_index", "sfq_get_first_headers", "sfq_decode_blocks",
     "sfq_decode_blocks_host", "sfq_synth_fastq", "sfq_abi_version", "sfq_get_qlt_prior", "sfq_set_qlt_prior",
     "sfq_archive_write", "sfq_pack_block_index", "sfq_ctx_device_memory", "sfq_get_chain_index", "sfq_set_chain_index", "sfq_get_rec_prior", "sfq_set_rec_prior", "sfq_build_priors",
-    "sfq_host_alloc", "sfq_host_free",
+    "sfq_host_alloc", "sfq_host_free", "sfq_count_priors", "sfq_prior_counts_words", "sfq_get_prior_counts", "sfq_set_prior_counts",
 ]
 
 
@@ -112,6 +113,11 @@ def lib():
         L.sfq_get_qlt_prior.restype = C.c_int64
         L.sfq_set_qlt_prior.argtypes = [vp, u8p, u64]
         L.sfq_build_priors.argtypes = [vp, u8p, u64, C.POINTER(Params)]
+        L.sfq_count_priors.argtypes = [vp, u8p, u64, C.POINTER(Params), C.c_uint32]
+        L.sfq_prior_counts_words.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.sfq_prior_counts_words.restype = None
+        L.sfq_get_prior_counts.argtypes = [vp, C.c_int, u8p, u8p]
+        L.sfq_set_prior_counts.argtypes = [vp, C.c_int, u8p, u8p]
         L.sfq_get_rec_prior.argtypes = [vp, u8p, u64]
         L.sfq_get_rec_prior.restype = C.c_int64
         L.sfq_set_rec_prior.argtypes = [vp, u8p, u64]
@@ -238,6 +244,24 @@ class Context:
         p = Params(level, block_reads, 0, 0, 0, 0, prior_step, tables, 0, 0)
         self._check(lib().sfq_build_priors(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p)))
         return self.prior(), self.rec_prior()
+
+    def count_priors(self, d_ptr, nbytes, level=3, block_reads=BLOCK_AUTO, prior_step=PRIOR_AUTO, tables=1, sample_scale=1):
+        """The sample COUNTS of a device-resident text (every sample_scale-th record of the automatic sample): for several
+        ranks that add their counts up (dist.allreduce_prior_counts) and code with prior_step = PRIOR_COUNTS."""
+        p = Params(level, block_reads, 0, 0, 0, 0, prior_step, tables, 0, 0)
+        self._check(lib().sfq_count_priors(self._h, C.c_void_p(d_ptr), nbytes, C.byref(p), sample_scale))
+
+    @staticmethod
+    def prior_counts_words(level=3):
+        nq, nr = C.c_uint64(), C.c_uint64()
+        lib().sfq_prior_counts_words(level, C.byref(nq), C.byref(nr))
+        return nq.value, nr.value
+
+    def get_prior_counts(self, level, d_qlt, d_rec):
+        self._check(lib().sfq_get_prior_counts(self._h, level, C.c_void_p(d_qlt), C.c_void_p(d_rec)))
+
+    def set_prior_counts(self, level, d_qlt, d_rec):
+        self._check(lib().sfq_set_prior_counts(self._h, level, C.c_void_p(d_qlt), C.c_void_p(d_rec)))
 
     def set_priors(self, prior: bytes, rec_prior: bytes = b""):
         L = lib()

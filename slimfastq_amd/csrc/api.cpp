@@ -56,6 +56,7 @@ struct sfq_ctx {
     bool blobs_from_encode = false;        // prior_blob / rec_prior_blob / chain_blob are what the last ENCODE left for sfq_get_*:
                                            // a decode never reads those (only what sfq_set_* installed)
     bool unsettled = false;                // a call returned with an error: its side streams may still be running
+    bool counts_only = false; u32 sample_scale = 1;      // sfq_count_priors: stop once the sample is counted; every sample_scale-th sampled record
     void* pin = nullptr; size_t pin_cap = 0;
     void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
@@ -384,15 +385,19 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
 #define PIN_GEN_OFF 0u
 #define PIN_REC_OFF 64u
 #define PIN_BYTES (PIN_REC_OFF + (size_t)PR_REC_ROWS * 256 * 4)
-int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, hipStream_t st) {
+int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool counted, hipStream_t st) {
     if (given) return SFQ_OK;
     int rc;
     if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
+    if (counted) {                                       // SFQ_PRIOR_COUNTS: the counts are there (sfq_set_prior_counts)
+        HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
+        return SFQ_OK;
+    }
     HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4, st));
     // (short runs, many of them: the pass's time is one lane's walk through its run -- 8192 runs of 18 records took 2.9 ms of
     //  every call on 128 wavefronts; the sample is the same 131 k counted records)
     const u32 run = REC_PRIOR_RUN;
-    const u32 nruns = (u32)std::min<u64>(REC_PRIOR_RUNS, std::max<u64>(1, nrec / run));
+    const u32 nruns = (u32)std::min<u64>(std::max<u32>(1u, REC_PRIOR_RUNS / std::max<u32>(1u, ctx->sample_scale)), std::max<u64>(1, nrec / run));
     const u64 stride = std::max<u64>(run, nrec / nruns);
     if ((rc = reserve(ctx, ctx->cflags, (size_t)REC_PRIOR_RUNS * 4))) return rc;
     HIPC(hipMemsetAsync(ctx->cflags.p, 0, (size_t)nruns * 4, st));
@@ -612,7 +617,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // the quality model's critical path for a millisecond (it shares the chip with the counting passes by then)
     const u32 q_rows0 = p.level == 1 ? (1u << 12) : (1u << 16);
     bool hist_cleared = false;
-    if (p.block_reads && (models & SFQ_M_QLT) && (p.prior_step || p.tables == SFQ_TABLES_FROZEN) && p.kernel == 0) {
+    if (p.block_reads && (models & SFQ_M_QLT) && (p.prior_step || p.tables == SFQ_TABLES_FROZEN) && p.kernel == 0 && p.prior_step != SFQ_PRIOR_COUNTS) {
         if ((rc = ensure_prior_buffers(ctx, q_rows0))) return rc;
         HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows0 * 64 * 4, st));
         hist_cleared = true;
@@ -752,6 +757,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // SFQ_PRIOR_GIVEN: the priors installed with sfq_set_qlt_prior / sfq_set_rec_prior (e.g. built once for a file that
     // several GPUs share, sfq_build_priors) instead of priors counted over this call's text
     const bool given = prior_step == SFQ_PRIOR_GIVEN;
+    const bool counted = prior_step == SFQ_PRIOR_COUNTS;       // the sample's counts are installed (sfq_set_prior_counts): nothing is counted here
+    if (counted && (!ctx->hist.p || (frozen && (models & SFQ_M_REC) && !ctx->hcnt.p))) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_COUNTS: no counts installed (sfq_set_prior_counts)");
     if (given && ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no quality prior installed (sfq_set_qlt_prior)");
     if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
     if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
@@ -828,7 +835,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (int m = 1; m < 4; m++) { HIPC(hipStreamWaitEvent(mst[m], ctx->ev[13], 0)); HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m])); }
             a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
             ca.m = a;
-            if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc; }
+            if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc; }
             if (models & SFQ_M_GEN) {
                 if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
                 launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
@@ -838,7 +845,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
         } else if (models & SFQ_M_REC) {                    // sfq_build_priors: the header sample beside the quality sample
             HIPC(hipStreamWaitEvent(mst[1], ctx->ev[13], 0));
-            if ((rc = rec_prior_begin(ctx, a, nrec, given, mst[1]))) return rc;
+            if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc;
         }
     }
     u32* h_rows66 = nullptr;
@@ -848,12 +855,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
     // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
     //  the longest walk)
-    if (prior_step == SFQ_PRIOR_AUTO) {
+    if (prior_step == SFQ_PRIOR_AUTO || (ctx->counts_only && prior_step == 0)) {
         const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
         prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 24000000ull), 0x7FFFFFFFull);
         // (short records: not more of them than the histogram kernel's workgroups hold on the chip at once -- 512 of 256 lanes, a
         //  record per lane: a second round of workgroups waits for the first while the other models' kernels take the chip)
         if (nbytes / nrec <= 4000) prior_step = (u32)std::max<u64>(prior_step, (nrec + 131071) / 131072);
+        prior_step = (u32)std::min<u64>((u64)prior_step * std::max<u32>(1u, ctx->sample_scale), 0x7FFFFFFFull);      // (sfq_count_priors: a share of the job's sample)
     }
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
@@ -863,8 +871,17 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         ctx->prior_on = true;
     } else if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
-        if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
-        launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
+        if (!counted) {
+            if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
+            launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
+        }
+        if (ctx->counts_only) {                              // sfq_count_priors: the sample is counted (the header sample beside it)
+            HIPC(hipStreamSynchronize(mst[1]));
+            HIPC(hipStreamSynchronize(st));
+            res->n_records = nrec; res->n_blocks = nblocks;
+            return SFQ_OK;
+        }
+
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
@@ -888,18 +905,16 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             if ((rc = build_qesc(ctx, st))) return rc;
             launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, nullptr, st);
             ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p;
-            ca.q_hot = 0;
-            // LDS staging of the rows the sample saw most (picked on the device, chains.hip k_hot_pick); without a sample of
+            ca.q_hot = 0; ca.q_rows = q_rows;
+            // LDS staging of the rows the sample saw most (picked on the device, chains.hip k_hot_select); without a sample of
             // this call's own there is nothing to rank by
-            // (off unless asked for: measured, DESIGN.md 4.4 -- the rows' LDS keeps the header chains' workgroups off the CU)
-            const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE || given || !prior_step) ? 0u : std::min<u32>(p.lds_rows, 240u);
+            const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE || given || !prior_step) ? 0u : std::min<u32>(p.lds_rows, 1024u);
             if (want_hot) {
-                if ((rc = reserve(ctx, ctx->qw, 8192 + 4096 + 512))) return rc;
-                HIPC(hipMemsetAsync(ctx->qw.p, 0, 8192 + 4096 + 512, st));
-                unsigned long long* best = (unsigned long long*)ctx->qw.p;
-                u32* tab = (u32*)((u8*)ctx->qw.p + 8192); u16* hot = (u16*)((u8*)ctx->qw.p + 8192 + 4096);
-                launch_hot_rows((const u32*)ctx->hist.p, q_rows, want_hot, best, tab, hot, st);
-                ca.q_hot = want_hot; ca.qh_tab = tab; ca.qh_ctx = hot;
+                const size_t img_bytes = (size_t)q_rows / 4 + (size_t)want_hot * 100 + 64;
+                if ((rc = reserve(ctx, ctx->qw, img_bytes + (size_t)q_rows * 4 + 256))) return rc;
+                u8* img = (u8*)ctx->qw.p; u32* info = (u32*)(img + ((img_bytes + 15) & ~(size_t)15)); u32* ctot = info + 16;
+                launch_hot_rows((const u32*)ctx->hist.p, (const u32*)ctx->rows66.p, (const u32*)ctx->qrows.p, q_rows, want_hot, ctot, img, info, st);
+                ca.q_hot = want_hot; ca.qh_img = img; ca.qh_info = info;
             }
             HIPC(hipEventRecord(ctx->ev[1], st));
         }
@@ -1143,6 +1158,42 @@ int sfq_encode_qlt_blocks(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes,
 int sfq_build_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params) {
     sfq_result res;
     return encode_impl(ctx, d_fastq, nbytes, params, nullptr, 0, &res, 0, true);
+}
+int sfq_count_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params, uint32_t sample_scale) {
+    if (!ctx || !params) return fail(ctx, SFQ_E_ARG, "null argument");
+    if (params->prior_step == SFQ_PRIOR_GIVEN || params->prior_step == SFQ_PRIOR_COUNTS || !params->block_reads)
+        return fail(ctx, SFQ_E_ARG, "sfq_count_priors: a sample of this text's own, in the block format (prior_step: a step or SFQ_PRIOR_AUTO)");
+    sfq_result res;
+    ctx->counts_only = true; ctx->sample_scale = sample_scale ? sample_scale : 1;
+    const int rc = encode_impl(ctx, d_fastq, nbytes, params, nullptr, 0, &res, 0, true);
+    ctx->counts_only = false; ctx->sample_scale = 1;
+    return rc;
+}
+void sfq_prior_counts_words(int level, uint64_t* qlt_words, uint64_t* rec_words) {
+    if (qlt_words) *qlt_words = (uint64_t)(clamp_level(level) == 1 ? (1u << 12) : (1u << 16)) * 64;
+    if (rec_words) *rec_words = (uint64_t)PR_REC_ROWS * 256;
+}
+int sfq_get_prior_counts(sfq_ctx* ctx, int level, uint32_t* d_qlt, uint32_t* d_rec) {
+    if (!ctx || !d_qlt || !d_rec) return fail(ctx, SFQ_E_ARG, "null argument");
+    uint64_t nq, nr; sfq_prior_counts_words(level, &nq, &nr);
+    if (!ctx->hist.p || ctx->hist.cap < nq * 4 || !ctx->hcnt.p) return fail(ctx, SFQ_E_ARG, "no counts (sfq_count_priors comes first)");
+    HIPC(hipSetDevice(ctx->dev));
+    HIPC(hipMemcpyAsync(d_qlt, ctx->hist.p, nq * 4, hipMemcpyDeviceToDevice, ctx->st));
+    HIPC(hipMemcpyAsync(d_rec, ctx->hcnt.p, nr * 4, hipMemcpyDeviceToDevice, ctx->st));
+    HIPC(hipStreamSynchronize(ctx->st));
+    return SFQ_OK;
+}
+int sfq_set_prior_counts(sfq_ctx* ctx, int level, const uint32_t* d_qlt, const uint32_t* d_rec) {
+    if (!ctx || !d_qlt || !d_rec) return fail(ctx, SFQ_E_ARG, "null argument");
+    uint64_t nq, nr; sfq_prior_counts_words(level, &nq, &nr);
+    HIPC(hipSetDevice(ctx->dev));
+    int rc;
+    if ((rc = ensure_prior_buffers(ctx, (u32)(nq / 64)))) return rc;
+    if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
+    HIPC(hipMemcpyAsync(ctx->hist.p, d_qlt, nq * 4, hipMemcpyDeviceToDevice, ctx->st));
+    HIPC(hipMemcpyAsync(ctx->hcnt.p, d_rec, nr * 4, hipMemcpyDeviceToDevice, ctx->st));
+    HIPC(hipStreamSynchronize(ctx->st));
+    return SFQ_OK;
 }
 int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
                            uint8_t* h_out, uint64_t out_cap, sfq_result* result) {
@@ -1486,7 +1537,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if ((rc = reserve(ctx, ctx->qdec, (size_t)q_rows * 72 * 2))) return rc;                 // chains.hip QDEC_ROW
         launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u16*)ctx->qdec.p, st);
         ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qdec = (const u16*)ctx->qdec.p;
-        ca.q_hot = 0;
+        ca.q_hot = 0; ca.q_rows = q_rows;
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));

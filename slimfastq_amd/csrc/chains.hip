@@ -69,38 +69,105 @@ void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec
     hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qdec);
 }
 
-// The rows a workgroup of the quality chains keeps in LDS, picked on the device (no host round trip between the sample and
-// the chains): every context competes for its slot of the direct-mapped table (qh_hash) with the number of symbols the
-// sample saw in it, and of the 1024 slot winners the `want` heaviest are staged.  tab[slot] = context | place << 16
-// (QH_EMPTY = none), hot[place] = context (zeroed by the caller: an unused place stages row 0, which nobody looks up there).
-#define QH_SLOTS 1024u
+// The rows the quality chains keep in LDS (BASELINE north_star: "ranger probability tables are staged in LDS"), picked on the
+// device from the sample's counts -- no host round trip between the sample and the chains.  What bounds the chain kernel is
+// the CU's vector memory path: a symbol's row entry is a gather whose 64 lanes touch 64 different lines (~128 cycles per wave
+// instruction); an entry that lives in LDS costs three LDS reads instead.  The HOT IMAGE, one per call:
+//   map   [q_rows / 32] x { u32 bits, u32 rank }   bit c & 31 of word c >> 5: context c is staged; its row = rank + the bits below it
+//   rows  [K] x u16[QH_ROW_U16]                    cum of symbols 0 .. QH_SYMS (an entry's freq is the next cum minus its own)
+// A context is eligible when its frozen row came from a prior row of at most QH_SYMS symbols (qualities up to 'P'); a symbol
+// >= QH_SYMS of a staged context, and every other context, is read from the table in L2 as before.  The K contexts the sample
+// saw most are staged (ties by count cut off together); where a row comes from does not show in the stream.
+#define QH_SYMS 48u
+#define QH_ROW_U16 50u
+#define QH_MAP_BYTES(q_rows) ((q_rows) / 32u * 8u)
 #define QH_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ u32 qh_hash(u32 ctx) { return (ctx * 0x9E3Bu >> 4) & (QH_SLOTS - 1); }
-__global__ __launch_bounds__(256) void k_hot_slots(const u32* __restrict__ hist, u32 q_rows, unsigned long long* __restrict__ best) {
+// ctot[c] = symbols the sample saw in context c (0: not eligible)
+__global__ __launch_bounds__(256) void k_hot_totals(const u32* __restrict__ hist, const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ ctot) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctx >= q_rows) return;
     u32 c = hist[(size_t)ctx * 64 + lane];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
-    if (lane == 0 && c) atomicMax(&best[qh_hash(ctx)], ((unsigned long long)c << 32) | (0xFFFFu - ctx));      // (of equals the lower context)
+    const u32 iend = rows66[(size_t)ctx * 66 + 65];
+    if (lane == 0) ctot[ctx] = (iend != 0 && iend <= QH_SYMS) ? c : 0u;
 }
-__global__ __launch_bounds__(1024) void k_hot_pick(const unsigned long long* __restrict__ best, u32 want, u32* __restrict__ tab, u16* __restrict__ hot) {
-    __shared__ unsigned long long k[QH_SLOTS];
-    const u32 t = threadIdx.x;
-    const unsigned long long key = best[t];
-    k[t] = key;
+// one workgroup: the smallest threshold T with at most `want` contexts of ctot >= T; then the map (info[0] = rows staged)
+__global__ __launch_bounds__(1024) void k_hot_select(const u32* __restrict__ ctot, u32 q_rows, u32 want, uint2* __restrict__ map, u32* __restrict__ info) {
+    __shared__ u32 red[16];
+    __shared__ u32 wsum[1024];
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u32 nwords = q_rows / 32u, wpt = (nwords + 1023u) / 1024u;      // map words per thread: 2 at 65536 contexts, 1 (of the first 128 threads) at 4096
+    u32 c[64];
+    u32 mx = 0;
+#pragma unroll
+    for (u32 k = 0; k < 64; k++) {
+        const u32 w = t * wpt + (k >> 5), ctx = w * 32u + (k & 31u);
+        c[k] = ((k >> 5) < wpt && w < nwords) ? ctot[ctx] : 0u;
+        mx = c[k] > mx ? c[k] : mx;
+    }
+    auto block_sum = [&](u32 v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += (u32)__shfl_xor((int)v, d, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        u32 s2 = 0;
+        for (u32 w = 0; w < 16; w++) s2 += red[w];
+        return s2;
+    };
+    auto block_max = [&](u32 v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        u32 s2 = 0;
+        for (u32 w = 0; w < 16; w++) s2 = red[w] > s2 ? red[w] : s2;
+        return s2;
+    };
+    u32 lo = 1, hi = block_max(mx) + 1u;                                 // count(>= hi) = 0 <= want
+    while (lo < hi) {                                                      // the smallest T in [lo, hi] with count(>= T) <= want
+        const u32 mid = lo + (hi - lo) / 2u;
+        u32 n = 0;
+#pragma unroll
+        for (u32 k = 0; k < 64; k++) n += c[k] >= mid;
+        if (block_sum(n) <= want) hi = mid; else lo = mid + 1u;
+    }
+    const u32 T = lo;
+    u32 bits[2] = {0, 0};
+#pragma unroll
+    for (u32 k = 0; k < 64; k++) if (c[k] >= T) bits[k >> 5] |= 1u << (k & 31u);
+    const u32 mine = (u32)__popc(bits[0]) + (u32)__popc(bits[1]);
+    wsum[t] = mine;
     __syncthreads();
-    u32 place = 0;
-    for (u32 j = 0; j < QH_SLOTS; j++) place += k[j] > key;
-    const u32 ctx = 0xFFFFu - (u32)(key & 0xFFFFu);
-    const bool in = key != 0 && place < want;
-    tab[t] = in ? (ctx | (place << 16)) : QH_EMPTY;
-    if (in) hot[place] = (u16)ctx;
+    if (t == 0) { u32 run = 0; for (u32 i = 0; i < 1024; i++) { const u32 v = wsum[i]; wsum[i] = run; run += v; } info[0] = run; }
+    __syncthreads();
+    u32 rank = wsum[t];
+    for (u32 j = 0; j < wpt && j < 2; j++) {
+        const u32 w = t * wpt + j;
+        if (w < nwords) map[w] = make_uint2(bits[j], rank);
+        rank += (u32)__popc(bits[j]);
+    }
 }
-void launch_hot_rows(const u32* hist, u32 q_rows, u32 want, unsigned long long* best /* [1024], zeroed */, u32* tab /* [1024] */, u16* hot /* [want], zeroed */, hipStream_t st) {
-    hipLaunchKernelGGL(k_hot_slots, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, best);
-    hipLaunchKernelGGL(k_hot_pick, dim3(1), dim3(QH_SLOTS), 0, st, (const unsigned long long*)best, want, tab, hot);
+// the staged rows: the cum of symbols 0 .. QH_SYMS of every staged context, at its place
+__global__ __launch_bounds__(256) void k_hot_image(const uint2* __restrict__ map, const u32* __restrict__ qrows, u32 q_rows, u16* __restrict__ rows) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    const uint2 mr = map[ctx >> 5];
+    const u32 bit = 1u << (ctx & 31u);
+    if (!(mr.x & bit)) return;
+    const u32 slot = mr.y + (u32)__popc(mr.x & (bit - 1u));
+    if (lane < QH_ROW_U16) rows[(size_t)slot * QH_ROW_U16 + lane] = lane <= QH_SYMS ? (u16)FZ_CUM(qrows[(size_t)ctx * 64 + lane]) : (u16)0;
+}
+// img: [QH_MAP_BYTES(q_rows)] map, then [want] rows; ctot: [q_rows] scratch; info[0] = rows staged
+void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot, u8* img, u32* info, hipStream_t st) {
+    hipLaunchKernelGGL(k_hot_totals, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, rows66, q_rows, ctot);
+    hipLaunchKernelGGL(k_hot_select, dim3(1), dim3(1024), 0, st, (const u32*)ctot, q_rows, want, reinterpret_cast<uint2*>(img), info);
+    hipLaunchKernelGGL(k_hot_image, dim3((q_rows + 3) / 4), dim3(256), 0, st, reinterpret_cast<const uint2*>(img), qrows, q_rows,
+                       reinterpret_cast<u16*>(img + QH_MAP_BYTES(q_rows)));
 }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
@@ -198,18 +265,19 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 // =========================================================================================================
 // quality encode: one chain per lane
 // =========================================================================================================
-// LDS staging of the hottest rows (BASELINE north_star: "ranger probability tables are staged in LDS"): the workgroup
-// copies the q_hot most used rows into LDS once; a symbol's context is looked up in a direct-mapped LDS table
-// (QH_SLOTS entries: context | slot << 16), a hit reads the row entry from LDS, a miss from the L2-resident table.
+// LDS staging of the hottest rows: the workgroup copies the call's hot image (above) into LDS once; a symbol whose context
+// is staged reads its entry there (map word, two cums), the others gather it from the L2-resident table.
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     __shared__ u32 ring[LaneEncB<THREADS, QLT_RING>::LDS_DWORDS];
-    extern __shared__ u32 lds[];                              // [QH_SLOTS] the context table, then [q_hot][64] row entries
-    u32* const ltab = lds; u32* const lrows = lds + QH_SLOTS;
+    extern __shared__ u32 lds[];                              // the hot image: map, then rows
+    const uint2* const lmap = reinterpret_cast<const uint2*>(lds);
+    const u16* const lrows = reinterpret_cast<const u16*>(lds + QH_MAP_BYTES(a.q_rows) / 4u);
     if constexpr (LDS) {
-        for (u32 i = threadIdx.x; i < QH_SLOTS; i += THREADS) ltab[i] = a.qh_tab[i];
-        for (u32 i = threadIdx.x; i < a.q_hot * 64; i += THREADS) lrows[i] = a.qrows[(size_t)a.qh_ctx[i >> 6] * 64 + (i & 63)];
+        const u32 nd = (QH_MAP_BYTES(a.q_rows) + a.qh_info[0] * QH_ROW_U16 * 2u + 3u) / 4u;
+        const u32* src = reinterpret_cast<const u32*>(a.qh_img);
+        for (u32 i = threadIdx.x; i < nd; i += THREADS) lds[i] = src[i];
         __syncthreads();
     }
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
@@ -241,8 +309,13 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
             lowest = min(lowest, b | ~vm);
             top = max(top, b & vm);
             if constexpr (LDS) {
-                const u32 hv = ltab[qh_hash(last)];
-                e[j] = (hv & 0xFFFFu) == last && hv != QH_EMPTY ? lrows[(hv >> 16) * 64 + sym] : a.qrows[(size_t)last * 64 + sym];
+                const uint2 mr = lmap[last >> 5];
+                const u32 bit = 1u << (last & 31u);
+                if ((mr.x & bit) && sym < QH_SYMS) {
+                    const u16* r = lrows + (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QH_ROW_U16 + sym;
+                    const u32 c0 = r[0], c1 = r[1];
+                    e[j] = c0 | ((c1 - c0) << 16);
+                } else e[j] = a.qrows[(size_t)last * 64 + sym];
             } else e[j] = a.qrows[(size_t)last * 64 + sym];
             if (level <= 2) last = (b | (last << 6)) & mask12;                           // qlts.hpp:52-57
             else {                                                                       // qlts.hpp:62-74
@@ -305,10 +378,17 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     }
 }
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
-    constexpr int T = 256;
-    const u32 grid = (a.geo.nchains + T - 1) / T;
-    if (a.q_hot) hipLaunchKernelGGL((k_qlt_encode_c<T, true>), dim3(grid), dim3(T), (QH_SLOTS + a.q_hot * 64) * 4, st, a);
-    else hipLaunchKernelGGL((k_qlt_encode_c<T, false>), dim3(grid), dim3(T), 0, st, a);
+    if (a.q_hot) {
+        // one workgroup of 1024 lanes per CU shares the image (a table per 256 lanes would hold a quarter of the rows)
+        constexpr int T = 1024;
+        const u32 dyn = QH_MAP_BYTES(a.q_rows) + a.q_hot * QH_ROW_U16 * 2u;
+        static u32 allowed = 0;
+        if (dyn > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed = dyn; }
+        hipLaunchKernelGGL((k_qlt_encode_c<T, true>), dim3((a.geo.nchains + T - 1) / T), dim3(T), dyn, st, a);
+    } else {
+        constexpr int T = 256;
+        hipLaunchKernelGGL((k_qlt_encode_c<T, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
+    }
 }
 
 // =========================================================================================================

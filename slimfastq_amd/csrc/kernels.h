@@ -63,9 +63,10 @@ struct ChainArgs {
     // quality: frozen rows, total 2^16 each
     const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
     const u16* qdec;            // decode: [q_rows][72] u16: the cum of every 8th symbol, then of all 64 (chains.hip QDEC_ROW)
-    u32 q_hot;                  // rows staged in LDS per workgroup (0 = none)
-    const u32* qh_tab;          // [1024] direct-mapped context -> (context | LDS slot << 16), 0xFFFFFFFF = empty
-    const u16* qh_ctx;          // [q_hot] the staged contexts
+    u32 q_rows;                 // quality contexts: 4096 (level 1) or 65536
+    u32 q_hot;                  // room for that many rows in the LDS image of the quality chains' workgroups (0 = no staging)
+    const u8* qh_img;           // the hot image: map, then rows (chains.hip k_hot_select)
+    const u32* qh_info;         // [0] = rows staged
     const u32* qesc;            // escape row (256 entries), qlts.cpp:80-86
     // headers: frozen PowerRanger rows, total 2^16 each
     const u32* rrows;           // [PR_REC_ROWS][256] cum | freq << 16
@@ -80,8 +81,8 @@ struct ChainArgs {
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
     const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
 };
-void launch_hot_rows(const u32* hist, u32 q_rows, u32 want, unsigned long long* best /* [1024], zeroed */, u32* tab /* [1024] */,
-                     u16* hot /* [want], zeroed */, hipStream_t st);
+void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
+                     u8* img /* q_rows / 4 bytes of map + want x 100 bytes of rows */, u32* info, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,

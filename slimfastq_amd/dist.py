@@ -68,3 +68,29 @@ def merge_indexes(per_rank_blocks, per_rank_first_hdrs):
             hoff += b["first_hdr_len"]
             out.append(nb)
     return out, b"".join(per_rank_first_hdrs)
+
+
+def allreduce_prior_counts(ctx, d_ptr: int, nbytes: int, device, level=3, block_reads=None, tables=1, group=None, via_cpu=False):
+    """ONE prior for a file that several ranks share, without a rank the others wait for: every rank counts the sample of
+    its own shard (a 1 / world share of what one call alone would sample), the count tables -- two u32 arrays, 16 MiB + 1 MiB
+    at levels 2..4 -- are summed over the ranks (all_reduce), and every rank installs the sums: the priors a following
+    encode with prior_step = PRIOR_COUNTS builds are identical everywhere.  `device`: the rank's GPU (torch.device);
+    via_cpu: the tensors of the collective live on the host (a "gloo" group)."""
+    from . import capi
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ctx.count_priors(d_ptr, nbytes, level=level, block_reads=capi.BLOCK_AUTO if block_reads is None else block_reads, tables=tables,
+                     sample_scale=world)
+    nq, nr = capi.Context.prior_counts_words(level)
+    q = torch.empty(nq, dtype=torch.int32, device=device)
+    r = torch.empty(nr, dtype=torch.int32, device=device)
+    ctx.get_prior_counts(level, q.data_ptr(), r.data_ptr())
+    if world > 1:
+        if via_cpu:
+            qc, rc = q.cpu(), r.cpu()
+            dist.all_reduce(qc, group=group); dist.all_reduce(rc, group=group)
+            q.copy_(qc); r.copy_(rc)
+        else:
+            dist.all_reduce(q, group=group); dist.all_reduce(r, group=group)
+        torch.cuda.current_stream(device).synchronize()
+    ctx.set_prior_counts(level, q.data_ptr(), r.data_ptr())
+    return q, r

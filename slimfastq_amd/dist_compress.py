@@ -217,25 +217,33 @@ def main(argv=None):
     def to_device(text):
         return torch.from_numpy(np.frombuffer(text, np.uint8).copy()).to(cdev)
 
-    # ONE prior for the whole file: rank 0 builds it from its first slab, everybody codes from it
+    # ONE prior for the whole file and no rank the others wait for: every rank counts a 1 / world share of the
+    # sample over its first slab, the counts are summed over the ranks (dist.allreduce_prior_counts), every rank builds the
+    # same priors from the sums (it takes them from its first encode call and codes its other slabs from them)
     prior = rec_prior = b""
     d_first = to_device(mm[spans[0][0]:spans[0][1]]) if spans else None
+    counted = False
     if world > 1:
-        if rank == 0 and spans:
-            prior, rec_prior = ctx.build_priors(d_first.data_ptr(), d_first.numel(), level=args.level, block_reads=br, tables=tables)
-        prior = bcast_bytes(prior, 0, xdev)
-        rec_prior = bcast_bytes(rec_prior, 0, xdev)
-    shared = bool(prior)
+        if d_first is None:                       # (a rank without records still takes part in the collective)
+            d_first = to_device(b"@e\nA\n+\nI\n")
+            sdist.allreduce_prior_counts(ctx, d_first.data_ptr(), d_first.numel(), cdev, level=args.level, block_reads=br, tables=tables, via_cpu=backend != "nccl")
+            d_first = None
+        else:
+            sdist.allreduce_prior_counts(ctx, d_first.data_ptr(), d_first.numel(), cdev, level=args.level, block_reads=br, tables=tables, via_cpu=backend != "nccl")
+        counted = True
+    shared = counted
     my_parts = []
     for k, (a, b) in enumerate(spans):
         d_in = d_first if k == 0 else to_device(mm[a:b])
         nb = b - a
         cap = capi.lib().sfq_encode_bound(nb)
         d_out = torch.empty(cap, dtype=torch.uint8, device=cdev)
-        if shared:
+        if shared and k:
             ctx.set_priors(prior, rec_prior)
         res = ctx.encode_device(d_in.data_ptr(), nb, d_out.data_ptr(), cap, level=args.level, block_reads=br,
-                                prior_step=capi.PRIOR_GIVEN if shared else capi.PRIOR_AUTO, tables=tables)
+                                prior_step=(capi.PRIOR_GIVEN if k else capi.PRIOR_COUNTS) if shared else capi.PRIOR_AUTO, tables=tables)
+        if shared and k == 0:
+            prior, rec_prior = ctx.prior(), ctx.rec_prior()           # the file's priors, the same on every rank
         blocks = list(ctx.index(res.n_blocks))
         # with a shared prior only the file's first segment carries it
         keep = (not shared) or (rank == 0 and k == 0)

@@ -139,3 +139,74 @@ def test_payload_of_one_batch_travels_while_the_next_is_prepared():
             n = 1000 * (rank + 1) + 13000 * k
             want = bytes((torch.arange(n, dtype=torch.int64).add(7 * k + rank).remainder(251)).to(torch.uint8).numpy())
             assert b == want, (k, rank)
+
+
+class _CountsOnlyCtx:
+    """Stand-in for capi.Context in dist.allreduce_prior_counts: the counting kernels' part is played by the oracle's
+    histogram over every `sample_scale`-th record of the rank's shard (the rule of sfq_count_priors), the count tables live in
+    host memory.  What the test checks is the collective around them."""
+
+    def __init__(self, fq, level):
+        import ctypes
+        self.fq, self.level, self.ct = fq, level, ctypes
+        self.q = self.r = None
+
+    def count_priors(self, d_ptr, nbytes, level=3, block_reads=None, tables=1, sample_scale=1):
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util
+        from oracle import oracle as O
+        starts, lens = util.line_table(self.fq)
+        self.q = O.qlt_histogram(self.fq, starts[3::4], np.minimum(lens[3::4], 4096), level, 0, sample_scale).astype(np.uint32)
+        nrec = len(starts) // 4
+        self.r = O.rec_count(self.fq, starts[0::4] + 1, lens[0::4] - 1, max(6, nrec // 8), 6, 8).astype(np.uint32)
+
+    def get_prior_counts(self, level, d_qlt, d_rec):
+        self.ct.memmove(d_qlt, self.q.ctypes.data, self.q.nbytes)
+        self.ct.memmove(d_rec, self.r.ctypes.data, self.r.nbytes)
+
+    def set_prior_counts(self, level, d_qlt, d_rec):
+        self.ct.memmove(self.q.ctypes.data, d_qlt, self.q.nbytes)
+        self.ct.memmove(self.r.ctypes.data, d_rec, self.r.nbytes)
+
+
+def _worker_counts(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from slimfastq_amd import capi, dist as sdist
+    lo, hi = sdist.shard_records(NREC, rank, world, BLOCK)
+    fq = capi.synth_fastq(hi - lo, 100, seed=3, first_read=lo)
+    ctx = _CountsOnlyCtx(fq, 3)
+    ctx.count_priors(0, len(fq), level=3, sample_scale=world)
+    mine = (ctx.q.copy(), ctx.r.copy())
+    import unittest.mock as mock
+    with mock.patch.object(torch.cuda, "current_stream", lambda dev=None: mock.Mock(synchronize=lambda: None)):
+        sdist.allreduce_prior_counts(ctx, 0, len(fq), torch.device("cpu"), level=3, tables=1, via_cpu=True)
+    q.put((rank, mine[0].tobytes(), mine[1].tobytes(), ctx.q.tobytes(), ctx.r.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prior_counts_are_summed_over_the_ranks_and_identical_everywhere():
+    """Multi-GPU priors without a serial head: every rank counts a share of the sample over its own
+    shard, dist.allreduce_prior_counts adds the tables up -- every rank must end with the same sums, and they must be the
+    sums of what the ranks counted."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_counts, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want_q = sum(np.frombuffer(g[1], np.uint32).astype(np.uint64) for g in got)
+    want_r = sum(np.frombuffer(g[2], np.uint32).astype(np.uint64) for g in got)
+    assert want_q.sum() > 0 and want_r.sum() > 0
+    for g in got:
+        assert np.array_equal(np.frombuffer(g[3], np.uint32), want_q.astype(np.uint32)), g[0]
+        assert np.array_equal(np.frombuffer(g[4], np.uint32), want_r.astype(np.uint32)), g[0]

@@ -196,6 +196,54 @@ def test_given_prior_makes_block_bytes_independent_of_the_sharding(ctx):
     ctx.set_priors(b"", b"")
 
 
+def test_summed_counts_give_every_rank_the_same_priors(ctx):
+    """Multi-GPU priors without a serial head (sfq_count_priors / sfq_set_prior_counts, prior_step = SFQ_PRIOR_COUNTS): two
+    "ranks" (two contexts on this GPU) count the sample of their halves of a file, the count tables are added up (what the
+    all-reduce of dist.allreduce_prior_counts does), both install the sums and code their halves: the priors they build are
+    identical, a block's quality and header bytes are what ONE call over the whole text with the same counts writes, and the
+    halves decode.  The counts themselves are the oracle's histogram over every second sampled record of a half."""
+    import torch
+    fq = capi.synth_fastq(8000, 150, seed=78)
+    halves = util.split_records(fq, 4000)
+    other = capi.Context(0, table_budget=8 << 30)
+    try:
+        ranks = [ctx, other]
+        nq, nr = capi.Context.prior_counts_words(3)
+        qs, rs, dins = [], [], []
+        for c, h in zip(ranks, halves):
+            d = torch.from_numpy(np.frombuffer(h, np.uint8).copy()).cuda()
+            dins.append(d)
+            c.count_priors(d.data_ptr(), len(h), level=3, block_reads=500, prior_step=1, tables=capi.TABLES_FROZEN, sample_scale=2)
+            q = torch.empty(nq, dtype=torch.int32, device="cuda"); r = torch.empty(nr, dtype=torch.int32, device="cuda")
+            c.get_prior_counts(3, q.data_ptr(), r.data_ptr())
+            starts, lens = util.line_table(h)
+            want = O.qlt_histogram(h, starts[3::4], np.minimum(lens[3::4], PRIOR_SYMBOLS), 3, 0, 2)
+            assert np.array_equal(q.cpu().numpy().view(np.uint32), want)
+            qs.append(q); rs.append(r)
+        qsum, rsum = qs[0] + qs[1], rs[0] + rs[1]
+        torch.cuda.synchronize()
+        encs = []
+        for c, h, d in zip(ranks, halves, dins):
+            c.set_prior_counts(3, qsum.data_ptr(), rsum.data_ptr())
+            encs.append(c.encode_host(h, level=3, block_reads=500, prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, chain_reads=50))
+        assert encs[0].prior == encs[1].prior and encs[0].rec_prior == encs[1].rec_prior and encs[0].prior
+        ctx.set_prior_counts(3, qsum.data_ptr(), rsum.data_ptr())
+        whole = ctx.encode_host(fq, level=3, block_reads=500, prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, chain_reads=50)
+        assert whole.prior == encs[0].prior and whole.rec_prior == encs[0].rec_prior
+        for name in ("qlt", "rec", "gen"):
+            assert whole.stream(name) == encs[0].stream(name) + encs[1].stream(name), name
+        for c, h, e in zip(ranks, halves, encs):
+            assert c.decode_host(e, level=3, out_cap=len(h) + 4096) == h
+        with pytest.raises(capi.SfqError):                    # a fresh context has no counts to code from
+            fresh = capi.Context(0, table_budget=4 << 30)
+            try:
+                fresh.encode_host(halves[0], level=3, block_reads=500, prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN)
+            finally:
+                fresh.close()
+    finally:
+        other.close()
+
+
 @pytest.mark.parametrize("level", (1, 3))
 def test_frozen_quality_rows_staged_in_lds_do_not_change_a_byte(ctx, level):
     """sfq_params.lds_rows: every workgroup of the quality chains keeps the N rows the sample saw most in LDS (picked on the
