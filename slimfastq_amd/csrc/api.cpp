@@ -861,8 +861,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // (short records: not more of them than the histogram kernel's workgroups hold on the chip at once -- 512 of 256 lanes, a
         //  record per lane: a second round of workgroups waits for the first while the other models' kernels take the chip)
         if (nbytes / nrec <= 4000) prior_step = (u32)std::max<u64>(prior_step, (nrec + 131071) / 131072);
-        prior_step = (u32)std::min<u64>((u64)prior_step * std::max<u32>(1u, ctx->sample_scale), 0x7FFFFFFFull);      // (sfq_count_priors: a share of the job's sample)
     }
+    if (ctx->counts_only && prior_step && prior_step < SFQ_PRIOR_COUNTS)        // sfq_count_priors: a share of the job's sample
+        prior_step = (u32)std::min<u64>((u64)prior_step * std::max<u32>(1u, ctx->sample_scale), 0x7FFFFFFFull);
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
