@@ -54,6 +54,7 @@ def parse():
                     "0 = adaptive tables, a wavefront per block (the reference's per-symbol updates)")
     ap.add_argument("--chain-reads", type=int, default=0)
     ap.add_argument("--lds-rows", type=int, default=0)
+    ap.add_argument("--dec-lds-rows", type=int, default=0, help="decode leg: quality rows the decoder stages in LDS (sfq_params.lds_rows)")
     ap.add_argument("--no-adaptive-leg", action="store_true", help="skip the secondary measurement with adaptive tables")
     ap.add_argument("--prior-step", type=int, default=-1, help="-1 = auto warm start (default), 0 = cold blocks, N = every N-th record")
     ap.add_argument("--models", type=int, default=0, help="debug: SFQ_M_* mask (1 rec, 2 gen, 4 qlt, 8 usr)")
@@ -306,11 +307,13 @@ def main():
         for _ in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             got, _r = ctx.decode_device(blocks, first, packed.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=args.level,
-                                        chains=chains, rec_prior=rec_prior)
+                                        chains=chains, rec_prior=rec_prior, lds_rows=args.dec_lds_rows)
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
         same = bool(got == nbytes and torch.equal(d_back[:nbytes], d_in))
         out["decode"] = {"value": round(nbytes / min(times) / 1e6, 2), "unit": "MB/s FASTQ restored", "ms": round(min(times) * 1e3, 3),
-                         "round_trip_identical": same}
+                         "round_trip_identical": same, "phase_ms": {"qlt": round(_r.kernel_ms[capi.T_QLT], 3), "gen": round(_r.kernel_ms[capi.T_GEN], 3),
+                                                                    "rec": round(_r.kernel_ms[capi.T_REC], 3), "assemble": round(_r.kernel_ms[capi.T_PACK], 3),
+                                                                    "device_total": round(_r.kernel_ms[capi.T_TOTAL], 3)}}
         del d_back, packed
     if not multi and args.tables and args.workload == "full" and not args.models and not args.no_adaptive_leg:
         # secondary: the same call with ADAPTIVE tables (every block runs the reference's per-symbol row updates, a wavefront per

@@ -98,6 +98,10 @@ typedef struct sfq_params {
 } sfq_params;
 #define SFQ_TABLES_ADAPTIVE 0u
 #define SFQ_TABLES_FROZEN   1u
+#define SFQ_TABLES_AUTO     2u   /* by the size of the text: frozen tables from 64 MiB on; below that their transmitted priors weigh too
+                                    much (samples/tst7.fq, 3.9 MB: 1.15 x the reference's bytes) and a GPU has nothing to win on so
+                                    little text -- adaptive tables in blocks of 65536 records (SFQ_BLOCK_AUTO), i.e. the reference's
+                                    own streams for a file of up to that many records */
 #define SFQ_LDS_ROWS_NONE  0xFFFFFFFFu
 #define SFQ_PRIOR_AUTO  0xFFFFFFFFu
 #define SFQ_PRIOR_GIVEN 0xFFFFFFFEu  /* prior_step: the priors installed with sfq_set_qlt_prior / sfq_set_rec_prior */

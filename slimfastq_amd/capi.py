@@ -16,7 +16,7 @@ PRIOR_AUTO = 0xFFFFFFFF
 PRIOR_GIVEN = 0xFFFFFFFE
 PRIOR_COUNTS = 0xFFFFFFFD
 BLOCK_AUTO = 0xFFFFFFFF
-TABLES_ADAPTIVE, TABLES_FROZEN = 0, 1
+TABLES_ADAPTIVE, TABLES_FROZEN, TABLES_AUTO = 0, 1, 2
 LDS_ROWS_NONE = 0xFFFFFFFF
 
 EXPORTS = [
@@ -315,7 +315,7 @@ class Context:
                                         C.c_void_p(d_streams), soff, C.c_void_p(d_out), out_cap, C.byref(n), C.byref(res)))
         return n.value, res
 
-    def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None, kernel=0) -> bytes:
+    def decode_host(self, enc_or_parts, level=3, version=0, out_cap=None, kernel=0, lds_rows=0) -> bytes:
         """Decode an Encoded (or a (blocks, first_hdrs, data, stream_offset) tuple) back to FASTQ text."""
         L = lib()
         prior = chains = rec_prior = b""
@@ -336,7 +336,7 @@ class Context:
         self._check(L.sfq_set_chain_index(self._h, chains if chains else None, len(chains)))
         self._check(L.sfq_set_rec_prior(self._h, rec_prior if rec_prior else None, len(rec_prior)))
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) else data
-        p = Params(level, 0, 0, 0, kernel, version, 0, 0, 0, 0)
+        p = Params(level, 0, 0, 0, kernel, version, 0, 0, 0, lds_rows)
         res = Result()
         if out_cap is None:
             out_cap = 64 * len(data) + (1 << 20)

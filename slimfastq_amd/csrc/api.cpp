@@ -605,6 +605,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
     if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
+    if (p.tables > SFQ_TABLES_AUTO) return fail(ctx, SFQ_E_ARG, "tables %u: 0 = adaptive, 1 = frozen, 2 = by the size of the text", p.tables);
+    bool small_auto = false;
+    if (p.tables == SFQ_TABLES_AUTO) {                          // include/slimfastq_amd.h
+        small_auto = nbytes < (64ull << 20) && p.prior_step != SFQ_PRIOR_GIVEN && p.prior_step != SFQ_PRIOR_COUNTS;
+        p.tables = small_auto ? SFQ_TABLES_ADAPTIVE : SFQ_TABLES_FROZEN;
+        if (small_auto) { p.prior_step = 0; if (p.block_reads == SFQ_BLOCK_AUTO) p.block_reads = 65536; }
+    }
     memset(res, 0, sizeof *res);
     res->abi_version = SFQ_ABI_VERSION;
     hipStream_t st = ctx->st;
@@ -1539,6 +1546,15 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u16*)ctx->qdec.p, st);
         ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qdec = (const u16*)ctx->qdec.p;
         ca.q_hot = 0; ca.q_rows = q_rows;
+        // the rows that carry the most weight live in LDS (sfq_params.lds_rows; chains.hip launch_hot_rows_dec)
+        const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE) ? 0u : std::min<u32>(p.lds_rows, 1024u);
+        if (want_hot) {
+            const size_t img_bytes = (size_t)q_rows / 4 + (size_t)want_hot * 112 + 64;
+            if ((rc = reserve(ctx, ctx->qw, img_bytes + (size_t)q_rows * 4 + 256))) return rc;
+            u8* img = (u8*)ctx->qw.p; u32* info = (u32*)(img + ((img_bytes + 15) & ~(size_t)15)); u32* ctot = info + 16;
+            launch_hot_rows_dec((const u32*)ctx->rows66.p, (const u16*)ctx->qdec.p, q_rows, want_hot, ctot, img, info, st);
+            ca.q_hot = want_hot; ca.qh_img = img; ca.qh_info = info;
+        }
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));

@@ -170,6 +170,35 @@ void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q
                        reinterpret_cast<u16*>(img + QH_MAP_BYTES(q_rows)));
 }
 
+// The decoder's image: the same map; a staged row = the decoder's form of the row (QDEC_ROW below) cut to QH_SYMS symbols --
+// the 8 coarse cums, then the cums of symbols 0 .. QH_SYMS - 1: QHD_ROW_U16 u16, 16-byte pieces.  A decoder has no sample
+// to rank by: it stages the contexts whose prior rows carry the most weight (rows66 total; the choice is free -- staging
+// does not show in the text).  A symbol's two dependent 16-byte fetches (the eighth of the row, then the symbol in it)
+// come from LDS instead of L2: the round trip the lane's serial walk is made of.
+#define QHD_ROW_U16 (8u + QH_SYMS)
+__global__ __launch_bounds__(256) void k_hot_totals_prior(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ ctot) {
+    const u32 ctx = blockIdx.x * 256 + threadIdx.x;
+    if (ctx >= q_rows) return;
+    const u32 iend = rows66[(size_t)ctx * 66 + 65];
+    ctot[ctx] = (iend != 0 && iend <= QH_SYMS) ? rows66[(size_t)ctx * 66 + 64] + 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_hot_image_dec(const uint2* __restrict__ map, const u16* __restrict__ qdec, u32 q_rows, u16* __restrict__ rows) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctx >= q_rows) return;
+    const uint2 mr = map[ctx >> 5];
+    const u32 bit = 1u << (ctx & 31u);
+    if (!(mr.x & bit)) return;
+    const u32 slot = mr.y + (u32)__popc(mr.x & (bit - 1u));
+    if (lane < QHD_ROW_U16) rows[(size_t)slot * QHD_ROW_U16 + lane] = qdec[(size_t)ctx * 72u + lane];          // (QDEC_ROW: 8 coarse, then the symbols in order)
+}
+void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 want, u32* ctot, u8* img, u32* info, hipStream_t st) {
+    hipLaunchKernelGGL(k_hot_totals_prior, dim3((q_rows + 255) / 256), dim3(256), 0, st, rows66, q_rows, ctot);
+    hipLaunchKernelGGL(k_hot_select, dim3(1), dim3(1024), 0, st, (const u32*)ctot, q_rows, want, reinterpret_cast<uint2*>(img), info);
+    hipLaunchKernelGGL(k_hot_image_dec, dim3((q_rows + 3) / 4), dim3(256), 0, st, reinterpret_cast<const uint2*>(img), qdec, q_rows,
+                       reinterpret_cast<u16*>(img + QH_MAP_BYTES(q_rows)));
+}
+
 // ---- chain geometry ---------------------------------------------------------------------------------------------
 struct ChainPos { u32 b; u64 r0; u32 nrec; };
 __device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
@@ -398,8 +427,17 @@ __device__ __forceinline__ void unpack8(const uint4& v, u32 (&o)[8]) {          
     o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16;
     o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
 }
-template <int THREADS>
+template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArgs da) {
+    extern __shared__ u32 lds[];                              // the decoder's hot image: map, then rows
+    const uint2* const lmap = reinterpret_cast<const uint2*>(lds);
+    const u16* const lrows = reinterpret_cast<const u16*>(lds + QH_MAP_BYTES(a.q_rows) / 4u);
+    if constexpr (LDS) {
+        const u32 nd = (QH_MAP_BYTES(a.q_rows) + a.qh_info[0] * QHD_ROW_U16 * 2u + 3u) / 4u;
+        const u32* src = reinterpret_cast<const u32*>(a.qh_img);
+        for (u32 i = threadIdx.x; i < nd; i += THREADS) lds[i] = src[i];
+        __syncthreads();
+    }
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.geo.nchains) return;
     const ChainPos cp = chain_pos(a, c);
@@ -418,11 +456,20 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
             // from how many places, is what this kernel's time is made of)
             const u16* qd = a.qdec + (size_t)last * QDEC_ROW;
             u32 cc[8], ff[8];
-            unpack8(*reinterpret_cast<const uint4*>(qd), cc);
+            u32 hot = ~0u;                                                  // the row's place in the LDS image, if it is staged
+            if constexpr (LDS) {
+                const uint2 mr = lmap[last >> 5];
+                const u32 bit = 1u << (last & 31u);
+                if (mr.x & bit) hot = (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QHD_ROW_U16;
+            }
+            uint4 v;
+            if (hot != ~0u) v = *reinterpret_cast<const uint4*>(lrows + hot); else v = *reinterpret_cast<const uint4*>(qd);
+            unpack8(v, cc);
             u32 k8 = 0;
 #pragma unroll
             for (u32 j = 1; j < 8; j++) k8 += cc[j] <= prob;
-            unpack8(*reinterpret_cast<const uint4*>(qd + 8 + k8 * 8), ff);
+            if (hot != ~0u && k8 < QH_SYMS / 8u) v = *reinterpret_cast<const uint4*>(lrows + hot + 8 + k8 * 8); else v = *reinterpret_cast<const uint4*>(qd + 8 + k8 * 8);
+            unpack8(v, ff);
             u32 i8 = 0, cum = ff[0], next = 65536u;
 #pragma unroll
             for (u32 j = 7; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;       // the first entry past prob: in the coarse list ...
@@ -456,9 +503,16 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st) {
-    constexpr int T = 256;
-    const u32 grid = (a.geo.nchains + T - 1) / T;
-    hipLaunchKernelGGL(k_qlt_decode_c<T>, dim3(grid), dim3(T), 0, st, a, da);
+    if (a.q_hot) {
+        constexpr int T = 1024;                                // one workgroup per CU shares the image
+        const u32 dyn = QH_MAP_BYTES(a.q_rows) + a.q_hot * QHD_ROW_U16 * 2u;
+        static u32 allowed = 0;
+        if (dyn > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_decode_c<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed = dyn; }
+        hipLaunchKernelGGL((k_qlt_decode_c<T, true>), dim3((a.geo.nchains + T - 1) / T), dim3(T), dyn, st, a, da);
+    } else {
+        constexpr int T = 256;
+        hipLaunchKernelGGL((k_qlt_decode_c<T, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a, da);
+    }
 }
 
 // =========================================================================================================

@@ -75,8 +75,10 @@ static void usage() {
            "-1, -2, -3, -4   : alias for -l 1, -l 2, etc \n"
            "-B reads         : records per independent GPU block (default: about 376 KiB of text, i.e. 1024 reads of 150 bp;\n"
            "                   0 = single block, reference-compatible file)\n"
-           "-A               : adaptive tables: every block updates its rows per symbol, as the reference does (slower);\n"
-           "                   default: frozen tables, built by counting passes, one coding chain per GPU lane\n"
+           "-A               : adaptive tables: every block updates its rows per symbol, as the reference does (slower)\n"
+           "-F               : frozen tables, built by counting passes, one coding chain per GPU lane\n"
+           "                   default: -F from 64 MiB of text on, -A in blocks of 65536 reads below that (the priors\n"
+           "                   frozen tables transmit weigh too much on a small file)\n"
            "-C reads         : frozen tables: records per chain (default: automatic)\n"
            "-S mbytes        : input is compressed in slabs of this many MiB, one archive segment each (default 512 for a\n"
            "                   regular file, read ahead while the GPU codes the slab before; 2048 for a pipe)\n"
@@ -104,6 +106,7 @@ struct Opts {
     int io_threads = 6;                           // -t: threads that read a slab
     int table_pct = 0;                                                 // -T: share of the device memory for model tables (0 = the library's default)
     bool adaptive = false;                                             // -A
+    bool force_frozen = false;                                         // -F
     long chain_reads = 0;                                              // -C
 };
 
@@ -170,7 +173,9 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     sfq_params p; memset(&p, 0, sizeof p);
     p.level = o.level; p.block_reads = o.block_reads < 0 ? SFQ_BLOCK_AUTO : (uint32_t)o.block_reads;
     p.prior_step = legacy ? 0 : SFQ_PRIOR_AUTO;                        // warm start needs the block format
-    const bool frozen = !legacy && !o.adaptive;
+    // tables: by the size of the text unless asked for (one decision per file: the first slab's size stands for a pipe's)
+    bool frozen = !legacy && !o.adaptive;
+    bool tables_decided = legacy || o.adaptive || o.force_frozen;
     p.tables = frozen ? SFQ_TABLES_FROZEN : SFQ_TABLES_ADAPTIVE;
     p.chain_reads = (uint32_t)std::max(0l, o.chain_reads);
 
@@ -182,6 +187,14 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
     //  by one, 4-10x slower than reading into an ordinary buffer first.)
     size_t file_left = SIZE_MAX;                                       // bytes not yet read, when the input is a regular file
     if (in != stdin) { struct stat st; if (fstat(fileno(in), &st) == 0 && S_ISREG(st.st_mode)) file_left = (size_t)st.st_size; }
+    auto decide_tables = [&](uint64_t text_bytes) {
+        if (tables_decided) return;
+        tables_decided = true;
+        frozen = text_bytes >= (64ull << 20);
+        p.tables = frozen ? SFQ_TABLES_FROZEN : SFQ_TABLES_ADAPTIVE;
+        if (!frozen) { p.prior_step = 0; if (o.block_reads < 0) p.block_reads = 65536; }      // include/slimfastq_amd.h SFQ_TABLES_AUTO
+    };
+    if (file_left != SIZE_MAX) decide_tables(file_left);
     // A one-shot process pays for every byte of model tables it allocates (device allocations of tens of GB take
     // seconds), and its time is file I/O anyway: size the tables for a fraction of the block slots the text could use.
     if (!g_batch) {
@@ -354,6 +367,7 @@ static void encode_file(sfq_ctx* ctx, const Opts& o, const std::string& usr, con
         if (!eof) { use = whole_records(fq.p, fq.n); if (use == 0) continue; }
         const uint8_t* text = fq.p;
         if (use == 0) break;
+        decide_tables(eof ? use : (64ull << 20));                          // (a pipe: more than one slab of text is a big file)
         const size_t bound = (size_t)sfq_encode_bound(use);
         if (!out.reserve(bound)) croak("out of memory");
         out.touch(use / 3 + (1 << 20));                                    // the streams rarely exceed a third of the text
@@ -609,7 +623,7 @@ int main(int argc, char** argv) {
     Opts o;
     bool statistics = false;
     if (argc == 1) usage();
-    for (int opt; (opt = getopt(argc, argv, "qPsvhdObzA1234u:f:l:B:g:S:T:C:t:")) != -1;) {
+    for (int opt; (opt = getopt(argc, argv, "qPsvhdObzAF1234u:f:l:B:g:S:T:C:t:")) != -1;) {
         switch (opt) {
         case 'u': g_usr = optarg; break;
         case 'f': fil = optarg; break;
@@ -626,6 +640,7 @@ int main(int argc, char** argv) {
         case 'b': g_batch = true; break;
         case 'z': g_timing = true; break;
         case 'A': o.adaptive = true; break;
+        case 'F': o.force_frozen = true; break;
         case 'C': o.chain_reads = strtol(optarg, 0, 0); break;
         case 't': o.io_threads = std::min(64, std::max(1, atoi(optarg))); break;
         case 'v': printf("Version %s\nInternal format version=%u (block format %u)\n", kUserVersion, kInternalVersion, kBlockVersion); exit(0);

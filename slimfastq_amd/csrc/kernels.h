@@ -83,6 +83,8 @@ struct ChainArgs {
 };
 void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
                      u8* img /* q_rows / 4 bytes of map + want x 100 bytes of rows */, u32* info, hipStream_t st);
+void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
+                         u8* img /* q_rows / 4 bytes of map + want x 112 bytes of rows */, u32* info, hipStream_t st);
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,

@@ -256,6 +256,8 @@ def test_frozen_quality_rows_staged_in_lds_do_not_change_a_byte(ctx, level):
         assert enc.stream("qlt") == base.stream("qlt"), rows
         assert enc.chains == base.chains and enc.prior == base.prior, rows
     assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+    for rows in (1, 300, 5000):                         # the decoder's own staging (rows picked by the prior's weights)
+        assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096, lds_rows=rows) == fq, rows
 
 
 def _odd_headers_fastq(n, seed):

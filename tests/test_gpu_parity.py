@@ -594,7 +594,7 @@ def test_cli_batch_worker_survives_a_damaged_second_segment(tmp_path):
     fq = capi.synth_fastq(12000, 150, seed=23)
     src = tmp_path / "big.fq"; src.write_bytes(fq)
     good = tmp_path / "good.sfq"
-    subprocess.check_call([cli, "-u", str(src), "-f", str(good), "-O", "-S", "1", "-B", "500"])
+    subprocess.check_call([cli, "-u", str(src), "-f", str(good), "-O", "-S", "1", "-B", "500", "-F"])
     a = O.parse(good.read_bytes())
     v = util._vints(a.streams["seg.idx"])
     assert v[0] >= 3 and len(v) == 1 + 5 * v[0]                 # nblocks, prior, raw, chain, rec.pri bytes per segment
@@ -614,6 +614,34 @@ def test_cli_batch_worker_survives_a_damaged_second_segment(tmp_path):
     # one-shot mode: the same archive ends the process with the reference's wording and exit code, not a crash
     p = subprocess.run([cli, "-d", "-f", str(bad), "-u", str(tmp_path / "bad2.out"), "-O"], capture_output=True)
     assert p.returncode == 1 and b"slimfastq: decoding" in p.stderr and b"segment index" in p.stderr
+
+
+def test_small_inputs_take_adaptive_tables_by_default(ctx, tmp_path):
+    """SFQ_TABLES_AUTO (the CLI's default): frozen tables transmit their priors, which weigh too much on a small file (the
+    reference's largest sample, tst7.fq, 3.9 MB: 1.15 x the reference's bytes) -- below 64 MiB of text the library codes with
+    adaptive tables in blocks of 65536 records, i.e. the reference's own streams for such a file, and stays within 1 %."""
+    import subprocess
+    fq = util.golden_fastq("tst7")
+    ref = O.compress(fq, 3)
+    ref_bytes = ref.payload_bytes() - len(ref.streams["<info>"])
+    enc = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_AUTO)
+    assert not enc.chains and not enc.prior and len(enc.blocks) == 1
+    assert enc.archive_bytes <= 1.01 * ref_bytes
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    frozen = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+    assert frozen.chains and frozen.archive_bytes > 1.05 * ref_bytes          # what the default avoids
+    # the CLI: the same decision by the file's size; -F forces frozen tables
+    cli = _cli()
+    src = tmp_path / "tst7.fq"; src.write_bytes(fq)
+    a, f, out = tmp_path / "auto.sfq", tmp_path / "frozen.sfq", tmp_path / "back.fq"
+    subprocess.check_call([cli, "-u", str(src), "-f", str(a), "-O", "-q"])
+    subprocess.check_call([cli, "-u", str(src), "-f", str(f), "-O", "-q", "-F"])
+    pa, pf = O.parse(a.read_bytes()), O.parse(f.read_bytes())
+    assert "blk.tables" not in pa.info and pf.info.get("blk.tables") == "1" and "chn.idx" in pf.streams and "chn.idx" not in pa.streams
+    assert sum(len(v) for k, v in pa.streams.items() if k != "<info>") <= 1.01 * ref_bytes
+    for arch in (a, f):
+        subprocess.check_call([cli, "-d", "-f", str(arch), "-u", str(out), "-O"])
+        assert out.read_bytes() == fq
 
 
 def test_multi_file_driver(tmp_path):
