@@ -1201,6 +1201,9 @@ __device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lan
 }
 template <u32 ML>
 __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags) {
+#ifndef NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __shared__ RecFastLds<ML> L;
     const u32 lane = threadIdx.x;
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < REC_LDS_ROWS ? sl : 0xFFu); }
@@ -1268,16 +1271,26 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32 max_hdr, hipStream_
 // header decode: one chain per lane.  DecodeArgs::hdr_stage_off / hdr_stage_cap are per CHAIN here.
 // largest s with cum[s] <= prob in a row of the decoder's form (RDEC_ROW): the sixteenth of the row, then the symbol in
 // it.  Two round trips of 32 bytes (a search that fetched entry by entry was nine dependent fetches).
-__device__ __forceinline__ u32 rdec_search(const u16* rd, u32 prob, u32& cum, u32& next) {
+// (P names the row's address space -- LDS or global: a search through a generic pointer that may be either is four flat loads)
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u16* lds_row;
+typedef const __attribute__((address_space(1))) u16* glb_row;
+template <typename V> __device__ __forceinline__ void unpack8v(V v, u32* o) {
+    o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16; o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
+}
+__device__ __forceinline__ u32x4 row16(lds_row p) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(p); }
+__device__ __forceinline__ u32x4 row16(glb_row p) { return *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(p); }
+template <typename P>
+__device__ __forceinline__ u32 rdec_search(P rd, u32 prob, u32& cum, u32& next) {
     u32 cc[16], ff[16];
-    unpack8(*reinterpret_cast<const uint4*>(rd), *reinterpret_cast<u32 (*)[8]>(cc));
-    unpack8(*reinterpret_cast<const uint4*>(rd + 8), *reinterpret_cast<u32 (*)[8]>(cc + 8));
+    unpack8v(row16(rd), cc);
+    unpack8v(row16(rd + 8), cc + 8);
     u32 k = 0;
 #pragma unroll
     for (u32 j = 1; j < 16; j++) k += cc[j] <= prob;
-    const u16* fr = rd + 16 + k * 16;
-    unpack8(*reinterpret_cast<const uint4*>(fr), *reinterpret_cast<u32 (*)[8]>(ff));
-    unpack8(*reinterpret_cast<const uint4*>(fr + 8), *reinterpret_cast<u32 (*)[8]>(ff + 8));
+    P fr = rd + 16 + k * 16;
+    unpack8v(row16(fr), ff);
+    unpack8v(row16(fr + 8), ff + 8);
     u32 s = 0;
     cum = ff[0]; next = 65536u;
 #pragma unroll
@@ -1294,7 +1307,7 @@ struct RecFrozenDec {
     __device__ __forceinline__ u32 get(u32 row) {
         const u32 prob = rc.get_freq16();
         u32 cum, next;
-        const u32 s = rdec_search(rdec + (size_t)row * RDEC_ROW, prob, cum, next);
+        const u32 s = rdec_search((glb_row)(rdec + (size_t)row * RDEC_ROW), prob, cum, next);
         rc.decode(cum, next - cum);
         return s;
     }
@@ -1337,8 +1350,8 @@ struct RecFastDecSrc {
         const u32 prob = rc.get_freq16();
         const u32 slot = L->map[row];
         u32 cum, next, s;
-        if (slot != 0xFFu) s = rdec_search(L->drows[slot], prob, cum, next);
-        else s = rdec_search(rdec + (size_t)row * RDEC_ROW, prob, cum, next);
+        if (slot != 0xFFu) s = rdec_search((lds_row)L->drows[slot], prob, cum, next);
+        else s = rdec_search((glb_row)(rdec + (size_t)row * RDEC_ROW), prob, cum, next);
         rc.decode(cum, next - cum);
         return s;
     }
@@ -1457,6 +1470,9 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
     return true;
 }
 __global__ __launch_bounds__(64) void k_rec_decode_f(ChainArgs a, DecodeArgs da, u32* flags) {
+#ifndef NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __shared__ RecFastDecLds L;
     const u32 lane = threadIdx.x;
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < RDEC_LDS_ROWS ? sl : 0xFFu); }

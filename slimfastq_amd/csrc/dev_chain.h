@@ -42,6 +42,7 @@ struct LaneEnc {
     }
     __device__ __forceinline__ void renorm() {                              // coder.hpp:74-80
         int guard = 0;
+#pragma nounroll
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             put((u32)(low >> 56));
@@ -272,6 +273,9 @@ struct LaneDec {
         low += temp; code -= temp;
         range *= freq;
         int guard = 0;
+        // (not unrolled: the guard bounds the trip count, and thirteen copies of the refill -- with its end-of-stream byte loads -- per
+        //  decoded symbol site are what the compiler makes of that)
+#pragma nounroll
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             code = (code << 8) | get();

@@ -68,6 +68,7 @@ struct RcEnc {
         low += (u64)(u32)(cum * r);
         range = r * freq;
         int guard = 0;
+#pragma nounroll
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             s.put((u8)(low >> 56));
@@ -108,6 +109,7 @@ struct RcDec {
         code -= temp;
         range *= freq;
         int guard = 0;
+#pragma nounroll
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             code = (code << 8) | s.get();

@@ -209,17 +209,17 @@ struct PwTab {
     }
     // PowerRangerU::get_u (power_ranger.hpp:165-190)
     __device__ u64 get_u(u32 row0, RcDec& rc, ByteSrc& s) const {
-        u64 num = get(row0, rc, s);
-        if (num > 0x7f) {
-            num = (num << 8) | get(row0 + 1, rc, s);
-            if (num < 0xfffe) num &= 0x7fff;
-            else if (num == 0xfffe) {
-                num = 0;
-                for (int sh = 0, i = 2; sh < 32; sh += 8, i++) num |= (u64)get(row0 + i, rc, s) << sh;
-            } else {
-                num = 0;
-                for (int sh = 0, i = 6; sh < 64; sh += 8, i++) num |= (u64)get(row0 + i, rc, s) << sh;
-            }
+        u64 num = 0; u32 n = 1;                                     // (one loop around one get, as put_u above: code size)
+#pragma nounroll
+        for (u32 j = 0; j < n; j++) {
+            const u32 row = j < 2 ? row0 + j : row0 + (n == 6 ? 2u : 6u) + (j - 2);
+            const u32 b = get(row, rc, s);
+            if (j == 0) { num = b; n = b > 0x7f ? 2u : 1u; }
+            else if (j == 1) {
+                num = (num << 8) | b;
+                if (num < 0xfffe) num &= 0x7fff;
+                else { n = num == 0xfffe ? 6u : 10u; num = 0; }
+            } else num |= (u64)b << (8 * (j - 2));
         }
         return num;
     }

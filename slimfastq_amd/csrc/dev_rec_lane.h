@@ -115,17 +115,19 @@ __device__ __forceinline__ void put_u_rows(C& cd, u32 row0, u64 num) {
 // PowerRangerU::get_u (power_ranger.hpp:165-190) on any coder with get(row)
 template <typename C>
 __device__ __forceinline__ u64 get_u_rows(C& cd, u32 row0) {
-    u64 num = cd.get(row0);
-    if (num > 0x7f) {
-        num = (num << 8) | cd.get(row0 + 1);
-        if (num < 0xfffe) num &= 0x7fff;
-        else if (num == 0xfffe) {
-            num = 0;
-            for (int sh = 0, i = 2; sh < 32; sh += 8, i++) num |= (u64)cd.get(row0 + i) << sh;
-        } else {
-            num = 0;
-            for (int sh = 0, i = 6; sh < 64; sh += 8, i++) num |= (u64)cd.get(row0 + i) << sh;
-        }
+    // (one loop around ONE get: a coder's get is a table search plus a renormalisation with its refills -- four copies of it per number
+    //  made the frozen header decoder 337 KB of code for a 64 KB instruction cache)
+    u64 num = 0; u32 n = 1;
+#pragma nounroll
+    for (u32 j = 0; j < n; j++) {
+        const u32 row = j < 2 ? row0 + j : row0 + (n == 6 ? 2u : 6u) + (j - 2);
+        const u32 s = cd.get(row);
+        if (j == 0) { num = s; n = s > 0x7f ? 2u : 1u; }
+        else if (j == 1) {
+            num = (num << 8) | s;
+            if (num < 0xfffe) num &= 0x7fff;
+            else { n = num == 0xfffe ? 6u : 10u; num = 0; }
+        } else num |= (u64)s << (8 * (j - 2));
     }
     return num;
 }

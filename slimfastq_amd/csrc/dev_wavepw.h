@@ -19,6 +19,7 @@ struct RcEncU {                // RCoder (coder.hpp) on uniform values, one symb
         low += (u64)(u32)(cum * r);
         range = r * freq;
         int guard = 0;
+#pragma nounroll
         while (range < RC_TOP) {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             s.put((u32)(low >> 56));
@@ -35,11 +36,31 @@ struct WavePw {
     // rows [hrow0, hrow0 + hn) live in the wave's LDS instead (k_gen_exc_w: the two rows nearly every gap goes through --
     // a gap's row is read, updated and written back, and the next gap reads it again: round trips through L2 otherwise)
     u32* hslots = nullptr; RowHdr* hhdr = nullptr; u32 hrow0 = 0, hn = 0;
+    // The header's accesses name their address space: through one generic pointer that is either, they are flat loads / stores, which
+    // take the vector memory path even when the row is in LDS.  (The slots stay behind a selected generic pointer: the same split for
+    // them -- a uniform branch around a ds_ and a global_ access inside the lanes' own conditions -- coded different bytes on the GPU
+    // and was taken out again, unexplained.)
+    typedef u32 v4 __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ u32* row_slots(u32 row) const { const u32 k = row - hrow0; return k < hn ? hslots + (size_t)k * PW_NSYM : slots + (size_t)row * PW_NSYM; }
-    __device__ __forceinline__ RowHdr* row_hdr(u32 row) const { const u32 k = row - hrow0; return k < hn ? hhdr + k : hdr + row; }
+    __device__ __forceinline__ uint4 ld_slots(u32 row, u32 i0) const { return *reinterpret_cast<const uint4*>(row_slots(row) + i0); }
+    __device__ __forceinline__ void st_slots(u32 row, u32 i0, const uint4& v) const { *reinterpret_cast<uint4*>(row_slots(row) + i0) = v; }
+    __device__ __forceinline__ RowHdr ld_hdr(u32 row) const {                  // RowHdr as its four dwords (dev_common.h)
+        const u32 k = row - hrow0; v4 r;
+        if (k < hn) r = *(const __attribute__((address_space(3))) v4*)(hhdr + k);
+        else        r = *(const __attribute__((address_space(1))) v4*)(hdr + row);
+        RowHdr h; h.total = r.x; h.iend = (u16)(r.y & 0xffffu); h.count = (u8)((r.y >> 16) & 0xffu); h.pad = 0; h.epoch = r.z; h.pad2 = 0;
+        return h;
+    }
+    __device__ __forceinline__ void st_hdr(u32 row, const RowHdr& h) const {
+        const u32 k = row - hrow0; v4 r; r.x = h.total; r.y = (u32)h.iend | ((u32)h.count << 16); r.z = h.epoch; r.w = 0;
+        if (k < hn) *(__attribute__((address_space(3))) v4*)(hhdr + k) = r;
+        else        *(__attribute__((address_space(1))) v4*)(hdr + row) = r;
+    }
+    // hot row k starts fresh: epoch 0 is no block's (written the way ld_hdr reads it)
+    __device__ __forceinline__ void fresh_hot(u32 k) const { v4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0; *(__attribute__((address_space(3))) v4*)(hhdr + k) = z; }
     __device__ __forceinline__ u32 comp(const uint4& v, u32 c) const { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
     // update_freq (power_ranger.hpp:66-84) of slot i = 4 hl + c (value cur), then the row and its header back to HBM
-    __device__ __forceinline__ void update(u32* rs, u32 row, u32 lane, u32 i, u32 hl, u32 c, u32 cur, u32 total, u32 iend, u32 count, uint4 v, u64 dirty) {
+    __device__ __forceinline__ void update(u32 row, u32 lane, u32 i, u32 hl, u32 c, u32 cur, u32 total, u32 iend, u32 count, uint4 v, u64 dirty) {
         const u32 i0 = 4 * lane;
         u32 f = cur & 0xffffu;
         bool upd = true;
@@ -77,10 +98,10 @@ struct WavePw {
             if (lane == al) { if (ac == 0) v.x = ns; else if (ac == 1) v.y = ns; else if (ac == 2) v.z = ns; else v.w = ns; }
             dirty |= 1ull << al;
         }
-        if ((dirty >> lane) & 1) *reinterpret_cast<uint4*>(rs + i0) = v;
+        if ((dirty >> lane) & 1) st_slots(row, i0, v);
         if (lane == 0) {
             RowHdr nh; nh.total = total; nh.iend = (u16)iend; nh.count = (u8)count; nh.pad = 0; nh.epoch = epoch; nh.pad2 = 0;
-            *row_hdr(row) = nh;
+            st_hdr(row, nh);
         }
     }
     // PowerRanger::get (power_ranger.hpp:106-130): the slot whose cumulative range holds the coder's value -- every slot's
@@ -88,14 +109,13 @@ struct WavePw {
     // the old iend and the one found come into being on the way (:118-119).  Every lane runs the same (uniform) coder.
     template <typename SRC>
     __device__ __forceinline__ u32 get(u32 row, RcDec& rc, SRC& src, u32 lane) {
-        u32* rs = row_slots(row);
-        const RowHdr h = *row_hdr(row);
+        const RowHdr h = ld_hdr(row);
         const bool live = rl(h.epoch, 0) == epoch;
         u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
         const u32 prob = rc.get_freq(total + PW_NSYM);
         const u32 i0 = 4 * lane;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);
+        if (i0 < iend) v = ld_slots(row, i0);
         if (i0 + 0 >= iend) v.x = (i0 + 0) << 16;                           // a slot not yet in the row: its own symbol, frequency 0
         if (i0 + 1 >= iend) v.y = (i0 + 1) << 16;
         if (i0 + 2 >= iend) v.z = (i0 + 2) << 16;
@@ -119,35 +139,35 @@ struct WavePw {
         if (i >= iend) { dirty |= __ballot(i0 + 3 >= iend && i0 <= i); iend = i + 1; }
         const u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
         rc.decode(src, sumf, (cur & 0xffffu) + 1);
-        update(rs, row, lane, i, hl, c, cur, total, iend, count, v, dirty);
+        update(row, lane, i, hl, c, cur, total, iend, count, v, dirty);
         return (cur >> 16) & 0xffu;
     }
     // PowerRangerU::get_u (power_ranger.hpp:165-190)
     template <typename SRC>
     __device__ __forceinline__ u64 get_u(u32 row0, RcDec& rc, SRC& s, u32 lane) {
-        u64 num = get(row0, rc, s, lane);
-        if (num > 0x7f) {
-            num = (num << 8) | get(row0 + 1, rc, s, lane);
-            if (num < 0xfffe) num &= 0x7fff;
-            else if (num == 0xfffe) {
-                num = 0;
-                for (int sh = 0, k = 2; sh < 32; sh += 8, k++) num |= (u64)get(row0 + k, rc, s, lane) << sh;
-            } else {
-                num = 0;
-                for (int sh = 0, k = 6; sh < 64; sh += 8, k++) num |= (u64)get(row0 + k, rc, s, lane) << sh;
-            }
+        // (one loop around ONE inlined get, as put_u below: four copies of the row search per number made these kernels 150-250 KB of code)
+        u64 num = 0; u32 n = 1;
+#pragma nounroll
+        for (u32 j = 0; j < n; j++) {
+            const u32 row = j < 2 ? row0 + j : row0 + (n == 6 ? 2u : 6u) + (j - 2);
+            const u32 b = get(row, rc, s, lane);
+            if (j == 0) { num = b; n = b > 0x7f ? 2u : 1u; }
+            else if (j == 1) {
+                num = (num << 8) | b;
+                if (num < 0xfffe) num &= 0x7fff;
+                else { n = num == 0xfffe ? 6u : 10u; num = 0; }
+            } else num |= (u64)b << (8 * (j - 2));
         }
         return num;
     }
     // PowerRanger::put minus Encode: returns the triple, updates the row in HBM.  sym uniform, < 256.
     __device__ __forceinline__ Triple model(u32 row, u32 sym, u32 lane) {
-        u32* rs = row_slots(row);
-        const RowHdr h = *row_hdr(row);
+        const RowHdr h = ld_hdr(row);
         const bool live = rl(h.epoch, 0) == epoch;
         u32 total = live ? rl(h.total, 0) : 0u, iend = live ? rl((u32)h.iend, 0) : 0u, count = live ? rl((u32)h.count, 0) : 0u;
         const u32 i0 = 4 * lane;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (i0 < iend) v = *reinterpret_cast<const uint4*>(rs + i0);       // only the lanes that hold live slots
+        if (i0 < iend) v = ld_slots(row, i0);                              // only the lanes that hold live slots
         u64 dirty = 0;                                                     // lanes to store back
         if (iend <= sym) {                                                 // :94-96
             if (i0 + 0 >= iend && i0 + 0 <= sym) v.x = (i0 + 0) << 16;
@@ -168,7 +188,7 @@ struct WavePw {
         const u32 sumf = i ? rl(wave_incl_scan(part), 63) : 0u;
         u32 cur = c == 0 ? rl(v.x, hl) : c == 1 ? rl(v.y, hl) : c == 2 ? rl(v.z, hl) : rl(v.w, hl);
         Triple t; t.cum = sumf + i; t.freq = (cur & 0xffffu) + 1; t.tot = total + PW_NSYM;               // :100
-        update(rs, row, lane, i, hl, c, cur, total, iend, count, v, dirty);
+        update(row, lane, i, hl, c, cur, total, iend, count, v, dirty);
         return t;
     }
     __device__ __forceinline__ void put(u32 row, RcEncU& rc, Sink0& s, u32 sym, u32 lane) {

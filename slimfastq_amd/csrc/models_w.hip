@@ -45,14 +45,14 @@
 // flags (from the quality and base chains, which have read every byte anyway): the records that may hold an N or a '!';
 // the others only move the base offset on, 64 records a step.  Null: every record is looked at.
 __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restrict__ flags, u32* ticket) {
-    __shared__ u32 hot_slots[2 * PW_NSYM];
-    __shared__ RowHdr hot_hdr[2];
+    __shared__ __attribute__((aligned(16))) u32 hot_slots[2 * PW_NSYM];
+    __shared__ __attribute__((aligned(16))) RowHdr hot_hdr[2];
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
         WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
         pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = PR_XF_BASE + XF_GEN_NS * PR_XF_ROWS; pw.hn = 2;
-        if (lane < 2) hot_hdr[lane].epoch = 0;             // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
+        if (lane < 2) pw.fresh_hot(lane);                  // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
         XfEncW x_ns, x_nn, x_lc;                           // the whole wave codes a gap: lane = four slots of the PowerRanger row
         x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
         x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
@@ -221,14 +221,14 @@ struct OverArgs {
     u64 out_off[3]; u32 out_cap[3];         // regions in the arena: lrec, lgen, lqlt
 };
 __global__ __launch_bounds__(64) void k_over_encode_w(ModelArgs a, OverArgs o) {
-    __shared__ u32 hot_slots[PW_NSYM];
-    __shared__ RowHdr hot_hdr[1];
+    __shared__ __attribute__((aligned(16))) u32 hot_slots[PW_NSYM];
+    __shared__ __attribute__((aligned(16))) RowHdr hot_hdr[1];
     const u32 lane = threadIdx.x, which = blockIdx.x;                    // 0 lrec, 1 lgen, 2 lqlt
     BlockDesc* d = &a.blocks[0];
     WavePw pw; pw.slots = a.p_slots; pw.hdr = a.p_hdr; pw.epoch = EPOCH_L(a.epoch_base + 1);      // block 0's rows (every XFile has rows of its own)
     XfEncW x; x.init(a.arena + o.out_off[which], o.out_cap[which], XF_USR_LREC + which);
     pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = x.row0 + 14; pw.hn = 1;
-    if (lane == 0) hot_hdr[0].epoch = 0;
+    if (lane == 0) pw.fresh_hot(0);
     u64 i_long = 0;                                                     // m_last.i_long usrs.cpp:271-272
     for (u32 i = 0; i < o.n_over; i++) {
         const u64 r = o.over_list[i];
@@ -268,15 +268,15 @@ struct OverDecArgs {
     u8* txt; u64 cap;
 };
 __global__ __launch_bounds__(64) void k_over_decode_w(ModelArgs a, OverDecArgs o) {
-    __shared__ u32 hot_slots[PW_NSYM];
-    __shared__ RowHdr hot_hdr[1];
+    __shared__ __attribute__((aligned(16))) u32 hot_slots[PW_NSYM];
+    __shared__ __attribute__((aligned(16))) RowHdr hot_hdr[1];
     const u32 lane = threadIdx.x, which = o.which;
     BlockDesc* d = &a.blocks[0];
     // (rows of the call's first table slot under an epoch of their own per pass: the counting pass and the storing pass both start fresh)
     WavePw pw; pw.slots = a.p_slots; pw.hdr = a.p_hdr; pw.epoch = EPOCH_L(a.epoch_base + 1 + o.store);
     XfDecW x; x.init(o.stream, o.size, XF_USR_LREC + which);
     pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = x.row0 + 14; pw.hn = 1;
-    if (lane == 0) hot_hdr[0].epoch = 0;
+    if (lane == 0) pw.fresh_hot(0);
     u64 pos = 0, nrecs = 0, number = 0; u32 bad = 0;
     // one line: characters up to and including the newline (a line that does not end within the buffer is a damaged stream)
     auto line = [&](u32 slot, u64 i) {

@@ -22,24 +22,39 @@ __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 
 // (ctx, symbol).  Plain global atomics serialise on the few very hot counters (memory-side atomics:
 // ~30 ns each on one address), so every workgroup first aggregates in an LDS hash table and flushes each
 // distinct key once.
-#define HIST_SLOTS 8192u            // 64 KiB of LDS: keys + counts (half of that was measured: the table overflows onto the hot
+#ifndef HIST_S
+#define HIST_S 8192u
+#endif
+#ifndef HIST_T
+#define HIST_T 256
+#endif
+#define HIST_SLOTS HIST_S            // 64 KiB of LDS: keys + counts (half of that was measured: the table overflows onto the hot
                                     // global counters and the kernel takes 34 ms instead of 4)
 #define HIST_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ void hist_add(u32* keys, u32* cnts, u32* hist, u32 key) {
-    u32 slot = (key * 2654435761u) >> 19;                 // 13 bits
+// (keys / cnts are named as LDS and hist as global memory: left as generic pointers, the compiler folds the table's add and the
+//  fallback's add into ONE flat_atomic_add on a selected address -- a flat atomic into the LDS aperture per symbol, which is what
+//  this kernel spent its time on: 3.2 ms alone, 8-10 ms beside the chain kernels)
+typedef __attribute__((address_space(3))) u32 lds_u32;
+typedef __attribute__((address_space(1))) u32 glb_u32;
+__device__ __forceinline__ void hist_add(lds_u32* keys, lds_u32* cnts, glb_u32* hist, u32 key) {
+    u32 slot = ((key * 2654435761u) >> 16) & (HIST_SLOTS - 1);
     // (as many probes as it takes while the table has room: a key that gives up after a few in a crowded neighbourhood goes to
     //  the global counters, and the ones that are hot there are hot in every workgroup -- those atomics were most of the kernel's time)
     for (int probe = 0; probe < 256; probe++) {
-        const u32 old = atomicCAS(&keys[slot], HIST_EMPTY, key);
-        if (old == HIST_EMPTY || old == key) { atomicAdd(&cnts[slot], 1u); return; }
+        u32 expect = HIST_EMPTY;
+        const bool took = __hip_atomic_compare_exchange_strong(&keys[slot], &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (took || expect == key) { __hip_atomic_fetch_add(&cnts[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
         slot = (slot + 1) & (HIST_SLOTS - 1);
     }
-    atomicAdd(&hist[key], 1u);                            // table crowded: count directly
+    __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // table crowded: count directly
 }
 template <u32 THREADS, u32 READS_PER_LANE>
 __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq, u64 nbytes, const u64* __restrict__ line_off,
                                                  const BlockDesc* __restrict__ blocks, u32 block_reads,
                                                  u64 nrec, u32 step, int level, u32 cap, u32* __restrict__ hist) {
+#ifndef NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __shared__ u32 keys[HIST_SLOTS];
     __shared__ u32 cnts[HIST_SLOTS];
     for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
                     const u32 pos = (u32)(w + k) * 4 + j;    // byte index from a0
                     if (pos < skip || done >= n) continue;
                     const u32 b = (u32)(u8)(((wd[k] >> (8 * j)) & 0xff) - '!');
-                    hist_add(keys, cnts, hist, last * 64 + (b < 63u ? b : 63u));
+                    hist_add((lds_u32*)keys, (lds_u32*)cnts, (glb_u32*)hist, last * 64 + (b < 63u ? b : 63u));
                     if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
                     else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
                     else if (++di & 1) { last = p_calc_last_delta(delta, b, q1, q2); q2 = b; }
@@ -95,8 +110,8 @@ void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockD
     } else {
         // (a record per lane: the kernel's time is one lane's walk -- with four records per lane and a 64 KiB table, two workgroups
         //  per CU, it took 4.6 ms of every call whatever the sample's size)
-        const u64 per_wg = 256ull;
-        hipLaunchKernelGGL((k_qlt_hist<256, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(256), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
+        const u64 per_wg = HIST_T;
+        hipLaunchKernelGGL((k_qlt_hist<HIST_T, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(HIST_T), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     }
 }
 
