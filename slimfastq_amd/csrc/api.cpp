@@ -48,7 +48,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, excf, cflags;
+    DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
     // format 6's oversize records (frame.hip): flags, kept bytes, their scans, the text without them, kept record -> file number, the list;
     // the file's own line index; decode: numbers, pieces, raw text of the three streams, sizes / offsets in file order
     DevBuf oflags, okbytes, ofpos, okoff, ofilt, orecmap, olist, line_off_o, ono, opiece, otxt[3], osize_all, oroff_all, oroff_k, ocnt;
@@ -537,7 +537,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -955,10 +955,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
             ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rdec = (const u16*)ctx->rdec.p;
             ca.rmap = (const u16*)ctx->rmap.p; ca.rhot = ca.rmap + PR_REC_ROWS; ca.r_hot = ctx->r_hot;
-            if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
-            HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, mst[1]));
+            if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4 * 3))) return rc;                     // flags, flags2, token counts
+            if ((rc = reserve(ctx, ctx->rtok, rec_token_bytes(nrec)))) return rc;
+            HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
-            HIPC(hipEventRecord(ctx->ev[18], mst[1])); launch_rec_encode_c(ca, (u32*)ctx->rflags.p, max_hdr, mst[1]); HIPC(hipEventRecord(ctx->ev[19], mst[1]));
+            HIPC(hipEventRecord(ctx->ev[18], mst[1]));
+            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1]);
+            HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
             if (rows66_copy_pending) {
                 HIPC(hipStreamWaitEvent(mst[1], ctx->ev[21], 0));

@@ -98,7 +98,9 @@ void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nru
                       u32* flags /* [nruns], zeroed */, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec /* the decoder's form; may be null */, hipStream_t st);
 // one header chain per lane; a.csz / a.rhb per chain; max_hdr = the call's longest header (picks the LDS image of the fast kernel)
-void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32 max_hdr, hipStream_t st);
+void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32* flags2 /* the same */, u32* tok /* rec_token_bytes(records) */, u32* ntok /* [rgeo.nchains] */,
+                         u32 n_hot, u32 max_hdr, hipStream_t st);
+u64 rec_token_bytes(u64 nrec);
 void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb /* or null */, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st);

@@ -22,28 +22,44 @@ __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 
 // (ctx, symbol).  Plain global atomics serialise on the few very hot counters (memory-side atomics:
 // ~30 ns each on one address), so every workgroup first aggregates in an LDS hash table and flushes each
 // distinct key once.
+// (context, symbol) pairs are mostly rare -- the 38 k symbols of a workgroup hold 6-8 k distinct ones -- so the table has to have
+// room for all of them WITHOUT filling up: with 8192 slots of key + count (8 bytes) it ran 75-95 % full and spent 75 LDS instructions
+// per symbol on probe chains (3.2 ms alone, 6-10 ms beside the other kernels; the quality chains wait for this).  A slot is now ONE
+// dword -- the key's 22 bits over a 10-bit count -- so the same 64 KiB hold 16384 of them; a count that reaches 256 is moved on to
+// the global counter by the lane that saw it get there (the few keys that take most of the symbols do that a few times per workgroup).
+// Counting a key that gives up its place in a crowded table directly in memory is no way out: the counters many workgroups add to
+// serialise in L2, and a two-slot cache in front of them took 30 ms.
 #ifndef HIST_S
-#define HIST_S 8192u
+#define HIST_S 16384u
 #endif
 #ifndef HIST_T
 #define HIST_T 256
 #endif
-#define HIST_SLOTS HIST_S            // 64 KiB of LDS: keys + counts (half of that was measured: the table overflows onto the hot
-                                    // global counters and the kernel takes 34 ms instead of 4)
+#define HIST_SLOTS HIST_S
 #define HIST_EMPTY 0xFFFFFFFFu
-// (keys / cnts are named as LDS and hist as global memory: left as generic pointers, the compiler folds the table's add and the
-//  fallback's add into ONE flat_atomic_add on a selected address -- a flat atomic into the LDS aperture per symbol, which is what
-//  this kernel spent its time on: 3.2 ms alone, 8-10 ms beside the chain kernels)
+#define HIST_CBITS 10u
+#define HIST_CMASK ((1u << HIST_CBITS) - 1u)
+#define HIST_HARVEST 256u
+// (the table is named as LDS and hist as global memory: through generic pointers the compiler folds the two adds into one flat atomic)
 typedef __attribute__((address_space(3))) u32 lds_u32;
 typedef __attribute__((address_space(1))) u32 glb_u32;
-__device__ __forceinline__ void hist_add(lds_u32* keys, lds_u32* cnts, glb_u32* hist, u32 key) {
+__device__ __forceinline__ void hist_add(lds_u32* slots, glb_u32* hist, u32 key) {
     u32 slot = ((key * 2654435761u) >> 16) & (HIST_SLOTS - 1);
-    // (as many probes as it takes while the table has room: a key that gives up after a few in a crowded neighbourhood goes to
-    //  the global counters, and the ones that are hot there are hot in every workgroup -- those atomics were most of the kernel's time)
-    for (int probe = 0; probe < 256; probe++) {
-        u32 expect = HIST_EMPTY;
-        const bool took = __hip_atomic_compare_exchange_strong(&keys[slot], &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (took || expect == key) { __hip_atomic_fetch_add(&cnts[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+    for (int probe = 0; probe < 128; probe++) {
+        u32 v = slots[slot];
+        if (v == HIST_EMPTY) {
+            u32 expect = HIST_EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&slots[slot], &expect, (key << HIST_CBITS) | 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+            v = expect;                                   // another lane's key got there first: maybe ours
+        }
+        if ((v >> HIST_CBITS) == key) {                   // (a slot keeps its key)
+            const u32 old = __hip_atomic_fetch_add(&slots[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & HIST_CMASK) == HIST_HARVEST - 1u) {           // exactly one lane sees the count get to HARVEST: it moves that much on
+                __hip_atomic_fetch_sub(&slots[slot], HIST_HARVEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&hist[key], HIST_HARVEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         slot = (slot + 1) & (HIST_SLOTS - 1);
     }
     __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // table crowded: count directly
@@ -55,9 +71,8 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
 #ifndef NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    __shared__ u32 keys[HIST_SLOTS];
-    __shared__ u32 cnts[HIST_SLOTS];
-    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { keys[i] = HIST_EMPTY; cnts[i] = 0; }
+    __shared__ u32 slots[HIST_SLOTS];
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) slots[i] = HIST_EMPTY;
     __syncthreads();
     for (u32 rr = 0; rr < READS_PER_LANE; rr++) {
         const u64 r = (((u64)blockIdx.x * READS_PER_LANE + rr) * THREADS + threadIdx.x) * step;
@@ -87,7 +102,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
                     const u32 pos = (u32)(w + k) * 4 + j;    // byte index from a0
                     if (pos < skip || done >= n) continue;
                     const u32 b = (u32)(u8)(((wd[k] >> (8 * j)) & 0xff) - '!');
-                    hist_add((lds_u32*)keys, (lds_u32*)cnts, (glb_u32*)hist, last * 64 + (b < 63u ? b : 63u));
+                    hist_add((lds_u32*)slots, (glb_u32*)hist, last * 64 + (b < 63u ? b : 63u));
                     if (level == 1)      last = (b | (last << 6)) & 0xFFFu;
                     else if (level == 2) last = (b | (last << 6)) & 0xFFFFu;
                     else if (++di & 1) { last = p_calc_last_delta(delta, b, q1, q2); q2 = b; }
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
         }
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) if (cnts[i]) atomicAdd(&hist[keys[i]], cnts[i]);
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { const u32 v = slots[i]; if (v != HIST_EMPTY && (v & HIST_CMASK)) atomicAdd(&hist[v >> HIST_CBITS], v & HIST_CMASK); }
 }
 void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
                      int level, u32 cap, u32* hist, hipStream_t st) {

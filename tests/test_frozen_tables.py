@@ -316,6 +316,33 @@ def test_frozen_headers_outside_the_fast_kernels_envelope(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq2) + 4096) == fq2
 
 
+def _field_history_fastq(n, seed):
+    """Headers built for the token step of the header chains (chains.hip k_rec_tokens: a record per lane, 64 at a time): what a
+    changed field codes depends on whether the field has changed since the chain began or the shape last changed, on the number
+    in the previous header, and on nothing else -- unless a field turns hexadecimal, which leaves the chain to the lane kernels."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        a = 1000 + i // 70                                               # still for 70 records: its first change meets a cold field type, across a round of 64 lanes
+        b = ("x%dy" % i) if (i // 45) % 3 == 1 else str(50000 - 3 * i if i < 900 else i)     # a number, a string for a while, a number again; falling, then rising
+        c = ("%x" % (0xabc000 + i)) if 1300 <= i < 1330 else str(i * 7)  # hexadecimal in one stretch only
+        d = "007" if i % 97 == 0 else str(i % 13)                        # leading zeros now and then
+        tail = (" " + "Z" * 80 + str(i)) if 1700 <= i < 1900 and i % 2 else ""       # the shape alternates over long headers: more symbols than the token buffer has room for
+        hdr = "@H%d:%s:%s:%s:%d%s" % (a, b, c, d, int(rng.integers(0, 100000)), tail)
+        ln = 40
+        seq = "".join("ACGT"[int(v)] for v in rng.integers(0, 4, ln))
+        q = "".join(chr(33 + int(v)) for v in rng.integers(2, 41, ln))
+        out.append("%s\n%s\n+\n%s\n" % (hdr, seq, q))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("br,cr", ((512, 64), (2400, 300), (200, 10)))
+def test_frozen_header_tokens_follow_the_field_history(ctx, br, cr):
+    fq = _field_history_fastq(2400, 11)
+    enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="field history, blocks of %d" % br)
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_frozen_fuzz_structurally_hostile_inputs(ctx, seed):
     """The hostile little FASTQs of test_gpu_parity (ragged lengths, header shapes that change, hex / leading-zero / shrinking
