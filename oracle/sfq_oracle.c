@@ -1711,15 +1711,21 @@ static void gen_walk_s(const u8* base, const u64* goff, const u32* glen, size_t 
         }
     }
 }
-typedef struct { u32* cnt; const u32* rows; u64 cost, nbases; } gcount;
+typedef struct { u32* cnt; const u32* rows; u64 cost, nbases; int price_only; } gcount;
 static void gcount_cb(void* arg, u32 ctx, int code) {
     gcount* g = arg;
-    g->cnt[(size_t)ctx * 4 + code]++;
+    if (!g->price_only) g->cnt[(size_t)ctx * 4 + code]++;
     if (g->rows) {
         const u32 v = g->rows[ctx];
         const u32 tot = (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24);
-        g->cost += log2fp(tot) - log2fp((v >> (8 * code)) & 0xff);
-        g->nbases++;
+        if (!g->price_only) {
+            g->cost += log2fp(tot) - log2fp((v >> (8 * code)) & 0xff);
+            g->nbases++;
+        } else if (v != 0x03030303u) {                       /* the pre-verdict's statistic (signed, in cost) and its sum of m (in nbases) */
+            const u32 m = (tot - 12u) >> 2;
+            g->cost += (u64)(long long)((int)((v >> (8 * code)) & 0xff) - 3 - (int)m);
+            g->nbases += m;
+        }
     }
 }
 typedef struct { chenc* c; const u32* rows; } gfz;
@@ -1742,9 +1748,25 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
     u32** rows = xcalloc(ngen + 1, sizeof(u32*));
     int on = 0;
 #define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
-    if (ngen >= 3) {
-        gcount gc = { cnt, NULL, 0, 0 };
+    int maybe = ngen >= 3;
 #define GSTRIDE(g) gen_count_stride((bound[(g) + 1] - bound[g]) * block_reads)
+    if (ngen >= 3 && (bound[1] - bound[0]) * block_reads / GSTRIDE(0) >= 16384) {
+        /* the pre-verdict (api.cpp gen_tables_begin): every 8th of generation 0's counted records counted; over every 8th of
+           generation 1's, and the bases whose context that sample has seen m times: s4 += 4 x (times it saw this base) - m.
+           Five deviations (sqrt(3 sum m)) above 0, or the full passes are skipped: no tables */
+        gcount pc = { cnt, NULL, 0, 0, 0 };
+        gen_walk_s(base, goff, glen, REC_OF(bound[0]), REC_OF(bound[1]), GSTRIDE(0) * 8, mask, gcount_cb, &pc);
+        u32* r1 = xmalloc(nctx * 4);
+        for (size_t c = 0; c < nctx; c++) r1[c] = gen_row(cnt + c * 4, step);
+        gcount pq = { cnt, r1, 0, 0, 1 };
+        gen_walk_s(base, goff, glen, REC_OF(bound[1]), REC_OF(bound[2]), GSTRIDE(1) * 8, mask, gcount_cb, &pq);
+        free(r1);
+        const long long s4 = (long long)pq.cost;
+        maybe = s4 > 0 && (u64)s4 * (u64)s4 > 75ull * pq.nbases;
+        memset(cnt, 0, nctx * 4 * sizeof(u32));              /* (the device counts the rest of generation 0 on top of the sample: the same counts) */
+    }
+    if (maybe) {
+        gcount gc = { cnt, NULL, 0, 0, 0 };
         gen_walk_s(base, goff, glen, REC_OF(bound[0]), REC_OF(bound[1]), GSTRIDE(0), mask, gcount_cb, &gc);
         u32* r1 = xmalloc(nctx * 4);
         for (size_t c = 0; c < nctx; c++) r1[c] = gen_row(cnt + c * 4, step);
@@ -1755,7 +1777,7 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
         if (on) for (size_t g = 2; g < ngen; g++) {
             rows[g] = xmalloc(nctx * 4);
             for (size_t c = 0; c < nctx; c++) rows[g][c] = gen_row(cnt + c * 4, step);
-            if (g + 1 < ngen) { gcount g2 = { cnt, NULL, 0, 0 }; gen_walk_s(base, goff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), GSTRIDE(g), mask, gcount_cb, &g2); }
+            if (g + 1 < ngen) { gcount g2 = { cnt, NULL, 0, 0, 0 }; gen_walk_s(base, goff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), GSTRIDE(g), mask, gcount_cb, &g2); }
         }
     }
     obuf o = { 0, 0, 0 };

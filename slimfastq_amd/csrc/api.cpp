@@ -421,7 +421,7 @@ int rec_prior_finish(sfq_ctx* ctx, bool given, hipStream_t st) {
 // Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
 // of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
 // Leaves ca.g_* describing which rows every generation codes with.
-struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; };
+struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; bool pre = false; };
 int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits, u32 max_line, hipStream_t st, GenPlan& gp) {
     u32* bound = gp.bound;
     const u32 ngen = gp.ngen = gen_bounds(nblocks, bound);
@@ -443,10 +443,18 @@ int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits,
     const u64 br = ca.block_reads;
     auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };          // an upper bound (the last block may be short): lanes past the end idle
     u32* rows = (u32*)ctx->grows.p;
-    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
-    launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
-    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
-    // the cost of generation 1 under generation 0's rows, and its bases (the initial row would cost 2 bits = 2048 units each)
+    // The pre-verdict (generations of 16384 counted records or more): every GEN_PRE-th record of generation 0 counted, then over every
+    // GEN_PRE-th of generation 1 the sum, over the bases whose context that sample has seen m times, of 4 x (times it saw this base) - m.
+    // For bases that do not depend on their context that sum is 0 +- sqrt(3 sum m); five deviations above 0, or a generation too
+    // small to tell, and the full passes follow (finish); else the call has no tables and the base chains start an eighth of two
+    // small passes into it.  (The COST under the sample's rows cannot tell: a context seen once prices the next base at 1.19 or
+    // 2.42 bits, and at low coverage the chance repeats' penalty hides the true repeats' gain.)
+    gp.pre = recs(bound[0], bound[1]) / gen_count_stride(recs(bound[0], bound[1])) >= 16384;
+    if (gp.pre) {
+        launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st, 1, 1);
+        launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
+        launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st, 1, 0);
+    }
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
     return SFQ_OK;
 }
@@ -461,6 +469,18 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
     u32* rows = (u32*)ctx->grows.p;
     HIPC(hipStreamSynchronize(st));
     const u64* h = (const u64*)((const u8*)ctx->pin + PIN_GEN_OFF);
+    if (gp.pre) {
+        const long long s4 = (long long)h[0]; const u64 m = h[1];
+        if (!(s4 > 0 && (u64)s4 * (u64)s4 > 75ull * m)) return SFQ_OK;        // nothing to learn: every chain codes with the initial row
+    }
+    // the verdict proper: (the rest of) generation 0 counted (on top of the sample's counts), then generation 1 counted and priced
+    // under generation 0's rows (the initial row would cost 2 bits = 2048 units a base)
+    HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
+    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st, gp.pre ? 2 : 0, 1);
+    launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
+    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     const u64 cost = h[0], nbases = h[1];
     if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // no gain: every chain codes with the initial row
     *gen_on = 1;

@@ -655,14 +655,17 @@ __device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec
 // cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
 // Long lines (seg_len != 0): a lane takes one stretch of seg_len bases of a record, lane id = record x segs + stretch --
 // a lane per 30 kb read made this pass 95 ms of the long-read workload's 108.
+// sub: 0 = every stride-th record; 2 = all of them but every GEN_PRE-th (what the pre-verdict's sample -- a launch with GEN_PRE times
+// the stride, api.cpp gen_tables_begin -- has counted already).  do_count = 0 (with rows): nothing is counted, and cost[] receives the
+// pre-verdict's statistic instead of the cost.
 __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32 stride, u32 seg_len, u32 segs, u32* __restrict__ cnt, const u32* __restrict__ rows,
-                                                  const u16* __restrict__ log2fp, u64* cost) {
+                                                  const u16* __restrict__ log2fp, u64* cost, u32 sub, u32 do_count) {
     const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
     u32 mybases = 0;
     const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
     const u64 r = first + (id / segs) * stride;                    // every stride-th record of the generation (gen_count_stride)
     const u32 seg = (u32)(id % segs);
-    const bool live = r < endr;
+    const bool live = r < endr && (sub == 0 || (id / segs) % GEN_PRE != 0);            // sub == 2: the records the pre-verdict's sample left
     u32 solid = 0, mask = 0;
     if (live) {
         // the block of record r: blocks are uniform (block_reads records) except the last
@@ -674,12 +677,20 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
     walk_bases(a, r, live ? 1u : 0u, solid, mask,
         [&](u32 j, u32 ctx) { cx[j] = ctx; rv[j] = rows ? rows[ctx] : 0u; },
         [&](u32 j, u32 code) {
-            atomicAdd(&cnt[((size_t)cx[j] << 2) | code], 1u);
+            if (do_count) atomicAdd(&cnt[((size_t)cx[j] << 2) | code], 1u);
             if (rows) {
-                mybases++;
                 const u32 v = rv[j];
                 const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-                mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
+                if (do_count) {
+                    mybases++;
+                    mycost += (u32)log2fp[(f0 + f1) + (f2 + f3)] - (u32)log2fp[(v >> (8 * code)) & 0xff];
+                } else if (v != 0x03030303u) {
+                    // the pre-verdict's statistic: over the bases whose context the sample has seen (m times), 4 x (times it saw THIS
+                    // base) - m.  Bases that do not depend on their context give 0 on average, with variance 3 m.
+                    const u32 m = ((f0 + f1) + (f2 + f3) - 12u) >> 2;
+                    mybases += m;
+                    mycost += (u64)(long long)((int)((v >> (8 * code)) & 0xff) - 3 - (int)m);
+                }
             }
         }, seg, seg_len);
     if (rows) {
@@ -688,14 +699,15 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mybases += (u32)__shfl_xor((int)mybases, d, 64);
         if ((threadIdx.x & 63) == 0 && mybases) {
-            atomicAdd((unsigned long long*)cost, (unsigned long long)mycost);
+            atomicAdd((unsigned long long*)cost, (unsigned long long)mycost);              // (two's complement: the pre-verdict's sum is signed)
             atomicAdd((unsigned long long*)cost + 1, (unsigned long long)mybases);
         }
     }
 }
-void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st) {
+void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st, u32 sub, u32 do_count) {
     if (!nrec_range) return;
-    const u32 stride = gen_count_stride(nrec_range);
+    u32 stride = gen_count_stride(nrec_range);
+    if (sub == 1) { stride *= GEN_PRE; sub = 0; }             // (the sample alone: a launch of its lanes only)
     // lines up to 1 KiB: a lane per record; longer: a lane per stretch of 512 bases (the lanes past a record's end idle).
     // A SMALL generation (the first ones: 1/64 of the call each, whose passes every base chain waits for) is latency, not
     // throughput: its time is one lane's walk through its record, so the records are cut into the shortest stretches (of 32
@@ -708,7 +720,7 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
     }
     const u32 segs = seg_len ? (max_line + seg_len - 1) / seg_len : 1u;
     const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
-    hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost);
+    hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost, sub, do_count);
 }
 // rows from counts
 __global__ __launch_bounds__(256) void k_gen_rows(const u32* __restrict__ cnt, u32* __restrict__ rows, u64 nctx, u32 step) {

@@ -88,7 +88,8 @@ void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 wan
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,
-                      u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st);
+                      u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st,
+                      u32 sub = 0 /* 0 every selected record, 1 every GEN_PRE-th of them, 2 the others */, u32 do_count = 1 /* 0: the cost only */);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
@@ -110,6 +111,7 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 // scattered atomic per base into a table of 2^gen_bits x 16 bytes -- was most of the time of inputs whose bases can be
 // learned (half of a 10 M-read call: 50 ms).  The decoder counts the same records.
 #define GEN_COUNT_CAP 524288ull
+#define GEN_PRE 8u                      /* the pre-verdict looks at every 8th of the records a counting pass takes (api.cpp gen_tables_begin) */
 static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP ? (n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP : 1); }
 
 // framing

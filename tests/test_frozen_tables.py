@@ -120,6 +120,24 @@ def test_frozen_big_generations_are_counted_through_every_nth_record(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_frozen_pre_verdict_leaves_the_tables_off_for_bases_that_cannot_be_learned(ctx):
+    """A generation 0 of 16384 counted records or more is first looked at through every 8th record (api.cpp gen_tables_begin: over
+    the bases whose context the sample has seen, does the sample's count of THIS base beat a quarter?): uniform bases end there,
+    tables off, the chains the oracle's; the genome-sampled reads of the test above pass it and go on to the full verdict."""
+    n = 1_200_000
+    fq = capi.synth_fastq(n, 50, seed=17, kind=0)
+    br, cr = 1024, 64
+    assert (-(-n // br) // 64) * br >= 16384
+    enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    ci = util.unpack_chains(enc.chains)
+    starts, lens = util.line_table(fq)
+    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    assert on == 0 and not (ci["flags"] & 1)
+    assert list(ci["gen"]) == list(sizes)
+    assert enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 def test_frozen_counting_passes_take_long_lines_a_stretch_per_lane(ctx):
     """Lines over 1 KiB: the base tables' counting passes give a lane a stretch of 512 bases (sixteen bases of warm-up in
     front of it) instead of a whole record; the counts -- and so every chain's bytes -- must not depend on the split."""
