@@ -820,6 +820,30 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     const u32 order[4] = { SFQ_M_QLT, frozen ? SFQ_M_REC : SFQ_M_GEN, SFQ_M_USR, frozen ? SFQ_M_GEN : SFQ_M_REC };
     const int tslot[4] = { SFQ_T_QLT, frozen ? SFQ_T_REC : SFQ_T_GEN, SFQ_T_USR, frozen ? SFQ_T_GEN : SFQ_T_REC };
     hipStream_t mst[4] = { st, ctx->st_aux[0], ctx->st_aux[1], ctx->st_aux[2] };
+    // auto: sample about 24 M quality symbols (~160 k records of 150 bp: one per lane of the histogram kernel, all of them on
+    // the chip at once; 60 M symbols code 0.06 % smaller; for long reads far fewer records --
+    // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
+    // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
+    //  the longest walk)
+    if (prior_step == SFQ_PRIOR_AUTO || (ctx->counts_only && prior_step == 0)) {
+        const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
+        prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 24000000ull), 0x7FFFFFFFull);
+        // (short records: not more of them than the histogram kernel's workgroups hold on the chip at once -- 512 of 256 lanes, a
+        //  record per lane: a second round of workgroups waits for the first while the other models' kernels take the chip)
+        if (nbytes / nrec <= 4000) prior_step = (u32)std::max<u64>(prior_step, (nrec + 131071) / 131072);
+    }
+    if (ctx->counts_only && prior_step && prior_step < SFQ_PRIOR_COUNTS)        // sfq_count_priors: a share of the job's sample
+        prior_step = (u32)std::min<u64>((u64)prior_step * std::max<u32>(1u, ctx->sample_scale), 0x7FFFFFFFull);
+    // The histogram of the quality sample goes FIRST and alone: its workgroups take 64 KiB of LDS each, and beside the other models'
+    // early passes -- thousands of small workgroups that keep every CU's LDS in use -- they wait for room: 0.5 ms alone, 6.7 ms
+    // beside them, and the quality chains wait for it.  Everything else forks behind it (ev[13] below).
+    bool hist_launched = false;
+    if (frozen && !given && !counted && prior_step && (models & SFQ_M_QLT)) {
+        if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
+        if (!hist_cleared) { HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st)); hist_cleared = true; }
+        launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
+        hist_launched = true;
+    }
     // frozen tables: chain geometry; then everything that reads only the text starts now, beside the quality prior
     ChainArgs ca;
     memset(&ca, 0, sizeof ca);
@@ -865,11 +889,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc; }
             if (models & SFQ_M_GEN) {
                 if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
-                launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
             }
-            if (models & SFQ_M_USR)
-                for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
-            HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
+            // (the pass over the exceptions and the framing exceptions are queued behind the chains' launches below: beside the two
+            //  counting passes the host waits for they made those take 1.7-1.9 ms instead of 0.3)
         } else if (models & SFQ_M_REC) {                    // sfq_build_priors: the header sample beside the quality sample
             HIPC(hipStreamWaitEvent(mst[1], ctx->ev[13], 0));
             if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc;
@@ -877,20 +899,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     }
     u32* h_rows66 = nullptr;
     bool rows66_copy_pending = false;
-    // auto: sample about 24 M quality symbols (~160 k records of 150 bp: one per lane of the histogram kernel, all of them on
-    // the chip at once; 60 M symbols coded 0.01 % smaller; for long reads far fewer records --
-    // the histogram walks a record on one lane, so its time is set by the longest record, not the sample size)
-    // (of a long record only the first PRIOR_SYMBOLS count: one lane walks a record, so the sample's time is set by
-    //  the longest walk)
-    if (prior_step == SFQ_PRIOR_AUTO || (ctx->counts_only && prior_step == 0)) {
-        const u64 per_rec = std::min<u64>(std::max<u64>(1, nbytes / nrec / 2), PRIOR_SYMBOLS);
-        prior_step = (u32)std::min<u64>(std::max<u64>(1, nrec * per_rec / 24000000ull), 0x7FFFFFFFull);
-        // (short records: not more of them than the histogram kernel's workgroups hold on the chip at once -- 512 of 256 lanes, a
-        //  record per lane: a second round of workgroups waits for the first while the other models' kernels take the chip)
-        if (nbytes / nrec <= 4000) prior_step = (u32)std::max<u64>(prior_step, (nrec + 131071) / 131072);
-    }
-    if (ctx->counts_only && prior_step && prior_step < SFQ_PRIOR_COUNTS)        // sfq_count_priors: a share of the job's sample
-        prior_step = (u32)std::min<u64>((u64)prior_step * std::max<u32>(1u, ctx->sample_scale), 0x7FFFFFFFull);
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
@@ -899,7 +907,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         ctx->prior_on = true;
     } else if (prior_step && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
-        if (!counted) {
+        if (!counted && !hist_launched) {
             if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));
             launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
         }
@@ -963,14 +971,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     u32 gen_on = 0;
     bool side_late = false;                            // the exception pass is still running when the packing starts
     if (frozen) {
-        // the quality chains go behind the prior on the context's stream; then the two host decisions, the shorter counting pass (headers) first
+        // The two host decisions first (the shorter counting pass, the headers', before the base tables' verdict), each followed by
+        // its chains; the quality chains LAST: their row gathers keep every CU's vector memory path full, and whatever small pass
+        // runs beside them crawls -- with the quality chains ahead of them the base tables' 0.1 ms row kernel took 3.5 ms and the
+        // base chains started 8 ms into the call.
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
         HIPC(hipEventRecord(ctx->ev[2], st));
-        if (models & SFQ_M_QLT) {
-            ca.m = a; ca.csz = (u32*)ctx->csz.p;
-            HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
-        }
-        HIPC(hipEventRecord(ctx->ev[3], st));
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
             ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rdec = (const u16*)ctx->rdec.p;
@@ -996,6 +1002,15 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3]); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
+        if (models & SFQ_M_QLT) {
+            ca.m = a; ca.csz = (u32*)ctx->csz.p;
+            HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
+        }
+        HIPC(hipEventRecord(ctx->ev[3], st));
+        if (models & SFQ_M_GEN) launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
+        if (models & SFQ_M_USR)
+            for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
+        HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
         side_late = false;
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 1], 0));        // header chains
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 3], 0));        // base chains

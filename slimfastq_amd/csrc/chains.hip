@@ -299,6 +299,9 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
+#ifdef PRIO_QLT
+    __builtin_amdgcn_s_setprio(PRIO_QLT);
+#endif
     __shared__ u32 ring[LaneEncB<THREADS, QLT_RING>::LDS_DWORDS];
     extern __shared__ u32 lds[];                              // the hot image: map, then rows
     const uint2* const lmap = reinterpret_cast<const uint2*>(lds);
@@ -748,6 +751,9 @@ __device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
 #define GEN_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four bases add at most 4 x 2
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
+#ifdef PRIO_GEN
+    __builtin_amdgcn_s_setprio(PRIO_GEN);
+#endif
     __shared__ u32 rcp[1024];                                 // reciprocals of the row totals (<= 1020)
     __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
     __shared__ u32 ring[LaneEncB<THREADS, GEN_RING>::LDS_DWORDS];
@@ -1341,6 +1347,9 @@ __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, 
 }
 template <u32 ML>
 __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict__ tok, u32* __restrict__ ntok, u32* __restrict__ flags) {
+#ifdef PRIO_REC
+    __builtin_amdgcn_s_setprio(PRIO_REC);
+#endif
     __shared__ RecTokLds<ML> L;
     const u32 lane = threadIdx.x, col = lane + 1;
     const u32 c = blockIdx.x;
@@ -1430,6 +1439,9 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
 #define RC_LDS_ROWS 16u
 struct RecCodeLds { u32 rows[RC_LDS_ROWS * 256]; u8 map[PR_REC_ROWS]; };
 __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __restrict__ tok, const u32* __restrict__ ntok, const u32* __restrict__ flags, u32 n_hot) {
+#ifdef PRIO_REC
+    __builtin_amdgcn_s_setprio(PRIO_REC);
+#endif
     __shared__ RecCodeLds L;
     for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 256) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < n_hot ? sl : 0xFFu); }
     for (u32 i = threadIdx.x; i < n_hot * 256; i += 256) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
