@@ -255,7 +255,7 @@ def main():
     # HIP events recorded around the kernel's launch on the stream it is launched on (a kernel trace shows the same
     # duration for it: profiles/); a model's PHASE (phase_ms) also holds its counting passes and row building.
     cslot = {capi.T_QLT: 0, capi.T_GEN: 1, capi.T_REC: 2}
-    kname = ({capi.T_QLT: "k_qlt_encode_c", capi.T_GEN: "k_gen_encode_c", capi.T_REC: "k_rec_encode_f"} if args.tables and args.block_reads else
+    kname = ({capi.T_QLT: "k_qlt_encode_c", capi.T_GEN: "k_gen_encode_c", capi.T_REC: "k_rec_tokens"} if args.tables and args.block_reads else
              {capi.T_QLT: "k_qlt_encode_k2", capi.T_GEN: "k_gen_encode_k", capi.T_REC: "k_rec_encode_w_fast"})
     dom = max(names, key=lambda k: coder[cslot[k]])
     dom_ms = float(coder[cslot[dom]])

@@ -11,7 +11,7 @@ summary = open(os.path.join(go, "pmc_summary.txt")).read()
 head = ("# %s: rocprofv3 --pmc, one counter group per pass, --kernel-trace only (profiles/r03_refresh.sh): the default bench call,\n"
         "# 10 M x 150 bp, -l 3, frozen tables; calls = warm-up + timed step.  FETCH_SIZE / WRITE_SIZE in KB as reported.\n" % tag)
 open(os.path.join(pr, "%s_pmc_summary.txt" % tag), "w").write(head + summary)
-kern = {"qlt_encode": "k_qlt_encode_c", "gen_encode": "k_gen_encode_c", "rec_encode": "k_rec_encode_f"}
+kern = {"qlt_encode": "k_qlt_encode_c", "gen_encode": "k_gen_encode_c", "rec_encode": "k_rec_tokens"}
 out = {"source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per launch)" % tag,
        "config": {"reads": 10000000, "read_len": 150, "level": 3, "kind": 0, "block_reads": 1024, "kernel": 0, "tables": 1},
        "note": "bytes = counter (KB) x 1024, as reported; kernels matched by name prefix.  The guide's gfx950 correction (FETCH_SIZE reads half of a wide "
