@@ -53,8 +53,13 @@ __device__ __forceinline__ void hist_add(lds_u32* slots, glb_u32* hist, u32 key)
             v = expect;                                   // another lane's key got there first: maybe ours
         }
         if ((v >> HIST_CBITS) == key) {                   // (a slot keeps its key)
+            // The count must never carry into the key.  Every time its low eight bits wrap, exactly one lane sees them at 255 and
+            // takes 256 off -- however late that lands behind the other lanes' adds (a few keys take most symbols of binned
+            // qualities: all 256 lanes queue on one slot), it lands once per wrap, so the count stays below 256 x (1 + subs in flight).
+            // And a lane that READS a count of 768 or more counts in memory instead: 255 other lanes can add before it, no more.
+            if ((v & HIST_CMASK) >= 768u) { __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
             const u32 old = __hip_atomic_fetch_add(&slots[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & HIST_CMASK) == HIST_HARVEST - 1u) {           // exactly one lane sees the count get to HARVEST: it moves that much on
+            if ((old & (HIST_HARVEST - 1u)) == HIST_HARVEST - 1u) {
                 __hip_atomic_fetch_sub(&slots[slot], HIST_HARVEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&hist[key], HIST_HARVEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

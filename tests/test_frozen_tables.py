@@ -71,6 +71,18 @@ def test_frozen_streams_equal_oracle_rule_synthetic(ctx, level):
     assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
 
 
+@pytest.mark.parametrize("level", (1, 3))
+def test_frozen_histogram_of_a_few_hot_contexts(ctx, level):
+    """4-level binned qualities put nearly all symbols of the sample on a handful of (context, symbol) pairs: every lane of a
+    histogram workgroup queues on the same few LDS slots, whose 10-bit counts are moved on 256 at a time (prior.hip hist_add).
+    The prior must be the oracle's count for count -- and the same on every run."""
+    fq = capi.synth_fastq(40000, 150, seed=9, kind=2)
+    enc = check_against_oracle(ctx, fq, level, br=1024, cr=64, step=1, what="binned qualities")
+    for _ in range(3):
+        again = ctx.encode_host(fq, level=level, block_reads=1024, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=64)
+        assert again.prior == enc.prior and again.stream("qlt") == enc.stream("qlt")
+
+
 def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
     """Reads sampled from a small genome: generation 1 is cheaper under generation 0's rows, the tables switch on, and the
     base stream gets well below 2 bits per base; iid bases leave them off."""
