@@ -1067,7 +1067,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
 
     // ---- pack ----------------------------------------------------------------------------------
     if ((rc = reserve(ctx, ctx->blk_stream_off, (size_t)nblocks * SFQ_NSTREAMS * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->stream_total, 2 * SFQ_NSTREAMS * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->stream_total, 2 * SFQ_NSTREAMS * 8 + 64))) return rc;                  // totals, bases, the packing's gate
     u32 chain_streams = 0;                             // streams packed chain by chain
     if (frozen) {
         ca.m = a;
@@ -1122,6 +1122,29 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         launch_block_stream_offsets((BlockDesc*)ctx->blocks.p, nblocks, (u64*)ctx->blk_stream_off.p, (u64*)ctx->stream_total.p, 3, SFQ_NSTREAMS, st);
         HIPC(hipMemcpyAsync(totals + 3, (u64*)ctx->stream_total.p + 3, (SFQ_NSTREAMS - 3) * 8, hipMemcpyDeviceToHost, st));
     }
+    // The packing follows the sizes on the device: k_stream_gate places the streams and holds the packing back where a block has
+    // failed or the caller's buffer is too small (the host reports that below, from the same numbers) -- no host round trip between
+    // the chains and the packing.  Everything the host wants comes back behind it in one go; the first headers too, as far as a
+    // guess at their size reaches.
+    u32* d_gate = (u32*)((u64*)ctx->stream_total.p + 2 * SFQ_NSTREAMS);
+    const u64 blob_guess = std::min<u64>(blob_cap, (u64)nblocks * 256);
+    if (!two_halves) {
+        launch_stream_gate((const BlockDesc*)ctx->blocks.p, nblocks, (const u64*)ctx->stream_total.p, out_cap, (u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_gate, st);
+        launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
+                       (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st, d_gate);
+        if (frozen) {
+            if (chain_streams & (1u << SFQ_S_QLT))
+                launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
+            if (chain_streams & (1u << SFQ_S_GEN))
+                launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
+            if (chain_streams & (1u << SFQ_S_REC))
+                launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
+            HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPC(hipEventRecord(ctx->ev[11], st));
+        ctx->first_hdrs.resize((size_t)blob_guess);
+        if (blob_guess) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)blob_guess, hipMemcpyDeviceToHost, st));
+    }
     HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(hboff, ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
@@ -1135,36 +1158,40 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
                            -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" :
                            -worst == SFQ_E_UNSUPPORTED ? "a '+' line that is neither empty nor its record's header: the block format refuses what it could not give back (usrs.cpp:236-239)" : "see status codes");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
-    HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
-    launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
-                   (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st);
-    if (frozen && !two_halves) {
-        if (chain_streams & (1u << SFQ_S_QLT))
-            launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        if (chain_streams & (1u << SFQ_S_GEN))
-            launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        if (chain_streams & (1u << SFQ_S_REC))
-            launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
-    }
-    HIPC(hipEventRecord(ctx->ev[11], st));
-    ctx->first_hdrs.resize((size_t)hboff[nblocks]);
     if (hboff[nblocks] > blob_cap) return fail(ctx, SFQ_E_OVERFLOW, "first-header blob overflow");
-    if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
+    if (two_halves) {
+        HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, sizeof bases, hipMemcpyHostToDevice, st));
+        launch_compact((const BlockDesc*)ctx->blocks.p, nblocks, (const u8*)ctx->arena.p, (const u64*)ctx->blk_stream_off.p,
+                       (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, chain_streams, st);
+        HIPC(hipEventRecord(ctx->ev[11], st));
+        ctx->first_hdrs.resize((size_t)hboff[nblocks]);
+        if (hboff[nblocks]) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)hboff[nblocks], hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    } else {
+        if (hboff[nblocks] > blob_guess) {                               // (long first headers: the rest of them)
+            ctx->first_hdrs.resize((size_t)hboff[nblocks]);
+            HIPC(hipMemcpyAsync(ctx->first_hdrs.data() + blob_guess, (const u8*)ctx->blob.p + blob_guess, (size_t)(hboff[nblocks] - blob_guess), hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+        } else ctx->first_hdrs.resize((size_t)hboff[nblocks]);
+    }
 
     ctx->prior_on = false;
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
+        // (half a million varints, written through a pointer into room for the longest: pushed byte by byte into the vector they
+        //  were 1.0 ms of every call, after the GPU had finished)
         std::vector<u8>& o = ctx->chain_blob;
-        o.reserve(((size_t)nchains * 2 + (size_t)nsub * 2) * 2 + 64);
+        o.resize(((size_t)nchains * 2 + (size_t)nsub * 2) * 5 + 64);
+        u8* w = o.data();
+        auto put = [&w](u32 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put_v(o, ca.geo.chain_reads); put_v(o, gen_on | (rec_chains ? 2u : 0u)); put_v(o, nchains);
-        for (u32 c = 0; c < 2 * nchains; c++) put_v(o, h_csz[c]);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u)); put(nchains);
+        for (u32 c = 0; c < 2 * nchains; c++) put(h_csz[c]);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
-            put_v(o, ca.rgeo.chain_reads); put_v(o, nsub);
-            for (u32 c = 0; c < 2 * nsub; c++) put_v(o, h_csz[(size_t)2 * nchains + c]);
+            put(ca.rgeo.chain_reads); put(nsub);
+            for (u32 c = 0; c < 2 * nsub; c++) put(h_csz[(size_t)2 * nchains + c]);
         }
+        o.resize((size_t)(w - o.data()));
     }
     res->n_chains = nchains;
     ctx->index.resize(nblocks);

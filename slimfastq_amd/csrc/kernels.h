@@ -104,7 +104,7 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroe
 u64 rec_token_bytes(u64 nrec);
 void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb /* or null */, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
-                           const u64* stream_base, u8* out, hipStream_t st);
+                           const u64* stream_base, u8* out, hipStream_t st, const u32* gate = nullptr /* frame.hip k_stream_gate */);
 #define GEN_STEP 4u             // a counted base adds GEN_STEP to its row entry (chains.hip)
 // A generation of n records (its blocks x block_reads: the last block of a call may be short) is counted through every
 // s-th record, s = ceil(n / GEN_COUNT_CAP): half a million records tell a row's shape, and the counting -- a
@@ -170,7 +170,8 @@ void launch_rec_decode_w(const DecodeArgs& a, hipStream_t st);
 // packing
 void launch_block_stream_offsets(BlockDesc* blocks, u32 nblocks, u64* blk_stream_off, u64* stream_total, u32 s0, u32 s1 /* streams [s0, s1) */, hipStream_t st);
 void launch_compact(const BlockDesc* blocks, u32 nblocks, const u8* arena, const u64* blk_stream_off,
-                    const u64* stream_base, u8* out, u32 skip_streams /* bit s: stream s is packed by launch_compact_chains */, hipStream_t st);
+                    const u64* stream_base, u8* out, u32 skip_streams /* bit s: stream s is packed by launch_compact_chains */, hipStream_t st, const u32* gate = nullptr);
+void launch_stream_gate(const BlockDesc* blocks, u32 nblocks, const u64* stream_total, u64 out_cap, u64* stream_base /* [SFQ_NSTREAMS] */, u32* gate /* [2]: go, worst status */, hipStream_t st);
 void launch_record_sizes(const DecodeArgs& a, u64 nrec, u32* rsize, hipStream_t st);
 void launch_assemble(const DecodeArgs& a, u64 nrec, const u64* roff, u8* out, hipStream_t st);
 void launch_first_hdr_lens(const BlockDesc* blocks, u32 nblocks, u32* lens, hipStream_t st);
