@@ -193,7 +193,9 @@ int sfq_build_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, cons
  * sample_scale-th record of what one call alone would sample -- sample_scale = the number of ranks keeps the job's sample the size
  * of one call's), the ranks add their counts up (an all-reduce of two u32 arrays: sfq_get_prior_counts -> the caller's device
  * buffers -> sfq_set_prior_counts), and every rank codes with prior_step = SFQ_PRIOR_COUNTS: identical priors everywhere, nobody
- * waits for a rank that builds them.  Array sizes in u32 words: sfq_prior_counts_words. */
+ * waits for a rank that builds them.  Array sizes in u32 words: sfq_prior_counts_words.
+ * An sfq_encode_blocks with SFQ_PRIOR_COUNTS that follows sfq_count_priors on the same context, buffer and size keeps that
+ * call's line index (the text is framed once per step, not twice): the text must not change between the two calls. */
 int  sfq_count_priors(sfq_ctx* ctx, const uint8_t* d_fastq, uint64_t nbytes, const sfq_params* params, uint32_t sample_scale);
 void sfq_prior_counts_words(int level, uint64_t* qlt_words, uint64_t* rec_words);
 int  sfq_get_prior_counts(sfq_ctx* ctx, int level, uint32_t* d_qlt, uint32_t* d_rec);

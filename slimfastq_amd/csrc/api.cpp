@@ -57,6 +57,9 @@ struct sfq_ctx {
                                            // a decode never reads those (only what sfq_set_* installed)
     bool unsettled = false;                // a call returned with an error: its side streams may still be running
     bool counts_only = false; u32 sample_scale = 1;      // sfq_count_priors: stop once the sample is counted; every sample_scale-th sampled record
+    // the line index sfq_count_priors left, for the encode of the SAME text that follows it (SFQ_PRIOR_COUNTS): a rank of a
+    // multi-GPU job frames its shard once per step, not twice (3 ms of a 21 ms step)
+    struct { const u8* ptr = nullptr; u64 nbytes = 0, nrec = 0; bool marks = false, valid = false; } framed;
     void* pin = nullptr; size_t pin_cap = 0;
     void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
@@ -651,7 +654,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     }
     const bool legacy = p.block_reads == 0;
     // frozen tables: the framing marks the records the pass over the N / quality-0 / case exceptions has to look at
-    const bool want_marks = p.tables == SFQ_TABLES_FROZEN && p.block_reads != 0 && p.kernel == 0 && (models & SFQ_M_GEN) && !priors_only;
+    const bool want_marks = p.tables == SFQ_TABLES_FROZEN && p.block_reads != 0 && p.kernel == 0 && (models & SFQ_M_GEN) && (!priors_only || ctx->counts_only);
     u64 nrec = 0;
     // the line index of the current text (d_fastq, nbytes) and the per-record checks
     auto frame = [&]() -> int {
@@ -683,7 +686,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, st);
         return SFQ_OK;
     };
-    if ((rc = frame())) return rc;
+    // (an encode from summed counts right behind sfq_count_priors on the same buffer: that call's line index, marks and checks stand)
+    const bool reframe = !(p.prior_step == SFQ_PRIOR_COUNTS && !legacy && ctx->framed.valid && ctx->framed.ptr == d_fastq && ctx->framed.nbytes == nbytes &&
+                           (!want_marks || ctx->framed.marks));
+    ctx->framed.valid = false;
+    if (!reframe) nrec = ctx->framed.nrec;
+    else if ((rc = frame())) return rc;
     // ---- format 6: the reference's oversize records (usrs.cpp:269-301; frame.hip) ---------------------------------------
     u64 nrec_file = nrec;                       // records of the file, the oversize ones included ("num_records", usrs.cpp:405)
     u32 n_over = 0;
@@ -915,6 +923,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipStreamSynchronize(mst[1]));
             HIPC(hipStreamSynchronize(st));
             res->n_records = nrec; res->n_blocks = nblocks;
+            if (!legacy && !n_over) { ctx->framed.ptr = d_fastq; ctx->framed.nbytes = nbytes; ctx->framed.nrec = nrec; ctx->framed.marks = want_marks; ctx->framed.valid = true; }
             return SFQ_OK;
         }
 
@@ -1363,6 +1372,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                        uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* res) {
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
+    ctx->framed.valid = false;                     // (a decode's scratch is not an encode's line index)
     const u32 version = p.version ? p.version : 6;
     if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
     if (version > 6) return fail(ctx, SFQ_E_UNSUPPORTED, "archive version %u is newer than 6 (config.cpp:373-377)", version);
