@@ -1,13 +1,18 @@
-// chains.hip -- lane-per-chain kernels with frozen tables (dev_chain.h): quality and base streams of block format 7.
+// chains.hip -- the kernels of the frozen-table mode (dev_chain.h): a coding chain per lane over tables that do not change
+// while chains are coded; the quality, base and header streams of the block format.
 //
 //   k_qlt_frozen_rows   prior rows (prior.hip, exchange form) -> dense direct-indexed rows {cum | freq << 16}[64]
+//   k_hot_*             (optional) the rows the sample saw most, as an LDS image for the quality kernels' workgroups
 //   k_qlt_encode_c      QltSave::save_1/2/3's symbol walk (qlts.cpp:74-136), one chain per lane, rows frozen
 //   k_qlt_decode_c      QltLoad::load_1/2/3 (qlts.cpp:163-234), likewise
 //   k_gen_count / k_gen_rows / k_gen_encode_c / k_gen_decode_c   bases: see the section below
+//   k_rec_count(_f) / k_rec_frozen_rows                          the header prior's counting pass and rows
+//   k_rec_tokens -> k_rec_code                                   headers: a record per lane makes the symbols, a chain per lane codes them
+//   k_rec_encode_f / k_rec_encode_c                              headers, a chain per lane all the way (what the token step leaves)
+//   k_rec_decode_f / k_rec_decode_c                              RecLoad::load (recs.cpp:374-461), a chain per lane
 //   k_chain_block_sizes / k_compact_chains   a block's chain streams packed back to back
 //
-// A workgroup stages the hottest quality rows (and the totals of all rows) in LDS once and serves its chains'
-// lookups from there; colder rows come from L2.  Text is read 16 aligned bytes per lane at a time.
+// Text is read 16 bytes per lane at a time (any alignment).
 #include "kernels.h"
 #include "dev_chain.h"
 
@@ -297,11 +302,9 @@ __device__ __forceinline__ u32 piece_byte(const uint4& w, u32 j) {          // j
 // LDS staging of the hottest rows: the workgroup copies the call's hot image (above) into LDS once; a symbol whose context
 // is staged reads its entry there (map word, two cums), the others gather it from the L2-resident table.
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
-template <int THREADS, bool LDS>
+// MARK: the chains mark the records with a '!' for the exception pass (a.exc_flag; the framing does that where it can)
+template <int THREADS, bool LDS, bool MARK>
 __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
-#ifdef PRIO_QLT
-    __builtin_amdgcn_s_setprio(PRIO_QLT);
-#endif
     __shared__ u32 ring[LaneEncB<THREADS, QLT_RING>::LDS_DWORDS];
     extern __shared__ u32 lds[];                              // the hot image: map, then rows
     const uint2* const lmap = reinterpret_cast<const uint2*>(lds);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
             const u32 vm = j < len ? ~0u : 0u;
             const u32 b = (piece_byte(f, j) - '!') & 0xffu;
             const u32 sym = b < LAST_QLT ? b : LAST_QLT;
-            lowest = min(lowest, b | ~vm);
+            if constexpr (MARK) lowest = min(lowest, b | ~vm);
             top = max(top, b & vm);
             if constexpr (LDS) {
                 const uint2 mr = lmap[last >> 5];
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
         const uint4& f = w;
         const u32 len = pc.j1;
         // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
-        if (a.exc_flag && lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
+        if constexpr (MARK) if (lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
         // (b) the serial part: the range coder
         if (!__any(top >= LAST_QLT)) {
 #pragma unroll
@@ -410,17 +413,21 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     }
 }
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
+    const dim3 g256((a.geo.nchains + 255) / 256), g1024((a.geo.nchains + 1023) / 1024);
     if (a.q_hot) {
         // one workgroup of 1024 lanes per CU shares the image (a table per 256 lanes would hold a quarter of the rows)
         constexpr int T = 1024;
         const u32 dyn = QH_MAP_BYTES(a.q_rows) + a.q_hot * QH_ROW_U16 * 2u;
-        static u32 allowed = 0;
-        if (dyn > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed = dyn; }
-        hipLaunchKernelGGL((k_qlt_encode_c<T, true>), dim3((a.geo.nchains + T - 1) / T), dim3(T), dyn, st, a);
-    } else {
-        constexpr int T = 256;
-        hipLaunchKernelGGL((k_qlt_encode_c<T, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
-    }
+        static u32 allowed[2] = {0, 0};
+        if (a.exc_flag) {
+            if (dyn > allowed[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed[1] = dyn; }
+            hipLaunchKernelGGL((k_qlt_encode_c<T, true, true>), g1024, dim3(T), dyn, st, a);
+        } else {
+            if (dyn > allowed[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed[0] = dyn; }
+            hipLaunchKernelGGL((k_qlt_encode_c<T, true, false>), g1024, dim3(T), dyn, st, a);
+        }
+    } else if (a.exc_flag) hipLaunchKernelGGL((k_qlt_encode_c<256, false, true>), g256, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_qlt_encode_c<256, false, false>), g256, dim3(256), 0, st, a);
 }
 
 // =========================================================================================================
@@ -758,15 +765,14 @@ __device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
 }
 
 #define GEN_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four bases add at most 4 x 2
-template <int THREADS>
+// FLAT: the call has no generation tables (api.cpp gen_tables_finish): only the initial row's path is compiled -- no row
+// values in flight, no reciprocal table -- so the kernel holds fewer registers and less LDS beside the other chains' kernels
+template <int THREADS, bool FLAT>
 __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
-#ifdef PRIO_GEN
-    __builtin_amdgcn_s_setprio(PRIO_GEN);
-#endif
-    __shared__ u32 rcp[1024];                                 // reciprocals of the row totals (<= 1020)
+    __shared__ u32 rcp[FLAT ? 1 : 1024];                      // reciprocals of the row totals (<= 1020)
     __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
     __shared__ u32 ring[LaneEncB<THREADS, GEN_RING>::LDS_DWORDS];
-    for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
+    if constexpr (!FLAT) for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
     for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)(gen_code_of(i) | (is_lower_base(i) ? 0x20u : 0u));    // 0x20: a lowercase base ("gen.lc")
     __syncthreads();
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
@@ -777,15 +783,15 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
     LaneEncB<THREADS, GEN_RING> rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
     rc.init(ring, threadIdx.x, outp, cap);
-    const u32* rows = live ? gen_rows_of(a, cp.b) : nullptr;
+    const u32* rows = (!FLAT && live) ? gen_rows_of(a, cp.b) : nullptr;
     u32 illegal = 0;
-    if (!__any(rows != nullptr)) {
+    if (FLAT || !__any(rows != nullptr)) {
         // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
         const u32 r12 = fz_recip(12u);
         illegal = walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
             [&](u32, u32 code, u32 vm) { rc.encode_if(vm, 3u * code, 3u, 12u, r12); },
             [&]() { rc.drain(); }, a.exc_flag);
-    } else {
+    } else if constexpr (!FLAT) {
         // a lane whose generation has no rows yet reads the initial row from a one-entry table
         const u32* rp = rows ? rows : a.g_init;
         const u32 mask = (live && rows) ? (1u << d->gen_bits) - 1u : 0u;
@@ -812,7 +818,8 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
 }
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
     constexpr int T = 256;
-    hipLaunchKernelGGL(k_gen_encode_c<T>, dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
+    if (!a.g_ngen) hipLaunchKernelGGL((k_gen_encode_c<T, true>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
+    else hipLaunchKernelGGL((k_gen_encode_c<T, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
 }
 
 // One base: the row's four frequencies -> the symbol under prob, its cum and freq (base2_ranger.hpp:86-104)
