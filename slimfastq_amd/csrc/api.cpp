@@ -953,7 +953,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             ca.q_hot = 0; ca.q_rows = q_rows;
             // LDS staging of the rows the sample saw most (picked on the device, chains.hip k_hot_select); without a sample of
             // this call's own there is nothing to rank by
-            const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE || given || !prior_step) ? 0u : std::min<u32>(p.lds_rows, 1024u);
+            // (0 = automatic: 800 rows.  Beside round 2's header kernel, which took 147 KiB of every CU's LDS, the image bought nothing in
+            //  the full call; with the headers' token step it takes the call from 17.3 to 15.9 ms -- the chains it serves from LDS are row
+            //  gathers the CU's vector memory path does not carry for the kernels beside the quality chains)
+            //  (the image is shared by a workgroup of 1024 chains, one per CU: automatic only where the call has chains for every CU several times
+            //   over -- 60 k long reads are 59 such workgroups, and coded at half the speed)
+            const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE || given || !prior_step) ? 0u : p.lds_rows ? std::min<u32>(p.lds_rows, 1024u)
+                                 : nchains >= 150000u ? 800u : 0u;
             if (want_hot) {
                 const size_t img_bytes = (size_t)q_rows / 4 + (size_t)want_hot * 100 + 64;
                 if ((rc = reserve(ctx, ctx->qw, img_bytes + (size_t)q_rows * 4 + 256))) return rc;

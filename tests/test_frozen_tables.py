@@ -281,7 +281,7 @@ def test_frozen_quality_rows_staged_in_lds_do_not_change_a_byte(ctx, level):
     fq = capi.synth_fastq(20000, 150, seed=21)
     kw = dict(level=level, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=25)
     base = ctx.encode_host(fq, lds_rows=capi.LDS_ROWS_NONE, **kw)
-    for rows in (1, 64, 240, 5000):
+    for rows in (0, 1, 64, 240, 5000):                  # 0: the automatic choice (800 rows)
         enc = ctx.encode_host(fq, lds_rows=rows, **kw)
         assert enc.stream("qlt") == base.stream("qlt"), rows
         assert enc.chains == base.chains and enc.prior == base.prior, rows
