@@ -412,22 +412,21 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
         else if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
     }
 }
+template <int T>
+static void launch_qlt_lds(const ChainArgs& a, u32 dyn, hipStream_t st) {
+    static u32 allowed = 0;
+    if (dyn > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed = dyn; }
+    hipLaunchKernelGGL((k_qlt_encode_c<T, true, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), dyn, st, a);
+}
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
-    const dim3 g256((a.geo.nchains + 255) / 256), g1024((a.geo.nchains + 1023) / 1024);
+    if (a.exc_flag) { hipLaunchKernelGGL((k_qlt_encode_c<256, false, true>), dim3((a.geo.nchains + 255) / 256), dim3(256), 0, st, a); return; }   // (chains that mark: no caller does)
     if (a.q_hot) {
-        // one workgroup of 1024 lanes per CU shares the image (a table per 256 lanes would hold a quarter of the rows)
-        constexpr int T = 1024;
+        // One workgroup of 1024 lanes per CU shares the image (a table per 256 lanes would hold a quarter of the rows).  205 k chains
+        // are 200 such workgroups: 56 CUs carry no quality chains -- and that is where the other kernels get their work done.  With
+        // workgroups of 832 lanes on 247 CUs the quality chains took as long and the header coder 6.1 ms instead of 2.5.
         const u32 dyn = QH_MAP_BYTES(a.q_rows) + a.q_hot * QH_ROW_U16 * 2u;
-        static u32 allowed[2] = {0, 0};
-        if (a.exc_flag) {
-            if (dyn > allowed[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed[1] = dyn; }
-            hipLaunchKernelGGL((k_qlt_encode_c<T, true, true>), g1024, dim3(T), dyn, st, a);
-        } else {
-            if (dyn > allowed[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qlt_encode_c<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); allowed[0] = dyn; }
-            hipLaunchKernelGGL((k_qlt_encode_c<T, true, false>), g1024, dim3(T), dyn, st, a);
-        }
-    } else if (a.exc_flag) hipLaunchKernelGGL((k_qlt_encode_c<256, false, true>), g256, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_qlt_encode_c<256, false, false>), g256, dim3(256), 0, st, a);
+        launch_qlt_lds<1024>(a, dyn, st);
+    } else hipLaunchKernelGGL((k_qlt_encode_c<256, false, false>), dim3((a.geo.nchains + 255) / 256), dim3(256), 0, st, a);
 }
 
 // =========================================================================================================
