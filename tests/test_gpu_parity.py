@@ -664,6 +664,32 @@ def test_multi_file_driver(tmp_path):
     assert not (tmp_path / "SFQ" / "bad.sfq").exists()
 
 
+def test_an_output_buffer_too_small_is_reported_and_left_untouched(ctx):
+    """The streams are packed into the caller's buffer behind a check that runs on the device (frame.hip k_stream_gate: no host
+    round trip between the chains and the packing): with too little room nothing is written, the call says how much it needs, and
+    the context codes the next text as if nothing had happened."""
+    import torch
+    fq = capi.synth_fastq(40000, 150, seed=12)
+    d_in = torch.from_numpy(np.frombuffer(fq, np.uint8).copy()).cuda()
+    for tables in (capi.TABLES_FROZEN, capi.TABLES_ADAPTIVE):
+        kw = dict(level=3, block_reads=1024, prior_step=capi.PRIOR_AUTO if tables else 0, tables=tables)
+        cap = capi.lib().sfq_encode_bound(len(fq))
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        res = ctx.encode_device(d_in.data_ptr(), len(fq), d_out.data_ptr(), cap, **kw)
+        torch.cuda.synchronize()
+        want = d_out[:res.total_bytes].clone()
+        small = res.total_bytes - 1000
+        d_small = torch.full((small,), 0xA5, dtype=torch.uint8, device="cuda")
+        with pytest.raises(capi.SfqError) as e:
+            ctx.encode_device(d_in.data_ptr(), len(fq), d_small.data_ptr(), small, **kw)
+        assert e.value.code == -5 and "output needs" in str(e.value)            # SFQ_E_OVERFLOW
+        torch.cuda.synchronize()
+        assert bool((d_small == 0xA5).all())
+        res2 = ctx.encode_device(d_in.data_ptr(), len(fq), d_out.data_ptr(), cap, **kw)
+        torch.cuda.synchronize()
+        assert res2.total_bytes == res.total_bytes and torch.equal(d_out[:res.total_bytes], want)
+
+
 # BASELINE configs at their full per-GPU sizes: C3 (10 M x 150 bp, -l 3), C4's per-GPU share (100 M reads over 8 GPUs = 12.5 M,
 # -l 4), binned qualities at -l 4, C5 long reads, the genome-sampled secondary workload; with frozen tables (the default
 # of block format 7) and with adaptive tables (a wavefront per block)
