@@ -1732,13 +1732,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
             cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
             cr.rmap = (const u16*)ctx->rmap.p; cr.rhot = cr.rmap + PR_REC_ROWS; cr.r_hot = ctx->r_hot_dec;
-            u32* rflags = nullptr;
+            u32* rflags = nullptr; u32* dtok = nullptr; u32* dtoff = nullptr; u32* dflags = nullptr;
             if (version >= 5) {                                        // (load_pre5 archives: the general path)
-                if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4))) return rc;
-                HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4, st_rec));
-                rflags = (u32*)ctx->rflags.p;
+                if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4 * 2))) return rc;                 // the lane kernels' flags, the two-step decoder's
+                HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, st_rec));
+                rflags = (u32*)ctx->rflags.p; dflags = rflags + nsub;
+                const u64 tb = (rec_dtok_bytes(nrec) + 15) & ~15ull;
+                if ((rc = reserve(ctx, ctx->rtok, (size_t)(tb + nrec * 4 + 16)))) return rc;          // tokens, then the records' places among them
+                dtok = (u32*)ctx->rtok.p; dtoff = (u32*)((u8*)ctx->rtok.p + tb);
             }
-            launch_rec_decode_c(cr, da, rflags, st_rec);
+            launch_rec_decode_c(cr, da, rflags, st_rec, dtok, dtoff, dflags);
         } else
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
             da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);

@@ -1701,24 +1701,292 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
     out.end();
     return true;
 }
-__global__ __launch_bounds__(64) void k_rec_decode_f(ChainArgs a, DecodeArgs da, u32* flags) {
+__global__ __launch_bounds__(64) void k_rec_decode_f(ChainArgs a, DecodeArgs da, u32* flags, const u32* only /* the chains to take; null = all */) {
     __builtin_amdgcn_s_setprio(3);         // (a wave per SIMD with a long serial walk beside the quality decoder's many: 19.2 -> 16.2 ms)
     __shared__ RecFastDecLds L;
     const u32 lane = threadIdx.x;
+    {
+        const u32 c0 = blockIdx.x * 64 + lane;
+        if (only && !__any(c0 < a.rgeo.nchains && only[c0] != 0)) return;
+    }
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < RDEC_LDS_ROWS ? sl : 0xFFu); }
     for (u32 i = lane; i < a.r_hot * RDEC_ROW; i += 64) L.drows[i / RDEC_ROW][i % RDEC_ROW] = a.rdec[(size_t)a.rhot[i / RDEC_ROW] * RDEC_ROW + i % RDEC_ROW];
     __syncthreads();
     const u32 c = blockIdx.x * 64 + lane;
     if (c >= a.rgeo.nchains) return;
+    if (only && !only[c]) return;
     const RecChainPos cp = rec_chain_pos(a, c);
     const BlockDesc* d = &da.m.blocks[cp.b];
     RecFastDecSrc cd; cd.rdec = a.rdec; cd.L = &L;
     cd.rc.init(da.streams + a.coff[c], a.csz[c]);
     if (!rec_fast_decode_lane(da, d, L, lane, cp.r0, cp.nrec, c, cd)) flags[c] = 1;
 }
+// ---- header decode in two steps: the symbols, then the text --------------------------------------------------------------------
+// k_rec_decode_f above walks a chain per lane with two headers, the field table and the field values of every lane in LDS
+// (38 KiB per wave: one wave per SIMD) -- 5.5 ms alone and 16-19 ms beside the quality decoder, the longest kernel of a decode.
+// But WHICH symbols a chain holds depends on the decoded values only, never on the text: flag, change map, then per changed field
+// a type and a gap or a string.  So step 1 (k_rec_dsym) is a decoder per lane with nothing but the coder and a cursor: it turns a
+// chain's stream into tokens -- per record the change map, then per changed field one word (type, a gap below 2^24) or more (a
+// longer gap, a string's bytes).  Step 2 (k_rec_dtext) takes a RECORD per lane, a chain per wave, 64 records a round, and rebuilds
+// the texts field by field: a changed number is the field's running value -- a segmented prefix sum of the signed gaps over the
+// lanes, reset where the field was a string (recs.cpp:333: the previous value counts only while the field is numeric) --, an
+// unchanged field is the text of its LAST WRITER -- a running maximum of lane numbers --, or of the round before (a carried copy of
+// the last record).  Chains with a header of another shape, more than 16 fields, headers over 127 bytes or a sign in a number are
+// left to the kernels above (dflags).
+#define RD_TOK_PER_REC 16u
+struct RecDsymLds { u16 drows[RDEC_LDS_ROWS][RDEC_ROW]; u8 map[PR_REC_ROWS]; };
+struct RecSymSrc {
+    const u16* rdec; const RecDsymLds* L; LaneDec rc;
+    __device__ __forceinline__ u32 get(u32 row) {
+        const u32 prob = rc.get_freq16();
+        const u32 slot = L->map[row];
+        u32 cum, next, s;
+        if (slot != 0xFFu) s = rdec_search((lds_row)L->drows[slot], prob, cum, next);
+        else s = rdec_search((glb_row)(rdec + (size_t)row * RDEC_ROW), prob, cum, next);
+        rc.decode(cum, next - cum);
+        return s;
+    }
+    __device__ __forceinline__ u64 get_u(u32 row0) { return get_u_rows(*this, row0); }
+};
+__global__ __launch_bounds__(256) void k_rec_dsym(ChainArgs a, DecodeArgs da, u32* __restrict__ dtok, u32* __restrict__ dtoff, u32* __restrict__ dflags) {
+    __shared__ RecDsymLds L;
+    for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 256) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < RDEC_LDS_ROWS ? sl : 0xFFu); }
+    for (u32 i = threadIdx.x; i < a.r_hot * RDEC_ROW; i += 256) L.drows[i / RDEC_ROW][i % RDEC_ROW] = a.rdec[(size_t)a.rhot[i / RDEC_ROW] * RDEC_ROW + i % RDEC_ROW];
+    __syncthreads();
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.rgeo.nchains) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    const BlockDesc* d = &da.m.blocks[cp.b];
+    RecSymSrc cd; cd.rdec = a.rdec; cd.L = &L;
+    cd.rc.init(da.streams + a.coff[c], a.csz[c]);
+    u32* const out = dtok + cp.r0 * RD_TOK_PER_REC;
+    const u32 cap = cp.nrec * RD_TOK_PER_REC;
+    u32 w = 0; bool bad = false;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    auto emit = [&](u32 word) {                                   // four words a store
+        const u32 q = w & 3u;
+        acc.x = q == 0 ? word : acc.x; acc.y = q == 1 ? word : acc.y; acc.z = q == 2 ? word : acc.z; acc.w = q == 3 ? word : acc.w;
+        if (q == 3u && w < cap) *reinterpret_cast<uint4*>(out + (w - 3u)) = acc;
+        w++;
+    };
+    for (u32 k = 0; k < cp.nrec && !bad; k++) {
+        const u64 r = cp.r0 + k;
+        if (r == d->rec0) { dtoff[r] = 0xFFFFFFFFu; continue; }           // the base itself: nothing is coded for it
+        dtoff[r] = w;
+        if (cd.get(REC_FLAG_ROW) != 0) { bad = true; break; }             // a header of another shape: the lane kernels' business
+        const u64 map = cd.get_u(0 * 16 + 2);
+        if (map >> RF_NF) { bad = true; break; }
+        emit((u32)map);
+        for (u32 f = 0; f < RF_NF && !bad; f++) {
+            if (!((map >> f) & 1)) continue;
+            const u32 rr = (f + 1) * 16;
+            const u32 type = cd.get(rr + 0);
+            if (type == ST_STR) {
+                const u64 len = cd.get_u(rr + 2);
+                if (len > RF_DML) { bad = true; break; }
+                emit(type | (2u << 4) | ((u32)len << 8));
+                u32 word = 0;
+                for (u32 j = 0; j < (u32)len; j++) {
+                    word |= cd.get(rr + 1) << (8 * (j & 3u));
+                    if ((j & 3u) == 3u) { emit(word); word = 0; }
+                }
+                if (len & 3u) emit(word);
+            } else if (type > ST_DLT_Z) bad = true;
+            else {
+                const u64 gap = cd.get_u(rr + 2);
+                if (gap < (1u << 24)) emit(type | ((u32)gap << 8));
+                else { emit(type | (1u << 4)); emit((u32)gap); emit((u32)(gap >> 32)); }
+            }
+        }
+        if (cd.rc.err || w + 8 > cap) bad = true;                        // (room for the next record's first words is checked as it goes)
+    }
+    if (!bad) {                                                         // what the last store left
+        const u32 q = w & 3u, b0 = w - q;
+        if (q > 0 && b0 < cap) out[b0] = acc.x;
+        if (q > 1 && b0 + 1 < cap) out[b0 + 1] = acc.y;
+        if (q > 2 && b0 + 2 < cap) out[b0 + 2] = acc.z;
+        if (w > cap) bad = true;
+    }
+    if (bad) dflags[c] = 1;
+}
+struct RecDtLds {
+    u8 scratch[RF_DML + 1][64];                                         // the changed fields' texts of the round's records: [byte][lane]
+    u8 soff[RF_NF][64], slen[RF_NF][64], wsrc[RF_NF][64];               // where a lane's field f lies in its scratch column; the lane that wrote field f last (0xFF: the round before)
+    u8 ctext[2][RF_DML + 1];                                            // the record before lane 0's, whole (two copies take turns)
+    u8 coff[2][RF_NF], cwln[2][RF_NF];
+    u8 csep[RF_NF];                                                     // the separators: the same for every record of a chain without shape changes
+    u64 cval[RF_NF];                                                    // the fields' running values behind that record (0: cold, or a string since)
+};
+__global__ __launch_bounds__(64) void k_rec_dtext(ChainArgs a, DecodeArgs da, const u32* __restrict__ dtok, const u32* __restrict__ dtoff, u32* __restrict__ dflags) {
+    __shared__ RecDtLds L;
+    const u32 lane = threadIdx.x;
+    const u32 c = blockIdx.x;
+    if (dflags[c]) return;
+    const RecChainPos cp = rec_chain_pos(a, c);
+    if (cp.nrec == 0) return;
+    const BlockDesc* d = &da.m.blocks[cp.b];
+    const u64 cap = da.hdr_stage_cap[c], stage_off = da.hdr_stage_off[c];
+    // the base: the block's first header (recs.cpp:113-119), tokenised by every lane alike (d_map_space, recs.cpp:141-157)
+    const u32 n0 = d->first_hdr_len;
+    if (n0 > RF_DML) { if (lane == 0) dflags[c] = 1; return; }
+    {
+        const u8* fh = da.first_hdrs + d->first_hdr_off;
+        for (u32 j = lane; j < n0; j += 64) L.ctext[0][j] = fh[j];
+        if (lane < RF_NF) L.cval[lane] = 0;
+    }
+    __syncthreads();
+    u32 nf = 0;
+    {
+        u32 start = 0; bool stop = false;
+        for (u32 pos = 0; pos <= n0; pos++) {
+            const u32 ch = pos < n0 ? L.ctext[0][pos] : '\n';
+            if (!stop && !isword(ch)) {
+                if (nf < RF_NF && lane == 0) { L.coff[0][nf] = (u8)start; L.cwln[0][nf] = (u8)(pos - start); L.csep[nf] = (u8)ch; }
+                nf++; start = pos + 1;
+                if (ch == 0) stop = true;
+            }
+        }
+    }
+    if (nf > RF_NF) { if (lane == 0) dflags[c] = 1; return; }
+    __syncthreads();
+    const u32* const T = dtok + cp.r0 * RD_TOK_PER_REC;
+    const u64 end = cp.r0 + cp.nrec;
+    u64 first = cp.r0;
+    u64 pos = 0;
+    if (cp.r0 == d->rec0) {                                             // the base itself is this chain's first record
+        if (lane == 0) { da.hlen[cp.r0] = n0; da.hoff[cp.r0] = stage_off; }
+        for (u32 j = lane; j < n0; j += 64) da.hdr_stage[stage_off + j] = L.ctext[0][j];
+        if (lane == 0) da.hdr_stage[stage_off + n0] = '\n';
+        pos = (u64)n0 + 1; first = cp.r0 + 1;
+    }
+    u32 cb = 0;
+    for (u64 rb = first; rb < end; rb += 64) {
+        const u64 r = rb + lane;
+        const bool valid = r < end;
+        u32 cur = 0, map = 0, spos = 0; bool bad = false;
+        if (valid) { cur = dtoff[r]; map = T[cur]; cur++; }
+        for (u32 f = 0; f < nf; f++) {
+            const bool ch = valid && ((map >> f) & 1u);
+            u32 type = 0, slen = 0, strw = 0; u64 gap = 0;
+            if (ch) {
+                const u32 t = T[cur++];
+                type = t & 15u;
+                const u32 kind = (t >> 4) & 3u;
+                if (kind == 0) gap = t >> 8;
+                else if (kind == 1) { gap = (u64)T[cur] | ((u64)T[cur + 1] << 32); cur += 2; }
+                else { slen = (t >> 8) & 0xffu; strw = cur; cur += (slen + 3u) >> 2; }
+            }
+            const bool isstr = ch && type == ST_STR, isnum = ch && !isstr;
+            const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC || type == ST_HLTC_Z || type == ST_DLT_Z;
+            // the field's running value: a sum of the signed gaps over the lanes, starting over behind a string
+            u32 rs = isstr ? 1u : 0u;
+            u64 sv = isnum ? (less ? (u64)0 - gap : gap) : 0ull;
+            int wl = ch ? (int)lane : -1;                                // ... and the lane that wrote the field last
+#pragma unroll
+            for (u32 dd = 1; dd < 64; dd <<= 1) {
+                const u32 ors = (u32)__shfl_up((int)rs, dd, 64);
+                const u64 osv = (u64)__shfl_up((unsigned long long)sv, dd, 64);
+                const int owl = __shfl_up(wl, dd, 64);
+                if (lane >= dd) { sv = rs ? sv : sv + osv; rs |= ors; wl = owl > wl ? owl : wl; }
+            }
+            const u64 before = L.cval[f];
+            const u64 val = rs ? sv : before + sv;
+            {
+                const u32 lrs = (u32)__shfl((int)rs, 63, 64); const u64 lsv = (u64)__shfl((unsigned long long)sv, 63, 64);
+                if (lane == 0) L.cval[f] = lrs ? lsv : before + lsv;
+            }
+            if (ch) {
+                u32 len = 0;
+                if (isstr) {
+                    len = slen;
+                    if (spos + len > RF_DML) bad = true;
+                    else for (u32 j = 0; j < len; j++) L.scratch[spos + j][lane] = (u8)(T[strw + (j >> 2)] >> (8 * (j & 3u)));
+                } else {                                                 // recs.cpp:430-456
+                    const bool deci = type < ST_STR || type >= ST_DGT_Z;
+                    const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z || type == ST_DGT_Z || type == ST_DLT_Z;
+                    const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
+                    if (spos + 24 > RF_DML) bad = true;
+                    else if (val == 0) { L.scratch[spos][lane] = '0'; len = 1; }      // recs.cpp:453-454
+                    else {
+                        if (lead) L.scratch[spos + len++][lane] = '0';
+                        if (deci) {                                      // "%lld"
+                            if ((i64)val < 0) bad = true;                // (a sign changes the fields: the general path's business)
+                            u32 nd = 0;
+                            for (u64 t = val; t; t /= 10) nd++;
+                            u64 t = val;
+                            for (u32 j = nd; j-- > 0;) { L.scratch[spos + len + j][lane] = (u8)('0' + t % 10); t /= 10; }
+                            len += nd;
+                        } else {                                         // "%llx" / "%llX"
+                            int sh = 60;
+                            while (sh > 0 && ((val >> sh) & 0xf) == 0) sh -= 4;
+                            for (; sh >= 0; sh -= 4) {
+                                const u32 dg = (u32)(val >> sh) & 0xf;
+                                L.scratch[spos + len++][lane] = (u8)(dg < 10 ? '0' + dg : (upper ? 'A' : 'a') + dg - 10);
+                            }
+                        }
+                    }
+                }
+                L.soff[f][lane] = (u8)spos; L.slen[f][lane] = (u8)len;
+                spos += len;
+            }
+            L.wsrc[f][lane] = (u8)(wl < 0 ? 0xFF : wl);
+        }
+        if (__any(bad)) { if (lane == 0) dflags[c] = 1; return; }
+        __syncthreads();
+        // the lengths, the places in the staging area, then the texts
+        u32 n = 0;
+        if (valid) {
+            for (u32 f = 0; f < nf; f++) { const u32 src = L.wsrc[f][lane]; n += src == 0xFFu ? L.cwln[cb][f] : L.slen[f][src]; }
+            n += nf - 1;                                                 // the separators between the fields (recs.cpp:460)
+        }
+        if (__any(valid && n > RF_DML)) { if (lane == 0) dflags[c] = 1; return; }
+        const u32 mine = valid ? n + 1 : 0;
+        const u32 incl = wave_incl_scan(mine);
+        const u32 round = rl(incl, 63);
+        if (pos + round + SFQ_MAX_ID_LLEN + 2 > cap) { if (lane == 0) dflags[c] = 1; return; }     // (the general path reports it)
+        const u32 nvalid = (u32)(end - rb < 64 ? end - rb : 64);
+        const bool keep = lane + 1 == nvalid && rb + 64 < end;           // this lane's record is what the next round starts from
+        if (valid) {
+            const u64 at = stage_off + pos + (incl - mine);
+            da.hlen[r] = n; da.hoff[r] = at;
+            LaneOut out; out.begin(da.hdr_stage + at);
+            u32 b = 0;
+            for (u32 f = 0; f < nf; f++) {
+                const u32 src = L.wsrc[f][lane];
+                u32 len;
+                if (keep) L.coff[cb ^ 1][f] = (u8)b;
+                if (src == 0xFFu) {
+                    len = L.cwln[cb][f]; const u32 o = L.coff[cb][f];
+                    for (u32 j = 0; j < len; j++) { const u32 ch = L.ctext[cb][o + j]; out.put(ch); if (keep) L.ctext[cb ^ 1][b + j] = (u8)ch; }
+                } else {
+                    len = L.slen[f][src]; const u32 o = L.soff[f][src];
+                    for (u32 j = 0; j < len; j++) { const u32 ch = L.scratch[o + j][src]; out.put(ch); if (keep) L.ctext[cb ^ 1][b + j] = (u8)ch; }
+                }
+                if (keep) L.cwln[cb ^ 1][f] = (u8)len;
+                b += len;
+                const u32 sp = f + 1 < nf ? L.csep[f] : '\n';
+                out.put(sp);
+                if (keep && f + 1 < nf) L.ctext[cb ^ 1][b] = (u8)sp;
+                b++;
+            }
+            out.end();
+        }
+        pos += round;
+        cb ^= 1u;
+        __syncthreads();
+    }
+}
 // flags: one dword per header chain, zeroed by the caller (null: every chain on the general path -- archives before version 5)
-void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags, hipStream_t st) {
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags, hipStream_t st, u32* dtok, u32* dtoff, u32* dflags) {
     const dim3 grid((a.rgeo.nchains + 63) / 64);
-    if (flags) hipLaunchKernelGGL(k_rec_decode_f, grid, dim3(64), 0, st, a, da, flags);
+    if (flags && dtok) {                                                 // symbols, texts, then the lane kernels on the chains those left (dflags)
+        hipLaunchKernelGGL(k_rec_dsym, dim3((a.rgeo.nchains + 255) / 256), dim3(256), 0, st, a, da, dtok, dtoff, dflags);
+        hipLaunchKernelGGL(k_rec_dtext, dim3(a.rgeo.nchains), dim3(64), 0, st, a, da, (const u32*)dtok, (const u32*)dtoff, dflags);
+        hipLaunchKernelGGL(k_rec_decode_f, grid, dim3(64), 0, st, a, da, flags, (const u32*)dflags);
+        hipLaunchKernelGGL(k_rec_decode_c, grid, dim3(64), 0, st, a, da, (const u32*)flags);
+        return;
+    }
+    if (flags) hipLaunchKernelGGL(k_rec_decode_f, grid, dim3(64), 0, st, a, da, flags, (const u32*)nullptr);
     hipLaunchKernelGGL(k_rec_decode_c, grid, dim3(64), 0, st, a, da, (const u32*)flags);
 }
+u64 rec_dtok_bytes(u64 nrec) { return nrec * RD_TOK_PER_REC * 4; }

@@ -155,7 +155,9 @@ void launch_usr_encode_w(const ModelArgs& a, hipStream_t st);      // framing ex
 
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
-void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags /* [rgeo.nchains], zeroed; null = general path only */, hipStream_t st);
+void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags /* [rgeo.nchains], zeroed; null = general path only */, hipStream_t st,
+                         u32* dtok = nullptr /* rec_dtok_bytes(records); null = the lane kernels alone */, u32* dtoff = nullptr /* [records] */, u32* dflags = nullptr /* [rgeo.nchains], zeroed */);
+u64 rec_dtok_bytes(u64 nrec);
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
 void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st);          // the same, a wave per block (models_w.hip); blocks [batch0, batch0 + nbatch), slot = workgroup
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st);

@@ -358,7 +358,9 @@ def _field_history_fastq(n, seed):
         c = ("%x" % (0xabc000 + i)) if 1300 <= i < 1330 else str(i * 7)  # hexadecimal in one stretch only
         d = "007" if i % 97 == 0 else str(i % 13)                        # leading zeros now and then
         tail = (" " + "Z" * 80 + str(i)) if 1700 <= i < 1900 and i % 2 else ""       # the shape alternates over long headers: more symbols than the token buffer has room for
-        hdr = "@H%d:%s:%s:%s:%d%s" % (a, b, c, d, int(rng.integers(0, 100000)), tail)
+        e = 4_000_000_000_000 + (i % 5) * 7_000_000_000 - (i % 3) * 70_000_000     # gaps over 2^32 and over 2^24, up and down
+        z = ("%X" % (0xAB00 + i)) if i % 2 else "0"                                 # upper-case hex against a bare 0
+        hdr = "@H%d:%s:%s:%s:%d:%d:%s%s" % (a, b, c, d, int(rng.integers(0, 100000)), e, z, tail)
         ln = 40
         seq = "".join("ACGT"[int(v)] for v in rng.integers(0, 4, ln))
         q = "".join(chr(33 + int(v)) for v in rng.integers(2, 41, ln))
