@@ -9,7 +9,8 @@
 //   k_rec_count(_f) / k_rec_frozen_rows                          the header prior's counting pass and rows
 //   k_rec_tokens -> k_rec_code                                   headers: a record per lane makes the symbols, a chain per lane codes them
 //   k_rec_encode_f / k_rec_encode_c                              headers, a chain per lane all the way (what the token step leaves)
-//   k_rec_decode_f / k_rec_decode_c                              RecLoad::load (recs.cpp:374-461), a chain per lane
+//   k_rec_dsym -> k_rec_dtext                                    headers back: a chain per lane decodes the symbols, a record per lane rebuilds the texts
+//   k_rec_decode_f / k_rec_decode_c                              RecLoad::load (recs.cpp:374-461), a chain per lane all the way (what those two leave)
 //   k_chain_block_sizes / k_compact_chains   a block's chain streams packed back to back
 //
 // Text is read 16 bytes per lane at a time (any alignment).
