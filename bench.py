@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the genome-sampled secondary workload (the honest stress of the base model, SURVEY 8d)")
     ap.add_argument("--genome-reads", type=int, default=10_000_000)
     ap.add_argument("--genome-ratio-reads", type=int, default=2_000_000, help="records the reference itself codes for the genome leg's ratio (30x coverage of the 10 Mbp genome)")
+    ap.add_argument("--no-size-sweep", action="store_true", help="skip the size sweep (prefixes of the same text: 0.25 / 0.5 / 1 / 2 GB and all of it, encode + decode)")
+    ap.add_argument("--sweep-gb", type=str, default="0.25,0.5,1,2", help="size sweep: prefix sizes in GB (the whole text is always the last point)")
+    ap.add_argument("--sweep-only", action="store_true", help="debug: the size sweep alone (no decode / adaptive / cpu / format-6 / genome legs)")
     args = ap.parse_args()
     if args.reads <= 0:
         args.reads = 60_000 if args.kind == 1 else 10_000_000
@@ -120,6 +123,63 @@ def cpu_baseline(args, seed):
         except Exception as e:  # the binary may not run on this host; keep the port number
             out["reference_error"] = str(e)[:100]
     return out, fq, ref_payload
+
+
+def size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models):
+    """The same call over prefixes of the text (whole records): encode and decode at every size, device-resident, each
+    timed on its own (the reference's loop, usrs.cpp:392-407, is size-agnostic: so should this be)."""
+    CH = 1 << 30                                              # (torch.nonzero takes at most 2^31 elements a call)
+    chunk_nl = [int((d_in[o:o + CH] == 10).sum().item()) for o in range(0, nbytes, CH)]
+
+    def end_of_line(k):                                       # offset behind the k-th newline (1-based)
+        o = 0
+        for c in chunk_nl:
+            if k <= c:
+                return o + int(torch.nonzero(d_in[o:o + CH] == 10).flatten()[k - 1].item()) + 1
+            k -= c; o += CH
+        return nbytes
+    per_rec = nbytes / args.reads
+    points = []
+    for gb in [float(x) for x in args.sweep_gb.split(",") if x]:
+        n = int(gb * 1e9 / per_rec)
+        if 0 < n < args.reads:
+            points.append(n)
+    points.append(args.reads)
+    d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
+    rows = []
+    for n in points:
+        cut = end_of_line(4 * n)
+        kw = dict(level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
+                  tables=args.tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
+        ctx.encode_device(d_in.data_ptr(), cut, d_out.data_ptr(), cap, **kw)
+        te = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = ctx.encode_device(d_in.data_ptr(), cut, d_out.data_ptr(), cap, **kw)
+            torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        row = {"reads": n, "raw_bytes": cut, "encode_MBps": round(cut / min(te) / 1e6, 1), "encode_ms": round(min(te) * 1e3, 3),
+               "ratio": round(cut / r.total_bytes, 4), "chains": int(r.n_chains),
+               "coder_ms": {"qlt": round(r.coder_ms[0], 3), "gen": round(r.coder_ms[1], 3), "rec": round(r.coder_ms[2], 3)},
+               "device_ms": round(r.kernel_ms[capi.T_TOTAL], 3)}
+        if not models:
+            blocks = ctx.index(r.n_blocks)
+            first = ctx.first_headers(r.first_hdr_bytes)
+            prior, chains, rec_prior = ctx.prior(), ctx.chains(), ctx.rec_prior()
+            row["archive_bytes"] = int(r.total_bytes) + len(first) + len(prior) + len(chains) + len(rec_prior) + 14 * len(blocks)
+            soff = list(r.stream_offset)
+            td = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                got, rd = ctx.decode_device(blocks, first, d_out.data_ptr(), soff, d_back.data_ptr(), d_back.numel(), prior=prior, level=args.level,
+                                            chains=chains, rec_prior=rec_prior, lds_rows=args.dec_lds_rows)
+                torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+            row.update(decode_MBps=round(cut / min(td[1:]) / 1e6, 1), decode_ms=round(min(td[1:]) * 1e3, 3),
+                       round_trip_identical=bool(got == cut and torch.equal(d_back[:cut], d_in[:cut])),
+                       decode_phase_ms={"qlt": round(rd.kernel_ms[capi.T_QLT], 3), "gen": round(rd.kernel_ms[capi.T_GEN], 3), "rec": round(rd.kernel_ms[capi.T_REC], 3),
+                                        "assemble": round(rd.kernel_ms[capi.T_PACK], 3)})
+        rows.append(row)
+    del d_back
+    return rows
 
 
 def _varints(blob: bytes, n: int):
@@ -294,6 +354,10 @@ def main():
                         "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
                         "device_total": round(phase[capi.T_TOTAL], 3)},
            "roofline": roofline, "synth_s": round(t_gen, 2)}
+    if args.sweep_only:
+        args.no_decode = args.no_adaptive_leg = args.no_cpu_baseline = args.no_format6_leg = args.no_genome_leg = True
+    if not multi and not args.no_size_sweep and args.kind != 1 and args.tables:
+        out["size_sweep"] = size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models)
     if not multi and args.workload == "full" and not args.models and not args.no_decode:
         # the way back ("decode MB/s secondarily"): the same blocks decoded in HBM and compared with the input;
         # outside the timed region, never part of `value`

@@ -59,7 +59,10 @@ struct sfq_ctx {
     bool counts_only = false; u32 sample_scale = 1;      // sfq_count_priors: stop once the sample is counted; every sample_scale-th sampled record
     // the line index sfq_count_priors left, for the encode of the SAME text that follows it (SFQ_PRIOR_COUNTS): a rank of a
     // multi-GPU job frames its shard once per step, not twice (3 ms of a 21 ms step)
-    struct { const u8* ptr = nullptr; u64 nbytes = 0, nrec = 0; bool marks = false, valid = false; } framed;
+    struct { const u8* ptr = nullptr; u64 nbytes = 0, nrec = 0, print = 0; bool marks = false, valid = false; } framed;       // print: frame.hip k_text_fingerprint of the text it indexes
+    // what `hist` / `hcnt` hold for an SFQ_PRIOR_COUNTS encode: set by sfq_count_priors and sfq_set_prior_counts, dropped by any
+    // call that samples into those buffers itself (an ordinary encode's leftovers are not "installed counts")
+    struct { bool valid = false, rec = false; u32 q_rows = 0; } counts;
     void* pin = nullptr; size_t pin_cap = 0;
     void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
@@ -371,12 +374,16 @@ u32 gen_bounds(u32 nblocks, u32* bound) {
     return n;                                              // number of generations
 }
 int default_chain_reads(u64 nrec, u64 nbytes) {
-    // chains are the unit of parallelism (64 per wavefront): aim at ~192 k of them, at least 16 KiB of text each
-    // (measured at 10 M x 150 bp, chains of 74 / 50 / 38 records = 137 k / 205 k / 264 k chains: 22.6 / 21.4 / 21.1 ms per
-    //  call, streams 5.0062 / 5.0055 / 5.0049 times smaller than the text: a chain costs its flush and two index varints)
+    // Chains are the unit of parallelism (64 per wavefront) and a lane's walk through its chain is the floor of a call's time, so
+    // the COUNT of chains is held, not their length: about 224 k of them -- the 262 144 lanes the quality chains' image kernel
+    // puts on the chip in one round (a workgroup of 1024 per CU), less a margin so that a last partial round never forms --
+    // down to chains of 4 KiB of text (12 records of 150 bp), below which a chain's flush and index entry start to show
+    // (round 4 size sweep, 0.25 / 0.5 / 1 / 2 / 3.7 GB of 150 bp reads: 12 / 12 / 12 / 24 / 49 records per chain; the streams of the
+    //  1 GB prefix are 0.14 % larger at 12 records than at 49).  Round 3 floored a chain at 16 KiB: a 740 MB call then had 45 k
+    //  chains -- a sixth of the chip -- each as long as a 3.7 GB call's, and took longer than that call.
     const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
-    u64 cr = std::max<u64>(1, nrec / 196608);
-    cr = std::max<u64>(cr, (16384 + per_rec - 1) / per_rec);
+    u64 cr = std::max<u64>(1, (nrec + 229375) / 229376);
+    cr = std::max<u64>(cr, (4096 + per_rec - 1) / per_rec);
     return (int)std::min<u64>(cr, 4096);
 }
 // The header prior of an encode with frozen tables: counted over this call's text -- the header model run over short runs
@@ -496,6 +503,18 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
         ca.g_rows[g] = rows + nctx * g;
         if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
     }
+    return SFQ_OK;
+}
+
+// frame.hip k_text_fingerprint of a device-resident text (one small kernel and eight bytes back)
+int text_fingerprint(sfq_ctx* ctx, const u8* d_text, u64 nbytes, hipStream_t st, u64* out) {
+    int rc;
+    if ((rc = reserve(ctx, ctx->status, 256))) return rc;
+    u64* d = (u64*)ctx->status.p + 24;                    // (status words 48..49: nothing else lives there)
+    HIPC(hipMemsetAsync(d, 0, 8, st));
+    launch_text_fingerprint(d_text, nbytes, d, st);
+    HIPC(hipMemcpyAsync(out, d, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     return SFQ_OK;
 }
 
@@ -631,7 +650,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (p.tables > SFQ_TABLES_AUTO) return fail(ctx, SFQ_E_ARG, "tables %u: 0 = adaptive, 1 = frozen, 2 = by the size of the text", p.tables);
     bool small_auto = false;
     if (p.tables == SFQ_TABLES_AUTO) {                          // include/slimfastq_amd.h
-        small_auto = nbytes < (64ull << 20) && p.prior_step != SFQ_PRIOR_GIVEN && p.prior_step != SFQ_PRIOR_COUNTS;
+        // (sfq_count_priors resolves it the way the SFQ_PRIOR_COUNTS encode that follows does: never by the size of one rank's share)
+        small_auto = nbytes < (64ull << 20) && p.prior_step != SFQ_PRIOR_GIVEN && p.prior_step != SFQ_PRIOR_COUNTS && !ctx->counts_only;
         p.tables = small_auto ? SFQ_TABLES_ADAPTIVE : SFQ_TABLES_FROZEN;
         if (small_auto) { p.prior_step = 0; if (p.block_reads == SFQ_BLOCK_AUTO) p.block_reads = 65536; }
     }
@@ -639,6 +659,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     res->abi_version = SFQ_ABI_VERSION;
     hipStream_t st = ctx->st;
     int rc;
+    if (p.prior_step != SFQ_PRIOR_COUNTS) ctx->counts.valid = false;      // this call may sample into hist / hcnt itself
 
     // ---- framing -------------------------------------------------------------------------------
     HIPC(hipEventRecord(ctx->ev[0], st));
@@ -691,8 +712,15 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         return SFQ_OK;
     };
     // (an encode from summed counts right behind sfq_count_priors on the same buffer: that call's line index, marks and checks stand)
-    const bool reframe = !(p.prior_step == SFQ_PRIOR_COUNTS && !legacy && ctx->framed.valid && ctx->framed.ptr == d_fastq && ctx->framed.nbytes == nbytes &&
-                           (!want_marks || ctx->framed.marks));
+    bool reframe = !(p.prior_step == SFQ_PRIOR_COUNTS && !legacy && ctx->framed.valid && ctx->framed.ptr == d_fastq && ctx->framed.nbytes == nbytes &&
+                     (!want_marks || ctx->framed.marks));
+    if (!reframe) {
+        // the same address and size are not the same TEXT (a caller's buffer refilled in place): 65 536 sixteen-byte pieces spread
+        // over the text must hash as they did when sfq_count_priors framed it, or it is framed again
+        u64 print = 0;
+        if ((rc = text_fingerprint(ctx, d_fastq, nbytes, st, &print))) return rc;
+        if (print != ctx->framed.print) reframe = true;
+    }
     ctx->framed.valid = false;
     if (!reframe) nrec = ctx->framed.nrec;
     else if ((rc = frame())) return rc;
@@ -789,7 +817,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // several GPUs share, sfq_build_priors) instead of priors counted over this call's text
     const bool given = prior_step == SFQ_PRIOR_GIVEN;
     const bool counted = prior_step == SFQ_PRIOR_COUNTS;       // the sample's counts are installed (sfq_set_prior_counts): nothing is counted here
-    if (counted && (!ctx->hist.p || (frozen && (models & SFQ_M_REC) && !ctx->hcnt.p))) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_COUNTS: no counts installed (sfq_set_prior_counts)");
+    if (counted) {
+        const bool need_rec = frozen && (models & SFQ_M_REC);
+        if (!ctx->counts.valid || !ctx->hist.p || (need_rec && !ctx->hcnt.p))
+            return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_COUNTS: no counts installed (sfq_set_prior_counts / sfq_count_priors come first; any other encode drops them)");
+        if (ctx->counts.q_rows != q_rows) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_COUNTS: the counts were installed for %u quality contexts, level %d has %u", ctx->counts.q_rows, p.level, q_rows);
+        if (need_rec && !ctx->counts.rec) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_COUNTS: the installed counts hold no header sample (they were counted for adaptive tables), frozen tables need one");
+    }
     if (given && ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no quality prior installed (sfq_set_qlt_prior)");
     if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
     if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
@@ -928,7 +962,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipStreamSynchronize(mst[1]));
             HIPC(hipStreamSynchronize(st));
             res->n_records = nrec; res->n_blocks = nblocks;
-            if (!legacy && !n_over) { ctx->framed.ptr = d_fastq; ctx->framed.nbytes = nbytes; ctx->framed.nrec = nrec; ctx->framed.marks = want_marks; ctx->framed.valid = true; }
+            ctx->counts.valid = true; ctx->counts.q_rows = q_rows; ctx->counts.rec = frozen && (models & SFQ_M_REC);
+            if (!legacy && !n_over) {
+                u64 print = 0;
+                if ((rc = text_fingerprint(ctx, d_fastq, nbytes, st, &print))) return rc;
+                ctx->framed.ptr = d_fastq; ctx->framed.nbytes = nbytes; ctx->framed.nrec = nrec; ctx->framed.marks = want_marks; ctx->framed.print = print; ctx->framed.valid = true;
+            }
             return SFQ_OK;
         }
 
@@ -1204,12 +1243,18 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         o.resize(((size_t)nchains * 2 + (size_t)nsub * 2) * 5 + 64);
         u8* w = o.data();
         auto put = [&w](u32 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
+        // a list of sizes: each as the zigzag difference to the one before it (neighbouring chains hold as many symbols of the same
+        // statistics: a byte a chain instead of two -- at 12 records a chain the index was 0.5 % of the archive)
+        auto put_list = [&put](const u32* v, size_t n) {
+            u32 prev = 0;
+            for (size_t i = 0; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
+        };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u)); put(nchains);
-        for (u32 c = 0; c < 2 * nchains; c++) put(h_csz[c]);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */); put(nchains);
+        put_list(h_csz, nchains); put_list(h_csz + nchains, nchains);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
             put(ca.rgeo.chain_reads); put(nsub);
-            for (u32 c = 0; c < 2 * nsub; c++) put(h_csz[(size_t)2 * nchains + c]);
+            put_list(h_csz + (size_t)2 * nchains, nsub); put_list(h_csz + (size_t)2 * nchains + nsub, nsub);
         }
         o.resize((size_t)(w - o.data()));
     }
@@ -1269,10 +1314,12 @@ void sfq_prior_counts_words(int level, uint64_t* qlt_words, uint64_t* rec_words)
 int sfq_get_prior_counts(sfq_ctx* ctx, int level, uint32_t* d_qlt, uint32_t* d_rec) {
     if (!ctx || !d_qlt || !d_rec) return fail(ctx, SFQ_E_ARG, "null argument");
     uint64_t nq, nr; sfq_prior_counts_words(level, &nq, &nr);
-    if (!ctx->hist.p || ctx->hist.cap < nq * 4 || !ctx->hcnt.p) return fail(ctx, SFQ_E_ARG, "no counts (sfq_count_priors comes first)");
+    if (!ctx->counts.valid || !ctx->hist.p || ctx->counts.q_rows != (u32)(nq / 64)) return fail(ctx, SFQ_E_ARG, "no counts for level %d (sfq_count_priors comes first)", level);
     HIPC(hipSetDevice(ctx->dev));
     HIPC(hipMemcpyAsync(d_qlt, ctx->hist.p, nq * 4, hipMemcpyDeviceToDevice, ctx->st));
-    HIPC(hipMemcpyAsync(d_rec, ctx->hcnt.p, nr * 4, hipMemcpyDeviceToDevice, ctx->st));
+    // (counted for adaptive tables: there is no header sample -- zeros, so that the ranks' sums stay sums)
+    if (ctx->counts.rec && ctx->hcnt.p) HIPC(hipMemcpyAsync(d_rec, ctx->hcnt.p, nr * 4, hipMemcpyDeviceToDevice, ctx->st));
+    else HIPC(hipMemsetAsync(d_rec, 0, nr * 4, ctx->st));
     HIPC(hipStreamSynchronize(ctx->st));
     return SFQ_OK;
 }
@@ -1281,11 +1328,14 @@ int sfq_set_prior_counts(sfq_ctx* ctx, int level, const uint32_t* d_qlt, const u
     uint64_t nq, nr; sfq_prior_counts_words(level, &nq, &nr);
     HIPC(hipSetDevice(ctx->dev));
     int rc;
+    const bool own_rec = ctx->counts.valid && ctx->counts.q_rows == (u32)(nq / 64) ? ctx->counts.rec : true;     // (sums of counts taken for adaptive tables stay "no header sample")
+    ctx->counts.valid = false;
     if ((rc = ensure_prior_buffers(ctx, (u32)(nq / 64)))) return rc;
     if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
     HIPC(hipMemcpyAsync(ctx->hist.p, d_qlt, nq * 4, hipMemcpyDeviceToDevice, ctx->st));
     HIPC(hipMemcpyAsync(ctx->hcnt.p, d_rec, nr * 4, hipMemcpyDeviceToDevice, ctx->st));
     HIPC(hipStreamSynchronize(ctx->st));
+    ctx->counts.valid = true; ctx->counts.q_rows = (u32)(nq / 64); ctx->counts.rec = own_rec;
     return SFQ_OK;
 }
 int sfq_encode_blocks_host(sfq_ctx* ctx, const uint8_t* h_fastq, uint64_t nbytes, const sfq_params* params,
@@ -1411,7 +1461,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if (!hb || !bso) return fail(ctx, SFQ_E_NOMEM, "decode: host scratch");
     u64 run[SFQ_NSTREAMS];
     for (int s = 0; s < SFQ_NSTREAMS; s++) run[s] = stream_offset[s];
-    u64 nrec = 0; u32 block_reads = h_blocks[0].n_records; int g_bits = 0;
+    u64 nrec = 0; u32 block_reads = h_blocks[0].n_records; int g_bits = 0, g_bits_min = 64;
     for (u32 b = 0; b < nblocks; b++) {
         const sfq_block_info& bi = h_blocks[b];
         BlockDesc& d = hb[b];
@@ -1424,7 +1474,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (bi.gen_bits < 2 || bi.gen_bits > 26) return fail(ctx, SFQ_E_ARG, "block %u: gen_bits %u", b, bi.gen_bits);
         d.rec0 = nrec; d.nrec = bi.n_records; d.llen = bi.llen; d.solid = bi.solid; d.two_id = bi.two_id;
         d.gen_bits = bi.gen_bits; d.n_byte = bi.n_byte; d.first_hdr_off = bi.first_hdr_off; d.first_hdr_len = bi.first_hdr_len;
-        g_bits = std::max<int>(g_bits, bi.gen_bits);
+        g_bits = std::max<int>(g_bits, bi.gen_bits); g_bits_min = std::min<int>(g_bits_min, bi.gen_bits);
         for (int s = 0; s < SFQ_NSTREAMS; s++) {
             if (bi.size[s] > 0xFFFFFFFFull) return fail(ctx, SFQ_E_UNSUPPORTED, "block %u: stream %s has %llu bytes (the kernels take streams below 4 GiB)", b, sfq_stream_name(s), (unsigned long long)bi.size[s]);
             d.size[s] = (u32)bi.size[s]; bso[(size_t)b * SFQ_NSTREAMS + s] = run[s]; run[s] += bi.size[s];
@@ -1449,6 +1499,20 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         chain_reads = (u32)v;
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         gen_on = (u32)v & 1u; rec_chains = ((u32)v >> 1) & 1u;
+        const bool deltas = ((u32)v >> 2) & 1u;              // sizes as zigzag differences to the entry before (round 4; version-8 archives of round 3: plain)
+        if (v >> 3) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        u64 lprev = 0;                                        // the running value of the list being read
+        auto get_size = [&](u64& out) -> bool {
+            if (!get_v(cb, cn, cp, out)) return false;
+            if (deltas) {
+                if (out > 0x1FFFFFFFFull) return false;
+                const i64 d = (i64)(out >> 1) ^ -(i64)(out & 1);
+                const i64 x = (i64)lprev + d;
+                if (x < 0 || x > 0xFFFFFFFFll) return false;
+                out = (u64)x; lprev = out;
+            }
+            return out <= 0xFFFFFFFFull;
+        };
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
         cpb = (block_reads + chain_reads - 1) / chain_reads;
@@ -1468,8 +1532,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if (!get_v(cb, cn, cp, v) || v != wantr || wantr > 0x7FFFFFFFull) return false;
             nsub = (u32)wantr;
             h_rsz.resize(nsub); h_rhb.resize(nsub);
-            for (u32 c = 0; c < nsub; c++) { if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return false; h_rsz[c] = (u32)v; }
-            for (u32 c = 0; c < nsub; c++) { if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return false; h_rhb[c] = (u32)v; }
+            lprev = 0;
+            for (u32 c = 0; c < nsub; c++) { if (!get_size(v)) return false; h_rsz[c] = (u32)v; }
+            lprev = 0;
+            for (u32 c = 0; c < nsub; c++) { if (!get_size(v)) return false; h_rhb[c] = (u32)v; }
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
                 for (u32 j = 0; j < rcpb && (u64)b * rcpb + j < nsub; j++) sum += h_rsz[(size_t)b * rcpb + j];
@@ -1480,11 +1546,12 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         for (int k = 0; k < 2; k++) {
             const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
             u64 at = stream_offset[sid];
+            lprev = 0;
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
                 for (u32 j = 0; j < cpb && (u64)b * cpb + j < nchains; j++) {
                     const size_t c = (size_t)k * nchains + (size_t)b * cpb + j;
-                    if (!get_v(cb, cn, cp, v) || v > 0xFFFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+                    if (!get_size(v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
                     h_csz[c] = (u32)v; h_coff[c] = at; at += v; sum += v;
                 }
                 if (sum != h_blocks[b].size[sid]) return fail(ctx, SFQ_E_CORRUPT, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid));
@@ -1681,7 +1748,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         launch_fill_u32((u32*)ctx->tab.g_tab.p, (u64)da.m.nbatch << g_bits, 0x03030303u, st_gen);
-        if (wave_dec && g_bits >= 6) launch_gen_decode_w(da, st_gen); else launch_gen_decode_l(da, st_gen);
+        // (the wave kernel's 64-entry window assumes every block of the call has the context bits it was picked for: an index
+        //  that mixes them -- no encoder writes one -- goes to the lane kernel, which follows each block's own)
+        if (wave_dec && g_bits_min >= 6 && g_bits_min == g_bits) launch_gen_decode_w(da, st_gen); else launch_gen_decode_l(da, st_gen);
     }
     }
     HIPC(hipEventRecord(ctx->ev[4], st_gen));

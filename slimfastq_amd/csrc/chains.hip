@@ -1079,40 +1079,10 @@ struct RecFastLds {
     u8  ctype[RF_NF][64];
     u8  map[PR_REC_ROWS];                // row -> LDS slot, 0xFF = not staged
 };
-// numberwang (recs.cpp:192-262) over text[buf][off ..][lane]
+// a field's type and value (dev_rec.h field_type) over text[buf][off ..][lane]
 template <typename LT>
 __device__ __forceinline__ u32 nw_lds(const LT& L, u32 buf, u32 lane, u32 off, int len, u64& num, u32 pctype) {
-    int i = 0;
-    const bool has_z = L.text[buf][off][lane] == '0';
-    if (has_z) if (L.text[buf][off + (++i)][lane] == '0') return ST_STR;
-    u32 caps = 0;
-    num = 0;
-    while (pctype != 2) {
-        if (i >= len) return has_z ? ST_DGT_Z : ST_DGT;
-        const u32 c = L.text[buf][off + i][lane];
-        if (isdig(c)) {
-            const u64 tnum = (num << 3) + (num << 1) + c - '0';
-            i++;
-            if (tnum < num) return ST_STR;
-            num = tnum;
-            continue;
-        }
-        if ((c | 0x20) < 'a' || (c | 0x20) > 'f') return ST_STR;
-        caps = 1 + (c < 'a');
-        i = has_z;
-        num = 0;
-        break;
-    }
-    if (len > 16) return ST_STR;
-    for (; i < len; i++) {
-        const u32 c = L.text[buf][off + i][lane]; u32 nib;
-        if (isdig(c)) nib = c - '0';
-        else if (c >= 'a' && c <= 'f') { if (caps == 2) return ST_STR; caps = 1; nib = 10 + (c - 'a'); }
-        else if (c >= 'A' && c <= 'F') { if (caps == 1) return ST_STR; caps = 2; nib = 10 + (c - 'A'); }
-        else return ST_STR;
-        num = (num << 4) + nib;
-    }
-    return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
+    return field_type([&](u32 j) -> u32 { return L.text[buf][off + j][lane]; }, (u32)len, num, pctype);
 }
 template <typename LT>
 struct RecFastEnc {

@@ -169,6 +169,30 @@ void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line
     hipLaunchKernelGGL(k_write_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_base, line_off, aligned, exc_flag);
 }
 
+// A fingerprint of a device-resident text: 65 536 sixteen-byte pieces spread evenly over it, each hashed with its number, the
+// hashes XORed (api.cpp: is the text at this address still the one sfq_count_priors framed?).  out[0] starts at zero.
+__global__ __launch_bounds__(256) void k_text_fingerprint(const u8* __restrict__ fq, u64 n, u64* out) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const u64 span = n > 16 ? n - 16 : 0;
+    const u64 pos = span >= 65535ull * 16 ? (u64)i * (span / 65535ull) : (u64)i * 16;
+    u64 h = 0;
+    if (pos + 16 <= n) {
+        const u32* q = reinterpret_cast<const u32*>(fq + pos);             // (global loads need no alignment on gfx9)
+        u32 x = q[0] * 0x9E3779B1u;
+        x = (x ^ q[1]) * 0x85EBCA77u; x = (x ^ q[2]) * 0xC2B2AE3Du; x = (x ^ q[3]) * 0x27D4EB2Fu;
+        h = ((u64)x << 32 | (x ^ (x >> 15))) * (2ull * i + 1);
+    } else if (pos < n) {
+        for (u64 p = pos; p < n; p++) h = (h ^ fq[p]) * 0x100000001B3ull;
+        h *= 2ull * i + 1;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) h ^= __shfl_xor(h, d, 64);
+    if ((threadIdx.x & 63) == 0 && h) atomicXor((unsigned long long*)out, (unsigned long long)h);
+}
+void launch_text_fingerprint(const u8* fq, u64 n, u64* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_text_fingerprint, dim3(256), dim3(256), 0, st, fq, n, out);
+}
+
 // ---- generic exclusive scan u32 -> u64 -------------------------------------------------------------
 #define SCAN_TILE 1024u
 __global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* in, u64 n, u64* sums) {

@@ -134,6 +134,7 @@ void launch_over_sizes(const u32* rec_map, const u32* rsize, u64 n_kept, const u
 void launch_gather_u64(const u64* src, const u32* idx, u64 n, u64* dst, hipStream_t st);
 void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
                           u64 nbytes, i32 level, i32 gen_bits_req, hipStream_t st);
+void launch_text_fingerprint(const u8* fq, u64 n, u64* out /* zeroed */, hipStream_t st);
 #define FRAME_CHUNK 16384u
 
 // generic exclusive scan u32 -> u64 (out has n+1 entries)

@@ -429,39 +429,9 @@ struct HdrRegs {
     u32 c0, c1;
     __device__ __forceinline__ u32 at(u32 pos) const { return pos < 64 ? rl(c0, pos) : rl(c1, pos - 64); }   // pos uniform
 };
-// numberwang (recs.cpp:192-262) over a field [off, off+len) of such a header
+// a field's type and value (dev_rec.h field_type) over a field [off, off+len) of such a header
 __device__ __forceinline__ u32 nw_lanes(const HdrRegs& h, u32 off, int len, u64& num, u32 pctype) {
-    int i = 0;
-    const bool has_z = h.at(off) == '0';
-    if (has_z) if (h.at(off + (++i)) == '0') return ST_STR;
-    u32 caps = 0;
-    num = 0;
-    while (pctype != 2) {
-        if (i >= len) return has_z ? ST_DGT_Z : ST_DGT;
-        const u32 c = h.at(off + i);
-        if (isdig(c)) {
-            const u64 tnum = (num << 3) + (num << 1) + c - '0';
-            i++;
-            if (tnum < num) return ST_STR;
-            num = tnum;
-            continue;
-        }
-        if ((c | 0x20) < 'a' || (c | 0x20) > 'f') return ST_STR;
-        caps = 1 + (c < 'a');
-        i = has_z;
-        num = 0;
-        break;
-    }
-    if (len > 16) return ST_STR;
-    for (; i < len; i++) {
-        const u32 c = h.at(off + i); u32 nib;
-        if (isdig(c)) nib = c - '0';
-        else if (c >= 'a' && c <= 'f') { if (caps == 2) return ST_STR; caps = 1; nib = 10 + (c - 'a'); }
-        else if (c >= 'A' && c <= 'F') { if (caps == 1) return ST_STR; caps = 2; nib = 10 + (c - 'A'); }
-        else return ST_STR;
-        num = (num << 4) + nib;
-    }
-    return caps == 2 ? (has_z ? ST_HGTC_Z : ST_HGTC) : (has_z ? ST_HGT_Z : ST_HGT);
+    return field_type([&](u32 j) -> u32 { return h.at(off + j); }, (u32)len, num, pctype);
 }
 // bits [a, b) of a 128-bit mask, as two 64-bit halves (per lane)
 __device__ __forceinline__ void mask128(u32 a, u32 b, u64& m0, u64& m1) {

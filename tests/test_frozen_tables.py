@@ -391,3 +391,61 @@ def test_frozen_fuzz_structurally_hostile_inputs(ctx, seed):
         what = "fuzz seed %d rep %d: %d records, level %d, blocks of %d, chains of %d" % (seed, rep, nrec, level, br, cr)
         enc = check_against_oracle(ctx, fq, level, br=br, cr=cr, step=1, what=what)
         assert ctx.decode_host(enc, level=level, out_cap=2 * len(fq) + 4096) == fq, what
+
+
+def test_installed_counts_are_tracked_and_a_refilled_buffer_is_framed_again(ctx):
+    """(a) SFQ_PRIOR_COUNTS codes only from counts that sfq_count_priors / sfq_set_prior_counts left -- what an
+    ordinary encode's own sample leaves in the same buffers is not "installed", nor are counts of another level; (b) counts taken for
+    ADAPTIVE tables hold no header sample: they travel as zeros, serve an adaptive encode and are refused by a frozen one;
+    (c) the line index sfq_count_priors leaves for the encode that follows is reused only while the TEXT at that address is the
+    one it indexed: a buffer refilled in place (same pointer, same size) is framed again."""
+    import torch
+    fq = capi.synth_fastq(6000, 150, seed=91)
+    d = torch.from_numpy(np.frombuffer(fq, np.uint8).copy()).cuda()
+    out = torch.empty(capi.lib().sfq_encode_bound(len(fq)), dtype=torch.uint8, device="cuda")
+    nq, nr = capi.Context.prior_counts_words(3)
+    q = torch.empty(nq, dtype=torch.int32, device="cuda"); r = torch.empty(nr, dtype=torch.int32, device="cuda")
+    kw = dict(level=3, block_reads=500)
+    # (a)
+    ctx.count_priors(d.data_ptr(), len(fq), prior_step=1, tables=capi.TABLES_FROZEN, **kw)
+    ctx.get_prior_counts(3, q.data_ptr(), r.data_ptr())
+    assert int(r.sum().item()) > 0
+    ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, **kw)
+    ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, **kw)   # an ordinary sample
+    with pytest.raises(capi.SfqError):
+        ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, **kw)
+    with pytest.raises(capi.SfqError):
+        ctx.get_prior_counts(3, q.data_ptr(), r.data_ptr())
+    ctx.set_prior_counts(3, q.data_ptr(), r.data_ptr())
+    with pytest.raises(capi.SfqError):                        # level 1 has 4096 quality contexts: these counts are not its
+        ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), level=1, block_reads=500, prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN)
+    # (b)
+    ctx.count_priors(d.data_ptr(), len(fq), prior_step=1, tables=capi.TABLES_ADAPTIVE, **kw)
+    ctx.get_prior_counts(3, q.data_ptr(), r.data_ptr())
+    assert int(r.abs().sum().item()) == 0 and int(q.sum().item()) > 0
+    ctx.set_prior_counts(3, q.data_ptr(), r.data_ptr())
+    with pytest.raises(capi.SfqError):
+        ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, **kw)
+    res = ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_ADAPTIVE, **kw)
+    back = torch.empty(len(fq) + 4096, dtype=torch.uint8, device="cuda")
+    got, _ = ctx.decode_device(ctx.index(res.n_blocks), ctx.first_headers(res.first_hdr_bytes), out.data_ptr(), list(res.stream_offset), back.data_ptr(), back.numel(),
+                               prior=ctx.prior(), level=3)
+    assert got == len(fq) and bytes(back[:got].cpu().numpy()) == fq
+    # (c) the same bytes in another record structure: two records of 150 bp become one of 300
+    lines = fq.split(b"\n")
+    other = b"\n".join(lines[0:1] + [lines[1] + lines[5]] + lines[2:3] + [lines[3] + lines[7]] + lines[8:])
+    pad = len(fq) - len(other)
+    assert 0 < pad < 200
+    hdr = lines[0] + b"x" * pad                       # (the first header grows by what the dropped lines took: same size)
+    other = hdr + other[len(lines[0]):]
+    assert len(other) == len(fq)
+    ctx.count_priors(d.data_ptr(), len(fq), prior_step=1, tables=capi.TABLES_FROZEN, **kw)
+    ctx.get_prior_counts(3, q.data_ptr(), r.data_ptr())
+    d.copy_(torch.from_numpy(np.frombuffer(other, np.uint8).copy()))
+    torch.cuda.synchronize()
+    ctx.set_prior_counts(3, q.data_ptr(), r.data_ptr())
+    res = ctx.encode_device(d.data_ptr(), len(fq), out.data_ptr(), out.numel(), prior_step=capi.PRIOR_COUNTS, tables=capi.TABLES_FROZEN, **kw)
+    assert res.n_records == 5999
+    got, _ = ctx.decode_device(ctx.index(res.n_blocks), ctx.first_headers(res.first_hdr_bytes), out.data_ptr(), list(res.stream_offset), back.data_ptr(), back.numel(),
+                               prior=ctx.prior(), level=3, chains=ctx.chains(), rec_prior=ctx.rec_prior())
+    assert got == len(other) and bytes(back[:got].cpu().numpy()) == other

@@ -839,6 +839,12 @@ def test_two_ranks_compress_one_file_into_one_archive(tmp_path):
     assert m and int(m.group(1)) == 4, p.stderr[-400:]
     subprocess.check_call([_cli(), "-d", "-f", str(sfq), "-u", str(back), "-O"])
     assert back.read_bytes() == fq
+    # adaptive tables (-A) on two ranks (the summed counts then hold no header sample, and none is needed)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29535", "-m", "slimfastq_amd.dist_compress", str(src), str(sfq), "-B", "700", "-A"],
+                   check=True, cwd=root, env=env, timeout=600)
+    subprocess.check_call([_cli(), "-d", "-f", str(sfq), "-u", str(back), "-O"])
+    assert back.read_bytes() == fq
     # one rank: a plain one-segment archive
     subprocess.run([sys.executable, "-m", "slimfastq_amd.dist_compress", str(src), str(tmp_path / "one.sfq")], check=True, cwd=root, env=env, timeout=600)
     p = subprocess.run([_cli(), "-d", "-f", str(tmp_path / "one.sfq")], capture_output=True, check=True)

@@ -106,14 +106,21 @@ def _vints(blob: bytes):
 
 
 def unpack_chains(blob: bytes):
-    """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp."""
+    """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp.
+    flags bit 2: every list of sizes is stored as zigzag differences to the entry before it."""
     v = _vints(blob)
     cr, flags, n = v[0], v[1], v[2]
-    out = {"chain_reads": cr, "flags": flags, "qlt": np.array(v[3:3 + n], np.uint32), "gen": np.array(v[3 + n:3 + 2 * n], np.uint32)}
+
+    def sizes(raw):
+        if not flags & 4:
+            return np.array(raw, np.uint32)
+        d = np.array([(x >> 1) ^ -(x & 1) for x in raw], np.int64)
+        return np.cumsum(d).astype(np.uint32)
+    out = {"chain_reads": cr, "flags": flags, "qlt": sizes(v[3:3 + n]), "gen": sizes(v[3 + n:3 + 2 * n])}
     p = 3 + 2 * n
     if flags & 2:
         rcr, m = v[p], v[p + 1]; p += 2
-        out.update(rec_chain_reads=rcr, rec=np.array(v[p:p + m], np.uint32), rec_hdr_bytes=np.array(v[p + m:p + 2 * m], np.uint32))
+        out.update(rec_chain_reads=rcr, rec=sizes(v[p:p + m]), rec_hdr_bytes=sizes(v[p + m:p + 2 * m]))
         p += 2 * m
     assert p == len(v)
     return out
