@@ -375,14 +375,15 @@ u32 gen_bounds(u32 nblocks, u32* bound) {
 }
 int default_chain_reads(u64 nrec, u64 nbytes) {
     // Chains are the unit of parallelism (64 per wavefront) and a lane's walk through its chain is the floor of a call's time, so
-    // the COUNT of chains is held, not their length: about 224 k of them -- the 262 144 lanes the quality chains' image kernel
-    // puts on the chip in one round (a workgroup of 1024 per CU), less a margin so that a last partial round never forms --
+    // the COUNT of chains is held, not their length: about 205 k of them -- 200 workgroups of the quality chains' image kernel
+    // (1024 lanes, one per CU, which its registers fill: the other models' kernels get their work done on the 56 CUs it leaves;
+    // 229 workgroups made the header steps take 10.1 ms instead of 7.3 and the 3.7 GB call 17.1 ms instead of 15.8) --
     // down to chains of 4 KiB of text (12 records of 150 bp), below which a chain's flush and index entry start to show
     // (round 4 size sweep, 0.25 / 0.5 / 1 / 2 / 3.7 GB of 150 bp reads: 12 / 12 / 12 / 24 / 49 records per chain; the streams of the
     //  1 GB prefix are 0.14 % larger at 12 records than at 49).  Round 3 floored a chain at 16 KiB: a 740 MB call then had 45 k
     //  chains -- a sixth of the chip -- each as long as a 3.7 GB call's, and took longer than that call.
     const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
-    u64 cr = std::max<u64>(1, (nrec + 229375) / 229376);
+    u64 cr = std::max<u64>(1, (nrec + 204799) / 204800);
     cr = std::max<u64>(cr, (4096 + per_rec - 1) / per_rec);
     return (int)std::min<u64>(cr, 4096);
 }
@@ -1695,14 +1696,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
         if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
         if ((rc = build_qesc(ctx, st))) return rc;
-        if ((rc = reserve(ctx, ctx->qdec, (size_t)q_rows * 72 * 2))) return rc;                 // chains.hip QDEC_ROW
+        if ((rc = reserve(ctx, ctx->qdec, (size_t)q_rows * 72 * 2 + 64))) return rc;            // chains.hip QDEC_ROW
         launch_qlt_frozen_rows((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->qrows.p, (u16*)ctx->qdec.p, st);
         ca.qrows = (const u32*)ctx->qrows.p; ca.qesc = (const u32*)ctx->qesc.p; ca.qdec = (const u16*)ctx->qdec.p;
         ca.q_hot = 0; ca.q_rows = q_rows;
-        // the rows that carry the most weight live in LDS (sfq_params.lds_rows; chains.hip launch_hot_rows_dec)
-        const u32 want_hot = (p.lds_rows == SFQ_LDS_ROWS_NONE) ? 0u : std::min<u32>(p.lds_rows, 1024u);
+        // the coarse lists of the contexts that carry the most weight live in LDS (chains.hip launch_hot_rows_dec); automatic where the
+        // call has chains for a 1024-lane workgroup on most CUs (as the encoder's image); sfq_params.lds_rows: a number, or none
+        const u32 want_hot = p.lds_rows == SFQ_LDS_ROWS_NONE ? 0u : p.lds_rows ? std::min<u32>(p.lds_rows, hot_rows_dec_max())
+                             : nchains >= 150000u ? hot_rows_dec_max() : 0u;
         if (want_hot) {
-            const size_t img_bytes = (size_t)q_rows / 4 + (size_t)want_hot * 112 + 64;
+            const size_t img_bytes = (size_t)q_rows / 4 + (size_t)want_hot * 16 + 64;       // chains.hip QHD_ROW_U16
             if ((rc = reserve(ctx, ctx->qw, img_bytes + (size_t)q_rows * 4 + 256))) return rc;
             u8* img = (u8*)ctx->qw.p; u32* info = (u32*)(img + ((img_bytes + 15) & ~(size_t)15)); u32* ctot = info + 16;
             launch_hot_rows_dec((const u32*)ctx->rows66.p, (const u16*)ctx->qdec.p, q_rows, want_hot, ctot, img, info, st);
@@ -1711,6 +1714,11 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));
+#ifdef SFQ_EXP_QDEC_ALONE          /* scratch experiments only: the quality decoder by itself, timed; the call then fails */
+        HIPC(hipStreamSynchronize(st));
+        fprintf(stderr, "EXP qdec alone: %.3f ms\n", ev_ms(ctx->ev[2], ctx->ev[3]));
+        return fail(ctx, SFQ_E_ARG, "experiment build");
+#endif
         HIPC(hipEventRecord(ctx->ev[7], st_gen));
         // bases: generation by generation -- a generation's rows come from the counts of everything decoded before it
         ca.csz = (u32*)ctx->csz.p + nchains; ca.coff = (const u64*)ctx->coff.p + nchains;

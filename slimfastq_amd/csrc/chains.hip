@@ -29,9 +29,17 @@
 // 65536 - sum g goes to the largest g (the first of them).  Entry s = cum(g[0..s)) | g[s] << 16  (g <= 65473).
 // A context the sample never saw has the uniform row (g = 1024).  Rows are indexed by the context itself: q_rows x 256 B,
 // of which a file touches a few thousand rows (L2-resident).
-// qdec (decode only, may be null): [q_rows][72] u16 -- the cum of every 8th symbol (8 of them), then the cum of all 64: a
-// decoder finds a symbol with two 16-byte fetches (the eighth of the row, then the symbol in it; QDEC_ROW below)
+// qdec (decode only, may be null): the decoder's form of a row, QDEC_ROW u16 -- the cum of every 8th symbol (8 of them: one
+// 16-byte piece), then the cums of symbols 1 .. 64 (cum[64], the row's total 65536, is stored as 0): group k = the sixteen bytes
+// that hold cum[8 k + 1 .. 8 k + 8].  A decoder finds a symbol with two 16-byte fetches -- the eighth of the row, then the
+// symbol in it -- and has its cum and the NEXT one in hand: the group's first cum is the coarse entry it has just found.
 #define QDEC_ROW 72u
+// lane s stores cum[s] where the decoder's form wants it; lane 63 also the total behind the last symbol (65536 = 0)
+__device__ __forceinline__ void qdec_store(u16* row, u32 s, u32 cum) {
+    if (s) row[8 + s - 1] = (u16)cum;
+    if ((s & 7u) == 0) row[s >> 3] = (u16)cum;
+    if (s == 63) row[8 + 63] = 0;
+}
 __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ qrows, u16* __restrict__ qdec) {
     const u32 lane = threadIdx.x & 63;
     const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -40,10 +48,7 @@ __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__
     const u32 slot = r[lane], iend = r[65];
     if (iend == 0) {
         qrows[(size_t)ctx * 64 + lane] = (lane << 10) | (1024u << 16);
-        if (qdec) {
-            qdec[(size_t)ctx * QDEC_ROW + 8 + lane] = (u16)(lane << 10);
-            if ((lane & 7) == 0) qdec[(size_t)ctx * QDEC_ROW + (lane >> 3)] = (u16)(lane << 10);
-        }
+        if (qdec) qdec_store(qdec + (size_t)ctx * QDEC_ROW, lane, lane << 10);
         return;
     }
     // slot order -> symbol order: lane j sends its frequency to lane sym(j) (lanes >= iend hold no slot: they send 0 to themselves)
@@ -66,10 +71,7 @@ __global__ __launch_bounds__(256) void k_qlt_frozen_rows(const u32* __restrict__
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
     qrows[(size_t)ctx * 64 + lane] = (incl - g) | (g << 16);
-    if (qdec) {
-        qdec[(size_t)ctx * QDEC_ROW + 8 + lane] = (u16)(incl - g);
-        if ((lane & 7) == 0) qdec[(size_t)ctx * QDEC_ROW + (lane >> 3)] = (u16)(incl - g);
-    }
+    if (qdec) qdec_store(qdec + (size_t)ctx * QDEC_ROW, lane, incl - g);
 }
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec, hipStream_t st) {
     hipLaunchKernelGGL(k_qlt_frozen_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, qrows, qdec);
@@ -176,34 +178,38 @@ void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q
                        reinterpret_cast<u16*>(img + QH_MAP_BYTES(q_rows)));
 }
 
-// The decoder's image: the same map; a staged row = the decoder's form of the row (QDEC_ROW below) cut to QH_SYMS symbols --
-// the 8 coarse cums, then the cums of symbols 0 .. QH_SYMS - 1: QHD_ROW_U16 u16, 16-byte pieces.  A decoder has no sample
-// to rank by: it stages the contexts whose prior rows carry the most weight (rows66 total; the choice is free -- staging
-// does not show in the text).  A symbol's two dependent 16-byte fetches (the eighth of the row, then the symbol in it)
-// come from LDS instead of L2: the round trip the lane's serial walk is made of.
-#define QHD_ROW_U16 (8u + QH_SYMS)
+// The decoder's image: the same map; a staged row = the COARSE list of the decoder's form of the row (QDEC_ROW above: the cums
+// of symbols 0, 8, .., 56 -- sixteen bytes).  Round 4: alone on the chip the quality decoder takes the same 10.5-12 ms with 3 or
+// with 6 waves a SIMD and with its rows in L2 or in LDS -- what it runs at is the rate at which ONE per-CU unit serves sixteen
+// bytes to each of a wave's 64 lanes from 64 different places: ~100 cycles a wave either through the vector memory path or out
+// of LDS (bank conflicts), and a symbol needs two such reads.  So the two reads go to the two units: the coarse list of (nearly)
+// every context the prior names out of LDS -- up to 6000 lists of sixteen bytes and the map are 110 KiB (9000 fit, and made the call slower: 23.9 ms against 20.0 -- the other decoders' workgroups then find no LDS beside it) --, the group of eight cums
+// from the table in L2.  The contexts the prior gives the most weight are staged first (the choice is free: staging does not
+// show in the text).
+#define QHD_ROW_U16 8u
+#define QHD_MAX_ROWS 6000u
 __global__ __launch_bounds__(256) void k_hot_totals_prior(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ ctot) {
     const u32 ctx = blockIdx.x * 256 + threadIdx.x;
     if (ctx >= q_rows) return;
     const u32 iend = rows66[(size_t)ctx * 66 + 65];
-    ctot[ctx] = (iend != 0 && iend <= QH_SYMS) ? rows66[(size_t)ctx * 66 + 64] + 1u : 0u;
+    ctot[ctx] = iend != 0 ? rows66[(size_t)ctx * 66 + 64] + 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_hot_image_dec(const uint2* __restrict__ map, const u16* __restrict__ qdec, u32 q_rows, u16* __restrict__ rows) {
-    const u32 lane = threadIdx.x & 63;
-    const u32 ctx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u32 ctx = blockIdx.x * 256 + threadIdx.x;
     if (ctx >= q_rows) return;
     const uint2 mr = map[ctx >> 5];
     const u32 bit = 1u << (ctx & 31u);
     if (!(mr.x & bit)) return;
     const u32 slot = mr.y + (u32)__popc(mr.x & (bit - 1u));
-    if (lane < QHD_ROW_U16) rows[(size_t)slot * QHD_ROW_U16 + lane] = qdec[(size_t)ctx * 72u + lane];          // (QDEC_ROW: 8 coarse, then the symbols in order)
+    *reinterpret_cast<uint4*>(rows + (size_t)slot * QHD_ROW_U16) = *reinterpret_cast<const uint4*>(qdec + (size_t)ctx * QDEC_ROW);
 }
 void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 want, u32* ctot, u8* img, u32* info, hipStream_t st) {
     hipLaunchKernelGGL(k_hot_totals_prior, dim3((q_rows + 255) / 256), dim3(256), 0, st, rows66, q_rows, ctot);
     hipLaunchKernelGGL(k_hot_select, dim3(1), dim3(1024), 0, st, (const u32*)ctot, q_rows, want, reinterpret_cast<uint2*>(img), info);
-    hipLaunchKernelGGL(k_hot_image_dec, dim3((q_rows + 3) / 4), dim3(256), 0, st, reinterpret_cast<const uint2*>(img), qdec, q_rows,
+    hipLaunchKernelGGL(k_hot_image_dec, dim3((q_rows + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint2*>(img), qdec, q_rows,
                        reinterpret_cast<u16*>(img + QH_MAP_BYTES(q_rows)));
 }
+u32 hot_rows_dec_max(void) { return QHD_MAX_ROWS; }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
 struct ChainPos { u32 b; u64 r0; u32 nrec; };
@@ -431,15 +437,115 @@ void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st) {
 }
 
 // =========================================================================================================
-// quality decode: one chain per lane; the symbol is found by a binary search over the row's cumulative entries
+// quality decode: one chain per lane
 // =========================================================================================================
-__device__ __forceinline__ void unpack8(const uint4& v, u32 (&o)[8]) {          // eight u16
-    o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16;
-    o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
+// Round 4.  The whole decode call runs at the chip's instruction-issue limit (10.8e9 wave instructions at ~4 cycles each on
+// 1024 SIMDs = the 22 ms it took; profiles/r03z_pmc_summary.txt), and this kernel was half of them: 179 VALU + 41 SALU a symbol.
+// What a symbol costs now:
+//   * GetFreq's divide (coder.hpp:85) is a float reciprocal and ONE exact fix-up (div_exact below) instead of the compiler's
+//     32-bit division sequence;
+//   * the symbol search is two binary searches over packed u16 pairs -- three compares and five selects in the coarse list,
+//     three compares and six selects in the group, the last select leaving (cum, next) in one dword (QDEC_ROW above);
+//   * the coder keeps `code` in 32 bits (code < range while the stream is sound; what is not is reported) and renormalises
+//     without branches: two masked steps, a loop only behind them (a symbol of probability below 2^-16);
+//   * stream bytes come through a 64-bit shift register topped up four bytes at a time, the next four always in flight.
+// floor(code / r), 256 <= r < 65536: the estimate is within one of the quotient (relative error of the conversion, the
+// reciprocal and the product: 2^-22; quotient < 2^24), the remainder says which way
+__device__ __forceinline__ u32 div_exact(u32 code, u32 r) {
+    u32 q = (u32)((float)code * __builtin_amdgcn_rcpf((float)r));
+    const i32 rem = (i32)(code - q * r);                    // (modulo 2^32: |code - q r| < 2 r)
+    q -= rem < 0 ? 1u : 0u;
+    q += rem >= (i32)r ? 1u : 0u;
+    return q;
 }
+struct LaneDecQ {
+    u64 low; u32 code, range;
+    u64 cur; u32 nxt, nsh;      // stream bytes ahead: `have` of them in cur (the next one in its low byte), then the dword nxt >> nsh
+    u32 have, fpos;             // fpos: the stream position behind nxt's bytes
+    const u8* p; u32 n, nsafe; u32 err;
+    // Four stream bytes from position at, zeros past the end (FilerLoad::get returns 0 there, filer.hpp:94-97): no branch and ONE
+    // load that nothing touches until the bytes are wanted -- the address is held inside the stream (nsafe = n - 4), and what
+    // then lies before `at` is shifted out (by sh bits) where the dword is USED.  (Two paths -- a dword where it fits, bytes at the
+    // tail -- or the shift next to the load made the wave wait for the load where it was issued: a round trip to L2 on every symbol.)
+    __device__ __forceinline__ void load4(u32 at, u32& raw, u32& sh) const {
+        const u32 at_c = at < nsafe ? at : nsafe;
+        const u32 ov = at - at_c;
+        raw = *reinterpret_cast<const u32*>(p + at_c);                               // (no alignment needed on gfx9)
+        sh = 8u * (ov < 4u ? ov : 4u);
+    }
+    static __device__ __forceinline__ u32 take(u32 raw, u32 sh) { return (u32)((u64)raw >> sh); }
+    __device__ __forceinline__ void init(const u8* ptr, u32 len, const u8* spare /* four readable bytes somewhere */) {
+        p = ptr; n = len; err = 0; low = 0; range = 0xFFFFFFFFu;
+        u32 w0, w1;
+        if (len >= 4) {
+            nsafe = len - 4;
+            u32 r0, s0, r1, s1;
+            load4(0, r0, s0); load4(4, r1, s1); load4(8, nxt, nsh);
+            w0 = take(r0, s0); w1 = take(r1, s1);
+        } else {                                             // a stream of under four bytes: taken whole, nothing of it is loaded later
+            w0 = 0;
+            for (u32 i = 0; i < len; i++) w0 |= (u32)ptr[i] << (8 * i);
+            w1 = 0; p = spare; n = 0; nsafe = 0; nxt = 0; nsh = 32;        // (load4(at >= 4) of this: zeros)
+        }
+        code = __builtin_bswap32(w0);                        // the four elided zero bytes, then four real ones (dev_chain.h)
+        cur = (u64)w1; have = 4; fpos = 12;
+    }
+    // at least four bytes in cur: once per coded symbol, ahead of its (at most two, see renorm) masked steps
+    __device__ __forceinline__ void top_up() {
+        if (__any(have <= 4u)) {
+            if (have <= 4u) {
+                cur |= (u64)take(nxt, nsh) << (8u * have);
+                have += 4u;
+                load4(fpos, nxt, nsh); fpos += 4u;
+            }
+        }
+    }
+    __device__ __forceinline__ void step() {                 // one round of coder.hpp:93-100, where range < TOP
+        const u32 nm = range < RC_TOP ? ~0u : 0u;
+        const u32 lo = (u32)low, hi = (u32)(low >> 32);
+        // coder.hpp:94-95: [low, low + range) crosses a multiple of 2^56 -- with range < 2^24 only where bits 24..55 of low are all
+        // ones: a cheap necessary test for the whole wavefront, the exact one behind it
+        if (__any((hi | 0xFF000000u) == 0xFFFFFFFFu)) {
+            const u32 thi = (u32)((low + range) >> 32);
+            const u32 sm = ((thi ^ hi) >> 24) ? ~0u : 0u;
+            range ^= (range ^ (~lo & (RC_TOP - 1))) & (nm & sm);
+        }
+        const u32 sh = 8u & nm;
+        code = (code << sh) | ((u32)cur & 0xffu & nm);
+        range <<= sh; low <<= sh; cur >>= sh;
+        have -= nm & 1u;
+    }
+    __device__ __forceinline__ void renorm() {
+        step(); step();
+        int guard = 0;
+#pragma nounroll
+        while (__any(range < RC_TOP)) {                      // rare: a symbol of probability below 2^-16
+            top_up();
+            step();
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+    // coder.hpp:83-86 for a row that totals 2^16; r = range >> 16 stays in `range`'s place until decode()
+    __device__ __forceinline__ u32 get_freq16(u32& r) {
+        r = range >> 16;
+        const u32 q = div_exact(code, r);
+        if (q > 0xFFFFu) err = 1;                            // (code >= range: not a stream an encoder wrote)
+        return q;
+    }
+    // coder.hpp:88-102
+    __device__ __forceinline__ void decode(u32 r, u32 cum, u32 freq) {
+        const u32 temp = cum * r;
+        low += temp; code -= temp;
+        range = r * freq;
+        renorm();
+    }
+};
 template <int THREADS, bool LDS>
 __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArgs da) {
-    extern __shared__ u32 lds[];                              // the decoder's hot image: map, then rows
+#ifdef PRIO_QDEC
+    __builtin_amdgcn_s_setprio(PRIO_QDEC);
+#endif
+    extern __shared__ u32 lds[];                              // the decoder's image: map, then the staged contexts' coarse lists
     const uint2* const lmap = reinterpret_cast<const uint2*>(lds);
     const u16* const lrows = reinterpret_cast<const u16*>(lds + QH_MAP_BYTES(a.q_rows) / 4u);
     if constexpr (LDS) {
@@ -451,58 +557,61 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.geo.nchains) return;
     const ChainPos cp = chain_pos(a, c);
-    LaneDec rc; rc.init(da.streams + a.coff[c], a.csz[c]);
+    LaneDecQ rc; rc.init(da.streams + a.coff[c], a.csz[c], reinterpret_cast<const u8*>(a.qesc));
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
+    u32 n_next = cp.nrec ? da.qlen[cp.r0] : 0u; u64 off_next = cp.nrec ? da.qoff[cp.r0] : 0ull;      // a record's length and place, a record ahead
     for (u32 k = 0; k < cp.nrec; k++) {
-        const u64 r = cp.r0 + k;
-        const u32 n = da.qlen[r];
-        LaneOut out; out.begin(da.qual_stage + da.qoff[r]);
+        const u32 n = n_next; const u64 off = off_next;
+        if (k + 1 < cp.nrec) { n_next = da.qlen[cp.r0 + k + 1]; off_next = da.qoff[cp.r0 + k + 1]; }
+        LaneOut out; out.begin(da.qual_stage + off);
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {
-            const u32 prob = rc.get_freq16();
-            // largest s with cum[s] <= prob (cum is increasing: every g >= 1): the eighth of the row from the coarse
-            // entries, then the symbol among its eight -- two dependent fetches of 16 bytes each (what a lane fetches, and
-            // from how many places, is what this kernel's time is made of)
+            // largest s with cum[s] <= prob (cum is increasing: every g >= 1): the eighth of the row from the coarse list, then the
+            // symbol among its eight -- two dependent fetches
             const u16* qd = a.qdec + (size_t)last * QDEC_ROW;
-            u32 cc[8], ff[8];
             u32 hot = ~0u;                                                  // the row's place in the LDS image, if it is staged
             if constexpr (LDS) {
                 const uint2 mr = lmap[last >> 5];
                 const u32 bit = 1u << (last & 31u);
                 if (mr.x & bit) hot = (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QHD_ROW_U16;
             }
-            uint4 v;
-            if (hot != ~0u) v = *reinterpret_cast<const uint4*>(lrows + hot); else v = *reinterpret_cast<const uint4*>(qd);
-            unpack8(v, cc);
-            u32 k8 = 0;
-#pragma unroll
-            for (u32 j = 1; j < 8; j++) k8 += cc[j] <= prob;
-            if (hot != ~0u && k8 < QH_SYMS / 8u) v = *reinterpret_cast<const uint4*>(lrows + hot + 8 + k8 * 8); else v = *reinterpret_cast<const uint4*>(qd + 8 + k8 * 8);
-            unpack8(v, ff);
-            u32 i8 = 0, cum = ff[0], next = 65536u;
-#pragma unroll
-            for (u32 j = 7; j >= 1; j--) next = cc[j] > prob ? cc[j] : next;       // the first entry past prob: in the coarse list ...
-#pragma unroll
-            for (u32 j = 7; j >= 1; j--) next = ff[j] > prob ? ff[j] : next;       // ... unless the symbol's own eighth has one
-#pragma unroll
-            for (u32 j = 1; j < 8; j++) { const bool le = ff[j] <= prob; i8 += le; cum = le ? ff[j] : cum; }
-            const u32 s = k8 * 8 + i8;
-            rc.decode(cum, next - cum);
+            uint4 cv;
+            if (hot != ~0u) cv = *reinterpret_cast<const uint4*>(lrows + hot); else cv = *reinterpret_cast<const uint4*>(qd);
+            rc.top_up();                                                    // (behind the row's fetch: the two loads travel together)
+            u32 r;
+            const u32 prob = rc.get_freq16(r);
+            const bool t4 = (cv.z & 0xffffu) <= prob;
+            const u32 A0 = t4 ? cv.z : cv.x, A1 = t4 ? cv.w : cv.y;
+            const bool t2 = (A1 & 0xffffu) <= prob;
+            const u32 B = t2 ? A1 : A0;
+            const bool t1 = (B >> 16) <= prob;
+            const u32 k8 = (t4 ? 4u : 0u) | (t2 ? 2u : 0u) | (t1 ? 1u : 0u);
+            const u32 ff0 = t1 ? B >> 16 : B & 0xffffu;                      // cum[8 k8]
+            // the group: w.x = (ff1, ff2), w.y = (ff3, ff4), w.z = (ff5, ff6), w.w = (ff7, ff8); ff[j] = cum[8 k8 + j]
+            const uint4 w = *reinterpret_cast<const uint4*>(qd + 8 + k8 * 8u);
+            // five in a row (x, y0 = two, y1 = two), then three (x, z = two), then the pair (cum, next)
+            const bool u4 = (w.y >> 16) <= prob;
+            const u32 x = u4 ? w.y >> 16 : ff0, y0 = u4 ? w.z : w.x, y1 = u4 ? w.w : w.y;
+            const bool u2 = (y0 >> 16) <= prob;
+            const u32 x2 = u2 ? y0 >> 16 : x, z = u2 ? y1 : y0;
+            const bool u1 = (z & 0xffffu) <= prob;
+            const u32 win = u1 ? z : (x2 | (z << 16));                      // cum | next << 16
+            const u32 s = k8 * 8u + ((u4 ? 4u : 0u) | (u2 ? 2u : 0u) | (u1 ? 1u : 0u));
+            const u32 cum = win & 0xffffu;
+            rc.decode(r, cum, ((win >> 16) - cum) & 0xffffu);                               // (a next of 0 is the total, 65536)
             u32 b = s;
-            if (s == LAST_QLT) {                                            // qlts.cpp:168-171
-                const u32 pe = rc.get_freq16();
-                u32 x = 0;
-#pragma unroll
-                for (u32 step = 128; step > 0; step >>= 1) { const u32 t = x + step; if (FZ_CUM(a.qesc[t]) <= pe) x = t; }
-                const u32 ee = a.qesc[x];
-                rc.decode(FZ_CUM(ee), FZ_FREQ(ee));
-                b = x;
+            if (s == LAST_QLT) {                                            // qlts.cpp:168-171: the raw value through the escape row,
+                rc.top_up();                                                // whose 256 values are equally likely (api.cpp build_qesc)
+                u32 re;
+                const u32 pe = rc.get_freq16(re);
+                b = pe >> 8; b = b > 255u ? 255u : b;
+                rc.decode(re, b << 8, 256u);
             }
             out.put(('!' + b) & 0xffu);
             if (level <= 2) last = (b | (last << 6)) & mask12;
             else {
-                if (p1 > b) delta += p1 - b;
+                delta += max(p1, b) - b;                                    // if (p1 > b) delta += p1 - b
                 const u32 d3 = delta >> 3;
                 last = (b | ((p1 < p2 ? p2 : p1) << 6) | ((u32)(p1 == p2) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
                 p2 = p1; p1 = b;

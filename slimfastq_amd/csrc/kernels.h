@@ -62,7 +62,7 @@ struct ChainArgs {
     const u64* coff;            // decode: [nchains] absolute offsets of the chains' streams
     // quality: frozen rows, total 2^16 each
     const u32* qrows;           // [q_rows][64] cum | freq << 16, in symbol order, indexed by the context
-    const u16* qdec;            // decode: [q_rows][72] u16: the cum of every 8th symbol, then of all 64 (chains.hip QDEC_ROW)
+    const u16* qdec;            // decode: [q_rows][72] u16: the cum of every 8th symbol, then the cums of symbols 1 .. 64 (chains.hip QDEC_ROW)
     u32 q_rows;                 // quality contexts: 4096 (level 1) or 65536
     u32 q_hot;                  // room for that many rows in the LDS image of the quality chains' workgroups (0 = no staging)
     const u8* qh_img;           // the hot image: map, then rows (chains.hip k_hot_select)
@@ -84,7 +84,8 @@ struct ChainArgs {
 void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
                      u8* img /* q_rows / 4 bytes of map + want x 100 bytes of rows */, u32* info, hipStream_t st);
 void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
-                         u8* img /* q_rows / 4 bytes of map + want x 112 bytes of rows */, u32* info, hipStream_t st);
+                         u8* img /* q_rows / 4 bytes of map + want x 16 bytes of coarse lists */, u32* info, hipStream_t st);
+u32 hot_rows_dec_max(void);     // how many coarse lists a workgroup's LDS holds beside the map
 void launch_qlt_frozen_rows(const u32* rows66, u32 q_rows, u32* qrows, u16* qdec /* decode; may be null */, hipStream_t st);
 void launch_qlt_encode_c(const ChainArgs& a, hipStream_t st);
 void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line /* the longest base line (picks lane per record / per stretch) */,
