@@ -2,7 +2,7 @@ import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/*/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-idx=[i for i,r in enumerate(rows) if r["Kernel_Name"].startswith("k_count_newlines")]
+idx=[i for i,r in enumerate(rows) if ("k_frame" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_count_newlines"))]
 s=idx[-1]
 t0=int(rows[s]["Start_Timestamp"])
 for r in rows[s:]:

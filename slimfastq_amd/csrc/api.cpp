@@ -682,34 +682,46 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // the line index of the current text (d_fastq, nbytes) and the per-record checks
     auto frame = [&]() -> int {
         int rc;
-        const u32 nchunks = (u32)((nbytes + FRAME_CHUNK - 1) / FRAME_CHUNK);
-        if ((rc = reserve(ctx, ctx->chunk_counts, (size_t)nchunks * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->chunk_base, ((size_t)nchunks + 1) * 8))) return rc;
-        if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nchunks / 1024 + 4) * 8 + 65536))) return rc;
-        HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
-        launch_count_newlines(d_fastq, nbytes, (u32*)ctx->chunk_counts.p, nchunks, st);
-        launch_scan_u32((const u32*)ctx->chunk_counts.p, (u64*)ctx->chunk_base.p, nchunks, (u64*)ctx->scan_tmp.p, st);
-        u64 nlines = 0; u8 last_byte = 0;
-        HIPC(hipMemcpyAsync(&nlines, (u64*)ctx->chunk_base.p + nchunks, 8, hipMemcpyDeviceToHost, st));
-        HIPC(hipMemcpyAsync(&last_byte, d_fastq + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
-        if (last_byte != '\n') return fail(ctx, SFQ_E_FORMAT, "fastq file: record seems truncated (no final newline)");   // usrs.cpp:169-172
+        const u32 tiles = frame_tiles(nbytes);
+        if ((rc = reserve(ctx, ctx->chunk_base, (size_t)tiles * 8))) return rc;          // the tiles' look-back words
+        if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)(nbytes / 16384) / 1024 + 4) * 8 + 65536))) return rc;      // (the scans of the packing: one entry per 1024 blocks)
+        // One pass (frame.hip k_frame): the index is sized before the lines are counted -- room for a line every 32 bytes (150 bp
+        // reads: one per 87), or what an earlier call left; a text of shorter lines is framed again with the count the pass returns
+        u64 cap = std::max<u64>(ctx->line_off.cap / 8 > 2 ? ctx->line_off.cap / 8 - 2 : 0, nbytes / 32 + 1024);
+        u64 nlines = 0;
+        for (int attempt = 0; ; attempt++) {
+            if ((rc = reserve(ctx, ctx->line_off, (size_t)(cap + 2) * 8))) return rc;
+            const u64 ecap = cap / 4 + 2;
+            if (want_marks) {
+                if ((rc = reserve(ctx, ctx->excf, (size_t)ecap))) return rc;
+                HIPC(hipMemsetAsync(ctx->excf.p, 0, (size_t)ecap, st));
+            }
+            HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
+            HIPC(hipMemsetAsync(ctx->chunk_base.p, 0, (size_t)tiles * 8, st));
+            void* d_fo = (u8*)ctx->status.p + 224;                                   // (status bytes 224..239: nothing else lives there)
+            launch_frame(d_fastq, nbytes, (u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, cap, (u32*)ctx->status.p, want_marks ? (u8*)ctx->excf.p : nullptr, ecap, d_fo, st);
+            struct { u64 nlines; u32 tripped, pad; } fo = {0, 0, 0};
+            u8 last_byte = 0;
+            HIPC(hipMemcpyAsync(&fo, d_fo, 16, hipMemcpyDeviceToHost, st));
+            HIPC(hipMemcpyAsync(&last_byte, d_fastq + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (fo.tripped) return fail(ctx, SFQ_E_HIP, "framing: a tile waited in vain for the tiles before it");
+            if (last_byte != '\n') return fail(ctx, SFQ_E_FORMAT, "fastq file: record seems truncated (no final newline)");   // usrs.cpp:169-172
+            nlines = fo.nlines;
+            if (nlines <= cap) break;
+            if (attempt) return fail(ctx, SFQ_E_HIP, "framing: %llu lines after a pass that counted fewer", (unsigned long long)nlines);
+            cap = nlines;
+        }
         if (nlines == 0 || (nlines & 3)) return fail(ctx, SFQ_E_FORMAT, "fastq file: %llu lines is not a multiple of 4", (unsigned long long)nlines);
         nrec = nlines / 4;
         if (nrec >= 3000000000ULL) return fail(ctx, SFQ_E_UNSUPPORTED, "more than 3e9 records (usrs.cpp:394)");
-        if ((rc = reserve(ctx, ctx->line_off, (size_t)(nlines + 1) * 8))) return rc;
-        if (want_marks) {
-            if ((rc = reserve(ctx, ctx->excf, (size_t)nrec))) return rc;
-            HIPC(hipMemsetAsync(ctx->excf.p, 0, (size_t)nrec, st));
-        }
-        launch_write_newlines(d_fastq, nbytes, (const u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, nchunks, want_marks ? (u8*)ctx->excf.p : nullptr, st);
         // headers up to 8190 bytes (usrs.hpp:34; format 6 sends longer ones to its oversize streams, below), base / quality lines
         // of any length: the block format codes them the usual way (a block's regions are sized by its text), format 6 has its
         // oversize streams
         // (the block format: the per-record checks run on a stream of their own, beside the block descriptors and the quality sample's
-        //  histogram -- 0.6 ms that nothing waited for but the host)
+        //  histogram)
         if (vst != st) { HIPC(hipEventRecord(ctx->ev[22], st)); HIPC(hipStreamWaitEvent(vst, ctx->ev[22], 0)); }
-        launch_validate_records(d_fastq, (const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, vst);
+        launch_validate_lines((const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, vst);
         return SFQ_OK;
     };
     // (an encode from summed counts right behind sfq_count_priors on the same buffer: that call's line index, marks and checks stand)

@@ -532,12 +532,34 @@ struct LaneDecQ {
         if (q > 0xFFFFu) err = 1;                            // (code >= range: not a stream an encoder wrote)
         return q;
     }
+    // coder.hpp:83-86 for any total: range / tot as a multiply-high by recip = floor(2^32 / tot) plus one exact fix-up (dev_chain.h)
+    __device__ __forceinline__ u32 get_freq(u32 tot, u32 recip, u32& r) {
+        r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        const u32 q = div_exact(code, r);                    // (quotient < tot + 1: far inside div_exact's reach; r >= 2^24 / 1020)
+        if (q >= tot) err = 1;
+        return q;
+    }
     // coder.hpp:88-102
     __device__ __forceinline__ void decode(u32 r, u32 cum, u32 freq) {
         const u32 temp = cum * r;
         low += temp; code -= temp;
         range = r * freq;
         renorm();
+    }
+    // the same where one step nearly always does (a base of a flat row: a quarter of the range, a byte every four bases)
+    __device__ __forceinline__ void decode1(u32 r, u32 cum, u32 freq) {
+        const u32 temp = cum * r;
+        low += temp; code -= temp;
+        range = r * freq;
+        step();
+        int guard = 0;
+#pragma nounroll
+        while (__any(range < RC_TOP)) {
+            top_up();
+            step();
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
     }
 };
 template <int THREADS, bool LDS>
@@ -932,16 +954,14 @@ void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
 }
 
 // One base: the row's four frequencies -> the symbol under prob, its cum and freq (base2_ranger.hpp:86-104)
-__device__ __forceinline__ u32 b2_pick(u32 v, LaneDec& rc, const u32* rcp) {
+__device__ __forceinline__ u32 b2_pick(u32 v, LaneDecQ& rc, const u32* rcp) {
     const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
-    const u32 tot = (f0 + f1) + (f2 + f3);
-    const u32 prob = rc.get_freq(tot, rcp[tot]);
-    u32 b, cum, f;
-    if (f0 > prob)                { b = 0; cum = 0;            f = f0; }
-    else if (f0 + f1 > prob)      { b = 1; cum = f0;           f = f1; }
-    else if (f0 + f1 + f2 > prob) { b = 2; cum = f0 + f1;      f = f2; }
-    else                          { b = 3; cum = f0 + f1 + f2; f = f3; if (prob >= tot) rc.err = 1; }
-    rc.decode(cum, f);
+    const u32 c1 = f0, c2 = f0 + f1, c3 = c2 + f2, tot = c3 + f3;
+    u32 r;
+    const u32 prob = rc.get_freq(tot, rcp[tot], r);
+    const u32 b = (prob >= c1 ? 1u : 0u) + (prob >= c2 ? 1u : 0u) + (prob >= c3 ? 1u : 0u);
+    const u32 cum = b == 0 ? 0u : b == 1 ? c1 : b == 2 ? c2 : c3;
+    rc.decode(r, cum, (v >> (8 * b)) & 0xff);
     return b;
 }
 // decode the chains of blocks [b0, b1): GenLoad::load_x (gens.cpp:215-249) without the N rules (k_gen_exc_decode).
@@ -951,6 +971,8 @@ __device__ __forceinline__ u32 b2_pick(u32 v, LaneDec& rc, const u32* rcp) {
 // vector memory instructions cost more than the round trip they hide -- 158 ms against 95 per 10 M genome-sampled reads).
 // (Also measured: the generation's counting pass folded into this kernel -- the atomics share the vector memory path
 // with the row fetch every base waits for: 109 ms against 95.)
+// Round 4: the quality decoder's lean coder (LaneDecQ); without rows a base is a divide by a twelfth of the range, two bits and
+// a byte every four bases -- 94 -> ~60 instructions a base.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArgs da, u32 b0, u32 b1) {
     __shared__ u32 rcp[1024];
@@ -960,30 +982,36 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     if (c >= a.geo.nchains || c >= b1 * a.geo.cpb) return;
     const ChainPos cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
-    LaneDec rc; rc.init(da.streams + a.coff[c], a.csz[c]);
+    LaneDecQ rc; rc.init(da.streams + a.coff[c], a.csz[c], reinterpret_cast<const u8*>(a.qesc));
     const u32* rows = gen_rows_of(a, cp.b);
     const u32 alphabet = d->solid ? 0x33323130u /* "0123" */ : 0x54474341u /* "ACGT" */;    // gens.cpp:173-178
     const u32 mask = (1u << d->gen_bits) - 1u;
     const u32 INIT = 0x007616c7u;                                                           // gens.cpp:139
+    const u32 r12 = fz_recip(12u);
+    u32 n_next = cp.nrec ? da.slen[cp.r0] : 0u; u64 off_next = cp.nrec ? da.soff[cp.r0] : 0ull;      // a record's length and place, a record ahead
     for (u32 k = 0; k < cp.nrec; k++) {
-        const u64 r = cp.r0 + k;
-        const u32 llen = da.slen[r];
-        LaneOut out; out.begin(da.seq_stage + da.soff[r]);
+        const u32 llen = n_next; const u64 off = off_next;
+        if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
+        LaneOut out; out.begin(da.seq_stage + off);
         u32 last = INIT;
         if (rows) {                                                                         // (gen_bits >= 2: the four candidates are in bounds)
             u32 v = rows[last & mask];
             for (u32 i = 0; i < llen; i++) {
                 const uint4 cand = *reinterpret_cast<const uint4*>(rows + ((last << 2) & mask));
+                rc.top_up();
                 const u32 b = b2_pick(v, rc, rcp);
                 out.put((alphabet >> (8 * b)) & 0xff);
                 last = (last << 2) | b;
                 v = b == 0 ? cand.x : b == 1 ? cand.y : b == 2 ? cand.z : cand.w;
             }
         } else {
-            for (u32 i = 0; i < llen; i++) {
-                const u32 b = b2_pick(B2_INIT, rc, rcp);
+            for (u32 i = 0; i < llen; i++) {                                                // the initial row (3, 3, 3, 3)
+                rc.top_up();
+                u32 r;
+                const u32 prob = rc.get_freq(12u, r12, r);
+                const u32 b = (prob >= 3u ? 1u : 0u) + (prob >= 6u ? 1u : 0u) + (prob >= 9u ? 1u : 0u);
+                rc.decode1(r, 3u * b, 3u);
                 out.put((alphabet >> (8 * b)) & 0xff);
-                last = (last << 2) | b;
             }
         }
         out.end();

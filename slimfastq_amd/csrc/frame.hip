@@ -1,19 +1,13 @@
 // frame.hip -- device-side FASTQ framing and packing.
 //
 // The reference frames records on one host core with a 1 MiB sliding buffer (UsrSave::get_record,
-// usrs.cpp:303-390).  Here the whole text is resident in HBM and framing is a newline index:
-//   count '\n' per 16 KiB chunk -> exclusive scan -> write line start offsets,
-// then per-record validation ('@' / '+' prefixes: usrs.cpp:311,346; line-length limits usrs.hpp:34-36)
-// and one descriptor per record block (the first-record analysis of UsrSave::determine_record,
-// usrs.cpp:186-267).  All of it is streaming, coalesced, HBM-bound work.
+// usrs.cpp:303-390).  Here the whole text is resident in HBM and framing is a newline index, built in ONE pass over
+// the text (k_frame: line start offsets, the '@' / '+' prefix checks of usrs.cpp:311,346, the marks of the exception pass),
+// then the per-record line limits (usrs.hpp:34-36) from the index alone and one descriptor per record block (the
+// first-record analysis of UsrSave::determine_record, usrs.cpp:186-267).  All of it is streaming, HBM-bound work.
 #include "kernels.h"
 
 #define HIP_KCHECK() do { } while (0)
-
-__device__ __forceinline__ u32 nl_mask(u32 x) {          // 0x80 in every byte of x that equals '\n'
-    u32 y = x ^ 0x0a0a0a0au;
-    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
-}
 
 // Block-wide exclusive scan of one u32 per thread (256 threads = 4 waves). Returns the exclusive
 // prefix; *total receives the block sum.
@@ -35,110 +29,263 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* lds /* >= 8 u32 *
     return base + incl - v;
 }
 
-// One 16-byte piece of the text as 4 dwords; bytes at or past n read as 0.
-__device__ __forceinline__ void load16(const u8* fq, u64 pos, u64 n, bool aligned, u32 w[4]) {
-    if (aligned && pos + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(fq + pos);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-        for (int k = 0; k < 4; k++) {
-            u32 x = 0;
-            for (int j = 0; j < 4; j++) { u64 p = pos + 4 * k + j; if (p < n) x |= (u32)fq[p] << (8 * j); }
-            w[k] = x;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_count_newlines(const u8* fq, u64 n, u32* chunk_counts, bool aligned) {
-    __shared__ u32 lds[8];
-    const u64 cbase = (u64)blockIdx.x * FRAME_CHUNK;
-    u32 cnt = 0;
+// =========================================================================================================
+// framing in ONE pass (round 4)
+//
+// k_count_newlines + the scan + k_write_newlines read the text twice and issued 1.76e9 wave instructions per 3.7 GB call (the second
+// kernel: a block scan per 4 KiB, a divergent loop per dword for the offsets, byte-wise attribution of the marks) -- 2.4 ms, and
+// k_validate_records another 0.8 ms of scattered byte reads.  k_frame reads the text once:
+//   * a thread owns 64 CONTIGUOUS bytes (four 16-byte loads): one newline count, one block scan per 16 KiB tile;
+//   * a tile's place in the file comes from a decoupled look-back over the tiles before it (tstat: flag | value in one 64-bit
+//     word, so no fence is needed) instead of a counting pass and a scan kernel;
+//   * newlines, '!' candidates and odd-base candidates are 64-bit masks per thread (a SWAR test per dword, four flag bits gathered
+//     with one multiply), so offsets and marks are a few bit operations per LINE END in the window, not per byte;
+//   * the '@' / '+' checks of UsrSave::get_record (usrs.cpp:311, 346) ride on the line ends: the byte behind a newline is in cache.
+// The line index must be sized before the number of lines is known: the caller guesses (cap entries), the kernel never writes
+// past it and reports the count; a text of shorter lines than guessed is framed again with the exact size.
+// =========================================================================================================
+struct FrameOut { u64 nlines; u32 guard_tripped; u32 pad; };
+__device__ __forceinline__ u32 flags4(u32 m) { return (m * 0x00204081u) >> 28; }      // the 0x80 flags of four bytes as four bits
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        u64 pos = cbase + (u64)j * 4096 + (u64)threadIdx.x * 16;
-        if (pos < n) {
-            u32 w[4]; load16(fq, pos, n, aligned, w);
-            cnt += __popc(nl_mask(w[0])) + __popc(nl_mask(w[1])) + __popc(nl_mask(w[2])) + __popc(nl_mask(w[3]));
-        }
-    }
-    u32 total;
-    block_excl_scan_256(cnt, lds, &total);
-    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
 }
-
-// 0x80 in every byte of x that equals the byte repeated in c
-__device__ __forceinline__ u32 eq_mask(u32 x, u32 c) {
-    const u32 y = x ^ c;
+#define TS_AGG  (1ull << 62)
+#define TS_PFX  (2ull << 62)
+#define TS_VAL  ((1ull << 62) - 1)
+// A workgroup takes a TILE of FRAME_TILE bytes in FRAME_WIN sub-tiles of 16 KiB, twice: first it only COUNTS the tile's
+// newlines (what the tiles behind it wait for), then -- its place in the file known from the look-back -- it goes over the
+// sub-tiles again, out of L2 this time, and writes offsets and marks.  The text is always LOADED coalesced -- 16 bytes a lane, a
+// wave's 64 lanes one KiB --; in the second round a sub-tile is handed through LDS to the threads that own 64 CONTIGUOUS bytes
+// of it each (windows 80 bytes apart in LDS: a thread's four 16-byte reads fall in banks no neighbour of its quarter wave uses).
+// (Measured on the way, per 3.7 GB: a thread loading its own 64 contiguous bytes straight from memory -- four loads of 16 bytes at a
+//  stride of 64 bytes or more across the lanes, every lane another sector -- 1.9-2.0 ms whatever the tile size: the vector memory
+//  path takes such a load a lane at a time.  One round with every window's masks kept in registers: 158-288 VGPRs.)
+#ifndef FRAME_WIN
+#define FRAME_WIN 8
+#endif
+#define FRAME_SUB 16384u
+#define FRAME_TILE (FRAME_SUB * FRAME_WIN)
+#define FRAME_PAD 80u                    /* bytes of LDS per 64-byte window */
+__device__ __forceinline__ u32 nl_flags(u32 x) {            // 0x80 where the byte is '\n'
+    const u32 y = x ^ 0x0a0a0a0au;
     return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
 }
-// the four 0x80 flags of a byte mask as four bits
-__device__ __forceinline__ u32 pack4(u32 m) { return ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; }
-// exc_flag (may be null): [records] set to 1 where a record's quality line holds a '!' or its base line an N-like or lowercase
-// character -- the records the pass over the N / quality-0 / case exceptions (models_w.hip k_gen_exc_w) has to look at.  The
-// text is in registers here anyway and such bytes are rare: a test per dword, the byte-by-byte attribution to lines only
-// where it fires.  (Marking a record too many costs that pass a look at it, nothing else.)
-__global__ __launch_bounds__(256) void k_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, bool aligned, u8* exc_flag) {
-    __shared__ u32 lds[8];
-    const u64 cbase = (u64)blockIdx.x * FRAME_CHUNK;
-    u64 run = chunk_base[blockIdx.x];          // newlines before this chunk
-    if (blockIdx.x == 0 && threadIdx.x == 0) line_off[0] = 0;
-    for (int j = 0; j < 4; j++) {
-        u64 pos = cbase + (u64)j * 4096 + (u64)threadIdx.x * 16;
-        u32 w[4] = {0, 0, 0, 0};
-        u32 cnt = 0;
-        if (pos < n) {
-            load16(fq, pos, n, aligned, w);
-            cnt = __popc(nl_mask(w[0])) + __popc(nl_mask(w[1])) + __popc(nl_mask(w[2])) + __popc(nl_mask(w[3]));
-        }
-        u32 total;
-        u32 ex = block_excl_scan_256(cnt, lds, &total);
-        u64 k = run + ex;
-        if (exc_flag && pos < n) {
-            // '!' in a quality line; 'N', '.' or a byte of 0x60..0x7f (the lowercase letters) in a base line.  A piece without a
-            // newline lies in ONE line (k & 3 says which): a test per dword of the kind its line asks for, none in a header or
-            // '+' line.  A piece that holds a line's end: the matches and the newlines as sixteen-bit masks, and a look at the
-            // matching bytes only (a loop over the piece's bytes had every wave walk all sixteen: 0.9 -> 2.3 ms for the kernel)
-            u32 bang = 0, oddb = 0;
-            const u32 type0 = (u32)k & 3u;
-            if (cnt == 0) {
-                if (type0 == 3u) {
+template <bool MARKS>
+__global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n, u64* __restrict__ tstat, u64* __restrict__ line_off, u64 cap,
+                                               u32* __restrict__ status, u8* __restrict__ exc_flag, u64 ecap, FrameOut* __restrict__ fo) {
+    __shared__ __attribute__((aligned(16))) u8 stage[256 * FRAME_PAD];
+    __shared__ u32 wtot[4];
+    __shared__ u32 s_last[4];
+    __shared__ u64 s_base;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 tile = blockIdx.x;
+    const u64 tb = tile * FRAME_TILE;
+    // a sub-tile's text, coalesced: piece j of a thread = bytes [sb + 4096 j + 16 tid, + 16); bytes at or past n read as 0
+    auto fetch = [&](u64 sb, uint4 (&v)[4]) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) bang |= eq_mask(w[q], 0x21212121u);
-                } else if (type0 == 1u) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) oddb |= eq_mask(w[q], 0x4e4e4e4eu) | eq_mask(w[q], 0x2e2e2e2eu) | ((w[q] << 1) & (w[q] << 2) & 0x80808080u);
-                }
-                if (bang | oddb) exc_flag[k >> 2] = 1;
-            } else {
-                u32 nl16 = 0, b16 = 0, o16 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    nl16 |= pack4(nl_mask(w[q])) << (4 * q);
-                    b16 |= pack4(eq_mask(w[q], 0x21212121u)) << (4 * q);
-                    o16 |= pack4(eq_mask(w[q], 0x4e4e4e4eu) | eq_mask(w[q], 0x2e2e2e2eu) | ((w[q] << 1) & (w[q] << 2) & 0x80808080u)) << (4 * q);
-                }
-                u32 cand = b16 | o16;
-                while (cand) {
-                    const u32 i = (u32)__ffs((int)cand) - 1u;
-                    cand &= cand - 1u;
-                    const u64 line = k + (u32)__popc(nl16 & ((1u << i) - 1u));
-                    const u32 type = (u32)line & 3u;
-                    if ((type == 3u && ((b16 >> i) & 1u)) || (type == 1u && ((o16 >> i) & 1u))) exc_flag[line >> 2] = 1;
-                }
+        for (int j = 0; j < 4; j++) {
+            const u64 pos = sb + 4096u * j + 16u * tid;
+            if (pos + 16 <= n) { const u32* q = reinterpret_cast<const u32*>(fq + pos); v[j] = make_uint4(q[0], q[1], q[2], q[3]); }      // (no alignment needed on gfx9)
+            else {
+                u32 w[4] = {0, 0, 0, 0};
+#pragma nounroll
+                for (u32 b = 0; b < 16; b++) if (pos + b < n) w[b >> 2] |= (u32)fq[pos + b] << (8 * (b & 3));
+                v[j] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
-        if (cnt) {
-            for (int q = 0; q < 4; q++) {
-                u32 m = nl_mask(w[q]);
-                while (m) {
-                    int bit = __ffs(m) - 1;           // 7, 15, 23, 31
-                    m &= m - 1;
-                    line_off[++k] = pos + 4 * q + (bit >> 3) + 1;
-                }
-            }
+    };
+    // ---- round 1: the tile's newlines ---------------------------------------------------------------------------------------------
+    u32 cnt = 0;
+    {
+        uint4 nx[4];
+        fetch(tb, nx);
+#pragma nounroll
+        for (u32 wi = 0; wi < FRAME_WIN; wi++) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = nx[j];
+            if (wi + 1 < FRAME_WIN) fetch(tb + (u64)FRAME_SUB * (wi + 1), nx);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                cnt += (u32)__popc(nl_flags(v[j].x)) + (u32)__popc(nl_flags(v[j].y)) + (u32)__popc(nl_flags(v[j].z)) + (u32)__popc(nl_flags(v[j].w));
         }
-        run += total;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += (u32)__shfl_xor((int)cnt, d, 64);
+    if (lane == 0) wtot[wave] = cnt;
+    __syncthreads();
+    const u32 total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    // ---- the tile among the file's (decoupled look-back) ------------------------------------------------------------------------------
+    if (wave == 0) {
+        if (lane == 0) __hip_atomic_store(&tstat[tile], (tile == 0 ? TS_PFX : TS_AGG) | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 excl = 0;
+        if (tile) {
+            long long j = (long long)tile - 1;
+            u32 spins = 0; bool tripped = false;
+            for (;;) {
+                const long long idx = j - (long long)lane;
+                u64 word = TS_PFX;                                                  // (before the file's first tile: a prefix of 0)
+                if (idx >= 0) word = __hip_atomic_load(&tstat[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any((word >> 62) == 0)) {                                     // a tile before this one has not published yet
+                    if (++spins > (1u << 22)) { tripped = true; break; }            // (never in a sound launch; every wave must end)
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                const u64 pm = __ballot((word >> 62) == 2);
+                if (pm) {
+                    const u32 first = (u32)__ffsll((long long)pm) - 1u;             // the nearest tile that knows its prefix
+                    excl += wave_sum_u64(lane <= first ? (word & TS_VAL) : 0ull);
+                    break;
+                }
+                excl += wave_sum_u64(word & TS_VAL);
+                j -= 64;
+            }
+            if (tripped && lane == 0) fo->guard_tripped = 1;
+            if (lane == 0) __hip_atomic_store(&tstat[tile], TS_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = excl;
+            if (tile + 1 == gridDim.x) fo->nlines = excl + total;
+        }
+    }
+    __syncthreads();
+    u64 run = s_base;                                        // newlines before the sub-tile at hand
+    if (tile == 0 && tid == 0) line_off[0] = 0;
+    // does a line start with the sub-tile at hand (thread 0's business)?  With the file it does; elsewhere the byte before says
+    u32 carry_nl = 0;
+    if (tid == 0) carry_nl = tb == 0 ? 1u : (tb <= n && fq[tb - 1] == '\n') ? 1u : 0u;
+    // ---- round 2: offsets, the '@' / '+' checks, the marks ------------------------------------------------------------------------------
+    uint4 nx[4];
+    fetch(tb, nx);
+#pragma nounroll
+    for (u32 wi = 0; wi < FRAME_WIN; wi++) {
+        const u64 sb = tb + (u64)FRAME_SUB * wi;
+        if (sb >= n) break;                                  // (the same for every thread)
+        // piece j of thread tid lies in window 64 j + tid / 4, at 16 (tid % 4)
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<uint4*>(stage + (64u * j + (tid >> 2)) * FRAME_PAD + 16u * (tid & 3u)) = nx[j];
+        __syncthreads();
+        if (wi + 1 < FRAME_WIN) fetch(sb + FRAME_SUB, nx);                       // (in flight while this sub-tile is worked on)
+        u32 w[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + tid * FRAME_PAD + 16u * j);
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        }
+        const u64 w0 = sb + 64u * tid;
+        u32 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const u32 x = w[q];
+            u32* d = q < 8 ? lo : hi;
+            const u32 sh = 4u * (q & 7);
+            d[0] |= flags4(nl_flags(x)) << sh;
+
+            if constexpr (MARKS) {
+                // '!' candidates: a byte b with (b & 0x5e) == 0 -- in a quality line (0x21 .. 0x7e) that is '!' alone
+                const u32 mb = ~((x & 0x5e5e5e5eu) + 0x7f7f7f7fu) & 0x80808080u;                  // (no carry between bytes: 0x5e + 0x7f < 0x100)
+                // odd-base candidates: bit 3 (N, '.') or bits 5 and 6 (lowercase) -- every N-like or lowercase base, and no A C G T 0 1 2 3
+                const u32 mo = ((x << 4) | ((x << 1) & (x << 2))) & 0x80808080u;
+                d[1] |= flags4(mb) << sh;
+                d[2] |= flags4(mo) << sh;
+            }
+        }
+        const u64 nlm = (u64)lo[0] | ((u64)hi[0] << 32);
+        const u32 first_byte = w[0] & 0xffu;
+        u64 bang = 0, odd = 0;
+        if constexpr (MARKS) {
+            const u64 live = w0 >= n ? 0ull : (n - w0) >= 64 ? ~0ull : ((1ull << (n - w0)) - 1);      // (bytes past the end read as 0: a '!' candidate)
+            bang = ((u64)lo[1] | ((u64)hi[1] << 32)) & live; odd = ((u64)lo[2] | ((u64)hi[2] << 32)) & live;
+        }
+        // this window's newlines among its sub-tile's
+        const u32 c = (u32)__popcll(nlm);
+        u32 incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
+        if (lane == 63) { wtot[wave] = incl; s_last[wave] = (u32)(nlm >> 63); }
+        __syncthreads();                                     // (also: every thread has read its window, the stage may be written again)
+        u32 bw = 0, tw = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) { const u32 t = wtot[k]; if (k < wave) bw += t; tw += t; }
+        u64 k = run + bw + incl - c;                         // newlines before the window = the number of the line its first byte lies in
+        run += tw;
+        // usrs.cpp:311, 346: a record's first line starts with '@', its third with '+'.  A line that starts WITH the window (the
+        // byte before it, the window before's last, is a newline -- handed over from lane to lane, wave to wave, sub-tile to sub-tile):
+        u32 prev_nl = (u32)__shfl_up((int)(u32)(nlm >> 63), 1, 64);
+        if (lane == 0) prev_nl = wave ? s_last[wave - 1] : carry_nl;
+        if (tid == 0) carry_nl = s_last[3];
+        if (prev_nl && w0 < n && ((u32)k & 1u) == 0u && first_byte != (((u32)k & 2u) ? '+' : '@')) atomicMax(status, (u32)(-SFQ_E_FORMAT));
+        if (w0 < n) {
+            u64 m = nlm;
+            u64 below = 0;                                   // the window's bytes up to the line end looked at last
+            while (m) {
+                const u32 i = (u32)__ffsll((long long)m) - 1u;
+                m &= m - 1;
+                const u64 upto = (1ull << i) - 1;            // bytes of the window before this line end
+                if constexpr (MARKS) {
+                    const u64 seg = upto & ~below;           // ... that belong to the line k
+                    const u32 type = (u32)k & 3u;
+                    if (((type == 3u && (bang & seg)) || (type == 1u && (odd & seg))) && (k >> 2) < ecap) exc_flag[k >> 2] = 1;
+                }
+                below = upto | (1ull << i);
+                k++;                                         // the line that starts behind this newline
+                const u64 start = w0 + i + 1;
+                if (k <= cap) line_off[k] = start;
+                // ... and a line that starts inside it: the byte behind the line end, still in the stage (written again only behind
+                // this round's last barrier)
+                if (i < 63u && start < n) {
+                    const u32 type = (u32)k & 3u;
+                    if ((type & 1u) == 0u && stage[tid * FRAME_PAD + i + 1] != (type ? '+' : '@')) atomicMax(status, (u32)(-SFQ_E_FORMAT));
+                }
+            }
+            if constexpr (MARKS) {                           // what lies behind the window's last line end (or the whole window)
+                const u64 seg = ~below;
+                const u32 type = (u32)k & 3u;
+                if (((type == 3u && (bang & seg)) || (type == 1u && (odd & seg))) && (k >> 2) < ecap) exc_flag[k >> 2] = 1;
+            }
+        }
+        __syncthreads();                                     // (wtot is written again in the next round)
+    }
+}
+u32 frame_tiles(u64 n) { return (u32)((n + FRAME_TILE - 1) / FRAME_TILE); }
+void launch_frame(const u8* fq, u64 n, u64* tstat /* [frame_tiles(n)], zeroed */, u64* line_off, u64 cap, u32* status, u8* exc_flag, u64 ecap, void* frame_out /* 16 bytes, zeroed */, hipStream_t st) {
+    const u32 tiles = frame_tiles(n);
+    if (exc_flag) hipLaunchKernelGGL(k_frame<true>, dim3(tiles), dim3(256), 0, st, fq, n, tstat, line_off, cap, status, exc_flag, ecap, reinterpret_cast<FrameOut*>(frame_out));
+    else hipLaunchKernelGGL(k_frame<false>, dim3(tiles), dim3(256), 0, st, fq, n, tstat, line_off, cap, status, exc_flag, ecap, reinterpret_cast<FrameOut*>(frame_out));
+}
+// the per-record checks that need the line index alone (the '@' / '+' prefixes are k_frame's): line limits (usrs.hpp:34-36) and the
+// call's longest header and base line
+__global__ __launch_bounds__(256) void k_validate_lines(const u64* __restrict__ line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 hl = 0, gl = 0, bad = 0, over = 0;
+    if (r < nrec) {
+        const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
+        // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367): max_line = 0xfffe
+        // where its format is written; the block format codes base / quality lines of any length the usual way
+        if ((l1 - l0 - 2) > max_hdr || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line) bad = (u32)(-SFQ_E_UNSUPPORTED);
+        else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);            // empty base line: usrs.cpp:217-222 mis-frames it
+        hl = (u32)(l1 - l0 - 2); gl = (u32)(l2 - l1 - 1);
+        // status[3] != 0: some record may be over format 6's line limits (usrs.hpp:34-36; a SOLiD line may be one longer -- the
+        // oversize pass decides exactly)
+        over = ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l4 - l3 - 1) > 0xfffe) ? 1u : 0u;
+        if ((l1 - l0) < 2 || (l3 - l2) < 2) bad = (u32)(-SFQ_E_FORMAT);        // (a header or '+' line without its prefix: k_frame has flagged it too)
+    }
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+        const u32 o1 = (u32)__shfl_xor((int)hl, dd, 64), o2 = (u32)__shfl_xor((int)gl, dd, 64), o3 = (u32)__shfl_xor((int)bad, dd, 64), o4 = (u32)__shfl_xor((int)over, dd, 64);
+        hl = o1 > hl ? o1 : hl; gl = o2 > gl ? o2 : gl; bad = o3 > bad ? o3 : bad; over |= o4;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicMax(status, bad);
+        if (hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
+        if (gl > status[2]) atomicMax(status + 2, gl);
+        if (over) status[3] = 1;
+    }
+}
+void launch_validate_lines(const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_validate_lines, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, line_off, nrec, max_hdr, max_line, status);
 }
 
 // out[0] = max(out[0], max of v[0..n)); a thread takes sixteen values, a wave one atomic
@@ -158,15 +305,6 @@ __global__ __launch_bounds__(256) void k_max_u32(const u32* __restrict__ v, u64 
 }
 void launch_max_u32(const u32* v, u64 n, u32* out, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_max_u32, dim3((u32)((n + 4095) / 4096)), dim3(256), 0, st, v, n, out);
-}
-
-void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st) {
-    bool aligned = ((uintptr_t)fq & 15) == 0;
-    hipLaunchKernelGGL(k_count_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_counts, aligned);
-}
-void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks, u8* exc_flag, hipStream_t st) {
-    bool aligned = ((uintptr_t)fq & 15) == 0;
-    hipLaunchKernelGGL(k_write_newlines, dim3(nchunks), dim3(256), 0, st, fq, n, chunk_base, line_off, aligned, exc_flag);
 }
 
 // A fingerprint of a device-resident text: 65 536 sixteen-byte pieces spread evenly over it, each hashed with its number, the
@@ -246,37 +384,6 @@ void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
     hipLaunchKernelGGL(k_scan_tile_sums, dim3((u32)ntiles), dim3(256), 0, st, in, n, tmp);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, tmp, ntiles);
     hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(256), 0, st, in, n, (const u64*)tmp, out, ntiles);
-}
-
-// ---- record validation ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
-    u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrec) return;
-    const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
-    u32 bad = 0;
-    if (fq[l0] != '@' || fq[l2] != '+') bad = (u32)(-SFQ_E_FORMAT);           // usrs.cpp:311, 346
-    // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367): max_line = 0xfffe
-    // where its format is written; the block format codes base / quality lines of any length the usual way
-    else if ((l1 - l0 - 2) > max_hdr || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line)
-        bad = (u32)(-SFQ_E_UNSUPPORTED);
-    else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);               // empty base line: usrs.cpp:217-222 mis-frames it
-    if (bad) atomicMax(status, bad);
-    // status[1] = the longest header of the call (the header kernel sizes its LDS image by it)
-    u32 hl = (u32)(l1 - l0 - 2);
-#pragma unroll
-    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)hl, dd, 64); hl = o > hl ? o : hl; }
-    if ((threadIdx.x & 63) == 0 && hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
-    // status[2] = the longest base line (the base model's counting passes take long lines a stretch per lane)
-    u32 gl = (u32)(l2 - l1 - 1);
-#pragma unroll
-    for (int dd = 32; dd > 0; dd >>= 1) { const u32 o = (u32)__shfl_xor((int)gl, dd, 64); gl = o > gl ? o : gl; }
-    if ((threadIdx.x & 63) == 0 && gl > status[2]) atomicMax(status + 2, gl);
-    // status[3] != 0: some record may be over format 6's line limits (usrs.hpp:34-36; a SOLiD line may be one longer -- the
-    // oversize pass below decides exactly)
-    if ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l4 - l3 - 1) > 0xfffe) status[3] = 1;
-}
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
-    hipLaunchKernelGGL(k_validate_records, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_hdr, max_line, status);
 }
 
 // ---- format 6: the reference's OVERSIZE records (usrs.cpp:269-301) -----------------------------------------------------

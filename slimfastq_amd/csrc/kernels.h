@@ -116,11 +116,7 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP ? (n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP : 1); }
 
 // framing
-void launch_count_newlines(const u8* fq, u64 n, u32* chunk_counts, u32 nchunks, hipStream_t st);
 void launch_max_u32(const u32* v, u64 n, u32* out /* raised to the largest of v */, hipStream_t st);
-void launch_write_newlines(const u8* fq, u64 n, const u64* chunk_base, u64* line_off, u32 nchunks,
-                           u8* exc_flag /* [records], zeroed, or null: marks the records with a '!' / N / lowercase base */, hipStream_t st);
-void launch_validate_records(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line /* longest header / base or quality line taken */, u32* status, hipStream_t st);
 // format 6's oversize records (frame.hip, models_w.hip)
 void launch_over_first(const u64* line_off, u64 nrec, u32* first /* 0xFFFFFFFF */, hipStream_t st);
 void launch_over_solid(const u8* fq, const u64* line_off, u64 r, u32* out, hipStream_t st);
@@ -135,6 +131,12 @@ void launch_over_sizes(const u32* rec_map, const u32* rsize, u64 n_kept, const u
 void launch_gather_u64(const u64* src, const u32* idx, u64 n, u64* dst, hipStream_t st);
 void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, u32 nblocks,
                           u64 nbytes, i32 level, i32 gen_bits_req, hipStream_t st);
+// framing in one pass (frame.hip k_frame): the line index (at most cap entries behind entry 0 are written), the '@' / '+' checks into
+// status[0], the marks of the exception pass; frame_out: { u64 lines, u32 look-back guard tripped }
+u32 frame_tiles(u64 n);
+void launch_frame(const u8* fq, u64 n, u64* tstat /* [frame_tiles(n)], zeroed */, u64* line_off, u64 cap, u32* status, u8* exc_flag /* or null */, u64 ecap /* its entries */,
+                  void* frame_out /* 16 bytes, zeroed */, hipStream_t st);
+void launch_validate_lines(const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st);
 void launch_text_fingerprint(const u8* fq, u64 n, u64* out /* zeroed */, hipStream_t st);
 #define FRAME_CHUNK 16384u
 

@@ -935,3 +935,65 @@ def test_automatic_block_size_follows_the_text(ctx):
     enc = ctx.encode_host(lr, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO)
     assert 2 <= enc.blocks[0].n_records <= 16 and len(enc.blocks) >= 300 // 16
     assert ctx.decode_host(enc, level=3, out_cap=len(lr) + 4096) == lr
+
+
+def _pad_to(records, j, want_mod, modulus, line):
+    """Lengthen the headers of the records before j so that line `line` (0 = header, 2 = '+') of record j starts at an offset
+    that is want_mod modulo `modulus`; returns the text."""
+    def start(recs):
+        off = sum(len(r) for r in recs[:j])
+        if line == 2:
+            parts = recs[j].split(b"\n")
+            off += len(parts[0]) + 1 + len(parts[1]) + 1
+        return off
+    need = (want_mod - start(records)) % modulus
+    recs = list(records)
+    k = 0
+    while need:
+        add = min(need, 60)
+        h, rest = recs[k].split(b"\n", 1)
+        recs[k] = h + b"x" * add + b"\n" + rest
+        need -= add; k += 1
+        assert k < j
+    assert start(recs) % modulus == want_mod
+    return recs
+
+
+def test_line_prefixes_are_checked_wherever_a_line_starts(ctx):
+    """The framing pass (frame.hip k_frame) checks '@' / '+' (usrs.cpp:311, 346) on the byte behind every line end -- from the
+    window's own bytes, or, where a line starts exactly with a 64-byte window, a 16 KiB sub-tile or a 128 KiB tile, from what the
+    thread, wave, sub-tile or tile before hands over.  A wrong prefix at each of those places is refused; the untouched text codes."""
+    base = [b"@r%d:%d\n%s\n+\n%s\n" % (i, i * 7, b"ACGT" * 25, b"I" * 100) for i in range(2500)]
+    for modulus in (64, 4096, 16384, 131072):
+        for line in (0, 2):
+            j = 2000 if modulus == 131072 else 700
+            recs = _pad_to(base, j, 0, modulus, line)
+            good = b"".join(recs)
+            enc = ctx.encode_host(good, level=3, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+            assert ctx.decode_host(enc, level=3, out_cap=len(good) + 4096) == good
+            off = sum(len(r) for r in recs[:j])
+            if line == 2:
+                parts = recs[j].split(b"\n")
+                off += len(parts[0]) + 1 + len(parts[1]) + 1
+            assert off % modulus == 0 and good[off:off + 1] == (b"+" if line else b"@")
+            bad = bytearray(good); bad[off] = ord("X")
+            with pytest.raises(capi.SfqError) as e:
+                ctx.encode_host(bytes(bad), level=3, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+            assert e.value.code == -4, (modulus, line, e.value)
+            # ... and one byte further on, inside the window
+            recs2 = _pad_to(base, j, 1, modulus, line)
+            bad = bytearray(b"".join(recs2))
+            off2 = sum(len(r) for r in recs2[:j])
+            if line == 2:
+                parts = recs2[j].split(b"\n")
+                off2 += len(parts[0]) + 1 + len(parts[1]) + 1
+            assert off2 % modulus == 1 and bytes(bad[off2:off2 + 1]) == (b"+" if line else b"@")
+            bad[off2] = ord("X")
+            with pytest.raises(capi.SfqError) as e:
+                ctx.encode_host(bytes(bad), level=3, block_reads=0)
+            assert e.value.code == -4
+    # the file's first byte
+    bad = bytearray(b"".join(base)); bad[0] = ord("X")
+    with pytest.raises(capi.SfqError) as e:
+        ctx.encode_host(bytes(bad), level=3, block_reads=500, tables=capi.TABLES_ADAPTIVE)
+    assert e.value.code == -4

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "slimfastq_amd", "csrc")
-HOT = {"models_w.hip": ("k_qlt_encode_k2", "k_rec_encode_w_fast"), "models_k.hip": ("k_gen_encode_kILi2E",),
+HOT = {"frame.hip": ("k_frame",), "models_w.hip": ("k_qlt_encode_k2", "k_rec_encode_w_fast"), "models_k.hip": ("k_gen_encode_kILi2E",),
        # the default path: one chain per lane over frozen tables (encoders and decoders)
        "chains.hip": ("k_qlt_encode_c", "k_gen_encode_c", "k_rec_encode_fILj62E", "k_rec_encode_fILj94E", "k_rec_encode_fILj127E",
                       "k_qlt_decode_c", "k_gen_decode_c", "k_rec_decode_f", "k_rec_tokens", "k_rec_code", "k_rec_dsym", "k_rec_dtext")}
