@@ -1071,7 +1071,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
             if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;
-            HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3]); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
+            // (Round 4 measured a generation's chains started as soon as its rows were there, on a stream of their own beside the counting
+            //  passes of the generations behind it: 57.4 ms per 10 M genome-sampled reads against 58.8 -- the passes' atomics and the chains'
+            //  row gathers wait for the same thing, random 64-byte sectors of tables larger than the caches, and their times add up.)
+            HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if (models & SFQ_M_QLT) {

@@ -899,15 +899,15 @@ __device__ __forceinline__ const u32* gen_rows_of(const ChainArgs& a, u32 b) {
 // FLAT: the call has no generation tables (api.cpp gen_tables_finish): only the initial row's path is compiled -- no row
 // values in flight, no reciprocal table -- so the kernel holds fewer registers and less LDS beside the other chains' kernels
 template <int THREADS, bool FLAT>
-__global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
+__global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u32 c1 /* the chains [c0, c1) */) {
     __shared__ u32 rcp[FLAT ? 1 : 1024];                      // reciprocals of the row totals (<= 1020)
     __shared__ u8 lut[256];                                   // character -> code (gen_code_of)
     __shared__ u32 ring[LaneEncB<THREADS, GEN_RING>::LDS_DWORDS];
     if constexpr (!FLAT) for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
     for (u32 i = threadIdx.x; i < 256; i += THREADS) lut[i] = (u8)(gen_code_of(i) | (is_lower_base(i) ? 0x20u : 0u));    // 0x20: a lowercase base ("gen.lc")
     __syncthreads();
-    const u32 c = blockIdx.x * THREADS + threadIdx.x;
-    const bool live = c < a.geo.nchains;
+    const u32 c = c0 + blockIdx.x * THREADS + threadIdx.x;
+    const bool live = c < c1;
     ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
     if (live) cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
@@ -947,10 +947,15 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a) {
         if (illegal) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_GENCHAR));
     }
 }
-void launch_gen_encode_c(const ChainArgs& a, hipStream_t st) {
+// the base chains of blocks [b0, b1) (b1 = 0: all of them); flat: every one of them codes with the initial row
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 b0, u32 b1, bool flat) {
     constexpr int T = 256;
-    if (!a.g_ngen) hipLaunchKernelGGL((k_gen_encode_c<T, true>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
-    else hipLaunchKernelGGL((k_gen_encode_c<T, false>), dim3((a.geo.nchains + T - 1) / T), dim3(T), 0, st, a);
+    const u64 lo = (u64)b0 * a.geo.cpb, hi = b1 ? (u64)b1 * a.geo.cpb : a.geo.nchains;
+    const u32 c0 = (u32)(lo < a.geo.nchains ? lo : a.geo.nchains), c1 = (u32)(hi < a.geo.nchains ? hi : a.geo.nchains);
+    if (c1 <= c0) return;
+    const dim3 grid((c1 - c0 + T - 1) / T);
+    if (flat) hipLaunchKernelGGL((k_gen_encode_c<T, true>), grid, dim3(T), 0, st, a, c0, c1);
+    else hipLaunchKernelGGL((k_gen_encode_c<T, false>), grid, dim3(T), 0, st, a, c0, c1);
 }
 
 // One base: the row's four frequencies -> the symbol under prob, its cum and freq (base2_ranger.hpp:86-104)

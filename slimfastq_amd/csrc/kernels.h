@@ -92,7 +92,7 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
                       u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st,
                       u32 sub = 0 /* 0 every selected record, 1 every GEN_PRE-th of them, 2 the others */, u32 do_count = 1 /* 0: the cost only */);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
-void launch_gen_encode_c(const ChainArgs& a, hipStream_t st);
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 b0 = 0, u32 b1 = 0 /* blocks [b0, b1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
 #define REC_COUNT_COPIES 32u        // the header prior's counting pass counts into this many copies of the table (chains.hip k_rec_count_sum)
@@ -111,7 +111,9 @@ void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stre
 // s-th record, s = ceil(n / GEN_COUNT_CAP): half a million records tell a row's shape, and the counting -- a
 // scattered atomic per base into a table of 2^gen_bits x 16 bytes -- was most of the time of inputs whose bases can be
 // learned (half of a 10 M-read call: 50 ms).  The decoder counts the same records.
+#ifndef GEN_COUNT_CAP
 #define GEN_COUNT_CAP 524288ull
+#endif
 #define GEN_PRE 8u                      /* the pre-verdict looks at every 8th of the records a counting pass takes (api.cpp gen_tables_begin) */
 static inline u32 gen_count_stride(u64 n) { return (u32)((n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP ? (n + GEN_COUNT_CAP - 1) / GEN_COUNT_CAP : 1); }
 
