@@ -69,8 +69,11 @@ def parse():
     ap.add_argument("--genome-ratio-reads", type=int, default=2_000_000, help="records the reference itself codes for the genome leg's ratio (30x coverage of the 10 Mbp genome)")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the size sweep (prefixes of the same text: 0.25 / 0.5 / 1 / 2 GB and all of it, encode + decode)")
     ap.add_argument("--sweep-gb", type=str, default="0.25,0.5,1,2", help="size sweep: prefix sizes in GB (the whole text is always the last point)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-to-host encode")
     ap.add_argument("--sweep-only", action="store_true", help="debug: the size sweep alone (no decode / adaptive / cpu / format-6 / genome legs)")
     args = ap.parse_args()
+    if args.sweep_only:
+        args.no_decode = args.no_adaptive_leg = args.no_cpu_baseline = args.no_format6_leg = args.no_genome_leg = args.no_host_leg = True
     if args.reads <= 0:
         args.reads = 60_000 if args.kind == 1 else 10_000_000
     if args.kind == 1:
@@ -125,9 +128,8 @@ def cpu_baseline(args, seed):
     return out, fq, ref_payload
 
 
-def size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models):
-    """The same call over prefixes of the text (whole records): encode and decode at every size, device-resident, each
-    timed on its own (the reference's loop, usrs.cpp:392-407, is size-agnostic: so should this be)."""
+def sweep_points(d_in, nbytes, args):
+    """(records, bytes) of the size sweep's prefixes: the CPU baseline's sample, the sizes of --sweep-gb, the whole text."""
     CH = 1 << 30                                              # (torch.nonzero takes at most 2^31 elements a call)
     chunk_nl = [int((d_in[o:o + CH] == 10).sum().item()) for o in range(0, nbytes, CH)]
 
@@ -139,16 +141,68 @@ def size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models):
             k -= c; o += CH
         return nbytes
     per_rec = nbytes / args.reads
-    points = []
+    points = [min(args.cpu_sample_reads, args.reads)] if not args.no_cpu_baseline else []
     for gb in [float(x) for x in args.sweep_gb.split(",") if x]:
         n = int(gb * 1e9 / per_rec)
-        if 0 < n < args.reads:
+        if 0 < n < args.reads and all(abs(n - q) > 0.2 * n for q in points):
             points.append(n)
-    points.append(args.reads)
+    points = sorted(set(points + [args.reads]))
+    return [(n, nbytes if n == args.reads else end_of_line(4 * n)) for n in points]
+
+
+class ReferenceRuns:
+    """The compiled reference (oracle/_ref, test infrastructure: the reported baseline only) over prefixes of the host text, one
+    process per prefix, fed through stdin by a thread each -- started when the timed legs are through, collected at the end of
+    the run: the sizes of the reference's streams at every point of the size sweep, without a serial hour of CPU time."""
+
+    def __init__(self, fq, cuts, level):
+        import subprocess, tempfile, threading
+        from oracle import oracle as O
+        self.O, self.jobs, self.dir = O, [], tempfile.mkdtemp(prefix="sfq_ref_")
+        exe = O.ref_binary()
+        if not exe:
+            return
+        view = memoryview(fq)
+        for cut in cuts:
+            out = os.path.join(self.dir, "%d.sfq" % cut)
+            p = subprocess.Popen([exe, "-f", out, "-O", "-l", str(level), "-q"], stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+            def feed(p=p, cut=cut):
+                try:
+                    p.stdin.write(view[:cut]); p.stdin.close()
+                except OSError:
+                    pass
+            t = threading.Thread(target=feed, daemon=True); t.start()
+            self.jobs.append((cut, p, t, out, time.perf_counter()))
+
+    def collect(self):
+        """{bytes of text: (bytes of the reference's streams, seconds)}"""
+        res = {}
+        for cut, p, t, out, t0 in self.jobs:
+            p.wait(); t.join()
+            dt = time.perf_counter() - t0
+            try:
+                a = self.O.parse(open(out, "rb").read())
+                res[cut] = (a.payload_bytes() - len(a.streams["<info>"]), dt)
+            except Exception:
+                pass
+            try:
+                os.remove(out)
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+        return res
+
+
+def size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models, points):
+    """The same call over prefixes of the text (whole records): encode and decode at every size, device-resident, each
+    timed on its own (the reference's loop, usrs.cpp:392-407, is size-agnostic: so should this be)."""
     d_back = torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda")
     rows = []
-    for n in points:
-        cut = end_of_line(4 * n)
+    for n, cut in points:
         kw = dict(level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
                   tables=args.tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
         ctx.encode_device(d_in.data_ptr(), cut, d_out.data_ptr(), cap, **kw)
@@ -234,6 +288,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")                       # read-only source: it is only copied to the device
         d_in = torch.from_numpy(np.frombuffer(fq, np.uint8)).cuda(non_blocking=False)
+    fq_host = fq if (not multi and not args.no_cpu_baseline and not args.no_size_sweep) else None       # (kept for the reference's runs over its prefixes)
     del fq
     ctx = capi.Context(local_rank)
     cap = capi.lib().sfq_encode_bound(nbytes)
@@ -354,10 +409,15 @@ def main():
                         "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
                         "device_total": round(phase[capi.T_TOTAL], 3)},
            "roofline": roofline, "synth_s": round(t_gen, 2)}
-    if args.sweep_only:
-        args.no_decode = args.no_adaptive_leg = args.no_cpu_baseline = args.no_format6_leg = args.no_genome_leg = True
+    if len(coder) > 3 and coder[3] > 0:
+        # the one part of the path that IS a stream: the framing kernel reads the text once and writes the line index
+        fr_bytes = nbytes + 8 * 4 * int(res.n_records)
+        out["roofline_framing"] = {"bound": "hbm", "kernel_name": "k_frame", "achieved": round(fr_bytes / (float(coder[3]) * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(fr_bytes / (float(coder[3]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(fr_bytes), "avg_ms": round(float(coder[3]), 3)}
+    points = None
     if not multi and not args.no_size_sweep and args.kind != 1 and args.tables:
-        out["size_sweep"] = size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models)
+        points = sweep_points(d_in, nbytes, args)
+        out["size_sweep"] = size_sweep(ctx, d_in, nbytes, d_out, cap, args, prior_step, models, points)
     if not multi and args.workload == "full" and not args.models and not args.no_decode:
         # the way back ("decode MB/s secondarily"): the same blocks decoded in HBM and compared with the input;
         # outside the timed region, never part of `value`
@@ -389,9 +449,32 @@ def main():
         torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / 3
         out["adaptive_tables"] = {"value": round(nbytes / ta / 1e6, 2), "unit": "MB/s", "ms_per_step": round(ta * 1e3, 3),
                                   "ratio": round(nbytes / ra.total_bytes, 4)}
+    if not multi and args.workload == "full" and not args.models and not args.no_host_leg and fq_host is not None:
+        # PCIe-inclusive (SURVEY 8d "wall clock including H2D/D2H"; never `value`): sfq_encode_blocks_host over page-locked buffers --
+        # the text crosses the link, the streams come back
+        L = capi.lib()
+        import ctypes as C
+        hin = L.sfq_host_alloc(ctx.handle, nbytes); hout = L.sfq_host_alloc(ctx.handle, cap)
+        if hin and hout:
+            C.memmove(hin, fq_host, nbytes)
+            pp = capi.Params(args.level, args.block_reads, 0, models, args.kernel, 0, prior_step, args.tables, args.chain_reads, args.lds_rows)
+            rr = capi.Result(); th = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc_ = L.sfq_encode_blocks_host(ctx.handle, C.c_void_p(hin), nbytes, C.byref(pp), C.c_void_p(hout), cap, C.byref(rr))
+                th.append(time.perf_counter() - t0)
+            if rc_ == 0:
+                out["host_to_host"] = {"value": round(nbytes / min(th[1:]) / 1e6, 2), "unit": "MB/s", "ms": round(min(th[1:]) * 1e3, 3),
+                                       "what": "sfq_encode_blocks_host: page-locked host text in, host streams out (H2D + the call + D2H)"}
+        if hin: L.sfq_host_free(ctx.handle, hin)
+        if hout: L.sfq_host_free(ctx.handle, hout)
     if not multi and not args.no_cpu_baseline:
         cb, sample, ref_payload = cpu_baseline(args, seed)
         out["cpu_baseline"] = cb
+        refs = None
+        if points and fq_host is not None and args.workload == "full" and not args.models:
+            # the reference over every other point of the sweep, a process each, while the legs below run
+            refs = ReferenceRuns(fq_host, [cut for n, cut in points if n != args.cpu_sample_reads], args.level)
         # ratio vs the reference on the same sample: ours in blocks vs the reference's single adaptive stream
         enc = ctx.encode_host(sample, level=args.level, block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=prior_step,
                               tables=args.tables, chain_reads=args.chain_reads)
@@ -467,6 +550,20 @@ def main():
             leg["ratio_vs_reference"] = {"sample_reads": lines // 4, "sample_raw": len(sample), "reference_stream_bytes": int(ref_payload), "ours_stream_bytes": int(enc.archive_bytes),
                                          "ours_over_reference": round(enc.archive_bytes / ref_payload, 4), "cpu_port_MBps": round(len(sample) / 1e6 / t_ref, 2)}
         out["genome_sampled"] = leg
+    if not multi and not args.no_cpu_baseline and points and "size_sweep" in out and args.workload == "full" and not args.models:
+        got = refs.collect() if refs is not None else {}
+        if "ratio_vs_reference" in out:
+            got[out["ratio_vs_reference"]["sample_raw"]] = (out["ratio_vs_reference"]["reference_stream_bytes"], None)
+        for row in out["size_sweep"]:
+            r = got.get(row["raw_bytes"])
+            if r and "archive_bytes" in row:
+                row["reference_stream_bytes"] = int(r[0]); row["ours_over_reference"] = round(row["archive_bytes"] / r[0], 4)
+                if r[1]:
+                    row["reference_MBps"] = round(row["raw_bytes"] / 1e6 / r[1], 2)       # (beside the other prefixes' processes: not the 1-core baseline)
+        full = [row for row in out["size_sweep"] if row["reads"] == args.reads and "ours_over_reference" in row]
+        if full:
+            out["ratio_vs_reference_full"] = {"sample_raw": full[0]["raw_bytes"], "reference_stream_bytes": full[0]["reference_stream_bytes"],
+                                              "ours_stream_bytes": full[0]["archive_bytes"], "ours_over_reference": full[0]["ours_over_reference"]}
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -144,7 +144,7 @@ typedef struct sfq_result {
     double   kernel_ms[8];                 /* device time of the last call, by phase (see SFQ_T_*): a model's phase is
                                               everything on its stream -- counting passes, row building, the coding kernel */
     double   coder_ms[4];                  /* encode: the coding kernel alone (HIP events around its launch on its stream):
-                                              [0] quality, [1] bases, [2] headers, [3] unused.  What a kernel trace shows as
+                                              [0] quality, [1] bases, [2] headers, [3] the framing kernel (k_frame).  What a kernel trace shows as
                                               k_qlt_encode_c / k_gen_encode_c / k_rec_encode_f (k_*_encode_k / _w with adaptive tables) */
 } sfq_result;
 

@@ -699,7 +699,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
             HIPC(hipMemsetAsync(ctx->chunk_base.p, 0, (size_t)tiles * 8, st));
             void* d_fo = (u8*)ctx->status.p + 224;                                   // (status bytes 224..239: nothing else lives there)
+            HIPC(hipEventRecord(ctx->ev[12], st));
             launch_frame(d_fastq, nbytes, (u64*)ctx->chunk_base.p, (u64*)ctx->line_off.p, cap, (u32*)ctx->status.p, want_marks ? (u8*)ctx->excf.p : nullptr, ecap, d_fo, st);
+            HIPC(hipEventRecord(ctx->ev[23], st));
             struct { u64 nlines; u32 tripped, pad; } fo = {0, 0, 0};
             u8 last_byte = 0;
             HIPC(hipMemcpyAsync(&fo, d_fo, 16, hipMemcpyDeviceToHost, st));
@@ -1108,7 +1110,14 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
                 // fill whatever is free: the three overlap from the start (measured: 225 -> 207 ms at 10 M reads).
                 if ((models & (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC)) == (SFQ_M_QLT | SFQ_M_GEN | SFQ_M_REC) &&
                     (order[m] == SFQ_M_QLT || order[m] == SFQ_M_GEN))
-                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, (ctx->wave_slots / 3 * KR) & ~(KR - 1)));
+                {
+#ifndef ADAPT_GEN_PCT
+#define ADAPT_GEN_PCT 33
+#define ADAPT_QLT_PCT 33
+#endif
+                    const u32 pct = order[m] == SFQ_M_GEN ? ADAPT_GEN_PCT : ADAPT_QLT_PCT;
+                    a.nbatch = std::min<u32>(a.nbatch, std::max<u32>(KR, ((u32)((u64)ctx->wave_slots * pct / 100) * KR) & ~(KR - 1)));
+                }
                 switch (order[m]) {
                 case SFQ_M_QLT: launch_qlt_encode_k(a, tickets + 0, mst[m]); break;
                 case SFQ_M_GEN: launch_gen_encode_k(a, tickets + 1, mst[m]); break;
@@ -1291,6 +1300,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     for (int m = 0; m < 4; m++) res->kernel_ms[tslot[m]] = ev_ms(ctx->ev[2 + 2 * m], ctx->ev[3 + 2 * m]);     // the models overlap: these do not add up
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
+    if (reframe) res->coder_ms[3] = ev_ms(ctx->ev[12], ctx->ev[23]);          // the framing kernel (frame.hip k_frame)
     if (frozen) {
         if (models & SFQ_M_QLT) res->coder_ms[0] = ev_ms(ctx->ev[14], ctx->ev[15]);
         if (models & SFQ_M_GEN) res->coder_ms[1] = ev_ms(ctx->ev[16], ctx->ev[17]);

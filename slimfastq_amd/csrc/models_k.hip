@@ -197,9 +197,13 @@ __global__ __launch_bounds__(64) void k_gen_encode_k(ModelArgs a, u32* ticket) {
     }
 }
 
+#ifndef GEN_K
+#define GEN_K 2
+#endif
 void launch_gen_encode_k(const ModelArgs& a, u32* ticket, hipStream_t st) {
-    // grid: one workgroup per pair of table slots (a.nbatch is even)
-    hipLaunchKernelGGL(k_gen_encode_k<2>, dim3((a.nbatch + 1) / 2), dim3(64), 0, st, a, ticket);
+    // grid: one workgroup per GEN_K table slots (a.nbatch is even; slots a last partial group would take stay unused)
+    const u32 groups = a.nbatch / GEN_K ? a.nbatch / GEN_K : 1u;
+    hipLaunchKernelGGL(k_gen_encode_k<GEN_K>, dim3(groups), dim3(64), 0, st, a, ticket);
 }
 
 // =========================================================================================================
