@@ -92,13 +92,17 @@ typedef struct sfq_params {
                               SFQ_TABLES_FROZEN (1) = the rows are built by counting passes and frozen while a chain
                               is coded -- qualities from the transmitted prior, bases from the counts of the earlier
                               generations of the same call -- one chain per LANE               */
-    uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic                                    */
+    uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic (about 205 000 chains a call, of 4 KiB of text or more; long
+                              reads -- fewer than 204 800 records, each a chain's worth or more -- are cut into SEGMENTS of one record);
+                              SFQ_CHAIN_SEGMENT(n): chains of (at most) n quality symbols / bases of ONE record                     */
     uint32_t lds_rows;     /* frozen tables: quality rows staged in LDS by every workgroup of the quality chains.  Encode: the N most used
                               rows (up to 1024); 0 = automatic (800 rows where the call has 150 000 chains or more: 17.3 -> 15.9 ms per 3.7 GB
                               call), SFQ_LDS_ROWS_NONE = none.  Decode: the coarse lists (16 bytes) of the N contexts the prior gives the most
                               weight (up to 6000); 0 = automatic (6000 where the call has 150 000 chains or more: 23.0 -> 20.0 ms),
                               SFQ_LDS_ROWS_NONE = none.  Where the rows come from never shows in the streams.                          */
 } sfq_params;
+#define SFQ_CHAIN_SEGMENT_FLAG 0x80000000u
+#define SFQ_CHAIN_SEGMENT(n) (SFQ_CHAIN_SEGMENT_FLAG | (uint32_t)(n))
 #define SFQ_TABLES_ADAPTIVE 0u
 #define SFQ_TABLES_FROZEN   1u
 #define SFQ_TABLES_AUTO     2u   /* by the size of the text: frozen tables from 64 MiB on; below that their transmitted priors weigh too

@@ -364,6 +364,47 @@ def gen_encode_chains(buf: bytes, goff, glen, gen_bits, block_reads, chain_reads
     return _take(out, n), sizes, on.value
 
 
+def seg_counts(length, other, seg_len):
+    """Segments per record (chains.hip): n = ceil(max(len, other) / seg_len), at least one."""
+    m = np.maximum(np.asarray(length, np.uint64), np.asarray(other, np.uint64))
+    return np.maximum(1, (m + seg_len - 1) // seg_len).astype(np.int64)
+
+
+def qlt_encode_segs(buf: bytes, off, length, other_len, level, seg_len, frozen_rows):
+    """Quality chains that are SEGMENTS of one record -> (chain streams back to back, per-chain sizes, escapes)."""
+    L = lib()
+    nseg = int(seg_counts(length, other_len, seg_len).sum())
+    off, po = _arr(off, np.uint64); length, pl = _arr(length, np.uint32); other_len, pt = _arr(other_len, np.uint32)
+    frozen_rows = np.ascontiguousarray(frozen_rows, np.uint32)
+    sizes = np.zeros(nseg, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); extra = C.c_uint32()
+    L.sfqo_qlt_encode_segs.restype = C.c_longlong
+    L.sfqo_qlt_encode_segs.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p,
+                                       C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_uint32)]
+    got = L.sfqo_qlt_encode_segs(buf, po, pl, pt, len(off), level, seg_len, frozen_rows.ctypes.data_as(C.c_void_p),
+                                 C.byref(out), C.byref(n), sizes.ctypes.data_as(C.c_void_p), C.byref(extra))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, extra.value
+
+
+def gen_encode_segs(buf: bytes, goff, glen, other_len, gen_bits, block_reads, seg_len, step=4):
+    """Base chains that are SEGMENTS of one record -> (chain streams back to back, per-chain sizes, gen_on)."""
+    L = lib()
+    nseg = int(seg_counts(glen, other_len, seg_len).sum())
+    goff, po = _arr(goff, np.uint64); glen, pl = _arr(glen, np.uint32); other_len, pt = _arr(other_len, np.uint32)
+    sizes = np.zeros(nseg, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); on = C.c_int()
+    L.sfqo_gen_encode_segs.restype = C.c_longlong
+    L.sfqo_gen_encode_segs.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int)]
+    got = L.sfqo_gen_encode_segs(buf, po, pl, pt, len(goff), gen_bits, block_reads, seg_len, step, C.byref(out), C.byref(n),
+                                 sizes.ctypes.data_as(C.c_void_p), C.byref(on))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, on.value
+
+
 REC_ROWS = 66 * 16
 
 

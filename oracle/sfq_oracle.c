@@ -1670,6 +1670,40 @@ long long sfqo_qlt_encode_chains(const u8* base, const u64* off, const u32* len,
     return g_failed ? -1 : (long long)nc;
 }
 
+/* Chains that are SEGMENTS of one record (long reads; chains.hip): a record of M = max(bases, qualities) symbols is cut into
+   n = ceil(M / seg_len) segments of L = ceil(M / n) symbols; segment s covers symbols [s L, (s + 1) L) of the line (as far as the line
+   goes) and is a chain of its own: its context starts as a line's does.  other_len: the other line's lengths (the bases'). */
+static void seg_geometry(u32 len, u32 other, u32 seg_len, size_t* n, size_t* L) {
+    const u64 M = len > other ? len : other;
+    size_t k = (size_t)((M + seg_len - 1) / seg_len); if (!k) k = 1;
+    size_t l = (size_t)((M + k - 1) / k); if (!l) l = 1;
+    *n = k; *L = l;
+}
+long long sfqo_qlt_encode_segs(const u8* base, const u64* off, const u32* len, const u32* other_len, size_t nrec, int level, u32 seg_len,
+                               const u32* frozen_rows, u8** out, size_t* out_len, u32* sizes, u32* extra_hi) {
+    g_failed = 0; g_err[0] = 0;
+    obuf o = { 0, 0, 0 };
+    size_t nc = 0; u32 extra = 0;
+    for (size_t r = 0; r < nrec; r++) {
+        size_t n, L; seg_geometry(len[r], other_len[r], seg_len, &n, &L);
+        for (size_t sg = 0; sg < n; sg++, nc++) {
+            const size_t lo = sg * L < len[r] ? sg * L : len[r];
+            const size_t cnt = len[r] - lo < L ? len[r] - lo : L;
+            chenc c; ch_init(&c);
+            qfz q = { &c, frozen_rows, 0 };
+            if (!g_failed) qlt_walk(base + off[r] + lo, cnt, level, qfz_cb, &q);
+            const size_t nb = ch_finish(&c);
+            ob_write(&o, c.out, nb);
+            if (sizes) sizes[nc] = (u32)nb;
+            extra += q.extra;
+            free(c.out);
+        }
+    }
+    if (extra_hi) *extra_hi = extra;
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : (long long)nc;
+}
+
 /* ---- bases: generation tables ---- */
 /* floor(1024 * log2(x)), x in 1..1023, by integer arithmetic (squaring a 1.31 fixed-point mantissa ten times) */
 static u32 log2fp(u32 x) {
@@ -1737,8 +1771,9 @@ static void gfz_cb(void* arg, u32 ctx, int code) {
     ch_encode(g->c, cum, f[code], f[0] + f[1] + f[2] + f[3]);                   /* base2_ranger.hpp:74-84 without the update */
 }
 /* gen_on: 1 = the generation tables were used (decided from generation 1's cost under generation 0's rows) */
-long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
-                                 size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
+                                 size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on,
+                                 u32 seg_len /* != 0: segments of one record */, const u32* other_len) {
     g_failed = 0; g_err[0] = 0;
     const size_t nblocks = (nrec + block_reads - 1) / block_reads;
     const size_t nctx = (size_t)1 << gen_bits; const u32 mask = (u32)nctx - 1;
@@ -1785,6 +1820,23 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
     for (size_t b = 0; b < nblocks; b++) {
         size_t g = 0; while (g + 1 < ngen && b >= bound[g + 1]) g++;
         const size_t b0 = REC_OF(b), b1 = REC_OF(b + 1);
+        if (seg_len) {
+            for (size_t r = b0; r < b1; r++) {
+                size_t n, L; seg_geometry(glen[r], other_len[r], seg_len, &n, &L);
+                for (size_t sg = 0; sg < n; sg++, nc++) {
+                    const size_t lo = sg * L < glen[r] ? sg * L : glen[r];
+                    const u64 o1 = goff[r] + lo; const u32 l1 = (u32)(glen[r] - lo < L ? glen[r] - lo : L);
+                    chenc c; ch_init(&c);
+                    gfz gz = { &c, on ? rows[g] : NULL };
+                    gen_walk(base, &o1, &l1, 0, 1, mask, gfz_cb, &gz);        /* (a segment starts from the seed, as a line) */
+                    const size_t nb = ch_finish(&c);
+                    ob_write(&o, c.out, nb);
+                    if (sizes) sizes[nc] = (u32)nb;
+                    free(c.out);
+                }
+            }
+            continue;
+        }
         for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
             const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
             chenc c; ch_init(&c);
@@ -1802,6 +1854,15 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
     if (gen_on) *gen_on = on;
     *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
     return g_failed ? -1 : (long long)nc;
+}
+
+long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
+                                 size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+    return gen_encode_chains_x(base, goff, glen, nrec, gen_bits, block_reads, chain_reads, step, out, out_len, sizes, gen_on, 0, NULL);
+}
+long long sfqo_gen_encode_segs(const u8* base, const u64* goff, const u32* glen, const u32* other_len, size_t nrec, int gen_bits, size_t block_reads,
+                               u32 seg_len, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+    return gen_encode_chains_x(base, goff, glen, nrec, gen_bits, block_reads, 1, step, out, out_len, sizes, gen_on, seg_len, other_len);
 }
 
 /* ---- headers: frozen PowerRanger rows ---- */

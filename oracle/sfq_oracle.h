@@ -110,6 +110,11 @@ long long sfqo_qlt_encode_chains(const uint8_t* base, const uint64_t* off, const
                                  size_t chain_reads, const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* extra_hi);
 long long sfqo_gen_encode_chains(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, size_t nrec, int gen_bits, size_t block_reads,
                                  size_t chain_reads, uint32_t step, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+/* the same for chains that are SEGMENTS of one record (long reads): other_len = the lengths of the record's other line */
+long long sfqo_qlt_encode_segs(const uint8_t* base, const uint64_t* off, const uint32_t* len, const uint32_t* other_len, size_t nrec, int level, uint32_t seg_len,
+                               const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* extra_hi);
+long long sfqo_gen_encode_segs(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint32_t* other_len, size_t nrec, int gen_bits, size_t block_reads,
+                               uint32_t seg_len, uint32_t step, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
 int sfqo_rec_count(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t stride, size_t run, size_t nruns, uint32_t* counts);
 int sfqo_rec_prior_freqs(const uint32_t* counts, uint32_t* f);
 int sfqo_rec_frozen_rows(const uint32_t* f, uint32_t* rows);

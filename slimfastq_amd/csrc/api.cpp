@@ -49,6 +49,7 @@ struct sfq_ctx {
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
+    DevBuf segn, segoff, segrec;           // chains that are segments of one record (long reads): segments per record, their scan, a chain's record
     // format 6's oversize records (frame.hip): flags, kept bytes, their scans, the text without them, kept record -> file number, the list;
     // the file's own line index; decode: numbers, pieces, raw text of the three streams, sizes / offsets in file order
     DevBuf oflags, okbytes, ofpos, okoff, ofilt, orecmap, olist, line_off_o, ono, opiece, otxt[3], osize_all, oroff_all, oroff_k, ocnt;
@@ -580,7 +581,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -911,8 +912,17 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     memset(&ca, 0, sizeof ca);
     u32 nchains = 0, nsub = 0;
     GenPlan gplan;
+    u32 seg_len = 0;                                   // chains that are segments of one record (chains.hip "segments")
+    std::vector<u32> seg_blk;                          // ... and how many each block has ("chn.idx")
     if (frozen) {
-        const u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
+        u32 cr = p.chain_reads ? p.chain_reads : (u32)default_chain_reads(nrec, nbytes);
+        if (p.chain_reads & SFQ_CHAIN_SEGMENT_FLAG) { seg_len = p.chain_reads & ~SFQ_CHAIN_SEGMENT_FLAG; cr = 1; if (!seg_len) return fail(ctx, SFQ_E_ARG, "SFQ_CHAIN_SEGMENT(0)"); }
+        else if (!p.chain_reads && cr == 1 && nrec < 204800) {
+            // long records, few of them: a lane that walks a 50 kb read alone takes as long as the rest of the call -- the call's
+            // symbols in about 204 800 segments (default_chain_reads), of 2048 symbols or more
+            const u64 want = std::min<u64>(std::max<u64>(2048, nbytes / 2 / 204800), 1u << 20);
+            if (max_line > want) seg_len = (u32)want;
+        }
         ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
         ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
         // the automatic choice: the block's chains of equal length (1024 records in chains of 50 would leave a last chain of
@@ -923,6 +933,24 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (nc > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu)", (unsigned long long)nc);
         nchains = ca.geo.nchains = (u32)nc;
         ca.nbytes = nbytes; ca.block_reads = block_reads;
+        if (seg_len) {
+            // segments per record (from the line index), their scan, the chains' records; the blocks' shares come back for "chn.idx"
+            if ((rc = reserve(ctx, ctx->segn, (size_t)nrec * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->segoff, ((size_t)nrec + 1) * 8))) return rc;
+            if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
+            launch_seg_count((const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, seg_len, (u32*)ctx->segn.p, st);
+            launch_scan_u32((const u32*)ctx->segn.p, (u64*)ctx->segoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+            std::vector<u64> h_off((size_t)nrec + 1);
+            HIPC(hipMemcpyAsync(h_off.data(), ctx->segoff.p, ((size_t)nrec + 1) * 8, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (h_off[nrec] > 0x7FFFFFFFull) return fail(ctx, SFQ_E_ARG, "too many chains (%llu segments)", (unsigned long long)h_off[nrec]);
+            nchains = ca.geo.nchains = (u32)h_off[nrec];
+            seg_blk.resize(nblocks);
+            for (u32 b = 0; b < nblocks; b++) seg_blk[b] = (u32)(h_off[std::min<u64>((u64)(b + 1) * block_reads, nrec)] - h_off[(u64)b * block_reads]);
+            if ((rc = reserve(ctx, ctx->segrec, (size_t)nchains * 4 + 16))) return rc;
+            launch_seg_fill((const u64*)ctx->segoff.p, nrec, (u32*)ctx->segrec.p, st);
+            ca.seg_len = seg_len; ca.seg_off = (const u64*)ctx->segoff.p; ca.seg_rec = (const u32*)ctx->segrec.p;
+        }
         // header chains: longer than the quality / base chains (each starts from the block's first header with cold field
         // types, which costs it a few bytes)
         {
@@ -1265,7 +1293,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // (half a million varints, written through a pointer into room for the longest: pushed byte by byte into the vector they
         //  were 1.0 ms of every call, after the GPU had finished)
         std::vector<u8>& o = ctx->chain_blob;
-        o.resize(((size_t)nchains * 2 + (size_t)nsub * 2) * 5 + 64);
+        o.resize(((size_t)nchains * 2 + (size_t)nsub * 2 + (seg_len ? nblocks : 0)) * 5 + 64);
         u8* w = o.data();
         auto put = [&w](u32 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
         // a list of sizes: each as the zigzag difference to the one before it (neighbouring chains hold as many symbols of the same
@@ -1275,7 +1303,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (size_t i = 0; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */); put(nchains);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u)); put(nchains);
+        if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
         put_list(h_csz, nchains); put_list(h_csz + nchains, nchains);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
             put(ca.rgeo.chain_reads); put(nsub);
@@ -1516,6 +1545,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
+    u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
     u32* h_csz = nullptr; u64* h_coff = nullptr; size_t ncs = 0;
     if (frozen) {
@@ -1526,7 +1556,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         gen_on = (u32)v & 1u; rec_chains = ((u32)v >> 1) & 1u;
         const bool deltas = ((u32)v >> 2) & 1u;              // sizes as zigzag differences to the entry before (round 4; version-8 archives of round 3: plain)
-        if (v >> 3) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        const bool segs = ((u32)v >> 3) & 1u;                // chains are segments of one record (long reads): their length and the blocks' shares follow
+        if (v >> 4) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
         u64 lprev = 0;                                        // the running value of the list being read
         auto get_size = [&](u64& out) -> bool {
             if (!get_v(cb, cn, cp, out)) return false;
@@ -1543,7 +1574,23 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
         cpb = (block_reads + chain_reads - 1) / chain_reads;
         const u32 last_nrec = h_blocks[nblocks - 1].n_records;
-        const u64 want = (u64)(nblocks - 1) * cpb + (last_nrec + chain_reads - 1) / chain_reads;
+        u64 want = (u64)(nblocks - 1) * cpb + (last_nrec + chain_reads - 1) / chain_reads;
+        if (segs) {
+            if (chain_reads != 1 || v > 0x7FFFFFFFull || nblocks > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: segments)");
+            want = v;
+            u64 sl = 0;
+            if (!get_v(cb, cn, cp, sl) || sl == 0 || sl > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: segments)");
+            seg_len = (u32)sl;
+            seg_c0.resize((size_t)nblocks + 1);
+            u64 run_c = 0;
+            for (u32 b = 0; b < nblocks; b++) {
+                u64 k = 0;
+                if (!get_v(cb, cn, cp, k) || k < h_blocks[b].n_records || k > want) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: a block's segments)");
+                seg_c0[b] = (u32)run_c; run_c += k;
+            }
+            seg_c0[nblocks] = (u32)run_c;
+            if (run_c != want) return fail(ctx, SFQ_E_CORRUPT, "chain index: the blocks' segments do not add up");
+        }
         if (v != want || want > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu chains, the blocks have %llu", (unsigned long long)v, (unsigned long long)want);
         nchains = (u32)want;
         h_csz = bump.take<u32>(cn + 16);
@@ -1575,8 +1622,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             lprev = 0;
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
-                for (u32 j = 0; j < cpb && (u64)b * cpb + j < nchains; j++) {
-                    const size_t c = (size_t)k * nchains + (size_t)b * cpb + j;
+                const u64 bc0 = seg_len ? seg_c0[b] : (u64)b * cpb, bc1 = seg_len ? seg_c0[b + 1] : std::min<u64>(bc0 + cpb, nchains);
+                for (u64 cc = bc0; cc < bc1; cc++) {
+                    const size_t c = (size_t)k * nchains + (size_t)cc;
                     if (!get_size(v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
                     h_csz[c] = (u32)v; h_coff[c] = at; at += v; sum += v;
                 }
@@ -1719,6 +1767,23 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ChainArgs ca;
         memset(&ca, 0, sizeof ca);
         ca.m = da.m; ca.geo.chain_reads = chain_reads; ca.geo.cpb = cpb; ca.geo.nchains = nchains; ca.block_reads = block_reads;
+        if (seg_len) {
+            // segments: a record's share of the chains follows from its line lengths (the usr streams have given them); what the
+            // index says of the blocks must agree
+            if ((rc = reserve(ctx, ctx->segn, (size_t)nrec * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->segoff, ((size_t)nrec + 1) * 8))) return rc;
+            launch_seg_count_dec(da.slen, da.qlen, nrec, seg_len, (u32*)ctx->segn.p, st);
+            launch_scan_u32((const u32*)ctx->segn.p, (u64*)ctx->segoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+            std::vector<u64> h_off((size_t)nrec + 1);
+            HIPC(hipMemcpyAsync(h_off.data(), ctx->segoff.p, ((size_t)nrec + 1) * 8, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            for (u32 b = 0; b <= nblocks; b++)
+                if (h_off[std::min<u64>((u64)b * block_reads, nrec)] != seg_c0[b]) return fail(ctx, SFQ_E_CORRUPT, "chain index: block %u's segments disagree with its records' line lengths", b);
+            if ((rc = reserve(ctx, ctx->segrec, (size_t)nchains * 4 + 16))) return rc;
+            launch_seg_fill((const u64*)ctx->segoff.p, nrec, (u32*)ctx->segrec.p, st);
+            ca.seg_len = seg_len; ca.seg_off = (const u64*)ctx->segoff.p; ca.seg_rec = (const u32*)ctx->segrec.p;
+        }
+        auto chain0_of = [&](u32 b) -> u32 { return seg_len ? seg_c0[b] : (u32)std::min<u64>((u64)b * cpb, nchains); };
         if ((rc = reserve(ctx, ctx->qrows, (size_t)q_rows * 64 * 4))) return rc;
         if ((rc = build_qesc(ctx, st))) return rc;
         if ((rc = reserve(ctx, ctx->qdec, (size_t)q_rows * 72 * 2 + 64))) return rc;            // chains.hip QDEC_ROW
@@ -1750,7 +1815,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ca.st_buf = da.seq_stage; ca.st_bytes = tot_s; ca.st_off = da.soff; ca.st_len = da.slen;
         u32 bound[GEN_MAX_GENERATIONS + 1];
         const u32 ngen = gen_bounds(nblocks, bound);
-        if (!gen_on || ngen < 3) launch_gen_decode_c(ca, da, 0, nblocks, st_gen);
+        if (!gen_on || ngen < 3) launch_gen_decode_c(ca, da, 0, nchains, st_gen);
         else {
             const u64 nctx = 1ull << g_bits;
             if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;
@@ -1764,7 +1829,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 // rows of generation g (two buffers in turn: a generation's rows are dead once it is decoded)
                 if (g >= 2) { launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * (g & 1), nctx, GEN_STEP, st_gen); ca.g_rows[g] = rows + nctx * (g & 1); }
                 else ca.g_rows[g] = nullptr;
-                launch_gen_decode_c(ca, da, bound[g], bound[g + 1], st_gen);
+                launch_gen_decode_c(ca, da, chain0_of(bound[g]), chain0_of(bound[g + 1]), st_gen);
                 if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, dec_max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
             }
         }

@@ -212,9 +212,21 @@ void launch_hot_rows_dec(const u32* rows66, const u16* qdec, u32 q_rows, u32 wan
 u32 hot_rows_dec_max(void) { return QHD_MAX_ROWS; }
 
 // ---- chain geometry ---------------------------------------------------------------------------------------------
-struct ChainPos { u32 b; u64 r0; u32 nrec; };
+// A chain is chain_reads whole records of a block -- or, where records are LONG (tens of kilobases: a call of 60 k reads has 60 k
+// records and a lane that walks one of 50 kb alone takes as long as the rest of the call), a SEGMENT of one record: a record of
+// M = max(bases, qualities) symbols is cut into n = ceil(M / seg_len) segments of ceil(M / n) symbols each; segment s of the
+// quality line and segment s of the base line are chain seg_off[r] + s of their streams.  A segment starts as a line does: the
+// quality context at its initial state (qlts.cpp:109-112), the base context at the seed (gens.cpp:139).
+struct ChainPos { u32 b; u64 r0; u32 nrec; u64 sub_lo, sub_len; u32 seg, nseg; };
 __device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
     ChainPos p;
+    p.sub_lo = 0; p.sub_len = 0; p.seg = 0; p.nseg = 1;
+    if (a.seg_len) {
+        const u64 r = a.seg_rec[c];
+        p.b = (u32)(r / a.block_reads); p.r0 = r; p.nrec = 1;
+        p.seg = (u32)(c - a.seg_off[r]); p.nseg = (u32)(a.seg_off[r + 1] - a.seg_off[r]);
+        return p;                                          // (sub_lo / sub_len: seg_range, once the record's M is at hand)
+    }
     p.b = c / a.geo.cpb;
     const u32 j = c - p.b * a.geo.cpb;
     const BlockDesc* d = &a.m.blocks[p.b];
@@ -223,13 +235,66 @@ __device__ __forceinline__ ChainPos chain_pos(const ChainArgs& a, u32 c) {
     p.r0 = d->rec0 + k0;
     return p;
 }
-// a chain's output region inside its block's region of the scratch arena: proportional to the text before it
+__device__ __forceinline__ u32 seg_count_of(u64 M, u32 seg_len) { const u64 n = (M + seg_len - 1) / seg_len; return n ? (u32)n : 1u; }
+// the symbols [sub_lo, sub_lo + sub_len) of a line that segment p.seg of p.nseg covers, M = max(bases, qualities) of the record
+__device__ __forceinline__ void seg_range(ChainPos& p, u64 M) {
+    const u64 L = (M + p.nseg - 1) / p.nseg;
+    p.sub_len = L ? L : 1;
+    p.sub_lo = (u64)p.seg * p.sub_len;
+}
+// M of record r from the text's line index (the lines as the walkers see them: without a SOLiD prefix character)
+__device__ __forceinline__ u64 rec_symbols(const u64* line_off, u64 r, u32 solid) {
+    const u64 g0 = line_off[4 * r + 1] + solid, g1 = line_off[4 * r + 2] - 1, q0 = line_off[4 * r + 3] + solid, q1 = line_off[4 * r + 4] - 1;
+    const u64 gl = g1 > g0 ? g1 - g0 : 0, ql = q1 > q0 ? q1 - q0 : 0;
+    return gl > ql ? gl : ql;
+}
+__device__ __forceinline__ void chain_seg_encode(const ChainArgs& a, ChainPos& p) {        // (encode: the segment's range from the text)
+    if (a.seg_len) seg_range(p, rec_symbols(a.m.line_off, p.r0, a.m.blocks[p.b].solid));
+}
+// the first chain of block b
+__device__ __forceinline__ u64 block_chain0(const ChainArgs& a, const ChainGeoArgs& geo, u32 b) {
+    return a.seg_len ? a.seg_off[a.m.blocks[b].rec0] : (u64)b * geo.cpb;
+}
+__device__ __forceinline__ u64 block_chain1(const ChainArgs& a, const ChainGeoArgs& geo, u32 b) {
+    if (a.seg_len) return a.seg_off[a.m.blocks[b].rec0 + a.m.blocks[b].nrec];
+    const u64 e = (u64)(b + 1) * geo.cpb;
+    return e < geo.nchains ? e : geo.nchains;
+}
+// a chain's output region inside its block's region of the scratch arena: proportional to the text before it (a segment: its
+// record's text in equal parts)
 __device__ __forceinline__ u8* chain_region(const ChainArgs& a, const ChainPos& p, int stream, u32 num, u32 den, u32& cap) {
     const BlockDesc* d = &a.m.blocks[p.b];
-    const u64 t0 = a.m.line_off[4 * d->rec0], tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
+    const u64 t0 = a.m.line_off[4 * d->rec0];
+    u64 tc = a.m.line_off[4 * p.r0], te = a.m.line_off[4 * (p.r0 + p.nrec)];
+    if (a.seg_len) { const u64 len = te - tc, base = tc; tc = base + len * p.seg / p.nseg; te = base + len * (p.seg + 1) / p.nseg; }
     const u64 lo = ((tc - t0) * num / den + 3) & ~3ull, hi = ((te - t0) * num / den) & ~3ull;        // (dword-aligned: LaneEncB::drain stores 16 bytes at such addresses)
     cap = hi > lo ? (u32)(hi - lo) : 0u;
     return a.m.arena + d->out_off[stream] + lo;
+}
+// segments per record: lane per record
+__global__ __launch_bounds__(256) void k_seg_count(const u64* __restrict__ line_off, const BlockDesc* __restrict__ blocks, u32 block_reads, u64 nrec, u32 seg_len, u32* __restrict__ nseg) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    nseg[r] = seg_count_of(rec_symbols(line_off, r, blocks[r / block_reads].solid), seg_len);
+}
+__global__ __launch_bounds__(256) void k_seg_count_dec(const u32* __restrict__ slen, const u32* __restrict__ qlen, u64 nrec, u32 seg_len, u32* __restrict__ nseg) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    nseg[r] = seg_count_of(slen[r] > qlen[r] ? slen[r] : qlen[r], seg_len);
+}
+__global__ __launch_bounds__(256) void k_seg_fill(const u64* __restrict__ seg_off, u64 nrec, u32* __restrict__ seg_rec) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    for (u64 c = seg_off[r]; c < seg_off[r + 1]; c++) seg_rec[c] = (u32)r;
+}
+void launch_seg_count(const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 seg_len, u32* nseg, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_count, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, line_off, blocks, block_reads, nrec, seg_len, nseg);
+}
+void launch_seg_count_dec(const u32* slen, const u32* qlen, u64 nrec, u32 seg_len, u32* nseg, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_count_dec, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, slen, qlen, nrec, seg_len, nseg);
+}
+void launch_seg_fill(const u64* seg_off, u64 nrec, u32* seg_rec, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_fill, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, seg_off, nrec, seg_rec);
 }
 
 // 16 text bytes of a lane: aligned loads, nothing read outside [fq, fq_end)
@@ -324,15 +389,15 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     }
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < a.geo.nchains;
-    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
-    if (live) cp = chain_pos(a, c);
+    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0; cp.sub_lo = cp.sub_len = 0; cp.seg = 0; cp.nseg = 1;
+    if (live) { cp = chain_pos(a, c); chain_seg_encode(a, cp); }
     const BlockDesc* d = &a.m.blocks[cp.b];
     LaneEncB<THREADS, QLT_RING> rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_QLT, 2, 1, cap) : nullptr;
     rc.init(ring, threadIdx.x, outp, cap);
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
-    LineWalk lw; lw.init(a, cp.r0, cp.nrec, 3, live ? d->solid : 0u);
+    LineWalk lw; lw.init(a, cp.r0, cp.nrec, 3, live ? d->solid : 0u, cp.sub_lo, cp.sub_len);
     u32 last = 0, p1 = 0, p2 = 0, delta = 5;
     u32 extra = 0;
     // (a) the contexts of a piece's symbols depend on the text alone: all of its row entries are fetched at once -- and a
@@ -578,11 +643,17 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
     }
     const u32 c = blockIdx.x * THREADS + threadIdx.x;
     if (c >= a.geo.nchains) return;
-    const ChainPos cp = chain_pos(a, c);
     LaneDecQ rc; rc.init(da.streams + a.coff[c], a.csz[c], reinterpret_cast<const u8*>(a.qesc));
     const int level = a.m.level;
     const u32 mask12 = level == 1 ? 0xFFFu : 0xFFFFu;
+    ChainPos cp = chain_pos(a, c);
     u32 n_next = cp.nrec ? da.qlen[cp.r0] : 0u; u64 off_next = cp.nrec ? da.qoff[cp.r0] : 0ull;      // a record's length and place, a record ahead
+    if (a.seg_len) {                                         // a segment of one record: its part of the quality line
+        const u32 sl = da.slen[cp.r0];
+        seg_range(cp, sl > n_next ? sl : n_next);
+        const u64 lo = cp.sub_lo < n_next ? cp.sub_lo : n_next;
+        n_next = (u32)(n_next - lo < cp.sub_len ? n_next - lo : cp.sub_len); off_next += lo;
+    }
     for (u32 k = 0; k < cp.nrec; k++) {
         const u32 n = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.qlen[cp.r0 + k + 1]; off_next = da.qoff[cp.r0 + k + 1]; }
@@ -665,8 +736,12 @@ __global__ __launch_bounds__(256) void k_chain_block_sizes(ChainArgs a, ChainGeo
     const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= a.m.nblocks) return;
     u32 sum = 0, hb = 0;
-    const u32 c0 = b * geo.cpb;
-    for (u32 j = lane; j < geo.cpb && c0 + j < geo.nchains; j += 64) { sum += csz[c0 + j]; if (rhb) hb += rhb[c0 + j]; }
+    // (the header chains have a geometry of their own, rgeo: never segments)
+    const bool seg = a.seg_len && stream != SFQ_S_REC;
+    const u64 c0 = seg ? block_chain0(a, geo, b) : (u64)b * geo.cpb;
+    u64 c1 = seg ? block_chain1(a, geo, b) : c0 + geo.cpb;
+    if (c1 > geo.nchains) c1 = geo.nchains;
+    for (u64 cc = c0 + lane; cc < c1; cc += 64) { sum += csz[cc]; if (rhb) hb += rhb[cc]; }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sum += (u32)__shfl_xor((int)sum, d, 64); hb += (u32)__shfl_xor((int)hb, d, 64); }
     if (lane == 0) {
@@ -683,12 +758,14 @@ __global__ __launch_bounds__(256) void k_compact_chains(ChainArgs a, ChainGeoArg
     const u32 c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= geo.nchains) return;
     if (gate && !gate[0]) return;                          // (frame.hip k_stream_gate: a failed block or too little room -- nothing is written)
+    const bool seg = a.seg_len && stream != SFQ_S_REC;    // (the header chains have a geometry of their own: never segments)
+    if (!seg) a.seg_len = 0;
     a.geo = geo;                                           // chain_pos / chain_region read the geometry from `a`
-    const ChainPos cp = chain_pos(a, c);
+    ChainPos cp = chain_pos(a, c);
     const u32 n = csz[c];
     if (!n) return;
     u32 before = 0;
-    for (u32 cc = cp.b * geo.cpb + lane; cc < c; cc += 64) before += csz[cc];
+    for (u64 cc = block_chain0(a, geo, cp.b) + lane; cc < c; cc += 64) before += csz[cc];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) before += (u32)__shfl_xor((int)before, d, 64);
     u32 cap;
@@ -766,8 +843,9 @@ __device__ __forceinline__ void walk_bases(const ChainArgs& a, u64 r0, u32 nrec,
 // bytes repeats the context before it, so its lookup is harmless), code(j, code, valid) likewise with a flag, and
 // piece_end() once per piece.
 template <typename LOOK, typename CODE, typename PEND>
-__device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, const u8* lut, LOOK&& look, CODE&& code, PEND&& piece_end, u8* exc_flag) {
-    LineWalk lw; lw.init(a, r0, nrec, 1, solid);
+__device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, u32 mask, const u8* lut, LOOK&& look, CODE&& code, PEND&& piece_end, u8* exc_flag,
+                                            u64 sub_lo = 0, u64 sub_len = 0) {
+    LineWalk lw; lw.init(a, r0, nrec, 1, solid, sub_lo, sub_len);
     u32 last = 0, illegal = 0;
     Piece pc = lw.next();
     uint4 w = lw.fetch(pc);
@@ -908,8 +986,8 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
     __syncthreads();
     const u32 c = c0 + blockIdx.x * THREADS + threadIdx.x;
     const bool live = c < c1;
-    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0;
-    if (live) cp = chain_pos(a, c);
+    ChainPos cp; cp.b = 0; cp.r0 = 0; cp.nrec = 0; cp.sub_lo = cp.sub_len = 0; cp.seg = 0; cp.nseg = 1;
+    if (live) { cp = chain_pos(a, c); chain_seg_encode(a, cp); }
     const BlockDesc* d = &a.m.blocks[cp.b];
     LaneEncB<THREADS, GEN_RING> rc; u32 cap = 0;
     u8* outp = live ? chain_region(a, cp, SFQ_S_GEN, 3, 4, cap) : nullptr;
@@ -921,7 +999,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
         const u32 r12 = fz_recip(12u);
         illegal = walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
             [&](u32, u32 code, u32 vm) { rc.encode_if(vm, 3u * code, 3u, 12u, r12); },
-            [&]() { rc.drain(); }, a.exc_flag);
+            [&]() { rc.drain(); }, a.exc_flag, cp.sub_lo, cp.sub_len);
     } else if constexpr (!FLAT) {
         // a lane whose generation has no rows yet reads the initial row from a one-entry table
         const u32* rp = rows ? rows : a.g_init;
@@ -938,7 +1016,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
                 const u32 cum = (below & 0xff) + ((below >> 8) & 0xff) + (below >> 16);
                 rc.encode_if(vm, cum, (v >> (8 * code)) & 0xff, tot, rcp[tot]);          // base2_ranger.hpp:74-84 without the update
             },
-            [&]() { rc.drain(); }, a.exc_flag);
+            [&]() { rc.drain(); }, a.exc_flag, cp.sub_lo, cp.sub_len);
     }
     if (live) {
         a.csz[c] = rc.finish();
@@ -947,11 +1025,10 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
         if (illegal) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_GENCHAR));
     }
 }
-// the base chains of blocks [b0, b1) (b1 = 0: all of them); flat: every one of them codes with the initial row
-void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 b0, u32 b1, bool flat) {
+// the base chains [c0, c1) (c1 = 0: all of them); flat: every one of them codes with the initial row
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 c0, u32 c1, bool flat) {
     constexpr int T = 256;
-    const u64 lo = (u64)b0 * a.geo.cpb, hi = b1 ? (u64)b1 * a.geo.cpb : a.geo.nchains;
-    const u32 c0 = (u32)(lo < a.geo.nchains ? lo : a.geo.nchains), c1 = (u32)(hi < a.geo.nchains ? hi : a.geo.nchains);
+    if (!c1 || c1 > a.geo.nchains) c1 = a.geo.nchains;
     if (c1 <= c0) return;
     const dim3 grid((c1 - c0 + T - 1) / T);
     if (flat) hipLaunchKernelGGL((k_gen_encode_c<T, true>), grid, dim3(T), 0, st, a, c0, c1);
@@ -979,13 +1056,13 @@ __device__ __forceinline__ u32 b2_pick(u32 v, LaneDecQ& rc, const u32* rcp) {
 // Round 4: the quality decoder's lean coder (LaneDecQ); without rows a base is a divide by a twelfth of the range, two bits and
 // a byte every four bases -- 94 -> ~60 instructions a base.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArgs da, u32 b0, u32 b1) {
+__global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArgs da, u32 c0, u32 c1 /* the chains [c0, c1) */) {
     __shared__ u32 rcp[1024];
     for (u32 i = threadIdx.x; i < 1024; i += THREADS) rcp[i] = i ? fz_recip(i) : 0u;
     __syncthreads();
-    const u32 c = b0 * a.geo.cpb + blockIdx.x * THREADS + threadIdx.x;
-    if (c >= a.geo.nchains || c >= b1 * a.geo.cpb) return;
-    const ChainPos cp = chain_pos(a, c);
+    const u32 c = c0 + blockIdx.x * THREADS + threadIdx.x;
+    if (c >= c1) return;
+    ChainPos cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
     LaneDecQ rc; rc.init(da.streams + a.coff[c], a.csz[c], reinterpret_cast<const u8*>(a.qesc));
     const u32* rows = gen_rows_of(a, cp.b);
@@ -994,6 +1071,12 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     const u32 INIT = 0x007616c7u;                                                           // gens.cpp:139
     const u32 r12 = fz_recip(12u);
     u32 n_next = cp.nrec ? da.slen[cp.r0] : 0u; u64 off_next = cp.nrec ? da.soff[cp.r0] : 0ull;      // a record's length and place, a record ahead
+    if (a.seg_len) {                                         // a segment of one record: its part of the base line
+        const u32 ql = da.qlen[cp.r0];
+        seg_range(cp, ql > n_next ? ql : n_next);
+        const u64 lo = cp.sub_lo < n_next ? cp.sub_lo : n_next;
+        n_next = (u32)(n_next - lo < cp.sub_len ? n_next - lo : cp.sub_len); off_next += lo;
+    }
     for (u32 k = 0; k < cp.nrec; k++) {
         const u32 llen = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
@@ -1023,11 +1106,11 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     }
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
 }
-void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st) {
+void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 c0, u32 c1, hipStream_t st) {
     constexpr int T = 256;
-    const u32 n = (b1 - b0) * a.geo.cpb;
-    if (!n) return;
-    hipLaunchKernelGGL(k_gen_decode_c<T>, dim3((n + T - 1) / T), dim3(T), 0, st, a, da, b0, b1);
+    if (c1 > a.geo.nchains) c1 = a.geo.nchains;
+    if (c1 <= c0) return;
+    hipLaunchKernelGGL(k_gen_decode_c<T>, dim3((c1 - c0 + T - 1) / T), dim3(T), 0, st, a, da, c0, c1);
 }
 
 // =========================================================================================================

@@ -73,6 +73,11 @@ struct ChainArgs {
     const u16* rdec;            // decode: [PR_REC_ROWS][272] u16: the cum at every 16th symbol, then of all 256 (chains.hip RDEC_ROW)
     const u16* rmap; const u16* rhot; u32 r_hot;   // rows staged in LDS: row -> place by weight (0xFFFF = none; a kernel stages the first few), place -> row, how many to stage
     u8* exc_flag;               // encode: [records] set to 1 by the quality / base chains where a record holds a '!' / an N (null = not wanted)
+    // chains that are PARTS of one record (long reads; chains.hip "segments"): seg_len != 0, geo.chain_reads = 1
+    u32 seg_len;                // symbols per segment asked for; a record of M = max(bases, qualities) symbols is cut into
+                                // n = ceil(M / seg_len) segments of ceil(M / n) symbols, a chain each, in both streams
+    const u64* seg_off;         // [records + 1] chains before each record
+    const u32* seg_rec;         // [nchains] the record a chain belongs to
     // bases: where a counting pass reads them (decode: the staged bases; null = the FASTQ text through line_off)
     const u8* st_buf; u64 st_bytes; const u64* st_off; const u32* st_len;
     // bases: generation tables
@@ -92,7 +97,7 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
                       u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st,
                       u32 sub = 0 /* 0 every selected record, 1 every GEN_PRE-th of them, 2 the others */, u32 do_count = 1 /* 0: the cost only */);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
-void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 b0 = 0, u32 b1 = 0 /* blocks [b0, b1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
+void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 c0 = 0, u32 c1 = 0 /* chains [c0, c1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
 #define REC_COUNT_COPIES 32u        // the header prior's counting pass counts into this many copies of the table (chains.hip k_rec_count_sum)
@@ -103,6 +108,10 @@ void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec /* th
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32* flags2 /* the same */, u32* tok /* rec_token_bytes(records) */, u32* ntok /* [rgeo.nchains] */,
                          u32 n_hot, u32 max_hdr, hipStream_t st);
 u64 rec_token_bytes(u64 nrec);
+// segments: chains per record (from the text's line index, or from the decoder's line lengths), then the chains' records
+void launch_seg_count(const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 seg_len, u32* nseg, hipStream_t st);
+void launch_seg_count_dec(const u32* slen, const u32* qlen, u64 nrec, u32 seg_len, u32* nseg, hipStream_t st);
+void launch_seg_fill(const u64* seg_off, u64 nrec, u32* seg_rec, hipStream_t st);
 void launch_chain_block_sizes(const ChainArgs& a, const ChainGeoArgs& geo, int stream, const u32* csz, const u32* rhb /* or null */, hipStream_t st);
 void launch_compact_chains(const ChainArgs& a, const ChainGeoArgs& geo, int stream, u32 num, u32 den, const u32* csz, const u64* blk_stream_off,
                            const u64* stream_base, u8* out, hipStream_t st, const u32* gate = nullptr /* frame.hip k_stream_gate */);
@@ -160,7 +169,7 @@ void launch_rec_encode_w(const ModelArgs& a, u32* ticket_fast, u32* ticket_slow,
 void launch_usr_encode_w(const ModelArgs& a, hipStream_t st);      // framing exceptions, a wave per block; blocks [batch0, batch0 + nbatch), slot = workgroup
 
 void launch_qlt_decode_c(const ChainArgs& a, const DecodeArgs& da, hipStream_t st);
-void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 b0, u32 b1, hipStream_t st);
+void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 c0, u32 c1 /* chains [c0, c1) */, hipStream_t st);
 void launch_rec_decode_c(const ChainArgs& a, const DecodeArgs& da, u32* flags /* [rgeo.nchains], zeroed; null = general path only */, hipStream_t st,
                          u32* dtok = nullptr /* rec_dtok_bytes(records); null = the lane kernels alone */, u32* dtoff = nullptr /* [records] */, u32* dflags = nullptr /* [rgeo.nchains], zeroed */);
 u64 rec_dtok_bytes(u64 nrec);

@@ -11,6 +11,7 @@
 // 256-record block codes as well as the reference's whole-file state (oracle/sfq_oracle.c restates the
 // rule for the tests).  One block and no prior stays byte-identical to the reference.
 #include "kernels.h"
+#include "dev_wave.h"
 
 // ---- 1. histogram --------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 p_calc_last_delta(u32& delta, u32 q, u32 q1, u32 q2) {   // qlts.hpp:62-74
@@ -120,13 +121,55 @@ __global__ __launch_bounds__(THREADS) void k_qlt_hist(const u8* __restrict__ fq,
     __syncthreads();
     for (u32 i = threadIdx.x; i < HIST_SLOTS; i += THREADS) { const u32 v = slots[i]; if (v != HIST_EMPTY && (v & HIST_CMASK)) atomicAdd(&hist[v >> HIST_CBITS], v & HIST_CMASK); }
 }
+// The same counts for LONG records, a WAVE per sampled record (round 4): a lane that walks the 4096 sampled symbols of a long read
+// alone is the sample's time -- 5.5 ms of a 19.6 ms call over 60 k reads of 10-50 kb.  Here 64 consecutive symbols are taken at
+// once, a lane each (one coalesced load), and the model's contexts -- functions of the three symbols before and, at levels 3 and 4,
+// of the running sum of the quality drops (qlts.hpp:52-74) -- come from lane shifts and a wave prefix sum: the same (context,
+// symbol) pairs as the lane's walk, so the same counts.
+__global__ __launch_bounds__(256) void k_qlt_hist_w(const u8* __restrict__ fq, const u64* __restrict__ line_off,
+                                                    const BlockDesc* __restrict__ blocks, u32 block_reads,
+                                                    u64 nrec, u32 step, int level, u32 cap, u32* __restrict__ hist) {
+    __shared__ u32 slots[HIST_SLOTS];
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) slots[i] = HIST_EMPTY;
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63;
+    const u64 r = ((u64)blockIdx.x * 4 + (threadIdx.x >> 6)) * step;
+    if (r < nrec) {
+        const u32 solid = blocks[r / block_reads].solid;
+        const u64 q0 = line_off[4 * r + 3] + solid, q1e = line_off[4 * r + 4] - 1;
+        const u32 nfull = q1e > q0 ? (u32)(q1e - q0) : 0;
+        const u32 n = nfull < cap ? nfull : cap;
+        const u32 mask = level == 1 ? 0xFFFu : 0xFFFFu;
+        u32 c1 = 0, c2 = 0, c3 = 0, dsum = 5;                // the three symbols before the step's first, the drops summed so far (+ 5)
+        for (u32 base = 0; base < n; base += 64) {
+            const u32 i = base + lane;
+            const bool in = i < n;
+            const u32 b = in ? (u32)(u8)(fq[q0 + i] - '!') : 0u;
+            const u32 b1 = wave_shr1(b, c1), b2 = wave_shr1(b1, c2), b3 = wave_shr1(b2, c3);
+            u32 ctx;
+            if (level <= 2) ctx = (b1 | (b2 << 6) | (b3 << 12)) & mask;                       // qlts.hpp:52-57, unrolled
+            else {
+                const u32 t = b1 > b ? b1 - b : 0u;                                           // this symbol's drop: counts for the ones behind it
+                const u32 incl = wave_incl_scan(t);
+                const u32 delta = dsum + incl - t;
+                const u32 d3 = delta >> 3;
+                ctx = (b1 | ((b2 < b3 ? b3 : b2) << 6) | ((u32)(b2 == b3) << 12) | ((d3 < 7 ? d3 : 7) << 13)) & 0xFFFFu;
+                if (i == 0) ctx = 0;                                                          // qlts.cpp:109-112: a line starts from context 0
+                dsum += rl(incl, 63);
+            }
+            if (in) hist_add((lds_u32*)slots, (glb_u32*)hist, ctx * 64 + (b < 63u ? b : 63u));
+            c1 = rl(b, 63); c2 = rl(b1, 63); c3 = rl(b2, 63);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < HIST_SLOTS; i += 256) { const u32 v = slots[i]; if (v != HIST_EMPTY && (v & HIST_CMASK)) atomicAdd(&hist[v >> HIST_CBITS], v & HIST_CMASK); }
+}
 void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 step,
                      int level, u32 cap, u32* hist, hipStream_t st) {
     const u64 nsamp = (nrec + step - 1) / step;
-    // long records (one lane walks a whole record): few records per workgroup, so that many workgroups share the work
+    // long records: a wave per sampled record, four to a workgroup and its table
     if (nbytes / (nrec ? nrec : 1) > 4000) {
-        const u64 per_wg = 64;
-        hipLaunchKernelGGL((k_qlt_hist<64, 1>), dim3((u32)((nsamp + per_wg - 1) / per_wg)), dim3(64), 0, st, fq, nbytes, line_off, blocks, block_reads, nrec, step, level, cap, hist);
+        hipLaunchKernelGGL(k_qlt_hist_w, dim3((u32)((nsamp + 3) / 4)), dim3(256), 0, st, fq, line_off, blocks, block_reads, nrec, step, level, cap, hist);
     } else {
         // (a record per lane: the kernel's time is one lane's walk -- with four records per lane and a 64 KiB table, two workgroups
         //  per CU, it took 4.6 ms of every call whatever the sample's size)

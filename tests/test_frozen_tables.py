@@ -449,3 +449,74 @@ def test_installed_counts_are_tracked_and_a_refilled_buffer_is_framed_again(ctx)
     got, _ = ctx.decode_device(ctx.index(res.n_blocks), ctx.first_headers(res.first_hdr_bytes), out.data_ptr(), list(res.stream_offset), back.data_ptr(), back.numel(),
                                prior=ctx.prior(), level=3, chains=ctx.chains(), rec_prior=ctx.rec_prior())
     assert got == len(other) and bytes(back[:got].cpu().numpy()) == other
+
+
+SEG = 0x80000000
+
+
+def _long_reads(rng, n, lo, hi, qdiff=False):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        seq = "".join(rng.choice(list("ACGT"), L, p=[0.3, 0.2, 0.2, 0.3]))
+        if i % 7 == 3:
+            seq = seq[:50] + "N" * 5 + seq[55:]
+        ql = L if not (qdiff and i % 5 == 2) else max(1, L - int(rng.integers(1, 40)))
+        q = np.clip(np.cumsum(rng.integers(-2, 3, ql)) + 20, 1, 60)
+        qual = bytes((q + 33).astype(np.uint8)).decode()
+        recs.append("@%08x-%04x-4a%02x_read%d ch=%d\n%s\n+\n%s\n" % (int(rng.integers(0, 2**32)), i * 7 % 65536, i % 256, i, i % 512, seq, qual))
+    return "".join(recs).encode()
+
+
+@pytest.mark.parametrize("seg,br,qdiff", ((1000, 4, False), (700, 7, True), (4096, 3, False)))
+def test_long_records_are_cut_into_segments(ctx, seg, br, qdiff):
+    """Chains that are SEGMENTS of one record (BASELINE config 5: reads of 10-50 kb; SFQ_CHAIN_SEGMENT, chains.hip): every
+    segment's quality and base bytes against the oracle's restatement of the rule -- a record of M = max(bases, qualities) symbols
+    in ceil(M / seg) equal segments, each starting as a line does --, the chain index's shape, and the way back; with quality lines
+    shorter than their base lines in between (the segments follow the longer of the two)."""
+    rng = np.random.default_rng(seg + br)
+    fq = _long_reads(rng, 40, 2500, 9000, qdiff)
+    enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=SEG | seg)
+    starts, lens = util.line_table(fq)
+    nrec = len(starts) // 4
+    nblocks = -(-nrec // br)
+    ci = util.unpack_chains(enc.chains, nblocks)
+    assert ci["flags"] & 8 and ci["seg_len"] == seg and ci["chain_reads"] == 1
+    qoff, qlen, goff, glen = starts[3::4], lens[3::4], starts[1::4], lens[1::4]
+    nseg = O.seg_counts(glen, qlen, seg)
+    assert [int(nseg[b * br:(b + 1) * br].sum()) for b in range(nblocks)] == list(ci["seg_blocks"])
+    assert enc.res.n_chains == int(nseg.sum()) and int(nseg.max()) >= 3
+    rows66 = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, np.minimum(qlen, PRIOR_SYMBOLS), 3, 0, 1))
+    want, sizes, extra = O.qlt_encode_segs(fq, qoff, qlen, glen, 3, seg, O.qlt_frozen_rows(rows66))
+    assert list(ci["qlt"]) == list(sizes) and enc.stream("qlt") == want
+    want, sizes, on = O.gen_encode_segs(fq, goff, glen, qlen, enc.blocks[0].gen_bits, br, seg, GEN_STEP)
+    assert (ci["flags"] & 1) == on and list(ci["gen"]) == list(sizes) and enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    # the index is untrusted: a block's share that disagrees with its records' line lengths is refused
+    bad = enc.clone()
+    blob = bytearray(bad.chains)
+    v = util._vints(bytes(blob))
+    assert v[3] == seg
+    # (rewrite the blob with one segment moved from block 0 to block 1)
+    moved = list(v); moved[4] -= 1; moved[5] += 1
+    out = bytearray()
+    for x in moved:
+        while x >= 0x80:
+            out.append((x & 0x7f) | 0x80); x >>= 7
+        out.append(x)
+    bad.chains = bytes(out)
+    with pytest.raises(capi.SfqError):
+        ctx.decode_host(bad, level=3, out_cap=len(fq) + 4096)
+
+
+def test_long_reads_take_segments_by_themselves(ctx):
+    """The automatic choice: records of a chain's worth or more, fewer than 204 800 of them and a line longer than a segment --
+    the call's symbols in about 204 800 segments of 2048 symbols or more; short reads stay with whole records."""
+    fq = capi.synth_fastq(300, 150, seed=5, kind=1)                       # 10-50 kb reads
+    enc = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+    ci = util.unpack_chains(enc.chains, len(enc.blocks))
+    assert ci["flags"] & 8 and ci["seg_len"] == 2048 and enc.res.n_chains > 5 * 300
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    short = capi.synth_fastq(3000, 150, seed=5)
+    enc = ctx.encode_host(short, level=3, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+    assert not util.unpack_chains(enc.chains)["flags"] & 8

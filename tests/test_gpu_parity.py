@@ -720,7 +720,8 @@ def test_baseline_sizes_round_trip_and_invariants(ctx, kind, n, level, tables):
         assert sum(b.size[s] for b in blocks) == res.stream_bytes[s]
     assert sum(res.stream_bytes) == res.total_bytes and all(b.status == 0 for b in blocks)
     if tables:
-        ci = util.unpack_chains(chains)
+        ci = util.unpack_chains(chains, res.n_blocks)
+        assert bool(ci["flags"] & 8) == (kind == 1)               # long reads: chains that are segments of one record
         assert len(ci["qlt"]) == res.n_chains and int(ci["qlt"].sum()) == res.stream_bytes[2] and int(ci["gen"].sum()) == res.stream_bytes[1]
         assert int(ci["rec"].sum()) == res.stream_bytes[0] and int(ci["rec_hdr_bytes"].sum()) == sum(b.hdr_bytes for b in blocks)
         if kind == 3:

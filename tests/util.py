@@ -105,19 +105,26 @@ def _vints(blob: bytes):
     return out
 
 
-def unpack_chains(blob: bytes):
-    """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp.
-    flags bit 2: every list of sizes is stored as zigzag differences to the entry before it."""
+def unpack_chains(blob: bytes, nblocks=None):
+    """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, seg_len, seg_blocks] [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp.
+    flags bit 2: every list of sizes is stored as zigzag differences to the entry before it; bit 3: the chains are SEGMENTS of one
+    record -- their length and every block's number of chains follow the chain count (nblocks must be given)."""
     v = _vints(blob)
     cr, flags, n = v[0], v[1], v[2]
+    p = 3
+    out = {"chain_reads": cr, "flags": flags}
+    if flags & 8:
+        assert nblocks is not None
+        out["seg_len"] = v[p]; out["seg_blocks"] = v[p + 1:p + 1 + nblocks]; p += 1 + nblocks
+        assert sum(out["seg_blocks"]) == n
 
     def sizes(raw):
         if not flags & 4:
             return np.array(raw, np.uint32)
         d = np.array([(x >> 1) ^ -(x & 1) for x in raw], np.int64)
         return np.cumsum(d).astype(np.uint32)
-    out = {"chain_reads": cr, "flags": flags, "qlt": sizes(v[3:3 + n]), "gen": sizes(v[3 + n:3 + 2 * n])}
-    p = 3 + 2 * n
+    out.update(qlt=sizes(v[p:p + n]), gen=sizes(v[p + n:p + 2 * n]))
+    p += 2 * n
     if flags & 2:
         rcr, m = v[p], v[p + 1]; p += 2
         out.update(rec_chain_reads=rcr, rec=sizes(v[p:p + m]), rec_hdr_bytes=sizes(v[p + m:p + 2 * m]))
