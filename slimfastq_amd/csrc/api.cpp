@@ -33,7 +33,8 @@ struct sfq_ctx {
     int dev = 0;
     hipStream_t st = nullptr;
     hipStream_t st_aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev[24] = {};
+    hipEvent_t ev[28] = {};
+    bool rec_blob_pending = false;     // "rec.pri" is still to be packed from the frequencies behind ev[24]
     std::string err;
     u64 table_budget = 0;
     u64 dev_total = 0;
@@ -49,6 +50,7 @@ struct sfq_ctx {
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
+    DevBuf pslot, plist;                   // the quality prior's listed rows, back to back (prior.hip launch_prior_list)
     DevBuf segn, segoff, segrec;           // chains that are segments of one record (long reads): segments per record, their scan, a chain's record
     // format 6's oversize records (frame.hip): flags, kept bytes, their scans, the text without them, kept record -> file number, the list;
     // the file's own line index; decode: numbers, pieces, raw text of the three streams, sizes / offsets in file order
@@ -185,21 +187,29 @@ bool get_v(const u8* b, size_t n, size_t& p, u64& v) {
     for (int sh = 0; sh < 64; sh += 7) { if (p >= n) return false; u8 c = b[p++]; v |= (u64)(c & 0x7f) << sh; if (!(c & 0x80)) return true; }
     return false;
 }
-std::vector<u8> pack_prior(const u32* rows66, u32 q_rows) {
-    std::vector<u8> o;
-    put_v(o, q_rows);
+// list: [0] = n, then per listed row (ascending contexts) 67 words: the context, 64 slots freq | sym << 16, total, iend
+#define PRIOR_LIST_ROW 67u
+#define PRIOR_LIST_HEAD 4u
+#define PRIOR_LIST_EAGER 16384u          /* rows copied to the host before their number is known (4.4 MB) */
+std::vector<u8> pack_prior(const u32* list, u32 q_rows) {
+    const u32 n = list[0];
+    std::vector<u8> o((size_t)n * (5 + 2 + 64 * 4) + 16);                  // (the most a row can take)
+    u8* w = o.data();
+    auto put = [&](u64 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };       // put_v
+    put(q_rows);
     u32 prev = 0;
-    for (u32 c = 0; c < q_rows; c++) {
-        const u32* r = rows66 + (size_t)c * 66;
-        const u32 iend = r[65];
-        if (!iend) continue;
+    for (u32 i = 0; i < n; i++) {
+        const u32* r = list + PRIOR_LIST_HEAD + (size_t)i * PRIOR_LIST_ROW;
+        const u32 c = r[0], iend = r[66];
+        r++;
         u32 nnz = 0;
         while (nnz < iend && (r[nnz] & 0xffff)) nnz++;
-        put_v(o, c - prev + 1); prev = c;
-        o.push_back((u8)iend); o.push_back((u8)nnz);
-        for (u32 j = 0; j < nnz; j++) { o.push_back((u8)(r[j] >> 16)); put_v(o, r[j] & 0xffff); }
+        put(c - prev + 1); prev = c;
+        *w++ = (u8)iend; *w++ = (u8)nnz;
+        for (u32 j = 0; j < nnz; j++) { *w++ = (u8)(r[j] >> 16); put(r[j] & 0xffff); }
     }
-    put_v(o, 0);
+    put(0);
+    o.resize((size_t)(w - o.data()));
     return o;
 }
 // "qlt.pri" -> the rows it lists, back to back (66 words each: 64 slots freq | sym << 16, total, iend), and their contexts
@@ -269,20 +279,16 @@ int upload_prior(sfq_ctx* ctx, u32 q_rows, hipStream_t st) {
 // ---- "rec.pri": the header prior.  Counts -> scaled frequencies f = (14 * count) >> s with the smallest s that brings
 // the row's largest to <= 32000 (the PowerRanger adds 14 per hit, power_ranger.hpp:37-41); the blob lists, per non-empty row,
 // varint(row - previous row + 1), varint(entries), entries x { byte value, varint(f) }, then a 0.
-std::vector<u8> pack_rec_prior(const std::vector<u32>& cnt, std::vector<u32>& f) {
+// "rec.pri" from the prior's frequencies f[PR_REC_ROWS][256] (chains.hip k_rec_prior_freqs makes them from the sample's counts):
+// per row that has any, its distance from the row before + 1, the number of symbols, then (symbol, frequency) pairs
+std::vector<u8> pack_rec_prior_f(const u32* f) {
     std::vector<u8> o;
-    f.assign((size_t)PR_REC_ROWS * 256, 0);
     put_v(o, PR_REC_ROWS);
     u32 prev = 0;
     for (u32 r = 0; r < PR_REC_ROWS; r++) {
-        const u32* c = cnt.data() + (size_t)r * 256;
-        u64 mx = 0; u32 nnz = 0;
-        for (u32 s = 0; s < 256; s++) mx = std::max<u64>(mx, c[s]);
-        if (!mx) continue;
-        u32 sh = 0;
-        while (((mx * 14) >> sh) > 32000) sh++;
-        u32* fr = f.data() + (size_t)r * 256;
-        for (u32 s = 0; s < 256; s++) { fr[s] = (u32)(((u64)c[s] * 14) >> sh); nnz += fr[s] != 0; }
+        const u32* fr = f + (size_t)r * 256;
+        u32 nnz = 0;
+        for (u32 s = 0; s < 256; s++) nnz += fr[s] != 0;
         if (!nnz) continue;
         put_v(o, r - prev + 1); prev = r;
         put_v(o, nnz);
@@ -391,7 +397,7 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
 // The header prior of an encode with frozen tables: counted over this call's text -- the header model run over short runs
 // of records spread over the call -- or the installed one (SFQ_PRIOR_GIVEN); leaves the frozen rows on the device.
 // Two halves, so that the launching thread can queue other streams' work while the counting pass runs: _begin queues the
-// pass and the copy of its counts to pinned host memory (PIN_REC_OFF), _finish waits for them and builds the rows.
+// pass, _finish the kernels that make the rows from its counts (no wait in either).
 #define REC_PRIOR_RUN 6u          // records per run of the header prior's counting pass: the base, one that warms the field types up, four counted
 #define REC_PRIOR_RUNS 32768u
 #define PIN_GEN_OFF 0u
@@ -401,10 +407,7 @@ int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool
     if (given) return SFQ_OK;
     int rc;
     if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
-    if (counted) {                                       // SFQ_PRIOR_COUNTS: the counts are there (sfq_set_prior_counts)
-        HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
-        return SFQ_OK;
-    }
+    if (counted) return SFQ_OK;                          // SFQ_PRIOR_COUNTS: the counts are there (sfq_set_prior_counts)
     HIPC(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4, st));
     // (short runs, many of them: the pass's time is one lane's walk through its run -- 8192 runs of 18 records took 2.9 ms of
     //  every call on 128 wavefronts; the sample is the same 131 k counted records)
@@ -414,20 +417,52 @@ int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool
     if ((rc = reserve(ctx, ctx->cflags, (size_t)REC_PRIOR_RUNS * 4))) return rc;
     HIPC(hipMemsetAsync(ctx->cflags.p, 0, (size_t)nruns * 4, st));
     launch_rec_count(a, nrec, stride, run, nruns, (u32*)ctx->hcnt.p, (u32*)ctx->cflags.p, st);
-    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hcnt.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
+    return SFQ_OK;
+}
+// The header prior's rows.  Given ("rec.pri" handed in): unpacked and uploaded.  Else from the counts of the pass above, all on
+// the device and without a wait: frequencies, the rows to stage, the frozen rows; the frequencies come back to page-locked memory
+// behind them and rec_prior_blob_now() packs "rec.pri" from them when the host has nothing better to do.
+// "qlt.pri" from the listed rows in page-locked memory (h: the list's head; the rows behind the first PRIOR_LIST_EAGER are
+// fetched here, if there are any)
+int qlt_prior_blob_now(sfq_ctx* ctx, u32* h, u32 q_rows, hipStream_t st) {
+    HIPC(hipEventSynchronize(ctx->ev[20]));
+    const u32 n = h[0];
+    if (n > q_rows) return fail(ctx, SFQ_E_HIP, "quality prior: %u rows listed of %u", n, q_rows);
+    if (n > PRIOR_LIST_EAGER) {
+        const size_t done = (size_t)PRIOR_LIST_HEAD + (size_t)PRIOR_LIST_EAGER * PRIOR_LIST_ROW;
+        HIPC(hipMemcpyAsync(h + done, (const u32*)ctx->plist.p + done, (size_t)(n - PRIOR_LIST_EAGER) * PRIOR_LIST_ROW * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    ctx->prior_blob = pack_prior(h, q_rows);
+    return SFQ_OK;
+}
+int rec_prior_blob_now(sfq_ctx* ctx) {
+    if (!ctx->rec_blob_pending) return SFQ_OK;
+    ctx->rec_blob_pending = false;
+    HIPC(hipEventSynchronize(ctx->ev[24]));
+    ctx->rec_prior_blob = pack_rec_prior_f((const u32*)((const u8*)ctx->pin + PIN_REC_OFF));
     return SFQ_OK;
 }
 int rec_prior_finish(sfq_ctx* ctx, bool given, hipStream_t st) {
-    std::vector<u32> hf;
     if (given) {
+        std::vector<u32> hf;
         if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), hf)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
-    } else {
-        HIPC(hipStreamSynchronize(st));
-        const u32* c = (const u32*)((const u8*)ctx->pin + PIN_REC_OFF);
-        std::vector<u32> hc(c, c + (size_t)PR_REC_ROWS * 256);
-        ctx->rec_prior_blob = pack_rec_prior(hc, hf);
+        return upload_rec_rows(ctx, hf, st);
     }
-    return upload_rec_rows(ctx, hf, st);
+    int rc;
+    const size_t nf = (size_t)PR_REC_ROWS * 256;
+    if ((rc = reserve(ctx, ctx->rmap, (size_t)PR_REC_ROWS * 2 + 64 * 2))) return rc;
+    if ((rc = reserve(ctx, ctx->hfreq, nf * 4 + (size_t)PR_REC_ROWS * 4))) return rc;           // frequencies, then the rows' sums
+    if ((rc = reserve(ctx, ctx->rrows, nf * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rdec, (size_t)PR_REC_ROWS * 272 * 2))) return rc;          // chains.hip RDEC_ROW
+    u16* map = (u16*)ctx->rmap.p;
+    launch_rec_prior_freqs((const u32*)ctx->hcnt.p, PR_REC_ROWS, (u32*)ctx->hfreq.p, (u32*)ctx->hfreq.p + nf, RDEC_LDS_ROWS, map, map + PR_REC_ROWS, st);
+    launch_rec_frozen_rows((const u32*)ctx->hfreq.p, PR_REC_ROWS, (u32*)ctx->rrows.p, (u16*)ctx->rdec.p, st);
+    ctx->r_hot = std::min<u32>(RDEC_LDS_ROWS, 8); ctx->r_hot_dec = RDEC_LDS_ROWS;          // (rows the sample never saw fill the list up: staging one is harmless)
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hfreq.p, nf * 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipEventRecord(ctx->ev[24], st));
+    ctx->rec_blob_pending = true;
+    return SFQ_OK;
 }
 
 // Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
@@ -581,7 +616,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -843,6 +878,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (given && ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no quality prior installed (sfq_set_qlt_prior)");
     if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
     if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
+    ctx->rec_blob_pending = false;
     ctx->chain_blob.clear();
     if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
     u32 slots = 0;
@@ -988,7 +1024,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         }
     }
     u32* h_rows66 = nullptr;
-    bool rows66_copy_pending = false;
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
@@ -1016,17 +1051,19 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
 
         launch_prior_rows((const u32*)ctx->hist.p, q_rows, (u32*)ctx->rows66.p, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p,
                           (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
-        if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
+        // "qlt.pri" is packed on the host from the rows the prior lists: gathered back to back on the device (a few thousand of
+        // the 65 536 -- round 3 copied the dense 17 MB table, which held a hardware queue for half a millisecond and had to wait
+        // behind the header chains), the first PRIOR_LIST_EAGER of them copied before their number is known
+        if ((rc = reserve(ctx, ctx->pslot, (size_t)q_rows * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->plist, ((size_t)PRIOR_LIST_HEAD + (size_t)q_rows * PRIOR_LIST_ROW) * 4))) return rc;
+        if ((rc = reserve_pinned(ctx, PIN_BYTES + ((size_t)PRIOR_LIST_HEAD + (size_t)q_rows * PRIOR_LIST_ROW) * 4))) return rc;
         h_rows66 = (u32*)((u8*)ctx->pin + PIN_BYTES);
-        // the 17 MB of rows go to the host for "qlt.pri"; with frozen tables on the framing stream, so that the copy does
-        // not sit between the sample and the quality chains on this one
-        // (with frozen tables the copy is queued later, behind the header chains on their stream: anywhere earlier it
-        //  holds up a model's kernels -- the streams share three hardware queues)
-        if (frozen && !priors_only && (models & SFQ_M_REC)) { HIPC(hipEventRecord(ctx->ev[21], st)); rows66_copy_pending = true; }
-        else {
-            HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, st));
-            HIPC(hipEventRecord(ctx->ev[20], st));
-        }
+        // (on a stream of its own: nothing on the device waits for the list)
+        HIPC(hipEventRecord(ctx->ev[21], st));
+        HIPC(hipStreamWaitEvent(mst[2], ctx->ev[21], 0));
+        launch_prior_list((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->pslot.p, (u32*)ctx->plist.p, mst[2]);
+        HIPC(hipMemcpyAsync(h_rows66, ctx->plist.p, ((size_t)PRIOR_LIST_HEAD + (size_t)std::min<u32>(q_rows, PRIOR_LIST_EAGER) * PRIOR_LIST_ROW) * 4, hipMemcpyDeviceToHost, mst[2]));
+        HIPC(hipEventRecord(ctx->ev[20], mst[2]));
         HIPC(hipEventRecord(ctx->ev[1], st));      // the model streams fork after the prior is built
         ctx->prior_on = true;
     }
@@ -1060,10 +1097,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (!frozen) { if ((rc = setup_tables())) return rc; }
     if (priors_only) {
         if (ctx->prior_on && !given) {                      // (packed while the header sample is still being counted)
-            HIPC(hipEventSynchronize(ctx->ev[20]));
-            ctx->prior_blob = pack_prior(h_rows66, q_rows);
+            if ((rc = qlt_prior_blob_now(ctx, h_rows66, q_rows, st))) return rc;
         }
-        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc; }
+        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc; if ((rc = rec_prior_blob_now(ctx))) return rc; }
         HIPC(hipStreamSynchronize(mst[1]));
         HIPC(hipStreamSynchronize(st));
         ctx->prior_on = false;
@@ -1088,15 +1124,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
+            HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));              // (the quality chains behind the header prior's passes, as when the host waited for those)
             launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1]);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
-            if (rows66_copy_pending) {
-                HIPC(hipStreamWaitEvent(mst[1], ctx->ev[21], 0));
-                HIPC(hipMemcpyAsync(h_rows66, ctx->rows66.p, (size_t)q_rows * 66 * 4, hipMemcpyDeviceToHost, mst[1]));
-                HIPC(hipEventRecord(ctx->ev[20], mst[1]));
-                rows66_copy_pending = false;
-            }
         } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
@@ -1210,16 +1241,22 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if ((rc = reserve_pinned_buf(ctx, ctx->pin2, ctx->pin2_cap, p2_end))) return rc;
     u64* totals = (u64*)ctx->pin2;
     HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, SFQ_NSTREAMS * 8, hipMemcpyDeviceToHost, st));
-    // host work that needs nothing of what is still running goes here, while the chains are coded: "qlt.pri"
-    if (ctx->prior_on && !given && h_rows66) {
-        HIPC(hipEventSynchronize(ctx->ev[20]));
-        ctx->prior_blob = pack_prior(h_rows66, q_rows);
-    }
+    // host work that needs nothing of what is still running -- "qlt.pri", 0.7 ms -- is done while the chains are coded, and behind
+    // the LAUNCHES of everything that follows them: a small call's chains are through before the host is, and the packing must
+    // not wait for it (round 4: 0.73 ms of idle GPU in a 4.1 ms call of 600 k reads)
+    auto pack_prior_now = [&]() -> int {
+        if (ctx->prior_on && !given && h_rows66) {
+            if ((rc = qlt_prior_blob_now(ctx, h_rows66, q_rows, mst[2]))) return rc;
+            h_rows66 = nullptr;
+        }
+        return rec_prior_blob_now(ctx);
+    };
     BlockDesc* hb = (BlockDesc*)((u8*)ctx->pin2 + p2_hb);
     u64* hboff = (u64*)((u8*)ctx->pin2 + p2_off);
     u32* h_csz = (u32*)((u8*)ctx->pin2 + p2_csz);
     u64 bases[SFQ_NSTREAMS], run = 0;
     if (two_halves) {
+        if ((rc = pack_prior_now())) return rc;
         HIPC(hipStreamSynchronize(st));                                 // the chains are through; totals[0..2] are here
         for (int s = 0; s < 3; s++) { bases[s] = run; run += totals[s]; }
         if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs more than %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
@@ -1254,11 +1291,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
         }
         HIPC(hipEventRecord(ctx->ev[11], st));
+        if ((rc = pack_prior_now())) return rc;               // (before the copy into pageable memory below: that one returns when the stream has reached it)
         ctx->first_hdrs.resize((size_t)blob_guess);
         if (blob_guess) HIPC(hipMemcpyAsync(ctx->first_hdrs.data(), ctx->blob.p, (size_t)blob_guess, hipMemcpyDeviceToHost, st));
     }
     HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(hboff, ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
+    if ((rc = pack_prior_now())) return rc;
     HIPC(hipStreamSynchronize(st));
     run = 0;
     for (int s = 0; s < SFQ_NSTREAMS; s++) { bases[s] = run; run += totals[s]; res->stream_bytes[s] = totals[s]; res->stream_offset[s] = bases[s]; }

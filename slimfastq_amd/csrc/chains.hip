@@ -104,15 +104,15 @@ __global__ __launch_bounds__(256) void k_hot_totals(const u32* __restrict__ hist
 // one workgroup: the smallest threshold T with at most `want` contexts of ctot >= T; then the map (info[0] = rows staged)
 __global__ __launch_bounds__(1024) void k_hot_select(const u32* __restrict__ ctot, u32 q_rows, u32 want, uint2* __restrict__ map, u32* __restrict__ info) {
     __shared__ u32 red[16];
-    __shared__ u32 wsum[1024];
+    __shared__ u32 wbits[2048];                                            // the map's words: 32 contexts each
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const u32 nwords = q_rows / 32u, wpt = (nwords + 1023u) / 1024u;      // map words per thread: 2 at 65536 contexts, 1 (of the first 128 threads) at 4096
-    u32 c[64];
+    const u32 nwords = q_rows / 32u;
+    u32 c[64];                                                             // context k * 1024 + t: a wave reads 64 neighbours at a time
     u32 mx = 0;
 #pragma unroll
     for (u32 k = 0; k < 64; k++) {
-        const u32 w = t * wpt + (k >> 5), ctx = w * 32u + (k & 31u);
-        c[k] = ((k >> 5) < wpt && w < nwords) ? ctot[ctx] : 0u;
+        const u32 ctx = k * 1024u + t;
+        c[k] = ctx < q_rows ? ctot[ctx] : 0u;
         mx = c[k] > mx ? c[k] : mx;
     }
     auto block_sum = [&](u32 v) {
@@ -144,20 +144,26 @@ __global__ __launch_bounds__(1024) void k_hot_select(const u32* __restrict__ cto
         if (block_sum(n) <= want) hi = mid; else lo = mid + 1u;
     }
     const u32 T = lo;
-    u32 bits[2] = {0, 0};
 #pragma unroll
-    for (u32 k = 0; k < 64; k++) if (c[k] >= T) bits[k >> 5] |= 1u << (k & 31u);
-    const u32 mine = (u32)__popc(bits[0]) + (u32)__popc(bits[1]);
-    wsum[t] = mine;
-    __syncthreads();
-    if (t == 0) { u32 run = 0; for (u32 i = 0; i < 1024; i++) { const u32 v = wsum[i]; wsum[i] = run; run += v; } info[0] = run; }
-    __syncthreads();
-    u32 rank = wsum[t];
-    for (u32 j = 0; j < wpt && j < 2; j++) {
-        const u32 w = t * wpt + j;
-        if (w < nwords) map[w] = make_uint2(bits[j], rank);
-        rank += (u32)__popc(bits[j]);
+    for (u32 k = 0; k < 64; k++) {                                         // a ballot = the two map words of 64 neighbouring contexts
+        const u64 m = __ballot(c[k] >= T);
+        if (lane == 0) { wbits[k * 32u + wave * 2u] = (u32)m; wbits[k * 32u + wave * 2u + 1u] = (u32)(m >> 32); }
     }
+    __syncthreads();
+    const u32 b0 = 2u * t < nwords ? wbits[2u * t] : 0u, b1 = 2u * t + 1u < nwords ? wbits[2u * t + 1u] : 0u;
+    const u32 mine = (u32)__popc(b0) + (u32)__popc(b1);
+    u32 inc = mine;                                                        // ranks: a scan over the threads' two words
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d, 64); if (lane >= (u32)d) inc += o; }
+    __syncthreads();
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    u32 before = 0, all = 0;
+    for (u32 w = 0; w < 16; w++) { const u32 v = red[w]; before += w < wave ? v : 0u; all += v; }
+    const u32 rank = before + inc - mine;
+    if (t == 0) info[0] = all;
+    if (2u * t < nwords) map[2u * t] = make_uint2(b0, rank);
+    if (2u * t + 1u < nwords) map[2u * t + 1u] = make_uint2(b1, rank + (u32)__popc(b0));
 }
 // the staged rows: the cum of symbols 0 .. QH_SYMS of every staged context, at its place
 __global__ __launch_bounds__(256) void k_hot_image(const uint2* __restrict__ map, const u32* __restrict__ qrows, u32 q_rows, u16* __restrict__ rows) {
@@ -301,7 +307,7 @@ void launch_seg_fill(const u64* seg_off, u64 nrec, u32* seg_rec, hipStream_t st)
 __device__ __forceinline__ uint4 load16(const u8* fq, u64 nbytes, u64 at) {          // any alignment (global loads need none on gfx9)
     const u8* p = fq + at;
     if (at + 16 <= nbytes) {
-        const u32* q = reinterpret_cast<const u32*>(p);
+        const u32* q = reinterpret_cast<const u32*>(p);               // (a non-temporal load here: the call 0.7 ms slower, round 4)
         return make_uint4(q[0], q[1], q[2], q[3]);
     }
     u32 w[4] = {0, 0, 0, 0};
@@ -657,7 +663,11 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
     for (u32 k = 0; k < cp.nrec; k++) {
         const u32 n = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.qlen[cp.r0 + k + 1]; off_next = da.qoff[cp.r0 + k + 1]; }
+#ifdef SFQ_EXP_OUT_LOCAL               /* scratch experiment: every lane's output into a small region that stays in L2 (the text comes out wrong) */
+        LaneOut out; out.begin(da.qual_stage + (size_t)(c & 8191u) * 64u + 0 * off);
+#else
         LaneOut out; out.begin(da.qual_stage + off);
+#endif
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {
             // largest s with cum[s] <= prob (cum is increasing: every g >= 1): the eighth of the row from the coarse list, then the
@@ -666,11 +676,28 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
             u32 hot = ~0u;                                                  // the row's place in the LDS image, if it is staged
             if constexpr (LDS) {
                 const uint2 mr = lmap[last >> 5];
+#ifndef SFQ_EXP_QDEC_FLAT
+                asm volatile("" :: "v"(mr.x), "v"(mr.y));                   // (both words in one read, not the rank behind a branch on the bits)
+#endif
                 const u32 bit = 1u << (last & 31u);
                 if (mr.x & bit) hot = (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QHD_ROW_U16;
             }
             uint4 cv;
+#ifdef SFQ_EXP_QDEC_FLAT
             if (hot != ~0u) cv = *reinterpret_cast<const uint4*>(lrows + hot); else cv = *reinterpret_cast<const uint4*>(qd);
+#else
+            // two loads, not one through a generic pointer (what `staged ? LDS : table` compiles to: a flat load, which takes the
+            // vector memory path for all 64 lanes): every lane reads LDS -- a lane whose row is not staged reads list 0 and drops
+            // it --, the few lanes without a staged row gather theirs
+            if constexpr (LDS) {
+                const uint4 cl = *reinterpret_cast<const uint4*>(lrows + (hot != ~0u ? hot : 0u));
+                uint4 cg = make_uint4(0, 0, 0, 0);
+                if (hot == ~0u) cg = *reinterpret_cast<const uint4*>(qd);
+                asm volatile("" :: "v"(cl.x), "v"(cl.y), "v"(cl.z), "v"(cl.w));        // (the LDS read is used whatever the lane: it stays an LDS read)
+                const bool st = hot != ~0u;
+                cv.x = st ? cl.x : cg.x; cv.y = st ? cl.y : cg.y; cv.z = st ? cl.z : cg.z; cv.w = st ? cl.w : cg.w;
+            } else cv = *reinterpret_cast<const uint4*>(qd);
+#endif
             rc.top_up();                                                    // (behind the row's fetch: the two loads travel together)
             u32 r;
             const u32 prob = rc.get_freq16(r);
@@ -1253,6 +1280,46 @@ __global__ __launch_bounds__(256) void k_rec_frozen_rows(const u32* __restrict__
     e.w = cum | (g[3] << 16);
     *reinterpret_cast<uint4*>(rrows + (size_t)row * 256 + lane * 4) = e;
 }
+// The transmitted header prior from the sample's counts, on the device (round 4: the host did this between two waits, 0.3 ms of
+// every call with the header chains behind it): a row's counts x 14, shifted down until the largest is at most 32000 --
+// api.cpp pack_rec_prior_f writes "rec.pri" from the result, unpack_rec_prior reads it back.  rtot[row] = the row's sum.
+__global__ __launch_bounds__(256) void k_rec_prior_freqs(const u32* __restrict__ cnt, u32 nrows, u32* __restrict__ f, u32* __restrict__ rtot) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const uint4 cv = *reinterpret_cast<const uint4*>(cnt + (size_t)row * 256 + lane * 4);
+    u32 mx = max(max(cv.x, cv.y), max(cv.z, cv.w));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
+    u32 sh = 0;
+    while ((((u64)mx * 14u) >> sh) > 32000u) sh++;
+    uint4 fv;
+    fv.x = (u32)(((u64)cv.x * 14u) >> sh); fv.y = (u32)(((u64)cv.y * 14u) >> sh); fv.z = (u32)(((u64)cv.z * 14u) >> sh); fv.w = (u32)(((u64)cv.w * 14u) >> sh);
+    *reinterpret_cast<uint4*>(f + (size_t)row * 256 + lane * 4) = fv;
+    u32 t = fv.x + fv.y + fv.z + fv.w;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += (u32)__shfl_xor((int)t, d, 64);
+    if (lane == 0) rtot[row] = t;
+}
+// the rows worth staging in LDS: the nh the prior gives the most weight, the lower row first among equals.  map[row] = its
+// place among them or 0xFFFF, hot[place] = row.  (One workgroup; a row's place = how many rows come before it.)
+__global__ __launch_bounds__(1024) void k_rec_hot_rows(const u32* __restrict__ rtot, u32 nrows, u32 nh, u16* __restrict__ map, u16* __restrict__ hot) {
+    __shared__ u32 tot[PR_REC_ROWS];
+    for (u32 r = threadIdx.x; r < nrows; r += 1024) tot[r] = rtot[r];
+    __syncthreads();
+    for (u32 r = threadIdx.x; r < nrows; r += 1024) {
+        const u32 t = tot[r];
+        u32 before = 0;
+#pragma unroll 16
+        for (u32 q = 0; q < nrows; q++) { const u32 o = tot[q]; before += (o > t || (o == t && q < r)) ? 1u : 0u; }
+        map[r] = before < nh ? (u16)before : (u16)0xFFFFu;
+        if (before < nh) hot[before] = (u16)r;
+    }
+}
+void launch_rec_prior_freqs(const u32* cnt, u32 nrows, u32* f, u32* rtot, u32 nh, u16* map, u16* hot, hipStream_t st) {
+    hipLaunchKernelGGL(k_rec_prior_freqs, dim3((nrows + 3) / 4), dim3(256), 0, st, cnt, nrows, f, rtot);
+    hipLaunchKernelGGL(k_rec_hot_rows, dim3(1), dim3(1024), 0, st, (const u32*)rtot, nrows, nh, map, hot);
+}
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, rdec);
 }
@@ -1649,6 +1716,10 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
 // step 2: a chain per lane codes its tokens through the frozen rows; sixteen of them staged in LDS for the workgroup
 #define RC_LDS_ROWS 16u
 struct RecCodeLds { u32 rows[RC_LDS_ROWS * 256]; u8 map[PR_REC_ROWS]; };
+__device__ __forceinline__ u32 rec_code_entry(const RecCodeLds& L, const u32* __restrict__ grows, u32 row, u32 sym) {
+    const u32 slot = L.map[row];
+    return slot != 0xFFu ? L.rows[slot * 256 + sym] : grows[(size_t)row * 256 + sym];
+}
 __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __restrict__ tok, const u32* __restrict__ ntok, const u32* __restrict__ flags, u32 n_hot) {
 #ifdef PRIO_REC
     __builtin_amdgcn_s_setprio(PRIO_REC);
@@ -1666,15 +1737,31 @@ __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __rest
     RecFastEnc<RecCodeLds> cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(outp, cap);
     const uint4* t = reinterpret_cast<const uint4*>(tok + cp.r0 * RT_TOK_PER_REC);       // (160 bytes per record: 16-byte aligned)
     const u32 n = ntok[c];
-    uint4 nx = n ? t[0] : make_uint4(0, 0, 0, 0);
+    // Tokens four at a time, two groups ahead; their row entries one group ahead of the coder -- the rows are frozen, so an
+    // entry depends on nothing the coder does.  (Round 4: written as fetch-then-code per token the coder's own stores kept the
+    // compiler from moving a fetch up, and a lane paid a memory round trip per symbol: 0.93 ms for the 128-record chains of
+    // a 600 k-read call, 600 ns a symbol.)
+    const u32* const grows = a.rrows;
+#define RC_ENTRY(tk, on) rec_code_entry(L, grows, (on) ? (tk) >> 8 : 0u, (tk) & 0xffu)
+#define RC_ENTRIES(v, i) make_uint4(RC_ENTRY((v).x, (i) < n), RC_ENTRY((v).y, (i) + 1 < n), RC_ENTRY((v).z, (i) + 2 < n), RC_ENTRY((v).w, (i) + 3 < n))
+    // (a token group is loaded under an `if`, not chosen by `? :` against a zero constant: that becomes a load through a chosen
+    //  POINTER, with the constant in scratch)
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+    if (n) v0 = t[0];
+    if (n > 4) v1 = t[1];
+    uint4 e = RC_ENTRIES(v0, 0u);
     for (u32 i = 0; i < n; i += 4) {
-        const uint4 v = nx;
-        if (i + 4 < n) nx = t[(i >> 2) + 1];
-        cd.put(v.x >> 8, v.x & 0xffu);
-        if (i + 1 < n) cd.put(v.y >> 8, v.y & 0xffu);
-        if (i + 2 < n) cd.put(v.z >> 8, v.z & 0xffu);
-        if (i + 3 < n) cd.put(v.w >> 8, v.w & 0xffu);
+        uint4 v2 = make_uint4(0, 0, 0, 0);
+        if (i + 8 < n) v2 = t[(i >> 2) + 2];
+        const uint4 e2 = RC_ENTRIES(v1, i + 4u);
+        cd.rc.encode16(FZ_CUM(e.x), FZ_FREQ(e.x));
+        if (i + 1 < n) cd.rc.encode16(FZ_CUM(e.y), FZ_FREQ(e.y));
+        if (i + 2 < n) cd.rc.encode16(FZ_CUM(e.z), FZ_FREQ(e.z));
+        if (i + 3 < n) cd.rc.encode16(FZ_CUM(e.w), FZ_FREQ(e.w));
+        v1 = v2; e = e2;
     }
+#undef RC_ENTRIES
+#undef RC_ENTRY
     a.csz[c] = cd.rc.finish();
     if (cd.rc.err & 2) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
     if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));

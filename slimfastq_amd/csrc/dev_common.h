@@ -109,4 +109,3 @@ __device__ __forceinline__ u32 gen_code_of(u32 c) {        // gens.cpp:72-77: 0.
     n = (l == 'n' || c == '.') ? 4u : n;
     return n;
 }
-

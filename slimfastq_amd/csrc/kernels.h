@@ -104,6 +104,8 @@ void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStrea
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt /* [REC_COUNT_COPIES][PR_REC_ROWS][256], zeroed; the sums end up in copy 0 */,
                       u32* flags /* [nruns], zeroed */, hipStream_t st);
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec /* the decoder's form; may be null */, hipStream_t st);
+// counts -> the transmitted prior's frequencies f[nrows][256], the rows' sums rtot[nrows], and the nh heaviest rows (map[nrows], hot[nh])
+void launch_rec_prior_freqs(const u32* cnt, u32 nrows, u32* f, u32* rtot, u32 nh, u16* map, u16* hot, hipStream_t st);
 // one header chain per lane; a.csz / a.rhb per chain; max_hdr = the call's longest header (picks the LDS image of the fast kernel)
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32* flags2 /* the same */, u32* tok /* rec_token_bytes(records) */, u32* ntok /* [rgeo.nchains] */,
                          u32 n_hot, u32 max_hdr, hipStream_t st);
@@ -199,5 +201,7 @@ void launch_qlt_hist(const u8* fq, u64 nbytes, const u64* line_off, const BlockD
                      int level, u32 cap /* symbols counted per sampled record */, u32* hist, hipStream_t st);
 #define PRIOR_SYMBOLS 4096u
 void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);
+// the listed rows of rows66 back to back: slot[q_rows] scratch; list[4 + 67 n]: [0] = n, then per row its context and 66 words
+void launch_prior_list(const u32* rows66, u32 q_rows, u32* slot, u32* list, hipStream_t st);
 void launch_prior_scatter(const u32* ctxs, const u32* rows /* [n][66] */, u32 n, u32* rows66 /* zeroed */, hipStream_t st);
 void launch_prior_spread(const u32* rows66, u32 q_rows, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st);

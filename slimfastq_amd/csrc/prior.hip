@@ -231,6 +231,58 @@ __global__ __launch_bounds__(256) void k_prior_rows(const u32* hist, u32 q_rows,
     if (lane < 60) w[4 + lane] = slot; else w_ovf[(size_t)ctx * 4 + (lane - 60)] = slot;
     if (lane == 0) { w[0] = tot; w[1] = iend; w[2] = 0; w[3] = 0; }
 }
+// The rows the prior lists (iend != 0), back to back and in context order, for the host that packs "qlt.pri" from them: the
+// dense table is 17 MB, of which a call's sample fills a few thousand rows -- the copy of all of it held a hardware queue for half
+// a millisecond and was the tail of every small call (round 4).  list: [0] = n, [4 + 67 i ..] = context, then the row's 66 words.
+// (two steps: which rows are listed -- a thread per context, all over the chip: the flags sit 264 bytes apart in the table, and
+//  one workgroup reading all 65 536 of them took 0.7 ms --, then ONE workgroup turns the flags into places, in place)
+__global__ __launch_bounds__(256) void k_prior_flags(const u32* __restrict__ rows66, u32 q_rows, u32* __restrict__ slot) {
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c < q_rows) slot[c] = rows66[(size_t)c * 66 + 65] != 0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(1024) void k_prior_slots(u32 q_rows, u32* __restrict__ slot, u32* __restrict__ list) {
+    __shared__ u32 wsum[16];
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u32 per = (((q_rows + 1023u) / 1024u) + 3u) & ~3u, c0 = t * per;            // contexts per thread, a multiple of 4 (q_rows is a power of two >= 4096)
+    u32 mine = 0;
+    for (u32 k = 0; k < per; k += 4) {
+        if (c0 + k + 4 <= q_rows) { const uint4 v = *reinterpret_cast<const uint4*>(slot + c0 + k); mine += v.x + v.y + v.z + v.w; }
+        else for (u32 j = 0; j < 4; j++) if (c0 + k + j < q_rows) mine += slot[c0 + k + j];
+    }
+    u32 inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d, 64); if (lane >= (u32)d) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    u32 before = 0, all = 0;
+    for (u32 w = 0; w < 16; w++) { const u32 v = wsum[w]; before += w < wave ? v : 0u; all += v; }
+    u32 at = before + inc - mine;
+    for (u32 k = 0; k < per; k++) {
+        const u32 c = c0 + k;
+        if (c >= q_rows) break;
+        const bool on = slot[c] != 0;
+        slot[c] = on ? at : ~0u;
+        at += on ? 1u : 0u;
+    }
+    if (t == 0) { list[0] = all; list[1] = list[2] = list[3] = 0; }
+}
+__global__ __launch_bounds__(256) void k_prior_gather(const u32* __restrict__ rows66, u32 q_rows, const u32* __restrict__ slot, u32* __restrict__ list) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= q_rows) return;
+    const u32 s = slot[c];
+    if (s == ~0u) return;
+    const u32* r = rows66 + (size_t)c * 66;
+    u32* o = list + 4 + (size_t)s * 67;
+    if (lane == 0) o[0] = c;
+    o[1 + lane] = r[lane];
+    if (lane < 2) o[65 + lane] = r[64 + lane];
+}
+void launch_prior_list(const u32* rows66, u32 q_rows, u32* slot, u32* list, hipStream_t st) {
+    hipLaunchKernelGGL(k_prior_flags, dim3((q_rows + 255) / 256), dim3(256), 0, st, rows66, q_rows, slot);
+    hipLaunchKernelGGL(k_prior_slots, dim3(1), dim3(1024), 0, st, q_rows, slot, list);
+    hipLaunchKernelGGL(k_prior_gather, dim3((q_rows + 3) / 4), dim3(256), 0, st, rows66, q_rows, (const u32*)slot, list);
+}
 void launch_prior_rows(const u32* hist, u32 q_rows, u32* rows66, u32* w_rows, u32* w_ovf, u32* l_slots, RowHdr* l_hdr, hipStream_t st) {
     hipLaunchKernelGGL(k_prior_rows, dim3((q_rows + 3) / 4), dim3(256), 0, st, hist, q_rows, rows66, w_rows, w_ovf, l_slots, l_hdr);
 }
