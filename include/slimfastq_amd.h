@@ -80,7 +80,10 @@ typedef struct sfq_params {
     int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (the reference loop on one lane:
-                              slow, the cross-check of the default kernels)                                       */
+                              slow, the cross-check of the default kernels; adaptive tables); 2 = the default kernels, but
+                              with frozen tables the base exceptions (gen.Ns / gen.Nn / gen.lc) keep the reference's own
+                              coding -- XFile streams through adaptive PowerRanger rows, what archives written before
+                              round 4 hold -- instead of Rice-coded gap lists ("chn.idx" flag bit 4)  */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);

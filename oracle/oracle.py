@@ -364,6 +364,31 @@ def gen_encode_chains(buf: bytes, goff, glen, gen_bits, block_reads, chain_reads
     return _take(out, n), sizes, on.value
 
 
+def exc_rice_block(buf: bytes, goff, glen, qoff, qlen):
+    """A block's base-exception lists as adaptive Rice codes (frozen tables, round 4) -> (gen.Ns, gen.Nn, gen.lc, n_byte)."""
+    L = lib()
+    goff, pg = _arr(goff, np.uint64); glen, pgl = _arr(glen, np.uint32); qoff, pq = _arr(qoff, np.uint64); qlen, pql = _arr(qlen, np.uint32)
+    out = (C.POINTER(C.c_uint8) * 3)(); n = (C.c_size_t * 3)(); nb = C.c_uint32()
+    L.sfqo_exc_rice_block.restype = C.c_int
+    L.sfqo_exc_rice_block.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    if L.sfqo_exc_rice_block(buf, pg, pgl, pq, pql, len(goff), out, n, C.byref(nb)) != 0:
+        raise _err()
+    return tuple(_take(out[i], C.c_size_t(n[i])) for i in range(3)) + (nb.value,)
+
+
+def exc_rice_decode(blob: bytes):
+    """The positions (from 1) a Rice-coded exception list holds."""
+    L = lib()
+    L.sfqo_exc_rice_decode.restype = C.c_longlong
+    L.sfqo_exc_rice_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    cnt = L.sfqo_exc_rice_decode(blob, len(blob), None, 0)
+    if cnt < 0:
+        raise OracleError("exception list does not end")
+    pos = np.zeros(max(cnt, 1), np.uint64)
+    L.sfqo_exc_rice_decode(blob, len(blob), pos.ctypes.data_as(C.c_void_p), cnt)
+    return pos[:cnt]
+
+
 def seg_counts(length, other, seg_len):
     """Segments per record (chains.hip): n = ceil(max(len, other) / seg_len), at least one."""
     m = np.maximum(np.asarray(length, np.uint64), np.asarray(other, np.uint64))

@@ -1865,6 +1865,99 @@ long long sfqo_gen_encode_segs(const u8* base, const u64* goff, const u32* glen,
     return gen_encode_chains_x(base, goff, glen, nrec, gen_bits, block_reads, 1, step, out, out_len, sizes, gen_on, seg_len, other_len);
 }
 
+/* ---- frozen tables: the base exceptions as adaptive Rice codes (round 4; chains.hip k_gen_exc_r) -------------------------
+   NOT the reference's coding: with frozen tables the three gap lists of a block -- "gen.Ns" (N-like bases whose quality is not
+   '!'), "gen.Nn" (real bases under quality '!'), "gen.lc" (lowercase bases), the gaps as the reference's XFile streams define
+   them (gens.cpp:91-114, the position of a base counted from 1 over the block's base lines, each gap against the list's
+   previous entry) -- are written as bit streams instead of through adaptive PowerRanger rows:
+     k = the smallest k <= 24 with (N << k) >= A;  q = v >> k;
+     q < 32: q one bits, a zero bit, the low k bits of v;   else: 32 one bits, then v in 40 bits (low 20 first)
+     A += v, N += 1; when N reaches 32 both are halved.   Start: A = 256, N = 1.
+   Bits fill bytes from the low end.  A list ends with v = 0 (no gap is 0) and zero bits up to a byte; an empty list is an
+   empty stream.                                                                                                         */
+typedef struct { u8* p; size_t n, cap; u64 acc; u32 nbits; u64 A; u32 N; int opened; } rice_w;
+static void rice_bits(rice_w* w, u32 v, u32 n) {                              /* n <= 32 */
+    if (!n) return;
+    w->acc |= (u64)(n == 32 ? v : (v & ((1u << n) - 1u))) << w->nbits;
+    w->nbits += n;
+    while (w->nbits >= 8) {
+        if (w->n == w->cap) { w->cap = w->cap ? w->cap * 2 : 64; w->p = xrealloc(w->p, w->cap); }
+        w->p[w->n++] = (u8)w->acc; w->acc >>= 8; w->nbits -= 8;
+    }
+}
+static u32 rice_k(u64 A, u32 N) { u32 k = 0; while (k < 24 && ((u64)N << k) < A) k++; return k; }
+static void rice_put(rice_w* w, u64 v) {
+    w->opened = 1;
+    const u32 k = rice_k(w->A, w->N);
+    const u64 q = v >> k;
+    if (q < 32) { rice_bits(w, (u32)((1ull << q) - 1), (u32)q); rice_bits(w, 0, 1); rice_bits(w, (u32)(v & ((1ull << k) - 1)), k); }
+    else { rice_bits(w, 0xFFFFFFFFu, 32); rice_bits(w, (u32)(v & 0xFFFFF), 20); rice_bits(w, (u32)((v >> 20) & 0xFFFFF), 20); }
+    w->A += v; w->N++;
+    if (w->N >= 32) { w->A >>= 1; w->N >>= 1; }
+}
+static void rice_finish(rice_w* w) {
+    if (!w->opened) return;
+    rice_put(w, 0);
+    if (w->nbits) rice_bits(w, 0, 8 - w->nbits);
+}
+/* One block's three lists: records [r0, r0 + n) of base lines (goff, glen) and quality lines (qoff, qlen), all offsets into
+   base (behind a SOLiD prefix, if any).  out[3] / out_len[3]: gen.Ns, gen.Nn, gen.lc (malloc'ed; free with sfqo_free).
+   n_byte: the block's N character (0: none).  Returns 0, or -1 for a base line the model refuses (an illegal character, two
+   different N characters). */
+int sfqo_exc_rice_block(const u8* base, const u64* goff, const u32* glen, const u64* qoff, const u32* qlen, size_t nrec,
+                        u8** out, size_t* out_len, u32* n_byte_out) {
+    g_failed = 0; g_err[0] = 0;
+    rice_w w[3]; memset(w, 0, sizeof w);
+    for (int i = 0; i < 3; i++) { w[i].A = 256; w[i].N = 1; }
+    u64 genofs = 0, last[3] = {0, 0, 0};
+    u32 n_byte = 0;
+    for (size_t r = 0; r < nrec && !g_failed; r++) {
+        for (u32 i = 0; i < glen[r]; i++) {
+            u8 g = base[goff[r] + i];
+            const u8 q = i < qlen[r] ? base[qoff[r] + i] : 40;                /* gens.cpp:153 */
+            if (g == 'a' || g == 'c' || g == 'g' || g == 't' || g == 'n') {
+                rice_put(&w[2], genofs + 1 - last[2]); last[2] = genofs + 1;
+                if (g == 'n') g = 'N';
+            }
+            const int n = gencode_of(g);
+            const int bad_q = q == '!', bad_n = n > 3;
+            if (n > 4) { fail("illegal base character %d", g); break; }
+            genofs++;
+            if (bad_n) {
+                if (!n_byte) n_byte = g;
+                if (g != n_byte) { fail("switched N_byte: %c", g); break; }
+                if (!bad_q) { rice_put(&w[0], genofs - last[0]); last[0] = genofs; }
+            } else if (bad_q) { rice_put(&w[1], genofs - last[1]); last[1] = genofs; }
+        }
+    }
+    for (int i = 0; i < 3; i++) { rice_finish(&w[i]); out[i] = w[i].p; out_len[i] = w[i].n; }
+    if (n_byte_out) *n_byte_out = n_byte;
+    return g_failed ? -1 : 0;
+}
+/* the way back: the positions (counted from 1) a list holds -> pos[cap]; returns their number, or -1 for a stream that does
+   not end properly */
+long long sfqo_exc_rice_decode(const u8* p, size_t n, u64* pos, size_t cap) {
+    if (!n) return 0;
+    u64 A = 256; u32 N = 1; size_t bit = 0, cnt = 0; u64 at = 0;
+    #define RBIT() ((bit >> 3) < n ? (p[bit >> 3] >> (bit & 7)) & 1u : 0u)
+    for (;;) {
+        if ((bit >> 3) >= n + 16) return -1;
+        const u32 k = rice_k(A, N);
+        u32 q = 0; while (q < 32 && RBIT()) { q++; bit++; }
+        u64 v = 0;
+        if (q < 32) { bit++; for (u32 j = 0; j < k; j++, bit++) v |= (u64)RBIT() << j; v |= (u64)q << k; }
+        else for (u32 j = 0; j < 40; j++, bit++) v |= (u64)RBIT() << j;
+        if (!v) break;
+        at += v;
+        if (cnt < cap) pos[cnt] = at;
+        cnt++;
+        A += v; N++;
+        if (N >= 32) { A >>= 1; N >>= 1; }
+    }
+    #undef RBIT
+    return (long long)cnt;
+}
+
 /* ---- headers: frozen PowerRanger rows ---- */
 #define REC_ROWS (66 * 16)
 static void hcount_hook(void* arg, int row, u8 sym) { u32** a = arg; if (a[1]) a[0][(size_t)row * 256 + sym]++; }

@@ -115,6 +115,11 @@ long long sfqo_qlt_encode_segs(const uint8_t* base, const uint64_t* off, const u
                                const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* extra_hi);
 long long sfqo_gen_encode_segs(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint32_t* other_len, size_t nrec, int gen_bits, size_t block_reads,
                                uint32_t seg_len, uint32_t step, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+/* frozen tables, round 4: a block's three base-exception lists ("gen.Ns", "gen.Nn", "gen.lc") as adaptive Rice codes
+   (chains.hip k_gen_exc_r; NOT the reference's XFile coding: DESIGN.md 4.10) and the way back */
+int sfqo_exc_rice_block(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint64_t* qoff, const uint32_t* qlen, size_t nrec,
+                        uint8_t** out, size_t* out_len, uint32_t* n_byte_out);
+long long sfqo_exc_rice_decode(const uint8_t* p, size_t n, uint64_t* pos, size_t cap);
 int sfqo_rec_count(const uint8_t* base, const uint64_t* off, const uint32_t* len, size_t nrec, size_t stride, size_t run, size_t nruns, uint32_t* counts);
 int sfqo_rec_prior_freqs(const uint32_t* counts, uint32_t* f);
 int sfqo_rec_frozen_rows(const uint32_t* f, uint32_t* rows);

@@ -34,6 +34,7 @@ struct sfq_ctx {
     hipStream_t st = nullptr;
     hipStream_t st_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[28] = {};
+    bool rec_copy_pending = false;     // the header prior's frequencies are still to be copied to the host (rec_prior_copy_back)
     bool rec_blob_pending = false;     // "rec.pri" is still to be packed from the frequencies behind ev[24]
     std::string err;
     u64 table_budget = 0;
@@ -459,7 +460,16 @@ int rec_prior_finish(sfq_ctx* ctx, bool given, hipStream_t st) {
     launch_rec_prior_freqs((const u32*)ctx->hcnt.p, PR_REC_ROWS, (u32*)ctx->hfreq.p, (u32*)ctx->hfreq.p + nf, RDEC_LDS_ROWS, map, map + PR_REC_ROWS, st);
     launch_rec_frozen_rows((const u32*)ctx->hfreq.p, PR_REC_ROWS, (u32*)ctx->rrows.p, (u16*)ctx->rdec.p, st);
     ctx->r_hot = std::min<u32>(RDEC_LDS_ROWS, 8); ctx->r_hot_dec = RDEC_LDS_ROWS;          // (rows the sample never saw fill the list up: staging one is harmless)
-    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hfreq.p, nf * 4, hipMemcpyDeviceToHost, st));
+    ctx->rec_copy_pending = true;
+    return SFQ_OK;
+}
+// the frequencies on their way to the host, for rec_prior_blob_now().  Queued BEHIND the header chains on their stream: in front
+// of them the copy -- a blit kernel that has to find room beside the base chains and the exception pass -- took 1.9 ms, with the
+// header chains and the quality chains waiting behind it
+int rec_prior_copy_back(sfq_ctx* ctx, hipStream_t st) {
+    if (!ctx->rec_copy_pending) return SFQ_OK;
+    ctx->rec_copy_pending = false;
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_REC_OFF, ctx->hfreq.p, (size_t)PR_REC_ROWS * 256 * 4, hipMemcpyDeviceToHost, st));
     HIPC(hipEventRecord(ctx->ev[24], st));
     ctx->rec_blob_pending = true;
     return SFQ_OK;
@@ -683,7 +693,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     sfq_params p = *pp;
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
-    if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
+    if (p.kernel > 2) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels, 2 = default kernels with the reference's coding of the base exceptions", p.kernel);
+    const bool exc_classic = p.kernel == 2;              // (everywhere below, kernel is 0 or 1)
+    if (exc_classic) p.kernel = 0;
     if (p.tables > SFQ_TABLES_AUTO) return fail(ctx, SFQ_E_ARG, "tables %u: 0 = adaptive, 1 = frozen, 2 = by the size of the text", p.tables);
     bool small_auto = false;
     if (p.tables == SFQ_TABLES_AUTO) {                          // include/slimfastq_amd.h
@@ -878,7 +890,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (given && ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no quality prior installed (sfq_set_qlt_prior)");
     if (given && frozen && (models & SFQ_M_REC) && ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "SFQ_PRIOR_GIVEN: no header prior installed (sfq_set_rec_prior)");
     if (!given) { ctx->prior_blob.clear(); ctx->rec_prior_blob.clear(); }
-    ctx->rec_blob_pending = false;
+    ctx->rec_blob_pending = false; ctx->rec_copy_pending = false;
     ctx->chain_blob.clear();
     if (frozen && !prior_step) prior_step = SFQ_PRIOR_AUTO;          // frozen rows ARE the prior
     u32 slots = 0;
@@ -1099,7 +1111,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (ctx->prior_on && !given) {                      // (packed while the header sample is still being counted)
             if ((rc = qlt_prior_blob_now(ctx, h_rows66, q_rows, st))) return rc;
         }
-        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc; if ((rc = rec_prior_blob_now(ctx))) return rc; }
+        if (frozen && (models & SFQ_M_REC)) { if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc; if ((rc = rec_prior_copy_back(ctx, mst[1]))) return rc; if ((rc = rec_prior_blob_now(ctx))) return rc; }
         HIPC(hipStreamSynchronize(mst[1]));
         HIPC(hipStreamSynchronize(st));
         ctx->prior_on = false;
@@ -1107,6 +1119,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         return SFQ_OK;
     }
     u32 gen_on = 0;
+    const bool exc_rice = frozen && !exc_classic;
     bool side_late = false;                            // the exception pass is still running when the packing starts
     if (frozen) {
         // The two host decisions first (the shorter counting pass, the headers', before the base tables' verdict), each followed by
@@ -1128,6 +1141,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1]);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
+            if ((rc = rec_prior_copy_back(ctx, mst[1]))) return rc;
         } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
@@ -1143,7 +1157,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
         }
         HIPC(hipEventRecord(ctx->ev[3], st));
-        if (models & SFQ_M_GEN) launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
+        // the base exceptions: Rice-coded gap lists (dev_rice.h; the pass itself is models_w.hip k_gen_exc_w); sfq_params.kernel = 2 keeps the reference's own
+        // coding of them (adaptive PowerRanger rows, a wave per block: what rounds 2 and 3 wrote)
+        if (models & SFQ_M_GEN) {
+            if (exc_rice) launch_gen_exc_r(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
+            else launch_gen_exc_w(a, want_marks ? (const u8*)ctx->excf.p : nullptr, tickets + 1, mst[2]);
+        }
         if (models & SFQ_M_USR)
             for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
@@ -1342,7 +1361,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (size_t i = 0; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u)); put(nchains);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u)); put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
         put_list(h_csz, nchains); put_list(h_csz + nchains, nchains);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
@@ -1529,6 +1548,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     p.level = clamp_level(p.level);
     ctx->framed.valid = false;                     // (a decode's scratch is not an encode's line index)
     const u32 version = p.version ? p.version : 6;
+    if (p.kernel == 2) p.kernel = 0;                     // (an encoder's choice; a decoder reads what "chn.idx" says)
     if (p.kernel > 1) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels", p.kernel);
     if (version > 6) return fail(ctx, SFQ_E_UNSUPPORTED, "archive version %u is newer than 6 (config.cpp:373-377)", version);
     hipStream_t st = ctx->st;
@@ -1584,6 +1604,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
+    bool exc_rice = false;
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
     u32* h_csz = nullptr; u64* h_coff = nullptr; size_t ncs = 0;
@@ -1596,7 +1617,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         gen_on = (u32)v & 1u; rec_chains = ((u32)v >> 1) & 1u;
         const bool deltas = ((u32)v >> 2) & 1u;              // sizes as zigzag differences to the entry before (round 4; version-8 archives of round 3: plain)
         const bool segs = ((u32)v >> 3) & 1u;                // chains are segments of one record (long reads): their length and the blocks' shares follow
-        if (v >> 4) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        exc_rice = ((u32)v >> 4) & 1u;                       // the base exceptions are Rice-coded gap lists (exc.hip; round 4)
+        if (v >> 5) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
         u64 lprev = 0;                                        // the running value of the list being read
         auto get_size = [&](u64& out) -> bool {
             if (!get_v(cb, cn, cp, out)) return false;
@@ -1872,7 +1894,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, dec_max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
             }
         }
-        for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_w(da, st_gen); }
+        if (exc_rice) launch_gen_exc_decode_r(da, nblocks, st_gen);
+        else for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_gen_exc_decode_w(da, st_gen); }
     } else {
     // adaptive tables: a wavefront per block (decode_w.hip); sfq_params.kernel = 1: the lane-per-block cross-check kernels
     const bool wave_dec = p.kernel == 0;

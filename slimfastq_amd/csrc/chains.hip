@@ -967,12 +967,15 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
     // A SMALL generation (the first ones: 1/64 of the call each, whose passes every base chain waits for) is latency, not
     // throughput: its time is one lane's walk through its record, so the records are cut into the shortest stretches (of 32
     // bases or more, sixteen bases of warm-up before each) that still fit the chip's 524 288 lanes at once
-    u32 seg_len = max_line > 1024u ? 512u : 0u;
-    if (!seg_len && max_line >= 64u) {
+    // (round 4: long lines too -- the pre-verdict's sample of a long-read call is a hundred records of 30 kb, and at 512 bases a
+    //  lane its two passes took 1.2 + 1.5 ms with every chain of the call waiting for them)
+    u32 seg_len = 0;
+    if (max_line >= 64u) {
         const u64 nsel = (nrec_range + stride - 1) / stride;
-        for (u32 sl = 32u; sl < max_line; sl *= 2u)
+        for (u32 sl = 32u; sl < max_line && sl <= 512u; sl *= 2u)
             if (nsel * ((max_line + sl - 1) / sl) <= 524288ull) { seg_len = sl; break; }
     }
+    if (!seg_len && max_line > 1024u) seg_len = 512u;
     const u32 segs = seg_len ? (max_line + seg_len - 1) / seg_len : 1u;
     const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
     hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost, sub, do_count);

@@ -100,6 +100,9 @@ void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t 
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 c0 = 0, u32 c1 = 0 /* chains [c0, c1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
+// the same lists as adaptive Rice codes (models_w.hip k_gen_exc_w<true>, dev_rice.h; frozen tables, "chn.idx" flag bit 4) and the way back, a lane per block (exc.hip)
+void launch_gen_exc_r(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
+void launch_gen_exc_decode_r(const struct DecodeArgs& a, u32 nblocks, hipStream_t st);
 #define REC_COUNT_COPIES 32u        // the header prior's counting pass counts into this many copies of the table (chains.hip k_rec_count_sum)
 void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nruns, u32* cnt /* [REC_COUNT_COPIES][PR_REC_ROWS][256], zeroed; the sums end up in copy 0 */,
                       u32* flags /* [nruns], zeroed */, hipStream_t st);

@@ -35,6 +35,8 @@
 #include "dev_rec.h"
 
 #include "dev_wavepw.h"
+#include "dev_rice.h"
+#include <type_traits>
 
 // =========================================================================================================
 // N / quality-0 exceptions alone (frozen-table mode: the bases themselves are coded by chains.hip): a wave per block
@@ -44,16 +46,25 @@
 // =========================================================================================================
 // flags (from the quality and base chains, which have read every byte anyway): the records that may hold an N or a '!';
 // the others only move the base offset on, 64 records a step.  Null: every record is looked at.
+// RICE (round 4, the default with frozen tables): the gap lists as adaptive Rice codes instead (dev_rice.h, exc.hip) -- the same
+// scan, the same gaps, a few scalar instructions per gap and no tables.
+struct XfRiceW {               // the XfEncW interface over a RiceWU
+    RiceWU w; Sink0 sink; struct { u32 err; } rc;
+    __device__ __forceinline__ void init(u8* p, u32 cap, u32) { w.init(p, cap); sink.p = p; sink.pos = 0; sink.cap = cap; rc.err = 0; }
+    __device__ __forceinline__ void put(WavePw&, u64 gap, u32 lane) { w.put(gap, lane); }
+    __device__ __forceinline__ u32 finish(WavePw&, u32 lane) { const u32 n = w.finish(lane); sink.pos = w.ovf ? sink.cap + 1 : n; return n; }
+};
+template <bool RICE>
 __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restrict__ flags, u32* ticket) {
-    __shared__ __attribute__((aligned(16))) u32 hot_slots[2 * PW_NSYM];
+    __shared__ __attribute__((aligned(16))) u32 hot_slots[RICE ? 4 : 2 * PW_NSYM];
     __shared__ __attribute__((aligned(16))) RowHdr hot_hdr[2];
     const u32 lane = threadIdx.x, t = blockIdx.x;
     for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
         BlockDesc* d = &a.blocks[b];
         WavePw pw; pw.slots = a.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.epoch_base + b + 1);
         pw.hslots = hot_slots; pw.hhdr = hot_hdr; pw.hrow0 = PR_XF_BASE + XF_GEN_NS * PR_XF_ROWS; pw.hn = 2;
-        if (lane < 2) pw.fresh_hot(lane);                  // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
-        XfEncW x_ns, x_nn, x_lc;                           // the whole wave codes a gap: lane = four slots of the PowerRanger row
+        if (!RICE && lane < 2) pw.fresh_hot(lane);         // (no block's epoch: the rows start fresh, power_ranger.hpp:36-47)
+        typename std::conditional<RICE, XfRiceW, XfEncW>::type x_ns, x_nn, x_lc;          // XfEncW: the whole wave codes a gap, lane = four slots of the PowerRanger row
         x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
         x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
         x_lc.init(a.arena + d->out_off[SFQ_S_GEN_LC], d->out_cap[SFQ_S_GEN_LC], XF_GEN_LC);
@@ -332,7 +343,11 @@ void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStrea
     // (persistent waves that take blocks off the ticket: not more of them than three quarters of the chip's wave slots --
     //  the packing kernels run beside this pass and would otherwise wait for a slot until it is through)
     const u32 grid = a.nbatch < 6144u ? a.nbatch : 6144u;
-    hipLaunchKernelGGL(k_gen_exc_w, dim3(grid), dim3(64), 0, st, a, flags, ticket);
+    hipLaunchKernelGGL(k_gen_exc_w<false>, dim3(grid), dim3(64), 0, st, a, flags, ticket);
+}
+void launch_gen_exc_r(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
+    const u32 grid = a.nbatch < 6144u ? a.nbatch : 6144u;
+    hipLaunchKernelGGL(k_gen_exc_w<true>, dim3(grid), dim3(64), 0, st, a, flags, ticket);
 }
 
 

@@ -54,14 +54,41 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     want, sizes, hb = O.rec_encode_chains_frozen(fq, hoff, hlen, br, rcr, O.rec_frozen_rows(f))
     assert list(ci["rec"]) == list(sizes) and list(ci["rec_hdr_bytes"]) == list(hb), what
     assert enc.stream("rec") == want, what
-    # the side streams are the reference's own, block by block
+    # the framing's side streams are the reference's own, block by block; the base exceptions are the reference's LISTS (gaps as
+    # gens.cpp:91-114 defines them) as Rice codes -- the oracle's restatement of exc.hip ("chn.idx" flag bit 4)
+    assert flags & 16
     chunks = util.split_records(fq, br)
     for b in (0, len(chunks) - 1):
         ref = util.block_reference(chunks[b], level, gen_bits=enc.blocks[b].gen_bits).streams
-        for name in ("gen.Ns", "gen.Nn", "gen.lc", "usr.x", "usr.x.q", "usr.pfg", "usr.pfq"):
+        for name in ("usr.x", "usr.x.q", "usr.pfg", "usr.pfq"):
             assert enc.stream(name, b) == ref.get(name, b""), (what, name, b)
+        rice = util.exc_rice_reference(chunks[b], solid=int(enc.blocks[b].solid))
+        for name in ("gen.Ns", "gen.Nn", "gen.lc"):
+            assert enc.stream(name, b) == rice[name], (what, name, b)
         assert enc.stream("rec.x", b) == b""             # a header whose shape changed is coded inside its chain
     return enc
+
+
+def test_base_exceptions_in_the_references_own_coding_on_request(ctx):
+    """sfq_params.kernel = 2 with frozen tables: the base exceptions go through the reference's adaptive PowerRanger rows (what
+    rounds 2 and 3 wrote; "chn.idx" flag bit 4 clear) -- byte for byte the reference's gen.Ns / gen.Nn of a file holding the
+    block -- and such an archive decodes; the default (Rice-coded lists, exc.hip) holds the same positions in fewer bytes."""
+    fq = capi.synth_fastq(5000, 150, seed=31)
+    br = 500
+    old = ctx.encode_host(fq, level=3, block_reads=br, prior_step=2, tables=capi.TABLES_FROZEN, chain_reads=64, kernel=2)
+    new = ctx.encode_host(fq, level=3, block_reads=br, prior_step=2, tables=capi.TABLES_FROZEN, chain_reads=64)
+    assert not util.unpack_chains(old.chains)["flags"] & 16 and util.unpack_chains(new.chains)["flags"] & 16
+    for b, chunk in enumerate(util.split_records(fq, br)):
+        ref = util.block_reference(chunk, 3, gen_bits=old.blocks[b].gen_bits).streams
+        for name in ("gen.Ns", "gen.Nn", "gen.lc"):
+            assert old.stream(name, b) == ref.get(name, b""), (name, b)
+            got = O.exc_rice_decode(new.stream(name, b))
+            assert len(got) or not ref.get(name, b"")
+    for name in ("rec", "gen", "qlt", "usr.x", "usr.x.q"):
+        assert old.stream(name) == new.stream(name)
+    assert sum(len(new.stream(n)) for n in ("gen.Ns", "gen.Nn")) < sum(len(old.stream(n)) for n in ("gen.Ns", "gen.Nn"))
+    assert ctx.decode_host(old, level=3, out_cap=len(fq) + 4096) == fq
+    assert ctx.decode_host(new, level=3, out_cap=len(fq) + 4096) == fq
 
 
 @pytest.mark.parametrize("level", (1, 2, 3, 4))

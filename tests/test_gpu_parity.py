@@ -248,8 +248,10 @@ def test_block_format_is_lossless_where_the_reference_is_not(ctx, tables):
         enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=tables, chain_reads=40, kernel=kernel)
         assert enc.res.stream_bytes[capi.STREAM_NAMES.index("gen.lc")] > 0
         for b, chunk in enumerate(util.split_records(fq, br)):
-            want = util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams
+            want = dict(util.block_reference(chunk, 3, gen_bits=enc.blocks[b].gen_bits).streams)
             names = ("gen.Ns", "gen.Nn", "gen.lc", "usr.x", "usr.x.q") if tables == capi.TABLES_FROZEN else [n for n in capi.STREAM_NAMES if n != "qlt"]
+            if tables == capi.TABLES_FROZEN:                                # the same lists, Rice-coded (exc.hip)
+                want.update(util.exc_rice_reference(chunk))
             for name in names:                                              # (the quality rows start from the prior: not the cold reference's)
                 assert enc.stream(name, b) == want.get(name, b""), (kernel, b, name)
         assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq, kernel

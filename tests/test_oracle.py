@@ -70,6 +70,46 @@ def test_xfile_roundtrip_boundaries():
     assert [int(v) for v in back] == [v & ((1 << 64) - 1) for v in vals]
 
 
+def test_rice_exception_lists_hold_the_references_positions():
+    """Frozen tables, round 4: a block's base-exception lists are Rice-coded (oracle sfqo_exc_rice_block, exc.hip).  The
+    POSITIONS they hold are the reference's (gens.cpp:91-114): N-like bases whose quality is not '!', real bases under '!',
+    lowercase bases, counted from 1 over the block's base lines -- checked against a numpy statement of that, through the
+    decoder; gaps over the escape threshold, empty lists and lists of one entry included."""
+    import numpy as np
+    from slimfastq_amd import capi
+    rng = np.random.default_rng(5)
+    for nrec, n_low, n_bang in ((3000, 200, 300), (40, 0, 0), (2000, 1, 1), (6000, 4000, 3000)):
+        fq = bytearray(capi.synth_fastq(nrec, 150, seed=nrec))
+        starts, lens = util.line_table(bytes(fq))
+        goff, glen, qoff, qlen = starts[1::4], lens[1::4], starts[3::4], lens[3::4]
+        for r in rng.integers(0, nrec, n_low):
+            at = goff[r] + int(rng.integers(0, 150))
+            if fq[at] in b"ACGTN":
+                fq[at] |= 0x20
+        if any(c == ord("n") for c in fq) and any(c == ord("N") for c in fq):       # (one N character per block)
+            fq = bytearray(bytes(fq).replace(b"n", b"a"))
+        for r in rng.integers(0, nrec, n_bang):
+            fq[qoff[r] + int(rng.integers(0, 150))] = ord("!")
+        fq = bytes(fq)
+        ns, nn, lc, n_byte = O.exc_rice_block(fq, goff, glen, qoff, qlen)
+        B = np.frombuffer(fq, np.uint8)
+        bases = np.concatenate([B[goff[r]:goff[r] + glen[r]] for r in range(nrec)])
+        quals = np.concatenate([B[qoff[r]:qoff[r] + qlen[r]] for r in range(nrec)])
+        is_n, bang = (bases == ord("N")) | (bases == ord("n")), quals == ord("!")
+        for blob, want in ((ns, is_n & ~bang), (nn, ~is_n & bang), (lc, bases >= 97)):
+            want = (np.nonzero(want)[0] + 1).astype(np.uint64)
+            assert np.array_equal(O.exc_rice_decode(blob), want)
+            assert (len(blob) == 0) == (len(want) == 0)
+        assert n_byte == (ord("N") if is_n.any() else 0)
+    # the escape (a gap of 32 << k or more: 32 one bits, then the gap in 40 bits): one N, 12 000 bases into a block whose lists start at k = 8
+    fq = bytearray(capi.synth_fastq(200, 150, seed=2).replace(b"N", b"A"))
+    starts, lens = util.line_table(bytes(fq))
+    fq[starts[1 + 4 * 80]] = ord("N")
+    fq = bytes(fq)
+    ns, _, _, _ = O.exc_rice_block(fq, starts[1::4], lens[1::4], starts[3::4], lens[3::4])
+    assert list(O.exc_rice_decode(ns)) == [80 * 150 + 1] and len(ns) == 11        # 32 + 40 bits, then the end: a zero bit and thirteen more
+
+
 @pytest.mark.skipif(O.ref_binary() is None or not os.path.isdir("/root/reference/samples"),
                     reason="compiled reference / samples only exist in the build container")
 def test_oracle_vs_compiled_reference_all_samples():

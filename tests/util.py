@@ -108,7 +108,8 @@ def _vints(blob: bytes):
 def unpack_chains(blob: bytes, nblocks=None):
     """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, seg_len, seg_blocks] [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp.
     flags bit 2: every list of sizes is stored as zigzag differences to the entry before it; bit 3: the chains are SEGMENTS of one
-    record -- their length and every block's number of chains follow the chain count (nblocks must be given)."""
+    record -- their length and every block's number of chains follow the chain count (nblocks must be given); bit 4: the base
+    exceptions are Rice-coded gap lists (exc.hip)."""
     v = _vints(blob)
     cr, flags, n = v[0], v[1], v[2]
     p = 3
@@ -167,3 +168,13 @@ def block_reference(chunk: bytes, level: int, gen_bits: int = 0):
     the block format departs from its bytes -- SURVEY H7; everywhere else the two are byte-identical)."""
     from oracle import oracle as O
     return O.compress(chunk, level, gen_bits=gen_bits, lossless=True)
+
+
+def exc_rice_reference(chunk: bytes, solid: int = 0):
+    """The oracle's Rice-coded base-exception lists of ONE block (frozen tables, "chn.idx" flag bit 4; exc.hip):
+    {"gen.Ns", "gen.Nn", "gen.lc"} -> bytes."""
+    from oracle import oracle as O
+    starts, lens = line_table(chunk)
+    ns, nn, lc, _ = O.exc_rice_block(chunk, starts[1::4] + solid, lens[1::4] - solid, starts[3::4] + solid, lens[3::4] - solid)
+    return {"gen.Ns": ns, "gen.Nn": nn, "gen.lc": lc}
+
