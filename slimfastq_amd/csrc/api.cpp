@@ -10,11 +10,21 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <functional>
+#include <future>
 
 #include "kernels.h"
 
 namespace {
 
+// where a call's HOST time goes (SFQ_HOST_TIMING=1 in the environment: marks printed to stderr when the call returns)
+struct HostTimes {
+    bool on; std::chrono::steady_clock::time_point t0; std::vector<std::pair<const char*, double>> marks;
+    HostTimes() : on(getenv("SFQ_HOST_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) { if (on) marks.push_back({ what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() }); }
+    ~HostTimes() { if (on) { for (auto& m : marks) fprintf(stderr, "  [host] %-28s %8.3f ms\n", m.first, m.second); } }
+};
 struct DevBuf {
     void*  p = nullptr;
     size_t cap = 0;
@@ -188,6 +198,38 @@ bool get_v(const u8* b, size_t n, size_t& p, u64& v) {
     for (int sh = 0; sh < 64; sh += 7) { if (p >= n) return false; u8 c = b[p++]; v |= (u64)(c & 0x7f) << sh; if (!(c & 0x80)) return true; }
     return false;
 }
+// n sizes of a "chn.idx" list into out[]: plain varints, or (deltas) zigzag differences to the entry before -- nearly all of
+// those one byte: eight at a time where eight bytes have no continuation bit (a call has half a million)
+bool read_sizes(const u8* b, size_t nb, size_t& p, bool deltas, u32* out, size_t n) {
+    u64 prev = 0;
+    size_t i = 0;
+    while (i < n) {
+        if (deltas && p + 8 <= nb && n - i >= 8) {
+            u64 w; memcpy(&w, b + p, 8);
+            if (!(w & 0x8080808080808080ull)) {
+                for (int j = 0; j < 8; j++) {
+                    const u32 x = (u32)(w >> (8 * j)) & 0x7fu;
+                    const i64 v = (i64)prev + ((i64)(x >> 1) ^ -(i64)(x & 1));
+                    if (v < 0 || v > 0xFFFFFFFFll) return false;
+                    prev = (u64)v; out[i + j] = (u32)v;
+                }
+                p += 8; i += 8;
+                continue;
+            }
+        }
+        u64 raw;
+        if (!get_v(b, nb, p, raw)) return false;
+        if (deltas) {
+            if (raw > 0x1FFFFFFFFull) return false;
+            const i64 v = (i64)prev + ((i64)(raw >> 1) ^ -(i64)(raw & 1));
+            if (v < 0 || v > 0xFFFFFFFFll) return false;
+            raw = (u64)v;
+        }
+        if (raw > 0xFFFFFFFFull) return false;
+        prev = raw; out[i++] = (u32)raw;
+    }
+    return true;
+}
 // list: [0] = n, then per listed row (ascending contexts) 67 words: the context, 64 slots freq | sym << 16, total, iend
 #define PRIOR_LIST_ROW 67u
 #define PRIOR_LIST_HEAD 4u
@@ -258,7 +300,8 @@ int ensure_prior_buffers(sfq_ctx* ctx, u32 q_rows) {
 
 // the quality prior of a call that was handed one ("qlt.pri"): rows66 on the device = zeros + the listed rows, scattered by
 // a kernel (the dense form is 17 MB, of which a file lists a few thousand rows), and the adaptive kernels' spread of it
-int upload_prior(sfq_ctx* ctx, u32 q_rows, hipStream_t st) {
+// spread: also the adaptive kernels' forms of the rows (a block's first touch of a row copies the prior's; frozen tables do not use them)
+int upload_prior(sfq_ctx* ctx, u32 q_rows, hipStream_t st, bool spread = true) {
     std::vector<u32> ctxs, rows;
     if (!unpack_prior(ctx->prior_blob.data(), ctx->prior_blob.size(), q_rows, ctxs, rows)) return fail(ctx, SFQ_E_CORRUPT, "bad quality prior (qlt.pri)");
     int rc;
@@ -271,7 +314,7 @@ int upload_prior(sfq_ctx* ctx, u32 q_rows, hipStream_t st) {
         HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
         launch_prior_scatter(d_ctx, d_rows, (u32)ctxs.size(), (u32*)ctx->rows66.p, st);
     }
-    launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
+    if (spread) launch_prior_spread((const u32*)ctx->rows66.p, q_rows, (u32*)ctx->prior_w.p, (u32*)ctx->prior_wovf.p, (u32*)ctx->prior_ls.p, (RowHdr*)ctx->prior_lh.p, st);
     HIPC(hipStreamSynchronize(st));            // the vectors are locals
     return SFQ_OK;
 }
@@ -1004,6 +1047,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         {
             // (at least 128 records; above that as many chains as the chip holds at once -- 60 k lanes of the LDS-heavy
             //  header kernel -- since a second round of chains would double its time)
+            // (a floor of 32 to 64 for small calls -- 600 k reads are 4700 lanes walking 128 headers each, the longest kernels of both
+            //  directions -- was tried in round 4 and taken back: the output of a 200 k-read call grew past 1.01 x the reference's)
             const u32 cpb_want = std::max<u32>(1u, 61440u / nblocks);
             const u32 rcr0 = std::max<u32>(128u, (block_reads + cpb_want - 1) / cpb_want);
             const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(rcr0, ca.geo.chain_reads), block_reads), nrec);
@@ -1039,7 +1084,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (given && (models & SFQ_M_QLT)) {
         if ((rc = ensure_prior_buffers(ctx, q_rows))) return rc;
         if (!hist_cleared) HIPC(hipMemsetAsync(ctx->hist.p, 0, (size_t)q_rows * 64 * 4, st));          // (no sample of its own: LDS staging has nothing to rank by)
-        if ((rc = upload_prior(ctx, q_rows, st))) return rc;
+        if ((rc = upload_prior(ctx, q_rows, st, !frozen))) return rc;
         HIPC(hipEventRecord(ctx->ev[1], st));
         ctx->prior_on = true;
     } else if (prior_step && (models & SFQ_M_QLT)) {
@@ -1545,6 +1590,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                        const uint8_t* d_streams, const uint64_t stream_offset[SFQ_NSTREAMS],
                        uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, sfq_result* res) {
     sfq_params p = *pp;
+    HostTimes ht;
     p.level = clamp_level(p.level);
     ctx->framed.valid = false;                     // (a decode's scratch is not an encode's line index)
     const u32 version = p.version ? p.version : 6;
@@ -1601,6 +1647,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if (h_blocks[b].size[SFQ_S_USR_LREC] | h_blocks[b].size[SFQ_S_USR_LGEN] | h_blocks[b].size[SFQ_S_USR_LQLT])
             return fail(ctx, SFQ_E_UNSUPPORTED, "block %u holds oversize records (usr.lrec): only a one-block (format 6) archive does", b);
     if (has_over && nblocks != 1) return fail(ctx, SFQ_E_UNSUPPORTED, "oversize records (usr.lrec) in an archive of %u blocks: only a one-block (format 6) archive has them", nblocks);
+    ht.mark("blocks checked");
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
@@ -1608,6 +1655,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
     u32* h_csz = nullptr; u64* h_coff = nullptr; size_t ncs = 0;
+    std::future<int> lists_job; std::string lists_err;          // the chain lists of "chn.idx", read beside the head of the call
     if (frozen) {
         const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
         size_t cp = 0; u64 v = 0;
@@ -1619,18 +1667,6 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         const bool segs = ((u32)v >> 3) & 1u;                // chains are segments of one record (long reads): their length and the blocks' shares follow
         exc_rice = ((u32)v >> 4) & 1u;                       // the base exceptions are Rice-coded gap lists (exc.hip; round 4)
         if (v >> 5) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
-        u64 lprev = 0;                                        // the running value of the list being read
-        auto get_size = [&](u64& out) -> bool {
-            if (!get_v(cb, cn, cp, out)) return false;
-            if (deltas) {
-                if (out > 0x1FFFFFFFFull) return false;
-                const i64 d = (i64)(out >> 1) ^ -(i64)(out & 1);
-                const i64 x = (i64)lprev + d;
-                if (x < 0 || x > 0xFFFFFFFFll) return false;
-                out = (u64)x; lprev = out;
-            }
-            return out <= 0xFFFFFFFFull;
-        };
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
         cpb = (block_reads + chain_reads - 1) / chain_reads;
@@ -1658,6 +1694,17 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         h_coff = bump.take<u64>(cn + 16);
         if (!h_csz || !h_coff || (size_t)nchains * 2 > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         ncs = (size_t)nchains * 2;
+        // what the call needs besides the streams is checked here, on host state alone, before any device work is queued
+        if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
+        if (rec_chains) {
+            if (ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "header chains need the header prior (rec.pri)");
+            if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), rec_prior_f)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
+        }
+        // The lists themselves -- half a million sizes, 1.2 ms of host time -- are read by a thread of their own (pure host work: no HIP
+        // call, no ctx state) while this one uploads the priors and queues the head of the call; joined before the chains' decoders
+        // are queued (lists_job)
+        lists_job = std::async(std::launch::async, [&, cb, cn, cp, deltas]() mutable -> int {
+        u64 v = 0;
         auto parse_rec_chains = [&]() -> bool {
             if (!get_v(cb, cn, cp, v) || v == 0 || v > block_reads) return false;
             rchain_reads = (u32)v;
@@ -1666,10 +1713,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if (!get_v(cb, cn, cp, v) || v != wantr || wantr > 0x7FFFFFFFull) return false;
             nsub = (u32)wantr;
             h_rsz.resize(nsub); h_rhb.resize(nsub);
-            lprev = 0;
-            for (u32 c = 0; c < nsub; c++) { if (!get_size(v)) return false; h_rsz[c] = (u32)v; }
-            lprev = 0;
-            for (u32 c = 0; c < nsub; c++) { if (!get_size(v)) return false; h_rhb[c] = (u32)v; }
+            if (!read_sizes(cb, cn, cp, deltas, h_rsz.data(), nsub) || !read_sizes(cb, cn, cp, deltas, h_rhb.data(), nsub)) return false;
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
                 for (u32 j = 0; j < rcpb && (u64)b * rcpb + j < nsub; j++) sum += h_rsz[(size_t)b * rcpb + j];
@@ -1679,36 +1723,27 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         };
         for (int k = 0; k < 2; k++) {
             const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
+            u32* const sz = h_csz + (size_t)k * nchains; u64* const off = h_coff + (size_t)k * nchains;
+            if (!read_sizes(cb, cn, cp, deltas, sz, nchains)) { lists_err = "bad chain index (chn.idx)"; return SFQ_E_CORRUPT; }
             u64 at = stream_offset[sid];
-            lprev = 0;
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
                 const u64 bc0 = seg_len ? seg_c0[b] : (u64)b * cpb, bc1 = seg_len ? seg_c0[b + 1] : std::min<u64>(bc0 + cpb, nchains);
-                for (u64 cc = bc0; cc < bc1; cc++) {
-                    const size_t c = (size_t)k * nchains + (size_t)cc;
-                    if (!get_size(v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
-                    h_csz[c] = (u32)v; h_coff[c] = at; at += v; sum += v;
-                }
-                if (sum != h_blocks[b].size[sid]) return fail(ctx, SFQ_E_CORRUPT, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid));
+                for (u64 cc = bc0; cc < bc1; cc++) { off[cc] = at + sum; sum += sz[cc]; }
+                at += sum;
+                if (sum != h_blocks[b].size[sid]) { char m[160]; snprintf(m, sizeof m, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid)); lists_err = m; return SFQ_E_CORRUPT; }
             }
         }
         if (rec_chains) {
-            if (!parse_rec_chains()) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
+            if (!parse_rec_chains()) { lists_err = "bad chain index (chn.idx: header chains)"; return SFQ_E_CORRUPT; }
             u64 at = stream_offset[SFQ_S_REC];
-            if (ncs + nsub > cn + 16) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: header chains)");
+            if (ncs + nsub > cn + 16) { lists_err = "bad chain index (chn.idx: header chains)"; return SFQ_E_CORRUPT; }
             for (u32 c = 0; c < nsub; c++) { h_csz[ncs] = h_rsz[c]; h_coff[ncs] = at; ncs++; at += h_rsz[c]; }
         }
-        // what the call needs besides the streams is checked here, on host state alone, before any device work is queued
-        if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
-        if (rec_chains) {
-            if (ctx->rec_prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "header chains need the header prior (rec.pri)");
-            if (!unpack_rec_prior(ctx->rec_prior_blob.data(), ctx->rec_prior_blob.size(), rec_prior_f)) return fail(ctx, SFQ_E_CORRUPT, "bad header prior (rec.pri)");
-        }
-        if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
-        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, ncs * 8, hipMemcpyHostToDevice, st));
+        return SFQ_OK;
+        });
     }
+    ht.mark("  header prior, chain sizes up");
     if ((rc = reserve(ctx, ctx->blocks, (size_t)nblocks * sizeof(BlockDesc)))) return rc;
     if ((rc = reserve(ctx, ctx->blk_stream_off, nbso * 8))) return rc;
     if ((rc = reserve(ctx, ctx->d_first, (size_t)first_hdr_bytes + 16))) return rc;
@@ -1735,7 +1770,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
 
     ctx->prior_on = false;
     if (!ctx->prior_blob.empty()) {
-        if ((rc = upload_prior(ctx, q_rows, st))) return rc;
+        ht.mark("  buffers reserved");
+        if ((rc = upload_prior(ctx, q_rows, st, !frozen))) return rc;
+        ht.mark("  quality prior up");
         ctx->prior_on = true;
     }
     DecodeArgs da;
@@ -1794,7 +1831,15 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         HIPC(hipMemcpyAsync(&((BlockDesc*)ctx->blocks.p)[0].nrec, &hb[0].nrec, 4, hipMemcpyHostToDevice, st));
         da.m.rec_map = (const u32*)ctx->orecmap.p;
     }
+    ht.mark("index, priors parsed; buffers");
     // 1. framing exceptions -> per-record line lengths
+    // the header rows from "rec.pri", while the chip is still idle (behind the decoders' launches k_rec_frozen_rows took 0.6 ms, with
+    // the header decoder waiting for it)
+    if (frozen && rec_chains != 0) { if ((rc = upload_rec_rows(ctx, rec_prior_f, st))) return rc; }
+    // "no header yet" for every record, while the chip is still idle: behind the decoders' launches these two fills -- 120 MB, a fill
+    // kernel that must find room beside them -- took 2.4 ms on the header decoder's stream (hdr_marks_cleared)
+    HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st));
+    HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st));
     const u32 usr_prefilled = (block_reads != 0 && !has_over && nblocks > 1) ? 1u : 0u;
     if (usr_prefilled) launch_usr_fill(da, nrec, st);
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_usr_decode_l(da, st, usr_prefilled); }
@@ -1819,6 +1864,15 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
 
+    ht.mark("head queued");
+    if (lists_job.valid()) {                              // frozen tables: the chain lists, then their copies to the device
+        if ((rc = lists_job.get())) return fail(ctx, rc, "%s", lists_err.c_str());
+        if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
+        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, ncs * 8, hipMemcpyHostToDevice, st));
+    }
+    ht.mark("chain lists read, copied");
     // 2. quality, bases and (3.) headers are independent chains: three streams.  (The one rule that ties bases to
     //    qualities -- quality '!' means N -- is applied when the records are assembled.)
     HIPC(hipEventRecord(ctx->ev[2], st));
@@ -1919,8 +1973,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipStreamWaitEvent(st, ctx->ev[4], 0));
 
     // 3. headers; the staging size comes from the index when known, else grows on overflow
+    ht.mark("quality + base decoders queued");
     const bool frozen_rec = frozen && rec_chains != 0;
-    if (frozen_rec) { if ((rc = upload_rec_rows(ctx, rec_prior_f, ctx->st_aux[0]))) return rc; }
     const u32 nstage = frozen_rec ? nsub : nblocks;            // staging slices: one per header chain / per block
     u64* hso = bump.take<u64>((size_t)nstage + 1);
     u32* hsc = bump.take<u32>(nstage);
@@ -1953,8 +2007,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         if ((rc = reserve(ctx, ctx->hdr_stage, (size_t)o + 16))) return rc;
         HIPC(hipMemcpyAsync(ctx->hso.p, hso, ((size_t)nstage + 1) * 8, hipMemcpyHostToDevice, st_rec));
         HIPC(hipMemcpyAsync(ctx->hsc.p, hsc, (size_t)nstage * 4, hipMemcpyHostToDevice, st_rec));
-        HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
-        HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
+        if (attempt) {                                     // (the first time round they were cleared at the head of the call: hdr_marks_cleared)
+            HIPC(hipMemsetAsync(ctx->hoff.p, 0xFF, (size_t)nrec * 8, st_rec));
+            HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st_rec));
+        }
         da.hdr_stage = (u8*)ctx->hdr_stage.p; da.hdr_stage_off = (const u64*)ctx->hso.p; da.hdr_stage_cap = (const u32*)ctx->hsc.p;
         if (attempt) { if ((rc = advance_epoch(ctx, nblocks))) return rc; da.m.epoch_base = ctx->epoch_base; ctx->epoch_base += nblocks; }
         if (frozen_rec) {
@@ -1993,6 +2049,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         for (u32 b = 0; b < nblocks; b++) hb[b].status = 0;
         HIPC(hipMemcpyAsync(ctx->blocks.p, hb, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
     }
+    ht.mark("decoders through (host waited)");
     HIPC(hipEventRecord(ctx->ev[5], st));
 
     // 4. lay the records out
@@ -2019,11 +2076,13 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if (h_st_end) return fail(ctx, SFQ_E_CORRUPT, "damaged oversize streams (usr.lgen / usr.lqlt)");
     *out_bytes = total;
     if (total > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "decoded text needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)out_cap);
+    ht.mark("sizes known");
     launch_assemble(da, nrec, d_roff, d_out, st);
     if (n_over) launch_over_place(n_over, (const u64*)ctx->ono.p, (const u64*)ctx->opiece.p, (const u8*)ctx->otxt[0].p, (const u8*)ctx->otxt[1].p, (const u8*)ctx->otxt[2].p,
                                   (const u64*)ctx->oroff_all.p, d_out, st);
     HIPC(hipEventRecord(ctx->ev[6], st));
     HIPC(hipStreamSynchronize(st));
+    ht.mark("assembled");
     res->n_records = nrec_file; res->n_blocks = nblocks; res->total_bytes = total;
     res->kernel_ms[SFQ_T_USR] = ev_ms(ctx->ev[0], ctx->ev[1]);
     res->kernel_ms[SFQ_T_QLT] = ev_ms(ctx->ev[2], ctx->ev[3]);
