@@ -61,6 +61,7 @@ struct sfq_ctx {
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
+    DevBuf chn_len, chn_off, chn_out;      // "chn.idx": the size lists as bytes (chains.hip launch_chain_index_bytes)
     DevBuf pslot, plist;                   // the quality prior's listed rows, back to back (prior.hip launch_prior_list)
     DevBuf segn, segoff, segrec;           // chains that are segments of one record (long reads): segments per record, their scan, a chain's record
     // format 6's oversize records (frame.hip): flags, kept bytes, their scans, the text without them, kept record -> file number, the list;
@@ -81,6 +82,7 @@ struct sfq_ctx {
     void* pin2 = nullptr; size_t pin2_cap = 0;     // the same for the end of an encode: block descriptors, chain sizes       // pinned host scratch: device -> host copies that must not block the launching thread
     std::vector<u8> chain_blob;            // "chn.idx" of the last encode / installed for the next decode
     std::vector<u8> rec_prior_blob;        // "rec.pri" likewise
+    std::vector<u8> chain_tmp;             // scratch the chain index is written into
     bool prior_on = false;                 // the device prior tables are valid for the running call
     std::vector<u8> prior_blob;            // packed prior of the last encode / installed for the next decode
     // last encode, host copies
@@ -669,7 +671,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -734,6 +736,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
                        sfq_result* res, u32 force_models, bool priors_only) {
     const u8* d_fastq = d_fastq_in; u64 nbytes = nbytes_in;       // (format 6 with oversize records: the text without them, below)
     sfq_params p = *pp;
+    HostTimes ht;
     p.level = clamp_level(p.level);
     u32 models = force_models ? force_models : (p.models ? p.models : SFQ_M_ALL);
     if (p.kernel > 2) return fail(ctx, SFQ_E_ARG, "kernel %u: 0 = default kernels, 1 = lane-per-block cross-check kernels, 2 = default kernels with the reference's coding of the base exceptions", p.kernel);
@@ -1270,6 +1273,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (m) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
     }
     }
+    ht.mark("chains queued");
     HIPC(hipEventRecord(ctx->ev[10], st));
 
     // ---- pack ----------------------------------------------------------------------------------
@@ -1318,6 +1322,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     BlockDesc* hb = (BlockDesc*)((u8*)ctx->pin2 + p2_hb);
     u64* hboff = (u64*)((u8*)ctx->pin2 + p2_off);
     u32* h_csz = (u32*)((u8*)ctx->pin2 + p2_csz);
+    bool chn_on_device = false; u32 chn_n = 0; size_t chn_eager = 0;       // "chn.idx": the size lists arrive as bytes ([info 16 B][bytes] where h_csz points)
     u64 bases[SFQ_NSTREAMS], run = 0;
     if (two_halves) {
         if ((rc = pack_prior_now())) return rc;
@@ -1352,7 +1357,24 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
                 launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
             if (chain_streams & (1u << SFQ_S_REC))
                 launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
-            HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
+            // "chn.idx": the size lists come back as the bytes the blob holds (chains.hip launch_chain_index_bytes: made from half a
+            // million sizes on the host they were 1.0 ms of every call's tail), as far as a guess at their number reaches
+            {
+                const bool recl = (chain_streams >> SFQ_S_REC) & 1;
+                chn_n = nchains * 2 + (recl ? nsub * 2 : 0u);
+                const u32 b1 = nchains, b2 = nchains * 2, b3 = recl ? nchains * 2 + nsub : chn_n;
+                if ((rc = reserve(ctx, ctx->chn_len, (size_t)chn_n * 4 + 16))) return rc;
+                if ((rc = reserve(ctx, ctx->chn_off, ((size_t)chn_n + 4) * 8))) return rc;
+                if ((rc = reserve(ctx, ctx->chn_out, (size_t)chn_n * 5 + 64))) return rc;
+                if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)chn_n / 1024 + 4) * 8 + 65536))) return rc;
+                u64* d_info = (u64*)ctx->chn_off.p + chn_n + 1;
+                launch_chain_index_bytes((const u32*)ctx->csz.p, chn_n, b1, b2 > chn_n ? chn_n : b2, b3, (u32*)ctx->chn_len.p, (u64*)ctx->chn_off.p, (u64*)ctx->scan_tmp.p,
+                                         (u8*)ctx->chn_out.p, d_info, st);
+                chn_eager = std::min<size_t>((size_t)chn_n * 5, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4 + 64 - 16);
+                HIPC(hipMemcpyAsync(h_csz, d_info, 16, hipMemcpyDeviceToHost, st));
+                if (chn_eager) HIPC(hipMemcpyAsync((u8*)h_csz + 16, ctx->chn_out.p, chn_eager, hipMemcpyDeviceToHost, st));
+                chn_on_device = true;
+            }
         }
         HIPC(hipEventRecord(ctx->ev[11], st));
         if ((rc = pack_prior_now())) return rc;               // (before the copy into pageable memory below: that one returns when the stream has reached it)
@@ -1361,8 +1383,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     }
     HIPC(hipMemcpyAsync(hb, ctx->blocks.p, (size_t)nblocks * sizeof(BlockDesc), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(hboff, ctx->blob_off.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, st));
+    ht.mark("packing queued");
     if ((rc = pack_prior_now())) return rc;
+    ht.mark("priors packed");
     HIPC(hipStreamSynchronize(st));
+    ht.mark("device through");
     run = 0;
     for (int s = 0; s < SFQ_NSTREAMS; s++) { bases[s] = run; run += totals[s]; res->stream_bytes[s] = totals[s]; res->stream_offset[s] = bases[s]; }
     res->total_bytes = run;
@@ -1372,6 +1397,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
                            -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" :
                            -worst == SFQ_E_UNSUPPORTED ? "a '+' line that is neither empty nor its record's header: the block format refuses what it could not give back (usrs.cpp:236-239)" : "see status codes");
+    ht.mark("  statuses looked at");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
     if (hboff[nblocks] > blob_cap) return fail(ctx, SFQ_E_OVERFLOW, "first-header blob overflow");
     if (two_halves) {
@@ -1390,31 +1416,61 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         } else ctx->first_hdrs.resize((size_t)hboff[nblocks]);
     }
 
+    ht.mark("  first headers home");
     ctx->prior_on = false;
     ctx->chain_blob.clear();
     if (frozen) {            // "chn.idx": chain_reads, flags (bit 0: generation tables of the bases in use), nchains, sizes
         // (half a million varints, written through a pointer into room for the longest: pushed byte by byte into the vector they
         //  were 1.0 ms of every call, after the GPU had finished)
-        std::vector<u8>& o = ctx->chain_blob;
-        o.resize(((size_t)nchains * 2 + (size_t)nsub * 2 + (seg_len ? nblocks : 0)) * 5 + 64);
+        // (written into a scratch vector that keeps its size from call to call -- growing the blob itself zero-fills 2.5 MB every call --
+        //  and copied out at its final size)
+        std::vector<u8>& o = ctx->chain_tmp;
+        const size_t o_need = ((size_t)nchains * 2 + (size_t)nsub * 2 + (seg_len ? nblocks : 0)) * 5 + 64;
+        if (o.size() < o_need) o.resize(o_need);
         u8* w = o.data();
         auto put = [&w](u32 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
         // a list of sizes: each as the zigzag difference to the one before it (neighbouring chains hold as many symbols of the same
         // statistics: a byte a chain instead of two -- at 12 records a chain the index was 0.5 % of the archive)
-        auto put_list = [&put](const u32* v, size_t n) {
-            u32 prev = 0;
-            for (size_t i = 0; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
+        // (half a million sizes: eight at a time where all eight differences take one byte -- nearly always; 0.86 -> 0.3 ms of the call's tail)
+        auto put_list = [&put, &w](const u32* v, size_t n) {
+            u32 prev = 0; size_t i = 0;
+            for (; i + 8 <= n; i += 8) {
+                u32 z[8], any = 0;
+                for (int j = 0; j < 8; j++) { const i32 d = (i32)(v[i + j] - (j ? v[i + j - 1] : prev)); z[j] = ((u32)d << 1) ^ (u32)(d >> 31); any |= z[j]; }
+                if (any < 0x80u) { u64 b8 = 0; for (int j = 0; j < 8; j++) b8 |= (u64)z[j] << (8 * j); memcpy(w, &b8, 8); w += 8; }
+                else for (int j = 0; j < 8; j++) put(z[j]);
+                prev = v[i + 7];
+            }
+            for (; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
         put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u)); put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
+        if (chn_on_device) {           // the lists as the device wrote them
+            const u64* info = (const u64*)h_csz;
+            const u8* lb = (const u8*)h_csz + 16;
+            const u64 la = info[0], lall = info[1];
+            if (la > lall || lall > (u64)chn_n * 5) return fail(ctx, SFQ_E_HIP, "chain index: %llu / %llu bytes of lists for %u sizes", (unsigned long long)la, (unsigned long long)lall, chn_n);
+            std::vector<u8> rest;
+            if (lall > chn_eager) {                                      // (sizes that take more bytes than the guess: the rest of them)
+                rest.resize((size_t)lall);
+                HIPC(hipMemcpyAsync(rest.data(), ctx->chn_out.p, (size_t)lall, hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                lb = rest.data();
+            }
+            if (o.size() < o_need + (size_t)lall) { const size_t used = (size_t)(w - o.data()); o.resize(o_need + (size_t)lall); w = o.data() + used; }
+            memcpy(w, lb, (size_t)la); w += la;
+            if (rec_chains) { put(ca.rgeo.chain_reads); put(nsub); memcpy(w, lb + la, (size_t)(lall - la)); w += lall - la; }
+        } else {
         put_list(h_csz, nchains); put_list(h_csz + nchains, nchains);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
             put(ca.rgeo.chain_reads); put(nsub);
             put_list(h_csz + (size_t)2 * nchains, nsub); put_list(h_csz + (size_t)2 * nchains + nsub, nsub);
         }
-        o.resize((size_t)(w - o.data()));
+        }
+        ctx->chain_blob.assign(o.data(), w);
     }
+    ht.mark("chain index written");
     res->n_chains = nchains;
     ctx->index.resize(nblocks);
     for (u32 b = 0; b < nblocks; b++) {
@@ -1433,6 +1489,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     res->kernel_ms[SFQ_T_PACK] = ev_ms(ctx->ev[10], ctx->ev[11]);
     res->kernel_ms[SFQ_T_TOTAL] = ev_ms(ctx->ev[0], ctx->ev[11]);
     if (reframe) res->coder_ms[3] = ev_ms(ctx->ev[12], ctx->ev[23]);          // the framing kernel (frame.hip k_frame)
+    ht.mark("block index built");
     if (frozen) {
         if (models & SFQ_M_QLT) res->coder_ms[0] = ev_ms(ctx->ev[14], ctx->ev[15]);
         if (models & SFQ_M_GEN) res->coder_ms[1] = ev_ms(ctx->ev[16], ctx->ev[17]);

@@ -1786,6 +1786,39 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, 
 }
 u64 rec_token_bytes(u64 nrec) { return nrec * RT_TOK_PER_REC * 4; }
 
+// ---- "chn.idx": the size lists as bytes, on the device ------------------------------------------------------------------
+// The four lists of a call's chain sizes (quality, bases, header chains, the header bytes they restore: csz[0 .. n), list k
+// = [b[k], b[k + 1])) each as zigzag differences to the entry before, every difference a LEB128 varint -- what api.cpp wrote on
+// the host from a copy of csz: half a million values, 1.0 ms AFTER the device had finished (round 4).  Two kernels around a
+// scan: the lengths, then the bytes; out[0 .. off[n]) = the lists back to back, info[0] = off[b[2]] (where the header chains'
+// lists begin), info[1] = off[n].
+__device__ __forceinline__ u32 chn_zz(const u32* __restrict__ csz, u32 i, u32 b1, u32 b2, u32 b3) {
+    const u32 prev = (i == 0 || i == b1 || i == b2 || i == b3) ? 0u : csz[i - 1];
+    const i32 d = (i32)(csz[i] - prev);
+    return ((u32)d << 1) ^ (u32)(d >> 31);
+}
+__global__ __launch_bounds__(256) void k_chn_len(const u32* __restrict__ csz, u32 n, u32 b1, u32 b2, u32 b3, u32* __restrict__ len) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 z = chn_zz(csz, i, b1, b2, b3);
+    len[i] = z < (1u << 7) ? 1u : z < (1u << 14) ? 2u : z < (1u << 21) ? 3u : z < (1u << 28) ? 4u : 5u;
+}
+__global__ __launch_bounds__(256) void k_chn_bytes(const u32* __restrict__ csz, u32 n, u32 b1, u32 b2, u32 b3, const u64* __restrict__ off, u8* __restrict__ out, u64* __restrict__ info) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { info[0] = off[b2]; info[1] = off[n]; }
+    if (i >= n) return;
+    u32 z = chn_zz(csz, i, b1, b2, b3);
+    u8* w = out + off[i];
+    while (z >= 0x80u) { *w++ = (u8)(z | 0x80u); z >>= 7; }
+    *w = (u8)z;
+}
+void launch_chain_index_bytes(const u32* csz, u32 n, u32 b1, u32 b2, u32 b3, u32* len, u64* off, u64* scan_tmp, u8* out, u64* info, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_chn_len, dim3((n + 255) / 256), dim3(256), 0, st, csz, n, b1, b2, b3, len);
+    launch_scan_u32((const u32*)len, off, n, scan_tmp, st);
+    hipLaunchKernelGGL(k_chn_bytes, dim3((n + 255) / 256), dim3(256), 0, st, csz, n, b1, b2, b3, (const u64*)off, out, info);
+}
+
 // header decode: one chain per lane.  DecodeArgs::hdr_stage_off / hdr_stage_cap are per CHAIN here.
 // largest s with cum[s] <= prob in a row of the decoder's form (RDEC_ROW): the sixteenth of the row, then the symbol in
 // it.  Two round trips of 32 bytes (a search that fetched entry by entry was nine dependent fetches).

@@ -99,6 +99,9 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 c0 = 0, u32 c1 = 0 /* chains [c0, c1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
+// "chn.idx": the size lists csz[0 .. n) (lists [0, b1), [b1, b2), [b2, b3), [b3, n)) as zigzag-difference varints, back to back in
+// out; len[n], off[n + 1], scan_tmp: scratch; info[0] = bytes before list b2, info[1] = all
+void launch_chain_index_bytes(const u32* csz, u32 n, u32 b1, u32 b2, u32 b3, u32* len, u64* off, u64* scan_tmp, u8* out, u64* info, hipStream_t st);
 void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
 // the same lists as adaptive Rice codes (models_w.hip k_gen_exc_w<true>, dev_rice.h; frozen tables, "chn.idx" flag bit 4) and the way back, a lane per block (exc.hip)
 void launch_gen_exc_r(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st);
