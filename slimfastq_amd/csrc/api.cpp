@@ -13,6 +13,9 @@
 #include <chrono>
 #include <functional>
 #include <future>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 #include "kernels.h"
 
@@ -39,8 +42,41 @@ struct Tables {
 
 }  // namespace
 
+// One host thread that stays with the context and runs a job beside the calling thread (a decode reads the chain lists of
+// "chn.idx" on it while the caller uploads priors and queues kernels).  Started with the first job -- a thread created per call
+// came up cold and took half as long again for the same work --, joined when the context goes.
+struct HostWorker {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::function<int()> job; bool has_job = false, done = true, quit = false; int result = 0;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<int()> j = std::move(job); has_job = false;
+            lk.unlock();
+            const int r = j();
+            lk.lock();
+            result = r; done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> j) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        job = std::move(j); has_job = true; done = false;
+        cv.notify_all();
+    }
+    bool busy() { std::unique_lock<std::mutex> lk(mu); return !done; }
+    int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); return result; }
+    ~HostWorker() {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); quit = true; cv.notify_all(); }
+        if (th.joinable()) th.join();
+    }
+};
 struct sfq_ctx {
     int dev = 0;
+    HostWorker worker;
     hipStream_t st = nullptr;
     hipStream_t st_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[28] = {};
@@ -1712,7 +1748,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
     u32* h_csz = nullptr; u64* h_coff = nullptr; size_t ncs = 0;
-    std::future<int> lists_job; std::string lists_err;          // the chain lists of "chn.idx", read beside the head of the call
+    // the chain lists of "chn.idx" are read beside the head of the call (ctx->worker); whatever way this function is left, the job is
+    // through before the locals it writes to are gone
+    std::string lists_err; bool lists_pending = false;
+    struct ListsGuard { sfq_ctx* c; bool* pending; ~ListsGuard() { if (*pending) (void)c->worker.wait(); } } lists_guard{ ctx, &lists_pending };
     if (frozen) {
         const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
         size_t cp = 0; u64 v = 0;
@@ -1760,7 +1799,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         // The lists themselves -- half a million sizes, 1.2 ms of host time -- are read by a thread of their own (pure host work: no HIP
         // call, no ctx state) while this one uploads the priors and queues the head of the call; joined before the chains' decoders
         // are queued (lists_job)
-        lists_job = std::async(std::launch::async, [&, cb, cn, cp, deltas]() mutable -> int {
+        lists_pending = true;
+        ctx->worker.submit([&, cb, cn, cp, deltas]() mutable -> int {
         u64 v = 0;
         auto parse_rec_chains = [&]() -> bool {
             if (!get_v(cb, cn, cp, v) || v == 0 || v > block_reads) return false;
@@ -1922,8 +1962,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
 
     ht.mark("head queued");
-    if (lists_job.valid()) {                              // frozen tables: the chain lists, then their copies to the device
-        if ((rc = lists_job.get())) return fail(ctx, rc, "%s", lists_err.c_str());
+    if (lists_pending) {                                  // frozen tables: the chain lists, then their copies to the device
+        rc = ctx->worker.wait(); lists_pending = false;
+        if (rc) return fail(ctx, rc, "%s", lists_err.c_str());
         if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
         if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
         HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
