@@ -485,7 +485,7 @@ int default_chain_reads(u64 nrec, u64 nbytes) {
 #define PIN_GEN_OFF 0u
 #define PIN_REC_OFF 64u
 #define PIN_BYTES (PIN_REC_OFF + (size_t)PR_REC_ROWS * 256 * 4)
-int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool counted, hipStream_t st) {
+int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool counted, hipStream_t st, u32 max_hdr) {
     if (given) return SFQ_OK;
     int rc;
     if ((rc = reserve(ctx, ctx->hcnt, (size_t)REC_COUNT_COPIES * PR_REC_ROWS * 256 * 4))) return rc;
@@ -494,7 +494,10 @@ int rec_prior_begin(sfq_ctx* ctx, const ModelArgs& a, u64 nrec, bool given, bool
     // (short runs, many of them: the pass's time is one lane's walk through its run -- 8192 runs of 18 records took 2.9 ms of
     //  every call on 128 wavefronts; the sample is the same 131 k counted records)
     const u32 run = REC_PRIOR_RUN;
-    const u32 nruns = (u32)std::min<u64>(std::max<u32>(1u, REC_PRIOR_RUNS / std::max<u32>(1u, ctx->sample_scale)), std::max<u64>(1, nrec / run));
+    u32 nruns = (u32)std::min<u64>(std::max<u32>(1u, REC_PRIOR_RUNS / std::max<u32>(1u, ctx->sample_scale)), std::max<u64>(1, nrec / run));
+    // (headers beyond the fast counting kernel's 127 bytes are walked by the general one, a lane per run: a sample of at most 4 MiB
+    //  of header text -- 60 k long reads' headers, all of them, were 4.2 ms with every chain of the call waiting)
+    if (max_hdr > 127) nruns = (u32)std::min<u64>(nruns, std::max<u64>(1, (4ull << 20) / ((u64)run * max_hdr)));
     const u64 stride = std::max<u64>(run, nrec / nruns);
     if ((rc = reserve(ctx, ctx->cflags, (size_t)REC_PRIOR_RUNS * 4))) return rc;
     HIPC(hipMemsetAsync(ctx->cflags.p, 0, (size_t)nruns * 4, st));
@@ -1089,7 +1092,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             // (a floor of 32 to 64 for small calls -- 600 k reads are 4700 lanes walking 128 headers each, the longest kernels of both
             //  directions -- was tried in round 4 and taken back: the output of a 200 k-read call grew past 1.01 x the reference's)
             const u32 cpb_want = std::max<u32>(1u, 61440u / nblocks);
-            const u32 rcr0 = std::max<u32>(128u, (block_reads + cpb_want - 1) / cpb_want);
+            // (long reads: a header is a thousandth of its record, so a chain's few bytes of overhead do not show -- and 60 k records in chains
+            //  of 128 were 470 lanes, the longest kernels of both directions: 16 records a chain there)
+            const u32 rfloor = nbytes / nrec > 4000 ? 16u : 128u;
+            const u32 rcr0 = std::max<u32>(rfloor, (block_reads + cpb_want - 1) / cpb_want);
             const u32 rcr = (u32)std::min<u64>(std::min<u32>(std::max<u32>(rcr0, ca.geo.chain_reads), block_reads), nrec);
             ca.rgeo.chain_reads = rcr;
             ca.rgeo.cpb = (block_reads + rcr - 1) / rcr;
@@ -1108,7 +1114,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (int m = 1; m < 4; m++) { HIPC(hipStreamWaitEvent(mst[m], ctx->ev[13], 0)); HIPC(hipEventRecord(ctx->ev[2 + 2 * m], mst[m])); }
             a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
             ca.m = a;
-            if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc; }
+            if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1], max_hdr))) return rc; }
             if (models & SFQ_M_GEN) {
                 if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
             }
@@ -1116,7 +1122,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             //  counting passes the host waits for they made those take 1.7-1.9 ms instead of 0.3)
         } else if (models & SFQ_M_REC) {                    // sfq_build_priors: the header sample beside the quality sample
             HIPC(hipStreamWaitEvent(mst[1], ctx->ev[13], 0));
-            if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1]))) return rc;
+            if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1], max_hdr))) return rc;
         }
     }
     u32* h_rows66 = nullptr;
@@ -1221,7 +1227,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
-            HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));              // (the quality chains behind the header prior's passes, as when the host waited for those)
+            if (nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
             launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1]);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
@@ -2117,16 +2123,35 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
             cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
             cr.rmap = (const u16*)ctx->rmap.p; cr.rhot = cr.rmap + PR_REC_ROWS; cr.r_hot = ctx->r_hot_dec;
-            u32* rflags = nullptr; u32* dtok = nullptr; u32* dtoff = nullptr; u32* dflags = nullptr;
+            u32* rflags = nullptr; u32* dtok = nullptr; u32* dtoff = nullptr; u32* dflags = nullptr; bool all_pre = false;
             if (version >= 5) {                                        // (load_pre5 archives: the general path)
                 if ((rc = reserve(ctx, ctx->rflags, (size_t)nsub * 4 * 2))) return rc;                 // the lane kernels' flags, the two-step decoder's
-                HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, st_rec));
+                // A chain that restores more than 127 bytes per header on average holds a header neither the two steps nor the fast lane
+                // kernel take: marked here for the general kernel (flags 1, dflags 2) -- 60 k long reads with 230-byte headers spent
+                // 3.6 + 7.8 ms in kernels that found that out record by record, the longest path of their decode
+                std::vector<u32> pre_v; u32* pre = nullptr; bool any_pre = false;
+                if (!attempt) {
+                    for (u32 c = 0; c < nsub && !any_pre; c++) any_pre = (u64)h_rhb[c] > 127ull * rchain_reads;      // (a first look: usually none)
+                    if (any_pre) { pre_v.assign((size_t)nsub * 2, 0u); pre = pre_v.data(); any_pre = false; }
+                }
+                u32 n_pre = 0;
+                if (pre) {
+                    for (u32 c = 0; c < nsub; c++) {
+                        const u32 b = c / rcpb, k0 = (c - b * rcpb) * rchain_reads, bn = h_blocks[b].n_records;
+                        const u64 n = k0 < bn ? std::min<u64>(rchain_reads, bn - k0) : 0;
+                        if (n && (u64)h_rhb[c] > 127ull * n) { pre[c] = 1; pre[nsub + c] = 2; any_pre = true; n_pre++; }
+                    }
+                }
+                all_pre = n_pre == nsub;                   // every chain: the general kernel alone is launched (below)
+                if (any_pre) { HIPC(hipMemcpyAsync(ctx->rflags.p, pre, (size_t)nsub * 8, hipMemcpyHostToDevice, st_rec)); HIPC(hipStreamSynchronize(st_rec)); }      // (pre_v is a local)
+                else HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, st_rec));
                 rflags = (u32*)ctx->rflags.p; dflags = rflags + nsub;
                 const u64 tb = (rec_dtok_bytes(nrec) + 15) & ~15ull;
                 if ((rc = reserve(ctx, ctx->rtok, (size_t)(tb + nrec * 4 + 16)))) return rc;          // tokens, then the records' places among them
                 dtok = (u32*)ctx->rtok.p; dtoff = (u32*)((u8*)ctx->rtok.p + tb);
             }
-            launch_rec_decode_c(cr, da, rflags, st_rec, dtok, dtoff, dflags);
+            if (all_pre) launch_rec_decode_c(cr, da, nullptr, st_rec, nullptr, nullptr, nullptr);
+            else launch_rec_decode_c(cr, da, rflags, st_rec, dtok, dtoff, dflags);
         } else
         for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
             da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);

@@ -1306,22 +1306,44 @@ __global__ __launch_bounds__(256) void k_rec_prior_freqs(const u32* __restrict__
 }
 // the rows worth staging in LDS: the nh the prior gives the most weight, the lower row first among equals.  map[row] = its
 // place among them or 0xFFFF, hot[place] = row.  (One workgroup; a row's place = how many rows come before it.)
-__global__ __launch_bounds__(1024) void k_rec_hot_rows(const u32* __restrict__ rtot, u32 nrows, u32 nh, u16* __restrict__ map, u16* __restrict__ hot) {
-    __shared__ u32 tot[PR_REC_ROWS];
-    for (u32 r = threadIdx.x; r < nrows; r += 1024) tot[r] = rtot[r];
-    __syncthreads();
-    for (u32 r = threadIdx.x; r < nrows; r += 1024) {
-        const u32 t = tot[r];
-        u32 before = 0;
-#pragma unroll 16
-        for (u32 q = 0; q < nrows; q++) { const u32 o = tot[q]; before += (o > t || (o == t && q < r)) ? 1u : 0u; }
-        map[r] = before < nh ? (u16)before : (u16)0xFFFFu;
-        if (before < nh) hot[before] = (u16)r;
+#define RHR_PER ((PR_REC_ROWS + 255u) / 256u)         /* rows per thread of k_rec_hot_rows */
+__global__ __launch_bounds__(256) void k_rec_hot_rows(const u32* __restrict__ rtot, u32 nrows, u32 nh, u16* __restrict__ map, u16* __restrict__ hot) {
+    // nh rounds of "the heaviest row not taken yet" (key = sum << 11 | 2047 - row: the lower row first among equals): a thread holds
+    // a few rows' keys, a round is a wave maximum and four words of LDS.  (A row's place counted against all 1056 others, a
+    // thousand LDS reads per thread: 0.07 ms alone, 1.2 ms on a CU the chains keep busy; and ONE workgroup of 1024 threads waits
+    // that long for a CU with sixteen free wave slots once the chains run -- 256 threads find room at once.)
+    __shared__ u64 wmax[4];
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    u64 k[RHR_PER];
+#pragma unroll
+    for (u32 j = 0; j < RHR_PER; j++) {
+        const u32 row = t + 256u * j;
+        k[j] = row < nrows ? ((u64)rtot[row] << 11) | (2047u - row) : 0ull;
+        if (row < nrows) map[row] = 0xFFFFu;
+    }
+    for (u32 i = 0; i < nh; i++) {
+        u64 m = 0;
+#pragma unroll
+        for (u32 j = 0; j < RHR_PER; j++) m = k[j] > m ? k[j] : m;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(m >> 32), d, 64) << 32) | (u32)__shfl_xor((int)(u32)m, d, 64);
+            m = o > m ? o : m;
+        }
+        __syncthreads();
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        u64 best = wmax[0];
+        for (u32 w = 1; w < 4; w++) best = wmax[w] > best ? wmax[w] : best;
+        if (best == 0) break;                                   // (fewer rows than nh)
+        const u32 row = 2047u - (u32)(best & 2047u);
+#pragma unroll
+        for (u32 j = 0; j < RHR_PER; j++) if (k[j] == best) { k[j] = 0; hot[i] = (u16)row; map[row] = (u16)i; }
     }
 }
 void launch_rec_prior_freqs(const u32* cnt, u32 nrows, u32* f, u32* rtot, u32 nh, u16* map, u16* hot, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_prior_freqs, dim3((nrows + 3) / 4), dim3(256), 0, st, cnt, nrows, f, rtot);
-    hipLaunchKernelGGL(k_rec_hot_rows, dim3(1), dim3(1024), 0, st, (const u32*)rtot, nrows, nh, map, hot);
+    hipLaunchKernelGGL(k_rec_hot_rows, dim3(1), dim3(256), 0, st, (const u32*)rtot, nrows, nh, map, hot);
 }
 void launch_rec_frozen_rows(const u32* f, u32 nrows, u32* rrows, u16* rdec, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_frozen_rows, dim3((nrows + 3) / 4), dim3(256), 0, st, f, nrows, rrows, rdec);
@@ -1506,7 +1528,7 @@ __global__ __launch_bounds__(64) void k_rec_encode_f(ChainArgs a, u32* flags, co
     const u32 lane = threadIdx.x;
     {   // (a workgroup none of whose chains is wanted leaves before it stages anything)
         const u32 c0 = blockIdx.x * 64 + lane;
-        if (only && !__any(c0 < a.rgeo.nchains && only[c0] != 0)) return;
+        if (only && !__any(c0 < a.rgeo.nchains && only[c0] == 1)) return;      // (2: marked by the host for the general kernel, its flag set there)
     }
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < REC_LDS_ROWS ? sl : 0xFFu); }
     for (u32 i = lane; i < a.r_hot * 256; i += 64) L.rows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
@@ -2026,14 +2048,14 @@ __global__ __launch_bounds__(64) void k_rec_decode_f(ChainArgs a, DecodeArgs da,
     const u32 lane = threadIdx.x;
     {
         const u32 c0 = blockIdx.x * 64 + lane;
-        if (only && !__any(c0 < a.rgeo.nchains && only[c0] != 0)) return;
+        if (only && !__any(c0 < a.rgeo.nchains && only[c0] == 1)) return;      // (2: marked by the host for the general kernel, its flag set there)
     }
     for (u32 i = lane; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; L.map[i] = (u8)(sl < RDEC_LDS_ROWS ? sl : 0xFFu); }
     for (u32 i = lane; i < a.r_hot * RDEC_ROW; i += 64) L.drows[i / RDEC_ROW][i % RDEC_ROW] = a.rdec[(size_t)a.rhot[i / RDEC_ROW] * RDEC_ROW + i % RDEC_ROW];
     __syncthreads();
     const u32 c = blockIdx.x * 64 + lane;
     if (c >= a.rgeo.nchains) return;
-    if (only && !only[c]) return;
+    if (only && only[c] != 1) return;
     const RecChainPos cp = rec_chain_pos(a, c);
     const BlockDesc* d = &da.m.blocks[cp.b];
     RecFastDecSrc cd; cd.rdec = a.rdec; cd.L = &L;
@@ -2074,6 +2096,7 @@ __global__ __launch_bounds__(256) void k_rec_dsym(ChainArgs a, DecodeArgs da, u3
     __syncthreads();
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     if (c >= a.rgeo.nchains) return;
+    if (dflags[c]) return;                                  // (marked by the host: headers too long for the two steps, api.cpp)
     const RecChainPos cp = rec_chain_pos(a, c);
     const BlockDesc* d = &da.m.blocks[cp.b];
     RecSymSrc cd; cd.rdec = a.rdec; cd.L = &L;
