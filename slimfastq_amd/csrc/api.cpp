@@ -678,15 +678,19 @@ int sfq_ctx_create(sfq_ctx** out, int hip_device) {
     ctx->dev = hip_device;
     // one stream per model (quality, bases, headers, framing)
     // (the context's stream carries the call's critical path -- framing, the quality sample, the quality chains -- and the
-    //  framing-exception stream the pass over the N / quality-0 / case exceptions: both at the higher priority, so that their
-    //  workgroups are placed first and they have hardware queues of their own)
+    //  first auxiliary stream the header model's two steps, the call's second-longest chain of kernels: both at the higher
+    //  priority.  Round 4: with the EXCEPTION stream there instead -- rounds 2 and 3 -- a step of the distributed path, whose
+    //  chains are queued earlier in the call, left the header tokens 9.6 ms behind the quality chains: 15.1 ms a step against
+    //  13.9 this way; a call with priors of its own takes 13.7 either way)
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if ((prio_hi != prio_lo ? hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking)) != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     // (the runtime maps streams of one priority onto three hardware queues: the framing stream shares one with the base
     //  model's, and two streams that share a queue run one after the other -- keep long kernels off the framing stream)
     for (int i = 0; i < 3; i++) {
-        const hipError_t e = (i == 1 && prio_hi != prio_lo) ? hipStreamCreateWithPriority(&ctx->st_aux[i], hipStreamNonBlocking, prio_hi)
+        const char* px = getenv("SFQ_EXP_PRIO");          /* scratch experiments: a mask of auxiliary streams created at the higher priority (default 1: the headers') */
+        const int pm = px ? atoi(px) : 1;
+        const hipError_t e = (((pm >> i) & 1) && prio_hi != prio_lo) ? hipStreamCreateWithPriority(&ctx->st_aux[i], hipStreamNonBlocking, prio_hi)
                                                               : hipStreamCreateWithFlags(&ctx->st_aux[i], hipStreamNonBlocking);
         if (e != hipSuccess) { delete ctx; return SFQ_E_HIP; }
     }
