@@ -1949,7 +1949,11 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipMemsetAsync(ctx->hlen.p, 0, (size_t)nrec * 4, st));
     const u32 usr_prefilled = (block_reads != 0 && !has_over && nblocks > 1) ? 1u : 0u;
     if (usr_prefilled) launch_usr_fill(da, nrec, st);
-    for (u32 b0 = 0; b0 < nblocks; b0 += slots) { da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0); launch_usr_decode_l(da, st, usr_prefilled); }
+    // (a wave per block -- decode_w.hip -- unless the cross-check kernels are asked for or format 6's oversize records break the count of the records)
+    for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
+        da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
+        if (p.kernel == 0 && !has_over) launch_usr_decode_w(da, st, usr_prefilled); else launch_usr_decode_l(da, st, usr_prefilled);
+    }
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     u64 tot_s = 0, tot_q = 0;

@@ -250,3 +250,79 @@ __global__ __launch_bounds__(64) void k_rec_decode_w(DecodeArgs a) {
 void launch_rec_decode_w(const DecodeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_rec_decode_w, dim3(a.m.nbatch), dim3(64), 0, st, a);
 }
+
+// ---- UsrLoad::update (usrs.cpp:471-510): per-record line lengths and SOLiD prefixes, a wave per block -------------------
+// decode_l.hip k_usr_decode_l walks a block's framing exceptions on ONE lane: every value a row search through dependent
+// reads of its adaptive PowerRanger row, ~60 us each -- 1.2 ms at the head of a long-read decode, where every record is an
+// exception, with nothing else running.  Here the row search is the wave's (WavePw::get) and the 64 records of a step get
+// their lengths a lane each: an exception at record p changes the running values of lanes >= p.
+__global__ __launch_bounds__(64) void k_usr_decode_w(DecodeArgs a, u32 prefilled) {
+    const u32 lane = threadIdx.x, t = blockIdx.x;
+    const u32 b = a.m.batch0 + t;
+    BlockDesc* d = &a.m.blocks[b];
+    if (prefilled && (d->size[SFQ_S_USR_X] | d->size[SFQ_S_USR_XQ] | d->size[SFQ_S_USR_PFG] | d->size[SFQ_S_USR_PFQ]) == 0) return;   // (decode_l.hip k_usr_fill has written this block)
+    WavePw pw; pw.slots = a.m.p_slots + (size_t)t * PR_ROWS * PW_NSYM; pw.hdr = a.m.p_hdr + (size_t)t * PR_ROWS; pw.epoch = EPOCH_L(a.m.epoch_base + b + 1);
+    XfDecW x_llen, x_qlen, x_sgen, x_sqlt;
+    x_llen.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_USR_X],   d->size[SFQ_S_USR_X],   XF_USR_X);
+    x_qlen.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_USR_XQ],  d->size[SFQ_S_USR_XQ],  XF_USR_XQ);
+    x_sgen.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_USR_PFG], d->size[SFQ_S_USR_PFG], XF_USR_PFG);
+    x_sqlt.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_USR_PFQ], d->size[SFQ_S_USR_PFQ], XF_USR_PFQ);
+    u64 i_llen = x_llen.get(pw, lane), i_qlen = x_qlen.get(pw, lane), i_sgen = x_sgen.get(pw, lane), i_sqlt = x_sqlt.get(pw, lane);
+    const u32 solid = d->solid, nrec = d->nrec;
+    const u64 rec0 = d->rec0;
+    u32 c_llen = d->llen, c_pfg = 0, c_pfq = 0;              // the running values behind the step at hand (uniform)
+    u32 bad = 0;
+    for (u32 k0 = 0; k0 < nrec; k0 += 64) {
+        const u32 k = k0 + lane;
+        const bool have = k < nrec;
+        const u64 r = rec0 + (have ? k : 0);
+        const u64 first_cnt = rec_count_of(a.m, rec0 + k0, rec0);                // the step's first record's number (the records of a block count up by one)
+        const u64 last_cnt = first_cnt + 63;
+        u32 llen = c_llen, qx = 0xFFFFFFFFu, pfg = c_pfg, pfq = c_pfq;          // qx: this record's own quality length, if it has one
+        // every exception that falls into this step, in the order the serial loop meets them
+        while (i_llen && i_llen >= first_cnt && i_llen <= last_cnt) {
+            const u32 p = (u32)(i_llen - first_cnt);
+            const u32 v = (u32)x_llen.get(pw, lane);
+            if (lane >= p) llen = v;
+            c_llen = v;
+            const u64 gap = x_llen.get(pw, lane);
+            if (!gap) { i_llen = 0; break; }
+            i_llen += gap;
+        }
+        while (i_qlen && i_qlen >= first_cnt && i_qlen <= last_cnt) {
+            const u32 p = (u32)(i_qlen - first_cnt);
+            const u32 v = (u32)x_qlen.get(pw, lane);
+            if (lane == p) qx = v;
+            const u64 gap = x_qlen.get(pw, lane);
+            if (!gap) { i_qlen = 0; break; }
+            i_qlen += gap;
+        }
+        if (solid) {
+            while (i_sgen && i_sgen >= first_cnt && i_sgen <= last_cnt) {
+                const u32 p = (u32)(i_sgen - first_cnt);
+                const u32 v = x_sgen.get_chr(pw, lane);
+                if (lane >= p) pfg = v;
+                c_pfg = v;
+                const u64 gap = x_sgen.get(pw, lane);
+                if (!gap) { i_sgen = 0; break; }
+                i_sgen += gap;
+            }
+            while (i_sqlt && i_sqlt >= first_cnt && i_sqlt <= last_cnt) {
+                const u32 p = (u32)(i_sqlt - first_cnt);
+                const u32 v = x_sqlt.get_chr(pw, lane);
+                if (lane >= p) pfq = v;
+                c_pfq = v;
+                const u64 gap = x_sqlt.get(pw, lane);
+                if (!gap) { i_sqlt = 0; break; }
+                i_sqlt += gap;
+            }
+        }
+        u32 qlen = qx != 0xFFFFFFFFu ? qx : llen;
+        if (llen > a.max_line || qlen > a.max_line) { bad = 1; llen = qlen = 0; }
+        if (have) { a.slen[r] = llen; a.qlen[r] = qlen; a.pfg[r] = (u8)pfg; a.pfq[r] = (u8)pfq; }
+    }
+    if (__any(bad != 0) | x_llen.rc.err | x_qlen.rc.err | x_sgen.rc.err | x_sqlt.rc.err) { if (lane == 0) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT)); }
+}
+void launch_usr_decode_w(const DecodeArgs& a, hipStream_t st, u32 prefilled) {
+    hipLaunchKernelGGL(k_usr_decode_w, dim3(a.m.nbatch), dim3(64), 0, st, a, prefilled);
+}

@@ -231,4 +231,5 @@ struct XfDecW {                // XFileLoad (xfile.cpp:76-99), wave-cooperative
         if (valid) rc.init(src); else { rc.low = rc.code = 0; rc.range = 0xFFFFFFFFu; rc.err = 0; }
     }
     __device__ __forceinline__ u64 get(WavePw& t, u32 lane) { return valid ? t.get_u(row0, rc, src, lane) : 0; }
+    __device__ __forceinline__ u32 get_chr(WavePw& t, u32 lane) { return valid ? t.get(row0 + 14, rc, src, lane) : 0; }       // xfile.cpp:101-106
 };

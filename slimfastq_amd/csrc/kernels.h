@@ -184,6 +184,7 @@ u64 rec_dtok_bytes(u64 nrec);
 void launch_gen_exc_decode_l(const DecodeArgs& a, hipStream_t st);          // applies gen.Ns / gen.Nn to the staged bases
 void launch_gen_exc_decode_w(const DecodeArgs& a, hipStream_t st);          // the same, a wave per block (models_w.hip); blocks [batch0, batch0 + nbatch), slot = workgroup
 void launch_usr_decode_l(const DecodeArgs& a, hipStream_t st, u32 prefilled = 0);          // prefilled: launch_usr_fill has written the blocks without framing exceptions
+void launch_usr_decode_w(const DecodeArgs& a, hipStream_t st, u32 prefilled);     // the same, a wave per block (decode_w.hip); blocks [batch0, batch0 + nbatch), slot = workgroup
 void launch_usr_fill(const DecodeArgs& a, u64 nrec, hipStream_t st);                                // block format: the records of blocks whose four usr.* streams are empty
 void launch_qlt_decode_l(const DecodeArgs& a, hipStream_t st);
 void launch_gen_decode_l(const DecodeArgs& a, hipStream_t st);
