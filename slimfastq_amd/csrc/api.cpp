@@ -1035,12 +1035,12 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         launch_qlt_hist(d_fastq, nbytes, (const u64*)ctx->line_off.p, (const BlockDesc*)ctx->blocks.p, block_reads, nrec, prior_step, p.level, PRIOR_SYMBOLS, (u32*)ctx->hist.p, st);
         hist_launched = true;
     }
-    u32 h_status2[3] = {0, 0, 0};
-    HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 12, hipMemcpyDeviceToHost, vst));
+    u32 h_status2[5] = {0, 0, 0, 0, 0};
+    HIPC(hipMemcpyAsync(h_status2, ctx->status.p, 20, hipMemcpyDeviceToHost, vst));
     HIPC(hipEventRecord(ctx->ev[1], st));
     if (vst != st) HIPC(hipStreamSynchronize(vst));
     else HIPC(hipStreamSynchronize(st));
-    const u32 h_status = h_status2[0], max_hdr = h_status2[1], max_line = h_status2[2];
+    const u32 h_status = h_status2[0], max_hdr = h_status2[1], max_line = h_status2[2], min_hdr = ~h_status2[4];      // (k_validate_lines keeps the shortest header as a maximum)
     if (h_status == (u32)(-SFQ_E_FORMAT)) return fail(ctx, SFQ_E_FORMAT, "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)");
     if (h_status) return fail(ctx, -(int)h_status, "record over the line limits: headers up to 8190 bytes; base and quality lines up to 65534 in format 6 (-B 0; the reference would write oversize side streams, usrs.cpp:269-301, which this library does not), up to 1 Gi in the block format; or an empty base line");
 
@@ -1232,7 +1232,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
             if (nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
-            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1]);
+            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1], min_hdr);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
             if ((rc = rec_prior_copy_back(ctx, mst[1]))) return rc;

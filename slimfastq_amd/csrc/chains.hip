@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* fla
     __shared__ u16 lmap[PR_REC_ROWS];
     __shared__ u32 ltext[64 * 2 * REC_HBUF / 4];
     const u32 c = blockIdx.x * 64 + threadIdx.x;
-    const bool mine = c < a.rgeo.nchains && flags[c] != 0;
+    const bool mine = c < a.rgeo.nchains && (!flags || flags[c] != 0);             // (flags null: every chain)
     if (!__any(mine)) return;
     for (u32 i = threadIdx.x; i < PR_REC_ROWS; i += 64) { const u32 sl = a.rmap[i]; lmap[i] = (u16)(sl < REC_LDS_ROWS ? sl : 0xFFFFu); }
     for (u32 i = threadIdx.x; i < a.r_hot * 256; i += 64) lrows[i] = a.rrows[(size_t)a.rhot[i >> 8] * 256 + (i & 255)];
@@ -1792,9 +1792,13 @@ __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __rest
     if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 // flags, flags2: one dword per header chain each, zeroed by the caller; tok: RT_TOK_PER_REC dwords per record of the call; ntok: [chains]
-void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, u32* ntok, u32 n_hot, u32 max_hdr, hipStream_t st) {
+void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, u32* ntok, u32 n_hot, u32 max_hdr, hipStream_t st, u32 min_hdr) {
     const u32 nc = a.rgeo.nchains;
     if (!nc) return;
+    if (min_hdr > 127) {           // every header is past the token step's and the fast lane kernel's 127 bytes (long reads' UUID headers): the general kernel alone
+        hipLaunchKernelGGL(k_rec_encode_c, dim3((nc + 63) / 64), dim3(64), 0, st, a, (const u32*)nullptr);
+        return;
+    }
     if (max_hdr <= 62) hipLaunchKernelGGL(k_rec_tokens<62>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);
     else if (max_hdr <= 94) hipLaunchKernelGGL(k_rec_tokens<94>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);
     else hipLaunchKernelGGL(k_rec_tokens<127>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);

@@ -259,14 +259,24 @@ void launch_frame(const u8* fq, u64 n, u64* tstat /* [frame_tiles(n)], zeroed */
 // call's longest header and base line
 __global__ __launch_bounds__(256) void k_validate_lines(const u64* __restrict__ line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    u32 hl = 0, gl = 0, bad = 0, over = 0;
+    const u32 lane = threadIdx.x & 63;
+    u32 hl = 0, gl = 0, bad = 0, over = 0, hmin = 0;
+    // a record's five line starts: its own four as two 16-byte loads (coalesced: thread after thread), the next record's first from the
+    // next lane (the wave's last lane reads it)
+    u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
     if (r < nrec) {
-        const u64 l0 = line_off[4 * r], l1 = line_off[4 * r + 1], l2 = line_off[4 * r + 2], l3 = line_off[4 * r + 3], l4 = line_off[4 * r + 4];
+        const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(line_off + 4 * r), a23 = *reinterpret_cast<const ulonglong2*>(line_off + 4 * r + 2);
+        l0 = a01.x; l1 = a01.y; l2 = a23.x; l3 = a23.y;
+    }
+    l4 = ((u64)(u32)__shfl_down((int)(u32)(l0 >> 32), 1, 64) << 32) | (u32)__shfl_down((int)(u32)l0, 1, 64);
+    if (r < nrec && (lane == 63 || r + 1 == nrec)) l4 = line_off[4 * r + 4];
+    if (r < nrec) {
         // the reference diverts longer lines to raw "oversize" streams (usrs.cpp:313-317, 333-337, 366-367): max_line = 0xfffe
         // where its format is written; the block format codes base / quality lines of any length the usual way
         if ((l1 - l0 - 2) > max_hdr || (l2 - l1 - 1) > max_line || (l3 - l2 - 2) > 0x1ffe || (l4 - l3 - 1) > max_line) bad = (u32)(-SFQ_E_UNSUPPORTED);
         else if (l2 - l1 - 1 == 0) bad = (u32)(-SFQ_E_UNSUPPORTED);            // empty base line: usrs.cpp:217-222 mis-frames it
         hl = (u32)(l1 - l0 - 2); gl = (u32)(l2 - l1 - 1);
+        hmin = ~hl;                                                            // (the shortest header, as a maximum: status[4] starts at 0)
         // status[3] != 0: some record may be over format 6's line limits (usrs.hpp:34-36; a SOLiD line may be one longer -- the
         // oversize pass decides exactly)
         over = ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l4 - l3 - 1) > 0xfffe) ? 1u : 0u;
@@ -274,14 +284,15 @@ __global__ __launch_bounds__(256) void k_validate_lines(const u64* __restrict__ 
     }
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) {
-        const u32 o1 = (u32)__shfl_xor((int)hl, dd, 64), o2 = (u32)__shfl_xor((int)gl, dd, 64), o3 = (u32)__shfl_xor((int)bad, dd, 64), o4 = (u32)__shfl_xor((int)over, dd, 64);
-        hl = o1 > hl ? o1 : hl; gl = o2 > gl ? o2 : gl; bad = o3 > bad ? o3 : bad; over |= o4;
+        const u32 o1 = (u32)__shfl_xor((int)hl, dd, 64), o2 = (u32)__shfl_xor((int)gl, dd, 64), o3 = (u32)__shfl_xor((int)bad, dd, 64), o4 = (u32)__shfl_xor((int)over, dd, 64), o5 = (u32)__shfl_xor((int)hmin, dd, 64);
+        hl = o1 > hl ? o1 : hl; gl = o2 > gl ? o2 : gl; bad = o3 > bad ? o3 : bad; over |= o4; hmin = o5 > hmin ? o5 : hmin;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         if (bad) atomicMax(status, bad);
         if (hl > status[1]) atomicMax(status + 1, hl);      // (the plain read only spares atomics that cannot raise it)
         if (gl > status[2]) atomicMax(status + 2, gl);
         if (over) status[3] = 1;
+        if (hmin > status[4]) atomicMax(status + 4, hmin);   // ~(the shortest header's length)
     }
 }
 void launch_validate_lines(const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
