@@ -1958,7 +1958,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     u64 tot_s = 0, tot_q = 0;
     u32 dec_max_line = 0;                              // the longest base line (how the base tables' counting passes split their work)
-    if (frozen) {
+    if (frozen && gen_on) {                            // (only the generation tables' counting passes ask: 0.12 ms of the head otherwise)
         if ((rc = reserve(ctx, ctx->status, 256))) return rc;
         HIPC(hipMemsetAsync(ctx->status.p, 0, 256, st));
         launch_max_u32(da.slen, nrec, (u32*)ctx->status.p, st);
