@@ -55,7 +55,10 @@ struct HostWorker {
             if (quit) return;
             std::function<int()> j = std::move(job); has_job = false;
             lk.unlock();
-            const int r = j();
+            int r;
+            try { r = j(); }                                  // (a job that throws fails its call; the thread and the process live)
+            catch (const std::bad_alloc&) { r = SFQ_E_NOMEM; }
+            catch (...) { r = SFQ_E_CORRUPT; }
             lk.lock();
             result = r; done = true;
             cv.notify_all();
@@ -96,7 +99,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
+    DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, gbins, gfill, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
     DevBuf chn_len, chn_off, chn_out;      // "chn.idx": the size lists as bytes (chains.hip launch_chain_index_bytes)
     DevBuf pslot, plist;                   // the quality prior's listed rows, back to back (prior.hip launch_prior_list)
     DevBuf segn, segoff, segrec;           // chains that are segments of one record (long reads): segments per record, their scan, a chain's record
@@ -562,7 +565,17 @@ int rec_prior_copy_back(sfq_ctx* ctx, hipStream_t st) {
 // Base-model generation tables for an encode: counts gen 0, 1; decides from generation 1's would-be cost under the rows
 // of generation 0 whether the tables pay (a >= 1 % gain over the initial row's 2 bits per base); if so counts on.
 // Leaves ca.g_* describing which rows every generation codes with.
-struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; bool pre = false; };
+struct GenPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; bool pre = false; GenBins gb; };
+// the bins of the counting passes (chains.hip "counting through bins"): scratch for the largest batch of keys this call can meet
+int gen_bins_reserve(sfq_ctx* ctx, u32 g_bits, u64 max_keys, hipStream_t st, GenBins& gb) {
+    gb = gen_bins_plan(g_bits, max_keys);
+    int rc;
+    if ((rc = reserve(ctx, ctx->gbins, (size_t)gb.bins_bytes + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->gfill, (size_t)gb.fill_bytes))) return rc;
+    gb.bins = (u16*)ctx->gbins.p; gb.fill = (u32*)ctx->gfill.p;
+    HIPC(hipMemsetAsync(gb.fill, 0, (size_t)gb.fill_bytes, st));
+    return SFQ_OK;
+}
 int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits, u32 max_line, hipStream_t st, GenPlan& gp) {
     u32* bound = gp.bound;
     const u32 ngen = gp.ngen = gen_bounds(nblocks, bound);
@@ -581,6 +594,7 @@ int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits,
     }
     HIPC(hipMemsetAsync(ctx->gcnt.p, 0, (size_t)nctx * 16, st));
     HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
+    if ((rc = gen_bins_reserve(ctx, g_bits, ca.nbytes, st, gp.gb))) return rc;
     const u64 br = ca.block_reads;
     auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };          // an upper bound (the last block may be short): lanes past the end idle
     u32* rows = (u32*)ctx->grows.p;
@@ -592,8 +606,7 @@ int gen_tables_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u32 g_bits,
     // 2.42 bits, and at low coverage the chance repeats' penalty hides the true repeats' gain.)
     gp.pre = recs(bound[0], bound[1]) / gen_count_stride(recs(bound[0], bound[1])) >= 16384;
     if (gp.pre) {
-        launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st, 1, 1);
-        launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
+        launch_gen_count_binned(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, gp.gb, (u32*)ctx->gcnt.p, rows + nctx * 1, GEN_STEP, st, 1);
         launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st, 1, 0);
     }
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
@@ -617,9 +630,9 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
     // the verdict proper: (the rest of) generation 0 counted (on top of the sample's counts), then generation 1 counted and priced
     // under generation 0's rows (the initial row would cost 2 bits = 2048 units a base)
     HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
-    launch_gen_count(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st, gp.pre ? 2 : 0, 1);
-    launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * 1, nctx, GEN_STEP, st);
-    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st);
+    // (round 5: the counting goes through bins -- chains.hip -- and the pass that sums a generation's bins writes the next one's rows)
+    launch_gen_count_binned(ca, bound[0], bound[1], recs(bound[0], bound[1]), max_line, gp.gb, (u32*)ctx->gcnt.p, rows + nctx * 1, GEN_STEP, st, gp.pre ? 2 : 0);
+    launch_gen_count(ca, bound[1], bound[2], recs(bound[1], bound[2]), max_line, (u32*)ctx->gcnt.p, rows + nctx * 1, (const u16*)ctx->glog.p, (u64*)ctx->gcost.p, st, 0, 2);
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
     const u64 cost = h[0], nbases = h[1];
@@ -629,10 +642,9 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
     ca.g_init = (const u32*)((const u8*)ctx->glog.p + 2048);
     for (u32 g = 0; g <= ngen; g++) ca.g_bound[g] = bound[g];
     ca.g_rows[0] = nullptr; ca.g_rows[1] = nullptr;                             // generations 0 and 1: the initial row
-    for (u32 g = 2; g < ngen; g++) {
-        launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * g, nctx, GEN_STEP, st);         // counts of generations < g
-        ca.g_rows[g] = rows + nctx * g;
-        if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st);
+    for (u32 g = 1; g + 1 < ngen; g++) {                                        // generation g counted -> the rows of generation g + 1
+        launch_gen_count_binned(ca, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, gp.gb, (u32*)ctx->gcnt.p, rows + nctx * (g + 1), GEN_STEP, st);
+        ca.g_rows[g + 1] = rows + nctx * (g + 1);
     }
     return SFQ_OK;
 }
@@ -714,7 +726,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->gbins, &ctx->gfill, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -1818,6 +1830,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             rcpb = (block_reads + rchain_reads - 1) / rchain_reads;
             const u64 wantr = (u64)(nblocks - 1) * rcpb + (h_blocks[nblocks - 1].n_records + rchain_reads - 1) / rchain_reads;
             if (!get_v(cb, cn, cp, v) || v != wantr || wantr > 0x7FFFFFFFull) return false;
+            // (every listed size takes a byte of the index or more: a count the index cannot hold is refused BEFORE anything is sized
+            //  by it -- a damaged archive could ask for 2^31 entries here, on a thread where bad_alloc would end the process)
+            if (wantr > cn - std::min(cn, cp) || ncs + wantr > cn + 16) return false;
             nsub = (u32)wantr;
             h_rsz.resize(nsub); h_rhb.resize(nsub);
             if (!read_sizes(cb, cn, cp, deltas, h_rsz.data(), nsub) || !read_sizes(cb, cn, cp, deltas, h_rhb.data(), nsub)) return false;
@@ -1978,7 +1993,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     ht.mark("head queued");
     if (lists_pending) {                                  // frozen tables: the chain lists, then their copies to the device
         rc = ctx->worker.wait(); lists_pending = false;
-        if (rc) return fail(ctx, rc, "%s", lists_err.c_str());
+        if (rc) return fail(ctx, rc, "%s", lists_err.empty() ? "chain index (chn.idx): out of memory or damaged" : lists_err.c_str());
         if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
         if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
         HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
@@ -1987,10 +2002,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     ht.mark("chain lists read, copied");
     // 2. quality, bases and (3.) headers are independent chains: three streams.  (The one rule that ties bases to
     //    qualities -- quality '!' means N -- is applied when the records are assembled.)
-    HIPC(hipEventRecord(ctx->ev[2], st));
-    HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
-    HIPC(hipStreamWaitEvent(ctx->st_aux[1], ctx->ev[2], 0));
+    //    The fork comes BEHIND the quality rows and the hot image's helper kernels (round 5): forked in front of them, the base and
+    //    header decoders' 205 k lanes filled the chip and k_hot_select -- one workgroup of 1024 threads -- waited 3.2 ms for a CU
+    //    with sixteen free wave slots, the quality decoder (the call's critical path) behind it.
     hipStream_t st_rec = ctx->st_aux[0], st_gen = ctx->st_aux[1];
+    auto fork_streams = [&]() -> int {
+        HIPC(hipEventRecord(ctx->ev[2], st));
+        HIPC(hipStreamWaitEvent(ctx->st_aux[0], ctx->ev[2], 0));
+        HIPC(hipStreamWaitEvent(ctx->st_aux[1], ctx->ev[2], 0));
+        return SFQ_OK;
+    };
     if (frozen) {
         // quality: dense frozen rows from the prior, one chain per lane
         ChainArgs ca;
@@ -2031,6 +2052,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             ca.q_hot = want_hot; ca.qh_img = img; ca.qh_info = info;
         }
         ca.csz = (u32*)ctx->csz.p; ca.coff = (const u64*)ctx->coff.p;
+        if ((rc = fork_streams())) return rc;
         launch_qlt_decode_c(ca, da, st);
         HIPC(hipEventRecord(ctx->ev[3], st));
 #ifdef SFQ_EXP_QDEC_ALONE          /* scratch experiments only: the quality decoder by itself, timed; the call then fails */
@@ -2050,16 +2072,22 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;
             if ((rc = reserve(ctx, ctx->grows, (size_t)nctx * 4 * 2))) return rc;
             HIPC(hipMemsetAsync(ctx->gcnt.p, 0, (size_t)nctx * 16, st_gen));
+            GenBins gbins;
+            if ((rc = gen_bins_reserve(ctx, (u32)g_bits, tot_s, st_gen, gbins))) return rc;
             ca.g_ngen = ngen;
             for (u32 g = 0; g <= ngen; g++) ca.g_bound[g] = bound[g];
             u32* rows = (u32*)ctx->grows.p;
             const u64 br = block_reads;
             for (u32 g = 0; g < ngen; g++) {
                 // rows of generation g (two buffers in turn: a generation's rows are dead once it is decoded)
-                if (g >= 2) { launch_gen_rows((const u32*)ctx->gcnt.p, rows + nctx * (g & 1), nctx, GEN_STEP, st_gen); ca.g_rows[g] = rows + nctx * (g & 1); }
-                else ca.g_rows[g] = nullptr;
-                launch_gen_decode_c(ca, da, chain0_of(bound[g]), chain0_of(bound[g + 1]), st_gen);
-                if (g + 1 < ngen) launch_gen_count(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, dec_max_line, (u32*)ctx->gcnt.p, nullptr, nullptr, nullptr, st_gen);
+                // (the pass that sums generation g - 1's bins has written them, below)
+                ca.g_rows[g] = g >= 2 ? rows + nctx * (g & 1) : nullptr;
+                // (generations 0 and 1 both code with the initial row: one launch -- each is a sixty-fourth of the call, a launch of
+                //  its own runs as long as ONE lane takes for its chain, 3 ms at 10 M reads)
+                if (g == 0) { ca.g_rows[1] = nullptr; launch_gen_decode_c(ca, da, chain0_of(bound[0]), chain0_of(bound[2]), st_gen); }
+                else if (g >= 2) launch_gen_decode_c(ca, da, chain0_of(bound[g]), chain0_of(bound[g + 1]), st_gen);
+                if (g + 1 < ngen) launch_gen_count_binned(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * br, dec_max_line, gbins, (u32*)ctx->gcnt.p,
+                                                          g >= 1 ? rows + nctx * ((g + 1) & 1) : nullptr, GEN_STEP, st_gen);
             }
         }
         if (exc_rice) launch_gen_exc_decode_r(da, nblocks, st_gen);
@@ -2067,6 +2095,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     } else {
     // adaptive tables: a wavefront per block (decode_w.hip); sfq_params.kernel = 1: the lane-per-block cross-check kernels
     const bool wave_dec = p.kernel == 0;
+    if ((rc = fork_streams())) return rc;
     for (u32 b0 = 0; b0 < nblocks; b0 += slots) {
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         if (wave_dec) launch_qlt_decode_w(da, st); else launch_qlt_decode_l(da, st);

@@ -912,7 +912,7 @@ __device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec
 // a lane per 30 kb read made this pass 95 ms of the long-read workload's 108.
 // sub: 0 = every stride-th record; 2 = all of them but every GEN_PRE-th (what the pre-verdict's sample -- a launch with GEN_PRE times
 // the stride, api.cpp gen_tables_begin -- has counted already).  do_count = 0 (with rows): nothing is counted, and cost[] receives the
-// pre-verdict's statistic instead of the cost.
+// pre-verdict's statistic instead of the cost; do_count = 2 (with rows): the cost alone (the counting goes through the bins, below).
 __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, u32 stride, u32 seg_len, u32 segs, u32* __restrict__ cnt, const u32* __restrict__ rows,
                                                   const u16* __restrict__ log2fp, u64* cost, u32 sub, u32 do_count) {
     const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_gen_count(ChainArgs a, u32 b0, u32 b1, 
     walk_bases(a, r, live ? 1u : 0u, solid, mask,
         [&](u32 j, u32 ctx) { cx[j] = ctx; rv[j] = rows ? rows[ctx] : 0u; },
         [&](u32 j, u32 code) {
-            if (do_count) atomicAdd(&cnt[((size_t)cx[j] << 2) | code], 1u);
+            if (do_count == 1) atomicAdd(&cnt[((size_t)cx[j] << 2) | code], 1u);
             if (rows) {
                 const u32 v = rv[j];
                 const u32 f0 = v & 0xff, f1 = (v >> 8) & 0xff, f2 = (v >> 16) & 0xff, f3 = v >> 24;
@@ -980,6 +980,169 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
     const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
     hipLaunchKernelGGL(k_gen_count, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, b0, b1, stride, seg_len, segs, cnt, rows, log2fp, cost, sub, do_count);
 }
+// ---- counting through bins (round 5) --------------------------------------------------------------------------------
+// A scattered atomic per base is what k_gen_count's counting costs: the chip retires 27 G of them a second whatever the table's
+// size (profiles/r02a_atomics_*), 330 M per 10 M-read call -- a third of the time of every input whose bases can be learned.  The
+// same counts without a global atomic per base, in two streaming passes:
+//   k_gen_bin        the walk of k_gen_count, but a base's key (context << 2 | base) goes to the BIN of its context's slice of the
+//                    table -- 2^slice_bits contexts, what pass two holds in LDS -- as a 16-bit remainder.  A workgroup collects a
+//                    tile of keys in LDS, counts them per bin (LDS atomics), reserves room in every bin with ONE global atomic per
+//                    bin and tile, and stores the remainders (a bin that is full sends its key to the table's counter directly:
+//                    the counts are exact whatever the bins' capacity);
+//   k_gen_bin_count  a workgroup per bin: the slice's counters in LDS (two u16 per word; the bin is taken 65 535 keys at a time, so
+//                    a field cannot overflow), then added to the table's slice with coalesced 16-byte accesses -- and, where the
+//                    caller wants the next generation's rows, those are written from the sums at once (k_gen_rows folded in).
+// Counts are sums: the order in which keys reach a bin does not show.  Both coders call this through launch_gen_count_binned.
+#define GB_T 256u                        // lanes of a binning workgroup
+#define GB_ROUNDS 2u                     // pieces of sixteen bases a lane adds to a tile
+#define GB_TILE (GB_T * 16u * GB_ROUNDS) // keys per tile
+#define GB_SLICE_BITS 14u                // contexts per bin at most: 16 384 x 8 bytes of counters = 128 KiB of LDS
+__host__ __device__ __forceinline__ u32 gb_slice_bits(u32 g_bits) { return g_bits < GB_SLICE_BITS ? g_bits : GB_SLICE_BITS; }
+
+__global__ __launch_bounds__(GB_T) void k_gen_bin(ChainArgs a, u32 b0, u32 b1, u32 stride, u32 seg_len, u32 segs, u32 sub, u64 id0, u64 id1, u32 g_bits,
+                                                  u16* __restrict__ bins, u32* __restrict__ fill, u32 cap, u32* __restrict__ cnt) {
+    extern __shared__ u32 lds[];
+    const u32 sb = gb_slice_bits(g_bits), nb = 1u << (g_bits - sb), sh = sb + 2u;
+    u32* keys = lds;                     // [GB_TILE], laid out [round x 16 + j][lane]
+    u32* hist = lds + GB_TILE;           // [nb] keys per bin of this tile; then the cursor inside the tile's reservation
+    u32* base = hist + nb;               // [nb] where the tile's keys of a bin go in the bin
+    const u32 tid = threadIdx.x;
+    const u64 first = a.m.blocks[b0].rec0, endr = a.m.blocks[b1 - 1].rec0 + a.m.blocks[b1 - 1].nrec;
+    const u64 id = id0 + (u64)blockIdx.x * GB_T + tid;
+    const u64 r = first + (id / segs) * stride;
+    const u32 seg = (u32)(id % segs);
+    const bool live = id < id1 && r < endr && (sub == 0 || (id / segs) % GEN_PRE != 0);
+    u32 solid = 0; const u32 mask = (1u << g_bits) - 1u;
+    if (live) solid = a.m.blocks[(u32)(r / a.block_reads)].solid;
+    const u32 warm = (seg_len && seg) ? 16u : 0u;
+    LineWalk lw;
+    if (seg_len) lw.init(a, r, live ? 1u : 0u, 1, solid, (u64)seg * seg_len - warm, (u64)seg_len + warm);
+    else lw.init(a, r, live ? 1u : 0u, 1, solid);
+    u32 last = 0, seen = 0;
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    for (;;) {
+        for (u32 i = tid; i < nb; i += GB_T) hist[i] = 0;
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (u32 rd = 0; rd < GB_ROUNDS; rd++) {
+            const Piece pn = lw.next();
+            const uint4 wn = lw.fetch(pn);
+            if (pc.newline) last = 0x007616c7u;                    // gens.cpp:139
+#pragma unroll
+            for (u32 j = 0; j < 16; j++) {
+                u32 k = ~0u;
+                if (j < pc.j1) {
+                    const u32 cd = gen_code_of(piece_byte(w, j)) & 3u;
+                    if (seen >= warm) k = ((last & mask) << 2) | cd;
+                    seen++;
+                    last = (last << 2) | cd;
+                }
+                keys[(rd * 16u + j) * GB_T + tid] = k;
+                if (k != ~0u) atomicAdd(&hist[k >> sh], 1u);
+            }
+            any |= pc.valid ? 1 : 0;
+            pc = pn; w = wn;
+        }
+        if (!__syncthreads_or(any)) break;
+        for (u32 i = tid; i < nb; i += GB_T) { const u32 n = hist[i]; base[i] = n ? atomicAdd(&fill[i], n) : 0u; hist[i] = 0; }
+        __syncthreads();
+        for (u32 i = tid; i < GB_TILE; i += GB_T) {
+            const u32 k = keys[i];
+            if (k == ~0u) continue;
+            const u32 b = k >> sh;
+            const u32 pos = base[b] + atomicAdd(&hist[b], 1u);
+            if (pos < cap) bins[(size_t)b * cap + pos] = (u16)(k & ((1u << sh) - 1u));
+            else atomicAdd(&cnt[k], 1u);                           // the bin is full: straight to the counter
+        }
+        __syncthreads();
+    }
+}
+// rows_out (may be null): the rows f = 3 + step x n of the contexts' sums, as k_gen_rows writes them
+__device__ __forceinline__ u32 gen_row_of(uint4 n, u32 step) {
+    u64 f0 = 3 + (u64)step * n.x, f1 = 3 + (u64)step * n.y, f2 = 3 + (u64)step * n.z, f3 = 3 + (u64)step * n.w;
+    while ((f0 | f1 | f2 | f3) > 255) {                     // any of them > 255 (all are < 2^35)
+        f0 = (f0 >> 1) | (f0 & 1); f1 = (f1 >> 1) | (f1 & 1); f2 = (f2 >> 1) | (f2 & 1); f3 = (f3 >> 1) | (f3 & 1);
+    }
+    return (u32)f0 | (u32)f1 << 8 | (u32)f2 << 16 | (u32)f3 << 24;
+}
+__global__ __launch_bounds__(1024) void k_gen_bin_count(const u16* __restrict__ bins, u32* __restrict__ fill, u32 cap, u32 g_bits, u32* __restrict__ cnt,
+                                                        u32* __restrict__ rows_out, u32 step) {
+    extern __shared__ u32 lds[];         // [2^sb][2]: word 0 = codes 0 | 1 << 16, word 1 = codes 2 | 3 << 16
+    const u32 sb = gb_slice_bits(g_bits), nctx = 1u << sb, b = blockIdx.x, tid = threadIdx.x;
+    u32 n = fill[b]; if (n > cap) n = cap;
+    const u16* bin = bins + (size_t)b * cap;
+    uint4* slice = reinterpret_cast<uint4*>(cnt + ((size_t)b << (sb + 2)));
+    if (!n && !rows_out) return;
+    for (u32 at = 0; ; at += 65535u) {
+        for (u32 i = tid; i < 2u * nctx; i += 1024u) lds[i] = 0;
+        __syncthreads();
+        const u32 m = n - at < 65535u ? n - at : 65535u;
+        for (u32 i = tid; i < m; i += 1024u) {
+            const u32 k = bin[at + i];
+            atomicAdd(&lds[k >> 1], 1u << ((k & 1u) * 16u));         // k = context << 2 | code: word (context, code >> 1), field code & 1
+        }
+        __syncthreads();
+        const bool last_chunk = at + m >= n;
+        for (u32 i = tid; i < nctx; i += 1024u) {
+            const u32 w0 = lds[2 * i], w1 = lds[2 * i + 1];
+            if (!(w0 | w1) && !(rows_out && last_chunk)) continue;
+            uint4 c = slice[i];
+            c.x += w0 & 0xffffu; c.y += w0 >> 16; c.z += w1 & 0xffffu; c.w += w1 >> 16;
+            if (w0 | w1) slice[i] = c;
+            if (rows_out && last_chunk) rows_out[((size_t)b << sb) + i] = gen_row_of(c, step);
+        }
+        if (last_chunk) break;
+        __syncthreads();
+    }
+    if (tid == 0) fill[b] = 0;           // (ready for the next batch)
+}
+// the counts of launch_gen_count(a, b0, b1, ..., cnt, null, null, null, st, sub, 1) through bins; rows_out: the rows of the sums as well
+// (then launch_gen_rows is not needed).  gb: scratch sized by gen_bins_plan(), gb.fill zeroed once by the caller.
+GenBins gen_bins_plan(u32 g_bits, u64 max_keys) {
+    // a pair of passes takes at most `batch` keys; a bin of a table whose contexts are hit evenly gets its share of them: the bins
+    // hold twice that and a tile's worth of slack (what does not fit is counted by the atomics the bins replace)
+    GenBins gb; gb.bins = nullptr; gb.fill = nullptr;
+    gb.g_bits = g_bits;
+    gb.batch = max_keys < GEN_BIN_BATCH ? (max_keys ? max_keys : 1) : GEN_BIN_BATCH;
+    const u32 nb = 1u << (g_bits - gb_slice_bits(g_bits));
+    gb.cap = (u32)((2ull * ((gb.batch + nb - 1) / nb) + 4096ull + 63ull) & ~63ull);
+    gb.bins_bytes = (u64)gb.cap * 2ull * nb; gb.fill_bytes = 4ull * nb;
+    return gb;
+}
+void launch_gen_count_binned(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, const GenBins& gb, u32* cnt, u32* rows_out, u32 step,
+                             hipStream_t st, u32 sub) {
+    const u32 g_bits = gb.g_bits, sb = gb_slice_bits(g_bits), nb = 1u << (g_bits - sb), cap = gb.cap;
+    const u32 dyn2 = (2u << sb) * 4u;
+    static u32 allowed = 0;
+    if (dyn2 > 65536u && dyn2 > allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen_bin_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2); allowed = dyn2; }
+    if (nrec_range) {
+        u32 stride = gen_count_stride(nrec_range);
+        if (sub == 1) { stride *= GEN_PRE; sub = 0; }
+        u32 seg_len = 0;                                            // (as launch_gen_count)
+        if (max_line >= 64u) {
+            const u64 nsel = (nrec_range + stride - 1) / stride;
+            for (u32 sl = 32u; sl < max_line && sl <= 512u; sl *= 2u)
+                if (nsel * ((max_line + sl - 1) / sl) <= 524288ull) { seg_len = sl; break; }
+        }
+        if (!seg_len && max_line > 1024u) seg_len = 512u;
+        const u32 segs = seg_len ? (max_line + seg_len - 1) / seg_len : 1u;
+        const u64 lanes = ((nrec_range + stride - 1) / stride) * segs;
+        // lanes of one batch: their keys (a lane holds seg_len bases, or a whole line of up to max_line) fit the bins' batch
+        const u64 per_lane = seg_len ? seg_len : (max_line ? max_line : 1u);
+        u64 lanes_per_batch = gb.batch / per_lane; if (!lanes_per_batch) lanes_per_batch = 1;
+        lanes_per_batch = (lanes_per_batch + GB_T - 1) / GB_T * GB_T;
+        const u32 dyn1 = (GB_TILE + 2u * nb) * 4u;
+        for (u64 id0 = 0; id0 < lanes; id0 += lanes_per_batch) {
+            const u64 id1 = id0 + lanes_per_batch < lanes ? id0 + lanes_per_batch : lanes;
+            const bool last = id1 >= lanes;
+            hipLaunchKernelGGL(k_gen_bin, dim3((u32)((id1 - id0 + GB_T - 1) / GB_T)), dim3(GB_T), dyn1, st, a, b0, b1, stride, seg_len, segs, sub, id0, id1, g_bits, gb.bins, gb.fill, cap, cnt);
+            hipLaunchKernelGGL(k_gen_bin_count, dim3(nb), dim3(1024), dyn2, st, (const u16*)gb.bins, gb.fill, cap, g_bits, cnt, last ? rows_out : nullptr, step);
+        }
+    } else if (rows_out) hipLaunchKernelGGL(k_gen_bin_count, dim3(nb), dim3(1024), dyn2, st, (const u16*)gb.bins, gb.fill, cap, g_bits, cnt, rows_out, step);
+}
+
 // rows from counts
 __global__ __launch_bounds__(256) void k_gen_rows(const u32* __restrict__ cnt, u32* __restrict__ rows, u64 nctx, u32 step) {
     const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;

@@ -97,6 +97,13 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
                       u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st,
                       u32 sub = 0 /* 0 every selected record, 1 every GEN_PRE-th of them, 2 the others */, u32 do_count = 1 /* 0: the cost only */);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
+// the same counts through bins (chains.hip "counting through bins": two streaming passes instead of a global atomic per base);
+// rows_out != null: the rows of the sums are written as well (launch_gen_rows folded in).  bins / fill: scratch, fill zeroed by the caller
+#define GEN_BIN_BATCH (1ull << 27)      /* keys a pair of passes takes at most (the bins hold twice that, 2 bytes a key) */
+struct GenBins { u16* bins; u32* fill; u32 cap, g_bits; u64 batch, bins_bytes, fill_bytes; };
+GenBins gen_bins_plan(u32 g_bits, u64 max_keys /* the bases a counting pass can meet (the call's text is a bound) */);
+void launch_gen_count_binned(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, const GenBins& gb, u32* cnt, u32* rows_out, u32 step,
+                             hipStream_t st, u32 sub = 0);
 void launch_gen_encode_c(const ChainArgs& a, hipStream_t st, u32 c0 = 0, u32 c1 = 0 /* chains [c0, c1); 0, 0 = all */, bool flat = false /* every chain: the initial row */);
 // gen.Ns / gen.Nn side streams, a wave per block (models_w.hip); flags: the records that may hold an exception (null = look at all)
 // "chn.idx": the size lists csz[0 .. n) (lists [0, b1), [b1, b2), [b2, b3), [b3, n)) as zigzag-difference varints, back to back in
