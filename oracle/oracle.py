@@ -430,6 +430,39 @@ def gen_encode_segs(buf: bytes, goff, glen, other_len, gen_bits, block_reads, se
     return _take(out, n), sizes, on.value
 
 
+def gm_encode_chains(buf: bytes, goff, glen, table_bits, block_reads, chain_reads):
+    """Base chains under the generation MATCH model (round 5) -> (chain streams back to back, per-chain sizes, gen_on)."""
+    L = lib()
+    goff, po = _arr(goff, np.uint64); glen, pl = _arr(glen, np.uint32)
+    sizes = np.zeros(_nchains(len(goff), block_reads, chain_reads), np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); on = C.c_int()
+    L.sfqo_gm_encode_chains.restype = C.c_longlong
+    L.sfqo_gm_encode_chains.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t,
+                                        C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int)]
+    got = L.sfqo_gm_encode_chains(buf, po, pl, len(goff), table_bits, block_reads, chain_reads, C.byref(out), C.byref(n),
+                                  sizes.ctypes.data_as(C.c_void_p), C.byref(on))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, on.value
+
+
+def gm_encode_segs(buf: bytes, goff, glen, other_len, table_bits, block_reads, seg_len):
+    """The same for chains that are SEGMENTS of one record."""
+    L = lib()
+    nseg = int(seg_counts(glen, other_len, seg_len).sum())
+    goff, po = _arr(goff, np.uint64); glen, pl = _arr(glen, np.uint32); other_len, pt = _arr(other_len, np.uint32)
+    sizes = np.zeros(nseg, np.uint32)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t(); on = C.c_int()
+    L.sfqo_gm_encode_segs.restype = C.c_longlong
+    L.sfqo_gm_encode_segs.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32,
+                                      C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int)]
+    got = L.sfqo_gm_encode_segs(buf, po, pl, pt, len(goff), table_bits, block_reads, seg_len, C.byref(out), C.byref(n),
+                                sizes.ctypes.data_as(C.c_void_p), C.byref(on))
+    if got != len(sizes):
+        raise _err()
+    return _take(out, n), sizes, on.value
+
+
 REC_ROWS = 66 * 16
 
 

@@ -1771,6 +1771,7 @@ static void gfz_cb(void* arg, u32 ctx, int code) {
     ch_encode(g->c, cum, f[code], f[0] + f[1] + f[2] + f[3]);                   /* base2_ranger.hpp:74-84 without the update */
 }
 /* gen_on: 1 = the generation tables were used (decided from generation 1's cost under generation 0's rows) */
+static int g_gen_force_off = 0;           /* sfqo_gm_*: the match model's verdict said no -- every chain codes with the initial row */
 static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
                                  size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on,
                                  u32 seg_len /* != 0: segments of one record */, const u32* other_len) {
@@ -1783,9 +1784,9 @@ static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32*
     u32** rows = xcalloc(ngen + 1, sizeof(u32*));
     int on = 0;
 #define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
-    int maybe = ngen >= 3;
+    int maybe = ngen >= 3 && !g_gen_force_off;
 #define GSTRIDE(g) gen_count_stride((bound[(g) + 1] - bound[g]) * block_reads)
-    if (ngen >= 3 && (bound[1] - bound[0]) * block_reads / GSTRIDE(0) >= 16384) {
+    if (ngen >= 3 && !g_gen_force_off && (bound[1] - bound[0]) * block_reads / GSTRIDE(0) >= 16384) {
         /* the pre-verdict (api.cpp gen_tables_begin): every 8th of generation 0's counted records counted; over every 8th of
            generation 1's, and the bases whose context that sample has seen m times: s4 += 4 x (times it saw this base) - m.
            Five deviations (sqrt(3 sum m)) above 0, or the full passes are skipped: no tables */
@@ -1863,6 +1864,169 @@ long long sfqo_gen_encode_chains(const u8* base, const u64* goff, const u32* gle
 long long sfqo_gen_encode_segs(const u8* base, const u64* goff, const u32* glen, const u32* other_len, size_t nrec, int gen_bits, size_t block_reads,
                                u32 seg_len, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
     return gen_encode_chains_x(base, goff, glen, nrec, gen_bits, block_reads, 1, step, out, out_len, sizes, gen_on, seg_len, other_len);
+}
+
+/* ---- bases: the generation MATCH model (round 5; gm.hip) ---------------------------------------------------------------
+   NOT the reference's model.  The reference's base model is a table of 2^24 rows addressed by the last twelve bases: one random
+   memory access per base, which is what bounds it on a CPU and on a GPU alike.  What that table learns from a file whose reads
+   overlap -- "after these bases comes that one" -- is also what an earlier read of the same place says outright.  So a chain
+   of generation g follows a POINTER into the bases of the generations before it:
+     * the call's base lines, with N coded as A (gens.cpp:116-136) and a sentinel behind every line, form the STAGE; position
+       soff[r] + i = base i of record r, soff[r + 1] = soff[r] + len[r] + 1;
+     * the INDEX is a table of 2^tb entries.  Over the records the counting passes take (every stride-th of a generation,
+       gen_count_stride), the k-mer of GM_K = 16 bases ending at base i (i + 1 >= 16, i + 1 < len) is hashed,
+       h = kmer * 0x9E3779B97F4A7C15 mod 2^64; where its top two bits are zero (a quarter of the k-mers) the entry
+       (h >> (62 - tb)) & (2^tb - 1) receives min(entry, p << 24 | check) with p = the stage position of base i + 1 and
+       check = (h >> (38 - tb)) & 0xFFFFFF: the EARLIEST occurrence stays, whatever the order of the insertions;
+     * a line (or a segment of one) is walked with a state (kmer, pointer, m = bases matched in a row, at most 31):
+       with a pointer, the base at it is the prediction e: the base is coded with e at 4096 - 3 Fo[m] of 4096 and the other three
+       at Fo[m] each, the pointer moves on; a miss sets m to 0, a miss while m < 8 drops the pointer; the pointer is dropped at a sentinel.
+       Without one the base is coded flat (1024 of 4096).  Without a pointer and none pending, after base i, with sixteen bases of
+       the line seen and i + 1 + GM_D < n: if the k-mer is one of the quarter, its entry holds its check bits and a position p
+       below the generation's first stage position, the pointer p + GM_D starts to predict at base i + 1 + GM_D -- unless a
+       sentinel lies in [p, p + GM_D].  (GM_D = 4 bases pass between lookup and use: a decoder has the entry and the bases at p
+       in flight meanwhile and never waits for memory.)
+   Whether a call uses the model at all is decided once: generation 0's counted records indexed, every eighth counted record of
+   generation 1 priced (integer log2 costs); on if that beats two bits a base by 1 %.                                        */
+#define GM_K 16
+#define GM_D 4
+#define GM_DROP 8
+#define GM_MCAP 31
+#define GM_EMPTY (~0ull)
+static u32 gm_fo(u32 m) { return m < 4 ? 64u : m < 8 ? 40u : m < 16 ? 24u : 16u; }
+typedef struct { const u8* st; const u64* T; int tb; u64 lim; chenc* c; u64 cost, nbases; } gmw;
+static void gm_walk(gmw* w, u64 q0, size_t n) {
+    u32 kmer = 0, seen = 0, m = 0; int have = 0; u64 ptr = 0; long long pend_at = -1; u64 pend_p = 0;
+    const u8* st = w->st;
+    for (size_t i = 0; i < n; i++) {
+        const u32 b = st[q0 + i];
+        if (pend_at == (long long)i) {
+            pend_at = -1;
+            int ok = 1; for (int d = 0; d <= GM_D; d++) if (st[pend_p + d] == 0xFF) { ok = 0; break; }
+            if (ok) { have = 1; m = GM_K; ptr = pend_p + GM_D; }
+        }
+        if (have && st[ptr] == 0xFF) have = 0;
+        if (have) {
+            const u32 e = st[ptr], fo = gm_fo(m), fm = 4096u - 3u * fo;
+            if (w->c) ch_encode(w->c, b * fo + (b > e ? fm - fo : 0u), b == e ? fm : fo, 4096);
+            else w->cost += 12 * 1024 - log2fp(b == e ? fm : fo);
+            if (b == e) { if (m < GM_MCAP) m++; ptr++; }
+            else if (m < GM_DROP) have = 0;
+            else { m = 0; ptr++; }
+        } else {
+            if (w->c) ch_encode(w->c, b * 1024u, 1024u, 4096);
+            else w->cost += 2048;
+        }
+        w->nbases++;
+        kmer = (kmer << 2) | b; seen++;
+        if (!have && pend_at < 0 && seen >= GM_K && i + 1 + GM_D < n) {
+            const u64 h = (u64)kmer * 0x9E3779B97F4A7C15ull;
+            if ((h >> 62) == 0) {
+                const u64 e = w->T[(h >> (62 - w->tb)) & ((1ull << w->tb) - 1)];
+                if (e != GM_EMPTY && (e & 0xFFFFFF) == ((h >> (38 - w->tb)) & 0xFFFFFF) && (e >> 24) < w->lim) { pend_at = (long long)(i + 1 + GM_D); pend_p = e >> 24; }
+            }
+        }
+    }
+}
+static void gm_insert(const u8* st, const u64* soff, const u32* glen, size_t r0, size_t r1, size_t stride, u64* T, int tb) {
+    for (size_t r = r0; r < r1; r += stride) {
+        u32 kmer = 0;
+        for (u32 i = 0; i + 1 < glen[r]; i++) {
+            kmer = (kmer << 2) | st[soff[r] + i];
+            if (i + 1 < GM_K) continue;
+            const u64 h = (u64)kmer * 0x9E3779B97F4A7C15ull;
+            if ((h >> 62) != 0) continue;
+            const u64 p = soff[r] + i + 1;
+            if (p >> 40) continue;
+            const u64 v = (p << 24) | ((h >> (38 - tb)) & 0xFFFFFF);
+            u64* e = &T[(h >> (62 - tb)) & ((1ull << tb) - 1)];
+            if (v < *e) *e = v;
+        }
+    }
+}
+static long long gm_encode_x(const u8* base, const u64* goff, const u32* glen, size_t nrec, int tb, size_t block_reads, size_t chain_reads,
+                             u8** out, size_t* out_len, u32* sizes, int* gen_on, u32 seg_len, const u32* other_len) {
+    g_failed = 0; g_err[0] = 0;
+    if (tb < 8 || tb > 26) { fail("gm: table bits %d", tb); return -1; }
+    const size_t nblocks = (nrec + block_reads - 1) / block_reads;
+    size_t bound[48];
+    const size_t ngen = gen_bounds(nblocks, bound);
+#define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
+#define GSTRIDE(g) gen_count_stride((bound[(g) + 1] - bound[g]) * block_reads)
+    int on = 0;
+    u8* st = NULL; u64* soff = NULL; u64* T = NULL;
+    if (ngen >= 3) {
+        u64 tot = 0; for (size_t r = 0; r < nrec; r++) tot += (u64)glen[r] + 1;
+        st = xmalloc(tot + 64); soff = xmalloc((nrec + 1) * sizeof(u64));
+        u64 sp = 0;
+        for (size_t r = 0; r < nrec; r++) {
+            soff[r] = sp;
+            for (u32 i = 0; i < glen[r]; i++) { const int c = gencode_of(base[goff[r] + i]); st[sp++] = (u8)(c > 4 ? 0 : c & 3); }
+            st[sp++] = 0xFF;
+        }
+        soff[nrec] = sp; memset(st + sp, 0xFF, 64);
+        T = xmalloc(sizeof(u64) << tb); memset(T, 0xFF, sizeof(u64) << tb);
+        gm_insert(st, soff, glen, REC_OF(bound[0]), REC_OF(bound[1]), GSTRIDE(0), T, tb);
+        gmw w = { st, T, tb, soff[REC_OF(bound[1])], NULL, 0, 0 };
+        for (size_t r = REC_OF(bound[1]); r < REC_OF(bound[2]); r += GSTRIDE(1) * 8) gm_walk(&w, soff[r], glen[r]);
+        on = w.nbases && w.cost * 100 < w.nbases * 2048 * 99;
+        if (on) for (size_t g = 1; g + 1 < ngen; g++) gm_insert(st, soff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), GSTRIDE(g), T, tb);
+    }
+    if (gen_on) *gen_on = on;
+    if (!on) {
+        free(st); free(soff); free(T);
+        g_gen_force_off = 1;
+        const long long rc = gen_encode_chains_x(base, goff, glen, nrec, 12, block_reads, chain_reads, 4, out, out_len, sizes, NULL, seg_len, other_len);
+        g_gen_force_off = 0;
+        return rc;
+    }
+    obuf o = { 0, 0, 0 };
+    size_t nc = 0;
+    for (size_t b = 0; b < nblocks; b++) {
+        size_t g = 0; while (g + 1 < ngen && b >= bound[g + 1]) g++;
+        const size_t b0 = REC_OF(b), b1 = REC_OF(b + 1);
+        const u64 lim = soff[REC_OF(bound[g])];
+        if (seg_len) {
+            for (size_t r = b0; r < b1; r++) {
+                size_t n, L; seg_geometry(glen[r], other_len[r], seg_len, &n, &L);
+                for (size_t sg = 0; sg < n; sg++, nc++) {
+                    const size_t lo = sg * L < glen[r] ? sg * L : glen[r];
+                    const size_t cnt = glen[r] - lo < L ? glen[r] - lo : L;
+                    chenc c; ch_init(&c);
+                    gmw w = { st, T, tb, lim, &c, 0, 0 };
+                    gm_walk(&w, soff[r] + lo, cnt);                              /* (a segment starts as a line does) */
+                    const size_t nb = ch_finish(&c);
+                    ob_write(&o, c.out, nb);
+                    if (sizes) sizes[nc] = (u32)nb;
+                    free(c.out);
+                }
+            }
+            continue;
+        }
+        for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
+            const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+            chenc c; ch_init(&c);
+            gmw w = { st, T, tb, lim, &c, 0, 0 };
+            for (size_t r = r0; r < r1; r++) gm_walk(&w, soff[r], glen[r]);
+            const size_t n = ch_finish(&c);
+            ob_write(&o, c.out, n);
+            if (sizes) sizes[nc] = (u32)n;
+            free(c.out);
+        }
+    }
+#undef REC_OF
+#undef GSTRIDE
+    free(st); free(soff); free(T);
+    *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
+    return g_failed ? -1 : (long long)nc;
+}
+long long sfqo_gm_encode_chains(const u8* base, const u64* goff, const u32* glen, size_t nrec, int table_bits, size_t block_reads,
+                                size_t chain_reads, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+    return gm_encode_x(base, goff, glen, nrec, table_bits, block_reads, chain_reads, out, out_len, sizes, gen_on, 0, NULL);
+}
+long long sfqo_gm_encode_segs(const u8* base, const u64* goff, const u32* glen, const u32* other_len, size_t nrec, int table_bits, size_t block_reads,
+                              u32 seg_len, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
+    return gm_encode_x(base, goff, glen, nrec, table_bits, block_reads, 1, out, out_len, sizes, gen_on, seg_len, other_len);
 }
 
 /* ---- frozen tables: the base exceptions as adaptive Rice codes (round 4; chains.hip k_gen_exc_r) -------------------------

@@ -115,6 +115,12 @@ long long sfqo_qlt_encode_segs(const uint8_t* base, const uint64_t* off, const u
                                const uint32_t* frozen_rows, uint8_t** out, size_t* out_len, uint32_t* sizes, uint32_t* extra_hi);
 long long sfqo_gen_encode_segs(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint32_t* other_len, size_t nrec, int gen_bits, size_t block_reads,
                                uint32_t seg_len, uint32_t step, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+/* bases, the generation MATCH model (round 5, gm.hip; sfq_oracle.c "the generation MATCH model"): same shapes as the two above,
+   table_bits = log2 of the index's entries ("chn.idx") */
+long long sfqo_gm_encode_chains(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, size_t nrec, int table_bits, size_t block_reads,
+                                size_t chain_reads, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+long long sfqo_gm_encode_segs(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint32_t* other_len, size_t nrec, int table_bits, size_t block_reads,
+                              uint32_t seg_len, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
 /* frozen tables, round 4: a block's three base-exception lists ("gen.Ns", "gen.Nn", "gen.lc") as adaptive Rice codes
    (chains.hip k_gen_exc_r; NOT the reference's XFile coding: DESIGN.md 4.10) and the way back */
 int sfqo_exc_rice_block(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint64_t* qoff, const uint32_t* qlen, size_t nrec,

@@ -16,7 +16,7 @@ CLI = os.path.join(HERE, "bin", "slimfastq-amd")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["api.cpp", "synth.cpp", "frame.hip", "models_l.hip", "decode_l.hip", "decode_w.hip", "models_w.hip", "models_k.hip", "chains.hip", "exc.hip", "prior.hip", "container.cpp", "archive_api.cpp"]
+LIB_SOURCES = ["api.cpp", "synth.cpp", "frame.hip", "models_l.hip", "decode_l.hip", "decode_w.hip", "models_w.hip", "models_k.hip", "chains.hip", "gm.hip", "exc.hip", "prior.hip", "container.cpp", "archive_api.cpp"]
 CLI_SOURCES = ["cli.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-ffp-contract=off"]

@@ -99,6 +99,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
+    DevBuf gm_T, gm_slen, gm_boff, gm_soff, gm_scan, gm_stage, gm_tok;     // bases under the match model (gm.hip): index, stage, tokens
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, gbins, gfill, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
     DevBuf chn_len, chn_off, chn_out;      // "chn.idx": the size lists as bytes (chains.hip launch_chain_index_bytes)
     DevBuf pslot, plist;                   // the quality prior's listed rows, back to back (prior.hip launch_prior_list)
@@ -649,6 +650,90 @@ int gen_tables_finish(sfq_ctx* ctx, ChainArgs& ca, u32 g_bits, u32 max_line, hip
     return SFQ_OK;
 }
 
+// ---- bases under the generation MATCH model (gm.hip; round 5) -----------------------------------------------------------------
+// floor(1024 * log2(x)) for any x >= 1 (log2_table's arithmetic)
+u32 log2fp_u32(u32 x) {
+    const u32 e = 31 - (u32)__builtin_clz(x);
+    u64 m = (u64)x << (31 - e);
+    u32 frac = 0;
+    for (int i = 0; i < 10; i++) { m = (m * m) >> 31; frac <<= 1; if (m >> 32) { frac |= 1; m >>= 1; } }
+    return e * 1024 + frac;
+}
+u32 gm_table_bits(u64 nbytes) {          // an entry per eight bases of the call, 2^16 .. 2^24 entries
+    u32 tb = 16;
+    while (tb < 24 && (1ull << tb) < nbytes / 16) tb++;
+    return tb;
+}
+struct GmPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; u32 tb = 0; u64 cap = 0; u64 r2 = 0; ChainArgs cg; };
+// the stage of records [0, n): line lengths, their scan, the places, the letters
+int gm_stage_upto(sfq_ctx* ctx, const ChainArgs& ca, u64 n, u64 from, hipStream_t st) {
+    launch_gm_lens(ca.m.line_off, ca.m.blocks, ca.block_reads, n, (u32*)ctx->gm_slen.p, st);
+    launch_scan_u32((const u32*)ctx->gm_slen.p, (u64*)ctx->gm_boff.p, n, (u64*)ctx->gm_scan.p, st);
+    launch_gm_soff((const u64*)ctx->gm_boff.p, n, (u64*)ctx->gm_soff.p, st);
+    launch_gm_stage(ca.m, ca.block_reads, from, n, ca.nbytes, (u8*)ctx->gm_stage.p, (const u64*)ctx->gm_soff.p, (const u32*)ctx->gm_slen.p, nullptr, st);
+    return SFQ_OK;
+}
+// Begin: the first two generations staged, generation 0's counted records indexed, every GEN_PRE-th counted record of generation 1
+// priced under that index; the sums on their way to the host.
+int gm_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u64 nrec, u32 max_line, hipStream_t st, GmPlan& gp) {
+    const u32 ngen = gp.ngen = gen_bounds(nblocks, gp.bound);
+    if (ngen < 3) return SFQ_OK;
+    const u32* bound = gp.bound;
+    int rc;
+    gp.tb = gm_table_bits(ca.nbytes);
+    gp.cap = ca.nbytes;                                            // (a staged byte is a byte of the text: a base, or its line's '\n')
+    if ((rc = reserve(ctx, ctx->gm_T, (size_t)8 << gp.tb))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_slen, (size_t)nrec * 4 + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_soff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_scan, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_stage, (size_t)gp.cap + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->gcost, 64))) return rc;
+    HIPC(hipMemsetAsync(ctx->gm_T.p, 0xFF, (size_t)8 << gp.tb, st));
+    HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
+    const u64 br = ca.block_reads;
+    gp.r2 = std::min<u64>(nrec, (u64)bound[2] * br);
+    if ((rc = gm_stage_upto(ctx, ca, gp.r2, 0, st))) return rc;
+    gp.cg = ca;
+    gp.cg.st_buf = (const u8*)ctx->gm_stage.p; gp.cg.st_bytes = gp.cap; gp.cg.st_off = (const u64*)ctx->gm_soff.p; gp.cg.st_len = (const u32*)ctx->gm_slen.p;
+    auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };
+    launch_gm_insert(gp.cg, bound[0], bound[1], recs(bound[0], bound[1]), max_line, (u64*)ctx->gm_T.p, gp.tb, st);
+    u16 costs[8];
+    for (u32 lv = 0; lv < 4; lv++) {
+        const u32 fo = lv == 0 ? 64u : lv == 1 ? 40u : lv == 2 ? 24u : 16u;
+        costs[lv] = (u16)(12 * 1024 - log2fp_u32(4096u - 3u * fo)); costs[4 + lv] = (u16)(12 * 1024 - log2fp_u32(fo));
+    }
+    const u64 r1 = (u64)bound[1] * br;
+    launch_gm_price(gp.cg, r1, gp.r2, (u64)gen_count_stride(recs(bound[1], bound[2])) * GEN_PRE, r1, (const u8*)ctx->gm_stage.p, gp.cap, (const u64*)ctx->gm_soff.p,
+                    (const u32*)ctx->gm_slen.p, (const u64*)ctx->gm_T.p, gp.tb, costs, (u64*)ctx->gcost.p, st);
+    HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
+    return SFQ_OK;
+}
+// Finish: the verdict (on if generation 1's sample costs 1 % less than two bits a base); then the rest staged, the other
+// generations' counted records indexed, the tokens planned -- the chains (launch_gm_code) are the caller's
+int gm_finish(sfq_ctx* ctx, ChainArgs& ca, u64 nrec, u32 max_line, hipStream_t st, GmPlan& gp, u32* gen_on) {
+    *gen_on = 0;
+    const u32 ngen = gp.ngen; const u32* bound = gp.bound;
+    if (ngen < 3) return SFQ_OK;
+    HIPC(hipStreamSynchronize(st));
+    const u64* h = (const u64*)((const u8*)ctx->pin + PIN_GEN_OFF);
+    const u64 cost = h[0], nbases = h[1];
+    if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // nothing to gain: every chain codes with the initial row
+    *gen_on = 1;
+    int rc;
+    if ((rc = reserve(ctx, ctx->gm_tok, (size_t)gp.cap + 64))) return rc;
+    if ((rc = gm_stage_upto(ctx, ca, nrec, gp.r2, st))) return rc;             // (the scan again over all the records: the first ones' places do not change)
+    const u64 br = ca.block_reads;
+    auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };
+    for (u32 g = 1; g + 1 < ngen; g++) launch_gm_insert(gp.cg, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u64*)ctx->gm_T.p, gp.tb, st);
+    gp.cg.m = ca.m; gp.cg.csz = ca.csz;
+    gp.cg.g_ngen = ngen;
+    for (u32 g = 0; g <= ngen; g++) gp.cg.g_bound[g] = bound[g];
+    launch_gm_plan(gp.cg, ca.seg_len ? (u64)ca.geo.nchains : nrec, (const u8*)ctx->gm_stage.p, gp.cap, (const u64*)ctx->gm_soff.p, (const u32*)ctx->gm_slen.p,
+                   (const u64*)ctx->gm_T.p, gp.tb, (u8*)ctx->gm_tok.p, st);
+    return SFQ_OK;
+}
+
 // frame.hip k_text_fingerprint of a device-resident text (one small kernel and eight bytes back)
 int text_fingerprint(sfq_ctx* ctx, const u8* d_text, u64 nbytes, hipStream_t st, u64* out) {
     int rc;
@@ -726,7 +811,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->gbins, &ctx->gfill, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->gbins, &ctx->gfill, &ctx->gm_T, &ctx->gm_slen, &ctx->gm_boff, &ctx->gm_soff, &ctx->gm_scan, &ctx->gm_stage, &ctx->gm_tok, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -1060,7 +1145,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     ChainArgs ca;
     memset(&ca, 0, sizeof ca);
     u32 nchains = 0, nsub = 0;
-    GenPlan gplan;
+    GenPlan gplan; GmPlan gmplan;
+    const bool gm = frozen && !exc_classic;            // bases: the match model (gm.hip); sfq_params.kernel = 2 keeps round 4's generation tables
     u32 seg_len = 0;                                   // chains that are segments of one record (chains.hip "segments")
     std::vector<u32> seg_blk;                          // ... and how many each block has ("chn.idx")
     if (frozen) {
@@ -1132,7 +1218,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             ca.m = a;
             if (models & SFQ_M_REC) { if ((rc = rec_prior_begin(ctx, a, nrec, given, counted, mst[1], max_hdr))) return rc; }
             if (models & SFQ_M_GEN) {
-                if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
+                if (gm) { if ((rc = gm_begin(ctx, ca, nblocks, nrec, max_line, mst[3], gmplan))) return rc; }
+                else if ((rc = gen_tables_begin(ctx, ca, nblocks, (u32)g_bits, max_line, mst[3], gplan))) return rc;
             }
             // (the pass over the exceptions and the framing exceptions are queued behind the chains' launches below: beside the two
             //  counting passes the host waits for they made those take 1.7-1.9 ms instead of 0.3)
@@ -1251,11 +1338,15 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
-            if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;
+            if (gm) { if ((rc = gm_finish(ctx, ca, nrec, max_line, mst[3], gmplan, &gen_on))) return rc; }
+            else if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;
             // (Round 4 measured a generation's chains started as soon as its rows were there, on a stream of their own beside the counting
             //  passes of the generations behind it: 57.4 ms per 10 M genome-sampled reads against 58.8 -- the passes' atomics and the chains'
             //  row gathers wait for the same thing, random 64-byte sectors of tables larger than the caches, and their times add up.)
-            HIPC(hipEventRecord(ctx->ev[16], mst[3])); launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on); HIPC(hipEventRecord(ctx->ev[17], mst[3]));
+            HIPC(hipEventRecord(ctx->ev[16], mst[3]));
+            if (gm && gen_on) launch_gm_code(gmplan.cg, (const u8*)ctx->gm_tok.p, mst[3]);
+            else launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on);
+            HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if (models & SFQ_M_QLT) {
@@ -1502,7 +1593,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u)); put(nchains);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u) | ((gm && gen_on) ? 32u : 0u) /* bases: the match model */);
+        if (gm && gen_on) put(gmplan.tb);
+        put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
         if (chn_on_device) {           // the lists as the device wrote them
             const u64* info = (const u64*)h_csz;
@@ -1765,7 +1858,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     ht.mark("blocks checked");
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
-    u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0;
+    u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0, gm_on = 0, gm_tb = 0;
     bool exc_rice = false;
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
@@ -1784,7 +1877,13 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         const bool deltas = ((u32)v >> 2) & 1u;              // sizes as zigzag differences to the entry before (round 4; version-8 archives of round 3: plain)
         const bool segs = ((u32)v >> 3) & 1u;                // chains are segments of one record (long reads): their length and the blocks' shares follow
         exc_rice = ((u32)v >> 4) & 1u;                       // the base exceptions are Rice-coded gap lists (exc.hip; round 4)
-        if (v >> 5) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        gm_on = ((u32)v >> 5) & 1u;                          // the bases are coded under the match model (gm.hip; round 5): the index's bits follow
+        if (v >> 6) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        if (gm_on) {
+            u64 t = 0;
+            if (!gen_on || !exc_rice || !get_v(cb, cn, cp, t) || t < 8 || t > 26) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: match model)");
+            gm_tb = (u32)t;
+        }
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
         cpb = (block_reads + chain_reads - 1) / chain_reads;
@@ -1969,6 +2068,13 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         if (p.kernel == 0 && !has_over) launch_usr_decode_w(da, st, usr_prefilled); else launch_usr_decode_l(da, st, usr_prefilled);
     }
+    if (gm_on) {
+        // the match model's stage: a '\n' behind every base line (gm.hip) -- soff[r] = (bases before r) + r
+        if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
+        launch_scan_u32(da.slen, (u64*)ctx->gm_boff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+        launch_gm_soff((const u64*)ctx->gm_boff.p, nrec, (u64*)ctx->soff.p, st);
+        da.boff = (const u64*)ctx->gm_boff.p;
+    } else
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
     u64 tot_s = 0, tot_q = 0;
@@ -1986,9 +2092,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // (a damaged usr stream can claim any lengths: what cannot fit the caller's buffer is refused before anything is decoded)
     if (tot_s > out_cap || tot_q > out_cap) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
                                                            (unsigned long long)tot_s, (unsigned long long)tot_q, (unsigned long long)out_cap);
-    if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 16))) return rc;
+    if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 64))) return rc;          // (gm.hip's windows read sixteen bytes at any place up to tot_s)
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
+    if (gm_on) launch_gm_sentinels(da.seq_stage, da.soff, da.slen, nrec, st);
 
     ht.mark("head queued");
     if (lists_pending) {                                  // frozen tables: the chain lists, then their copies to the device
@@ -2066,6 +2173,16 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         ca.st_buf = da.seq_stage; ca.st_bytes = tot_s; ca.st_off = da.soff; ca.st_len = da.slen;
         u32 bound[GEN_MAX_GENERATIONS + 1];
         const u32 ngen = gen_bounds(nblocks, bound);
+        if (gm_on) {
+            // the match model: generation by generation, each indexed behind its chains (gm.hip)
+            if (ngen < 3) return fail(ctx, SFQ_E_CORRUPT, "chain index: the match model on a call of %u generations", ngen);
+            if ((rc = reserve(ctx, ctx->gm_T, (size_t)8 << gm_tb))) return rc;
+            HIPC(hipMemsetAsync(ctx->gm_T.p, 0xFF, (size_t)8 << gm_tb, st_gen));
+            for (u32 g = 0; g < ngen; g++) {
+                launch_gm_decode_c(ca, da, chain0_of(bound[g]), chain0_of(bound[g + 1]), (u64)bound[g] * block_reads, (const u64*)ctx->gm_T.p, gm_tb, tot_s, st_gen);
+                if (g + 1 < ngen) launch_gm_insert(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * block_reads, dec_max_line, (u64*)ctx->gm_T.p, gm_tb, st_gen);
+            }
+        } else
         if (!gen_on || ngen < 3) launch_gen_decode_c(ca, da, 0, nchains, st_gen);
         else {
             const u64 nctx = 1ull << g_bits;

@@ -147,6 +147,12 @@ struct LaneEncB {
         range ^= (range ^ (r * freq)) & vm;
         renorm();
     }
+    __device__ __forceinline__ void encode_bits_if(u32 vm, u32 cum, u32 freq, u32 bits) {       // a row that totals 2^bits
+        const u32 r = range >> bits;
+        low += (u64)(cum & vm) * r;
+        range ^= (range ^ (r * freq)) & vm;
+        renorm();
+    }
     __device__ __forceinline__ void encode(u32 cum, u32 freq, u32 tot, u32 recip) {
         u32 r = __umulhi(range, recip);
         r += (range - r * tot) >= tot ? 1u : 0u;
@@ -286,6 +292,128 @@ struct LaneDec {
             if ((low ^ (low + range)) >> 56) range = (((u32)low | (RC_TOP - 1)) - (u32)low);
             code = (code << 8) | get();
             range <<= 8; low <<= 8;
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+};
+
+// The quality / base decoders' lean coder (round 4; chains.hip k_qlt_decode_c has the account of what a symbol costs)
+// floor(code / r), 256 <= r < 65536: the estimate is within one of the quotient (relative error of the conversion, the
+// reciprocal and the product: 2^-22; quotient < 2^24), the remainder says which way
+__device__ __forceinline__ u32 div_exact(u32 code, u32 r) {
+    u32 q = (u32)((float)code * __builtin_amdgcn_rcpf((float)r));
+    const i32 rem = (i32)(code - q * r);                    // (modulo 2^32: |code - q r| < 2 r)
+    q -= rem < 0 ? 1u : 0u;
+    q += rem >= (i32)r ? 1u : 0u;
+    return q;
+}
+struct LaneDecQ {
+    u64 low; u32 code, range;
+    u64 cur; u32 nxt, nsh;      // stream bytes ahead: `have` of them in cur (the next one in its low byte), then the dword nxt >> nsh
+    u32 have, fpos;             // fpos: the stream position behind nxt's bytes
+    const u8* p; u32 n, nsafe; u32 err;
+    // Four stream bytes from position at, zeros past the end (FilerLoad::get returns 0 there, filer.hpp:94-97): no branch and ONE
+    // load that nothing touches until the bytes are wanted -- the address is held inside the stream (nsafe = n - 4), and what
+    // then lies before `at` is shifted out (by sh bits) where the dword is USED.  (Two paths -- a dword where it fits, bytes at the
+    // tail -- or the shift next to the load made the wave wait for the load where it was issued: a round trip to L2 on every symbol.)
+    __device__ __forceinline__ void load4(u32 at, u32& raw, u32& sh) const {
+        const u32 at_c = at < nsafe ? at : nsafe;
+        const u32 ov = at - at_c;
+        raw = *reinterpret_cast<const u32*>(p + at_c);                               // (no alignment needed on gfx9)
+        sh = 8u * (ov < 4u ? ov : 4u);
+    }
+    static __device__ __forceinline__ u32 take(u32 raw, u32 sh) { return (u32)((u64)raw >> sh); }
+    __device__ __forceinline__ void init(const u8* ptr, u32 len, const u8* spare /* four readable bytes somewhere */) {
+        p = ptr; n = len; err = 0; low = 0; range = 0xFFFFFFFFu;
+        u32 w0, w1;
+        if (len >= 4) {
+            nsafe = len - 4;
+            u32 r0, s0, r1, s1;
+            load4(0, r0, s0); load4(4, r1, s1); load4(8, nxt, nsh);
+            w0 = take(r0, s0); w1 = take(r1, s1);
+        } else {                                             // a stream of under four bytes: taken whole, nothing of it is loaded later
+            w0 = 0;
+            for (u32 i = 0; i < len; i++) w0 |= (u32)ptr[i] << (8 * i);
+            w1 = 0; p = spare; n = 0; nsafe = 0; nxt = 0; nsh = 32;        // (load4(at >= 4) of this: zeros)
+        }
+        code = __builtin_bswap32(w0);                        // the four elided zero bytes, then four real ones (dev_chain.h)
+        cur = (u64)w1; have = 4; fpos = 12;
+    }
+    // at least four bytes in cur: once per coded symbol, ahead of its (at most two, see renorm) masked steps
+    __device__ __forceinline__ void top_up() {
+        if (__any(have <= 4u)) {
+            if (have <= 4u) {
+                cur |= (u64)take(nxt, nsh) << (8u * have);
+                have += 4u;
+                load4(fpos, nxt, nsh); fpos += 4u;
+            }
+        }
+    }
+    __device__ __forceinline__ void step() {                 // one round of coder.hpp:93-100, where range < TOP
+        const u32 nm = range < RC_TOP ? ~0u : 0u;
+        const u32 lo = (u32)low, hi = (u32)(low >> 32);
+        // coder.hpp:94-95: [low, low + range) crosses a multiple of 2^56 -- with range < 2^24 only where bits 24..55 of low are all
+        // ones: a cheap necessary test for the whole wavefront, the exact one behind it
+        if (__any((hi | 0xFF000000u) == 0xFFFFFFFFu)) {
+            const u32 thi = (u32)((low + range) >> 32);
+            const u32 sm = ((thi ^ hi) >> 24) ? ~0u : 0u;
+            range ^= (range ^ (~lo & (RC_TOP - 1))) & (nm & sm);
+        }
+        const u32 sh = 8u & nm;
+        code = (code << sh) | ((u32)cur & 0xffu & nm);
+        range <<= sh; low <<= sh; cur >>= sh;
+        have -= nm & 1u;
+    }
+    __device__ __forceinline__ void renorm() {
+        step(); step();
+        int guard = 0;
+#pragma nounroll
+        while (__any(range < RC_TOP)) {                      // rare: a symbol of probability below 2^-16
+            top_up();
+            step();
+            if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
+        }
+    }
+    // coder.hpp:83-86 for a row that totals 2^16; r = range >> 16 stays in `range`'s place until decode()
+    __device__ __forceinline__ u32 get_freq16(u32& r) {
+        r = range >> 16;
+        const u32 q = div_exact(code, r);
+        if (q > 0xFFFFu) err = 1;                            // (code >= range: not a stream an encoder wrote)
+        return q;
+    }
+    // the same for a row that totals 2^bits (bits <= 16)
+    __device__ __forceinline__ u32 get_freq_bits(u32 bits, u32& r) {
+        r = range >> bits;
+        const u32 q = div_exact(code, r);
+        if (q >> bits) err = 1;
+        return q & ((1u << bits) - 1u);
+    }
+    // coder.hpp:83-86 for any total: range / tot as a multiply-high by recip = floor(2^32 / tot) plus one exact fix-up (dev_chain.h)
+    __device__ __forceinline__ u32 get_freq(u32 tot, u32 recip, u32& r) {
+        r = __umulhi(range, recip);
+        r += (range - r * tot) >= tot ? 1u : 0u;
+        const u32 q = div_exact(code, r);                    // (quotient < tot + 1: far inside div_exact's reach; r >= 2^24 / 1020)
+        if (q >= tot) err = 1;
+        return q;
+    }
+    // coder.hpp:88-102
+    __device__ __forceinline__ void decode(u32 r, u32 cum, u32 freq) {
+        const u32 temp = cum * r;
+        low += temp; code -= temp;
+        range = r * freq;
+        renorm();
+    }
+    // the same where one step nearly always does (a base of a flat row: a quarter of the range, a byte every four bases)
+    __device__ __forceinline__ void decode1(u32 r, u32 cum, u32 freq) {
+        const u32 temp = cum * r;
+        low += temp; code -= temp;
+        range = r * freq;
+        step();
+        int guard = 0;
+#pragma nounroll
+        while (__any(range < RC_TOP)) {
+            top_up();
+            step();
             if (++guard > 12) { err = 1; range = 0xFFFFFFFFu; break; }
         }
     }

@@ -33,14 +33,18 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_r(DecodeArgs a, u32 nbloc
     r_lc.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_LC], (u32)d->size[SFQ_S_GEN_LC]);
     const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
     u8* const g = a.seq_stage + a.soff[d->rec0];
-    const u64 nb = a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
+    // (the match model's stage -- gm.hip -- keeps a '\n' behind every line: a list's positions count BASES, so the record a position
+    //  lies in is followed along, the lists being ascending, and one byte per record before it added)
+    const u64* const bo = a.boff ? a.boff + d->rec0 : nullptr;
+    const u64 b0 = bo ? bo[0] : 0;
+    const u64 nb = bo ? bo[d->nrec] - b0 : a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
     u32 bad = 0;
-    u64 at = 0;
-    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1] = (u8)n_byte; }
-    at = 0;
-    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1] |= 0x80u; }
-    at = 0;
-    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1] |= 0x20u; }
+    u64 at = 0; u32 k = 0;
+    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] = (u8)n_byte; }
+    at = 0; k = 0;
+    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] |= 0x80u; }
+    at = 0; k = 0;
+    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] |= 0x20u; }
     if (bad | r_ns.err | r_nn.err | r_lc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_gen_exc_decode_r(const DecodeArgs& a, u32 nblocks, hipStream_t st) {

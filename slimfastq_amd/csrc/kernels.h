@@ -37,6 +37,7 @@ struct DecodeArgs {
     u32* slen; u32* qlen;                   // per record (device), filled by the usr kernel
     u8*  pfg;  u8* pfq;                     // per record solid prefixes
     const u64* soff; const u64* qoff;       // exclusive scans of slen/qlen
+    const u64* boff;                        // match model (gm.hip): soff[r] = boff[r] + r -- a '\n' behind every staged base line; null: soff is the plain scan
     u8*  seq_stage; u8* qual_stage;         // decoded bases / qualities
     u8*  hdr_stage; u32* hlen;              // decoded headers, back to back per block
     const u64* hdr_stage_off;               // per block base into hdr_stage
@@ -97,6 +98,19 @@ void launch_gen_count(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
                       u32* cnt, const u32* rows, const u16* log2fp, u64* cost, hipStream_t st,
                       u32 sub = 0 /* 0 every selected record, 1 every GEN_PRE-th of them, 2 the others */, u32 do_count = 1 /* 0: the cost only */);
 void launch_gen_rows(const u32* cnt, u32* rows, u64 nctx, u32 step, hipStream_t st);
+// ---- bases under the generation MATCH model (gm.hip, round 5) ----
+void launch_gm_lens(const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 n, u32* slen, hipStream_t st);       // base-line lengths of records [0, n)
+void launch_gm_soff(const u64* boff, u64 n, u64* soff, hipStream_t st);                                                       // soff[r] = boff[r] + r, r in [0, n]
+void launch_gm_sentinels(u8* stage, const u64* soff, const u32* slen, u64 n, hipStream_t st);
+void launch_gm_stage(const ModelArgs& m, u32 block_reads, u64 r0, u64 r1, u64 nbytes /* of the text */, u8* stage, const u64* soff, const u32* slen, u8* exc_flag /* or null */, hipStream_t st);
+// (a: ChainArgs whose st_buf / st_off / st_len describe the stage)
+void launch_gm_insert(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u64* T, u32 tb, hipStream_t st);
+void launch_gm_plan(const ChainArgs& a, u64 nlanes /* records, or chains where they are segments */, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen,
+                    const u64* T, u32 tb, u8* tok, hipStream_t st);
+void launch_gm_price(const ChainArgs& a, u64 r0, u64 r1, u64 step, u64 lim_rec, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb,
+                     const u16* costs /* hit[4], miss[4] in 1/1024 bit */, u64* cost /* [0] += cost, [1] += bases */, hipStream_t st);
+void launch_gm_code(const ChainArgs& a, const u8* tok, hipStream_t st);
+void launch_gm_decode_c(const ChainArgs& a, const struct DecodeArgs& da, u32 c0, u32 c1, u64 lim_rec, const u64* T, u32 tb, u64 stage_bytes, hipStream_t st);
 // the same counts through bins (chains.hip "counting through bins": two streaming passes instead of a global atomic per base);
 // rows_out != null: the rows of the sums are written as well (launch_gen_rows folded in).  bins / fill: scratch, fill zeroed by the caller
 #define GEN_BIN_BATCH (1ull << 27)      /* keys a pair of passes takes at most (the bins hold twice that, 2 bytes a key) */

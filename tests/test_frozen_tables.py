@@ -21,6 +21,26 @@ def rec_sample(nrec, max_hdr=0):
     return max(run, nrec // nruns), run, nruns
 
 
+def gm_table_bits(nbytes):
+    tb = 16                                       # api.cpp gm_table_bits: an entry per eight bases of the call, 2^16 .. 2^24 entries
+    while tb < 24 and (1 << tb) < nbytes // 16:
+        tb += 1
+    return tb
+
+
+def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None):
+    """The base chains as the oracle's restatement of the generation MATCH model (gm.hip; sfq_oracle.c sfqo_gm_*) writes them, and
+    its verdict; "chn.idx" must say the same (flag bit 0: the model is on; bit 5 + the index's bits: it is the match model)."""
+    tb = gm_table_bits(len(fq))
+    if seg:
+        want, sizes, on = O.gm_encode_segs(fq, goff, glen, other, tb, br, seg)
+    else:
+        want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, cr)
+    assert (ci["flags"] & 1) == on and bool(ci["flags"] & 32) == bool(on)
+    assert not on or ci["gm_table_bits"] == tb
+    return want, sizes, on
+
+
 def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     enc = ctx.encode_host(fq, level=level, block_reads=br, prior_step=step, tables=capi.TABLES_FROZEN, chain_reads=cr)
     starts, lens = util.line_table(fq)
@@ -39,8 +59,7 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     assert sum(b.extra_hi for b in enc.blocks) == extra
     # bases: generation tables
     goff, glen = starts[1::4] + solid, lens[1::4] - solid
-    want, sizes, on = O.gen_encode_chains(fq, goff, glen, enc.blocks[0].gen_bits, br, got_cr, GEN_STEP)
-    assert (flags & 1) == on, what
+    want, sizes, on = base_chains_oracle(fq, goff, glen, ci, br, got_cr)
     assert list(gsz) == list(sizes), what
     assert enc.stream("gen") == want, what
     # headers: counted sample -> "rec.pri" -> frozen rows -> one chain per block
@@ -94,6 +113,39 @@ def test_base_exceptions_in_the_references_own_coding_on_request(ctx):
     assert ctx.decode_host(new, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def _folded_genome_reads(n=60000, seed=5):
+    """Reads of a tiny genome (300 reads of a 10 Mbp one, rotated): enough coverage at test size for the base model to pay."""
+    fq = capi.synth_fastq(n, 150, seed=seed, kind=3)
+    lines = fq.split(b"\n")[:-1]
+    reads = [lines[i + 1] for i in range(0, len(lines), 4)][:300]
+    rng = np.random.default_rng(3)
+    out = []
+    for i in range(0, len(lines), 4):
+        src = reads[rng.integers(len(reads))]
+        k = int(rng.integers(0, 40))
+        out += [lines[i], src[k:] + src[:k], lines[i + 2], lines[i + 3]]
+    return b"\n".join(out) + b"\n"
+
+
+def test_round_4_generation_tables_are_still_written_on_request_and_read(ctx):
+    """sfq_params.kernel = 2 also keeps round 4's base model -- generation tables of Base2 rows, counted per generation (through the
+    LDS bins of round 5: the same counts) -- so that what archives of rounds 2-4 hold can still be produced and is still read:
+    the chains against the oracle's restatement of THAT rule, "chn.idx" without flag bit 5, and the way back."""
+    fq = _folded_genome_reads()
+    br, cr = 128, 32
+    old = ctx.encode_host(fq, level=3, block_reads=br, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=cr, kernel=2)
+    ci = util.unpack_chains(old.chains)
+    assert ci["flags"] & 1 and not ci["flags"] & 32
+    starts, lens = util.line_table(fq)
+    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], old.blocks[0].gen_bits, br, cr, GEN_STEP)
+    assert on == 1 and list(ci["gen"]) == list(sizes) and old.stream("gen") == want
+    assert ctx.decode_host(old, level=3, out_cap=len(fq) + 4096) == fq
+    new = ctx.encode_host(fq, level=3, block_reads=br, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    assert util.unpack_chains(new.chains)["flags"] & 32
+    # (which of the two is smaller here says nothing: these reads start at 12 000 distinct places, so the table knows even a read's
+    #  first bases; reads that start anywhere -- tests/test_gpu_parity.py's ratio test, bench.py's genome leg -- are the comparison)
+
+
 @pytest.mark.parametrize("level", (1, 2, 3, 4))
 def test_frozen_streams_equal_oracle_rule_synthetic(ctx, level):
     fq = capi.synth_fastq(7000, 150, seed=70 + level)
@@ -117,17 +169,7 @@ def test_frozen_generation_tables_switch_on_for_genome_like_bases(ctx):
     """Reads sampled from a small genome: generation 1 is cheaper under generation 0's rows, the tables switch on, and the
     base stream gets well below 2 bits per base; iid bases leave them off."""
     fq = capi.synth_fastq(60000, 150, seed=5, kind=3)
-    # kind 3 samples a 10 Mbp genome: too thin at this size -- fold the reads onto a tiny genome by reusing few reads
-    lines = fq.split(b"\n")[:-1]
-    reads = [lines[i + 1] for i in range(0, len(lines), 4)][:300]
-    rng = np.random.default_rng(3)
-    out = []
-    for i in range(0, len(lines), 4):
-        src = reads[rng.integers(len(reads))]
-        k = int(rng.integers(0, 40))
-        seq = (src[k:] + src[:k])
-        out += [lines[i], seq, lines[i + 2], lines[i + 3]]
-    fq2 = b"\n".join(out) + b"\n"
+    fq2 = _folded_genome_reads()
     enc = check_against_oracle(ctx, fq2, 3, br=128, cr=32, step=1, what="genome-like")
     ci = util.unpack_chains(enc.chains)
     assert ci["flags"] & 1
@@ -155,7 +197,7 @@ def test_frozen_big_generations_are_counted_through_every_nth_record(ctx):
     bound.append(nblocks)
     assert max((bound[g + 1] - bound[g]) * br for g in range(len(bound) - 2)) > 524288        # a counted generation over the cap
     starts, lens = util.line_table(fq)
-    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    want, sizes, on = base_chains_oracle(fq, starts[1::4], lens[1::4], ci, br, cr)
     assert on == 1
     assert list(ci["gen"]) == list(sizes)
     assert enc.stream("gen") == want
@@ -173,7 +215,7 @@ def test_frozen_pre_verdict_leaves_the_tables_off_for_bases_that_cannot_be_learn
     enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=cr)
     ci = util.unpack_chains(enc.chains)
     starts, lens = util.line_table(fq)
-    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    want, sizes, on = base_chains_oracle(fq, starts[1::4], lens[1::4], ci, br, cr)
     assert on == 0 and not (ci["flags"] & 1)
     assert list(ci["gen"]) == list(sizes)
     assert enc.stream("gen") == want
@@ -189,7 +231,7 @@ def test_frozen_counting_passes_take_long_lines_a_stretch_per_lane(ctx):
     ci = util.unpack_chains(enc.chains)
     starts, lens = util.line_table(fq)
     assert int(lens[1::4].max()) > 1024
-    want, sizes, on = O.gen_encode_chains(fq, starts[1::4], lens[1::4], enc.blocks[0].gen_bits, br, cr, GEN_STEP)
+    want, sizes, on = base_chains_oracle(fq, starts[1::4], lens[1::4], ci, br, cr)
     assert on == 1 and (ci["flags"] & 1)
     assert list(ci["gen"]) == list(sizes)
     assert enc.stream("gen") == want
@@ -519,8 +561,8 @@ def test_long_records_are_cut_into_segments(ctx, seg, br, qdiff):
     rows66 = O.qlt_prior_rows(O.qlt_histogram(fq, qoff, np.minimum(qlen, PRIOR_SYMBOLS), 3, 0, 1))
     want, sizes, extra = O.qlt_encode_segs(fq, qoff, qlen, glen, 3, seg, O.qlt_frozen_rows(rows66))
     assert list(ci["qlt"]) == list(sizes) and enc.stream("qlt") == want
-    want, sizes, on = O.gen_encode_segs(fq, goff, glen, qlen, enc.blocks[0].gen_bits, br, seg, GEN_STEP)
-    assert (ci["flags"] & 1) == on and list(ci["gen"]) == list(sizes) and enc.stream("gen") == want
+    want, sizes, on = base_chains_oracle(fq, goff, glen, ci, br, 1, seg, qlen)
+    assert list(ci["gen"]) == list(sizes) and enc.stream("gen") == want
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
     # the index is untrusted: a block's share that disagrees with its records' line lengths is refused
     bad = enc.clone()

@@ -109,11 +109,15 @@ def unpack_chains(blob: bytes, nblocks=None):
     """"chn.idx" -> dict(chain_reads, flags, qlt, gen [, seg_len, seg_blocks] [, rec_chain_reads, rec, rec_hdr_bytes]); mirrors api.cpp.
     flags bit 2: every list of sizes is stored as zigzag differences to the entry before it; bit 3: the chains are SEGMENTS of one
     record -- their length and every block's number of chains follow the chain count (nblocks must be given); bit 4: the base
-    exceptions are Rice-coded gap lists (exc.hip)."""
+    exceptions are Rice-coded gap lists (exc.hip); bit 5: the bases are coded under the generation match model (gm.hip), the bits of its index
+    follow the flags."""
     v = _vints(blob)
-    cr, flags, n = v[0], v[1], v[2]
-    p = 3
+    cr, flags = v[0], v[1]
+    p = 2
     out = {"chain_reads": cr, "flags": flags}
+    if flags & 32:                                   # bit 5: the bases are coded under the match model (gm.hip): the index's bits
+        out["gm_table_bits"] = v[p]; p += 1
+    n = v[p]; p += 1
     if flags & 8:
         assert nblocks is not None
         out["seg_len"] = v[p]; out["seg_blocks"] = v[p + 1:p + 1 + nblocks]; p += 1 + nblocks
