@@ -99,7 +99,7 @@ struct sfq_ctx {
     // quality warm start
     DevBuf hist, rows66, ptmp, prior_w, prior_wovf, prior_ls, prior_lh, tickets;
     // frozen tables (sfq_params.tables = SFQ_TABLES_FROZEN): dense quality rows, chain sizes, generation tables of the bases
-    DevBuf gm_T, gm_slen, gm_boff, gm_soff, gm_scan, gm_stage, gm_tok;     // bases under the match model (gm.hip): index, stage, tokens
+    DevBuf gm_T, gm_slen, gm_boff, gm_soff, gm_scan, gm_stage, gm_tok, gm_csz, gm_idx;     // bases under the match model (gm.hip): index, stage, tokens
     DevBuf qrows, qdec, qesc, qw, csz, coff, gcnt, grows, glog, gcost, gbins, gfill, hcnt, hfreq, rrows, rdec, rmap, rflags, rtok, excf, cflags;
     DevBuf chn_len, chn_off, chn_out;      // "chn.idx": the size lists as bytes (chains.hip launch_chain_index_bytes)
     DevBuf pslot, plist;                   // the quality prior's listed rows, back to back (prior.hip launch_prior_list)
@@ -664,7 +664,7 @@ u32 gm_table_bits(u64 nbytes) {          // an entry per eight bases of the call
     while (tb < 24 && (1ull << tb) < nbytes / 16) tb++;
     return tb;
 }
-struct GmPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; u32 tb = 0; u64 cap = 0; u64 r2 = 0; ChainArgs cg; };
+struct GmPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; u32 tb = 0; u64 cap = 0; u64 r2 = 0; ChainArgs cg; ChainGeoArgs ggeo; u32* gcsz = nullptr; };
 // the stage of records [0, n): line lengths, their scan, the places, the letters
 int gm_stage_upto(sfq_ctx* ctx, const ChainArgs& ca, u64 n, u64 from, hipStream_t st) {
     launch_gm_lens(ca.m.line_off, ca.m.blocks, ca.block_reads, n, (u32*)ctx->gm_slen.p, st);
@@ -726,7 +726,8 @@ int gm_finish(sfq_ctx* ctx, ChainArgs& ca, u64 nrec, u32 max_line, hipStream_t s
     const u64 br = ca.block_reads;
     auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };
     for (u32 g = 1; g + 1 < ngen; g++) launch_gm_insert(gp.cg, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u64*)ctx->gm_T.p, gp.tb, st);
-    gp.cg.m = ca.m; gp.cg.csz = ca.csz;
+    gp.cg.m = ca.m; gp.cg.csz = gp.gcsz ? gp.gcsz : ca.csz;
+    gp.cg.geo = gp.ggeo;                                           // (the base chains' own geometry: api.cpp sfq_encode_blocks)
     gp.cg.g_ngen = ngen;
     for (u32 g = 0; g <= ngen; g++) gp.cg.g_bound[g] = bound[g];
     launch_gm_plan(gp.cg, ca.seg_len ? (u64)ca.geo.nchains : nrec, (const u8*)ctx->gm_stage.p, gp.cap, (const u64*)ctx->gm_soff.p, (const u32*)ctx->gm_slen.p,
@@ -811,7 +812,7 @@ void sfq_ctx_destroy(sfq_ctx* ctx) {
         &ctx->slen, &ctx->qlen, &ctx->pfg, &ctx->pfq, &ctx->soff, &ctx->qoff, &ctx->seq_stage, &ctx->qual_stage,
         &ctx->hdr_stage, &ctx->hlen, &ctx->hoff, &ctx->hso, &ctx->hsc, &ctx->rsize, &ctx->roff, &ctx->d_first,
         &ctx->hist, &ctx->rows66, &ctx->prior_w, &ctx->prior_wovf, &ctx->prior_ls, &ctx->prior_lh, &ctx->tickets,
-        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->gbins, &ctx->gfill, &ctx->gm_T, &ctx->gm_slen, &ctx->gm_boff, &ctx->gm_soff, &ctx->gm_scan, &ctx->gm_stage, &ctx->gm_tok, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
+        &ctx->hcnt, &ctx->hfreq, &ctx->rrows, &ctx->rdec, &ctx->rmap, &ctx->rflags, &ctx->rtok, &ctx->ptmp, &ctx->qrows, &ctx->qdec, &ctx->qesc, &ctx->qw, &ctx->csz, &ctx->coff, &ctx->gcnt, &ctx->grows, &ctx->glog, &ctx->gcost, &ctx->gbins, &ctx->gfill, &ctx->gm_T, &ctx->gm_slen, &ctx->gm_boff, &ctx->gm_soff, &ctx->gm_scan, &ctx->gm_stage, &ctx->gm_tok, &ctx->gm_csz, &ctx->gm_idx, &ctx->excf, &ctx->cflags, &ctx->segn, &ctx->segoff, &ctx->segrec, &ctx->pslot, &ctx->plist, &ctx->chn_len, &ctx->chn_off, &ctx->chn_out,
         &ctx->oflags, &ctx->okbytes, &ctx->ofpos, &ctx->okoff, &ctx->ofilt, &ctx->orecmap, &ctx->olist, &ctx->line_off_o, &ctx->ono, &ctx->opiece,
         &ctx->otxt[0], &ctx->otxt[1], &ctx->otxt[2], &ctx->osize_all, &ctx->oroff_all, &ctx->oroff_k, &ctx->ocnt };
     for (DevBuf* b : all) release(*b);
@@ -1146,6 +1147,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     memset(&ca, 0, sizeof ca);
     u32 nchains = 0, nsub = 0;
     GenPlan gplan; GmPlan gmplan;
+    ChainGeoArgs ggeo; memset(&ggeo, 0, sizeof ggeo);   // the base chains' geometry: the quality chains', or shorter ones (below)
+    const u32* gen_csz = nullptr;                      // ... and where their sizes are
     const bool gm = frozen && !exc_classic;            // bases: the match model (gm.hip); sfq_params.kernel = 2 keeps round 4's generation tables
     u32 seg_len = 0;                                   // chains that are segments of one record (chains.hip "segments")
     std::vector<u32> seg_blk;                          // ... and how many each block has ("chn.idx")
@@ -1205,6 +1208,26 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         }
         if ((rc = reserve(ctx, ctx->csz, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4))) return rc;
         HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
+        // The base chains of a call that takes the match model (gm.hip) are SHORTER than the quality chains: 4 KiB of text each (the
+        // floor of default_chain_reads).  A decoder walks the generations one after the other and each takes as long as ONE lane needs for
+        // its chain -- 6.6 ms at 49 records whatever the generation's size, seven times over; at 12 records the same call decodes in
+        // 30 ms instead of 60 and is 0.13 % larger (bench.py --kind 3 --chain-reads 12 / 49, profiles/r05g).  Known only with the
+        // verdict: their sizes go to a list of their own.
+        ggeo = ca.geo;
+        if (gm && !seg_len) {
+            const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
+            const u32 gfloor = (u32)std::min<u64>((4096 + per_rec - 1) / per_rec, ca.geo.chain_reads);
+            ggeo.cpb = (block_reads + gfloor - 1) / gfloor;
+            ggeo.chain_reads = std::max<u32>(1u, (u32)((std::min<u64>(block_reads, nrec) + ggeo.cpb - 1) / ggeo.cpb));
+            ggeo.cpb = (block_reads + ggeo.chain_reads - 1) / ggeo.chain_reads;
+            const u64 ngc = (u64)(nblocks - 1) * ggeo.cpb + (last_nrec + ggeo.chain_reads - 1) / ggeo.chain_reads;
+            if (ngc > 0x7FFFFFFFull || ggeo.chain_reads >= ca.geo.chain_reads) ggeo = ca.geo;
+            else {
+                ggeo.nchains = (u32)ngc;
+                if ((rc = reserve(ctx, ctx->gm_csz, (size_t)ggeo.nchains * 4))) return rc;
+                HIPC(hipMemsetAsync(ctx->gm_csz.p, 0, (size_t)ggeo.nchains * 4, st));
+            }
+        }
         if ((rc = reserve_pinned(ctx, PIN_BYTES + (size_t)q_rows * 66 * 4))) return rc;
         if ((rc = setup_tables())) return rc;
         // the pass over the N / quality-0 / case exceptions looks only at the records the framing has marked (frame.hip
@@ -1338,8 +1361,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
         if (models & SFQ_M_GEN) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p + nchains;
-            if (gm) { if ((rc = gm_finish(ctx, ca, nrec, max_line, mst[3], gmplan, &gen_on))) return rc; }
+            if (gm) {
+                gmplan.ggeo = ggeo; gmplan.gcsz = ggeo.nchains != ca.geo.nchains ? (u32*)ctx->gm_csz.p : nullptr;
+                if ((rc = gm_finish(ctx, ca, nrec, max_line, mst[3], gmplan, &gen_on))) return rc;
+                if (!gen_on) ggeo = ca.geo;                  // (no match model: the base chains are the quality chains' records)
+            }
             else if ((rc = gen_tables_finish(ctx, ca, (u32)g_bits, max_line, mst[3], gplan, &gen_on))) return rc;
+            gen_csz = (gm && gen_on && ggeo.nchains != ca.geo.nchains) ? (const u32*)ctx->gm_csz.p : (const u32*)ctx->csz.p + nchains;
             // (Round 4 measured a generation's chains started as soon as its rows were there, on a stream of their own beside the counting
             //  passes of the generations behind it: 57.4 ms per 10 M genome-sampled reads against 58.8 -- the passes' atomics and the chains'
             //  row gathers wait for the same thing, random 64-byte sectors of tables larger than the caches, and their times add up.)
@@ -1432,7 +1460,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (frozen) {
         ca.m = a;
         if (models & SFQ_M_QLT) { launch_chain_block_sizes(ca, ca.geo, SFQ_S_QLT, (const u32*)ctx->csz.p, nullptr, st); chain_streams |= 1u << SFQ_S_QLT; }
-        if (models & SFQ_M_GEN) { launch_chain_block_sizes(ca, ca.geo, SFQ_S_GEN, (const u32*)ctx->csz.p + nchains, nullptr, st); chain_streams |= 1u << SFQ_S_GEN; }
+        if (models & SFQ_M_GEN) { launch_chain_block_sizes(ca, ggeo, SFQ_S_GEN, gen_csz, nullptr, st); chain_streams |= 1u << SFQ_S_GEN; }
         if (models & SFQ_M_REC) {
             const u32* rs = (const u32*)ctx->csz.p + 2 * (size_t)nchains;
             launch_chain_block_sizes(ca, ca.rgeo, SFQ_S_REC, rs, rs + nsub, st); chain_streams |= 1u << SFQ_S_REC;
@@ -1454,7 +1482,19 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     // what comes back to the host at the end lands in page-locked memory: [totals][block descriptors][blob offsets][chain sizes]
     const size_t p2_hb = 128, p2_off = p2_hb + (((size_t)nblocks * sizeof(BlockDesc) + 63) & ~(size_t)63);
     const size_t p2_csz = p2_off + ((((size_t)nblocks + 1) * 8 + 63) & ~(size_t)63);
-    const size_t p2_end = p2_csz + ((size_t)nchains * 2 + (size_t)nsub * 2) * 4 + 64;
+    const u32 ngc = frozen ? ggeo.nchains : 0;             // base chains (the quality chains' number unless the match model cut its own)
+    const bool gsplit = frozen && ngc != nchains;
+    const size_t n_sizes = (size_t)nchains + ngc + (size_t)nsub * 2;
+    const u32* d_sizes = (const u32*)ctx->csz.p;            // the size lists back to back: quality, bases, headers, header bytes
+    if (gsplit) {
+        if ((rc = reserve(ctx, ctx->gm_idx, n_sizes * 4 + 64))) return rc;
+        u32* di = (u32*)ctx->gm_idx.p;
+        HIPC(hipMemcpyAsync(di, ctx->csz.p, (size_t)nchains * 4, hipMemcpyDeviceToDevice, st));
+        HIPC(hipMemcpyAsync(di + nchains, ctx->gm_csz.p, (size_t)ngc * 4, hipMemcpyDeviceToDevice, st));
+        HIPC(hipMemcpyAsync(di + nchains + ngc, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (size_t)nsub * 2 * 4, hipMemcpyDeviceToDevice, st));
+        d_sizes = di;
+    }
+    const size_t p2_end = p2_csz + n_sizes * 4 + 64;
     if ((rc = reserve_pinned_buf(ctx, ctx->pin2, ctx->pin2_cap, p2_end))) return rc;
     u64* totals = (u64*)ctx->pin2;
     HIPC(hipMemcpyAsync(totals, ctx->stream_total.p, SFQ_NSTREAMS * 8, hipMemcpyDeviceToHost, st));
@@ -1480,9 +1520,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs more than %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);
         HIPC(hipMemcpyAsync((u64*)ctx->stream_total.p + SFQ_NSTREAMS, bases, 3 * 8, hipMemcpyHostToDevice, st));
         launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
+        launch_compact_chains(ca, ggeo, SFQ_S_GEN, 3, 4, gen_csz, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
         launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st);
-        HIPC(hipMemcpyAsync(h_csz, ctx->csz.p, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(h_csz, d_sizes, n_sizes * 4, hipMemcpyDeviceToHost, st));
         // the side streams: behind the exception pass and the framing exceptions
         HIPC(hipStreamWaitEvent(st, ctx->ev[12], 0));
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 2], 0));
@@ -1503,23 +1543,23 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             if (chain_streams & (1u << SFQ_S_QLT))
                 launch_compact_chains(ca, ca.geo, SFQ_S_QLT, 2, 1, (const u32*)ctx->csz.p, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
             if (chain_streams & (1u << SFQ_S_GEN))
-                launch_compact_chains(ca, ca.geo, SFQ_S_GEN, 3, 4, (const u32*)ctx->csz.p + nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
+                launch_compact_chains(ca, ggeo, SFQ_S_GEN, 3, 4, gen_csz, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
             if (chain_streams & (1u << SFQ_S_REC))
                 launch_compact_chains(ca, ca.rgeo, SFQ_S_REC, 3, 2, (const u32*)ctx->csz.p + 2 * (size_t)nchains, (const u64*)ctx->blk_stream_off.p, (const u64*)ctx->stream_total.p + SFQ_NSTREAMS, d_out, st, d_gate);
             // "chn.idx": the size lists come back as the bytes the blob holds (chains.hip launch_chain_index_bytes: made from half a
             // million sizes on the host they were 1.0 ms of every call's tail), as far as a guess at their number reaches
             {
                 const bool recl = (chain_streams >> SFQ_S_REC) & 1;
-                chn_n = nchains * 2 + (recl ? nsub * 2 : 0u);
-                const u32 b1 = nchains, b2 = nchains * 2, b3 = recl ? nchains * 2 + nsub : chn_n;
+                chn_n = nchains + ngc + (recl ? nsub * 2 : 0u);
+                const u32 b1 = nchains, b2 = nchains + ngc, b3 = recl ? nchains + ngc + nsub : chn_n;
                 if ((rc = reserve(ctx, ctx->chn_len, (size_t)chn_n * 4 + 16))) return rc;
                 if ((rc = reserve(ctx, ctx->chn_off, ((size_t)chn_n + 4) * 8))) return rc;
                 if ((rc = reserve(ctx, ctx->chn_out, (size_t)chn_n * 5 + 64))) return rc;
                 if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)chn_n / 1024 + 4) * 8 + 65536))) return rc;
                 u64* d_info = (u64*)ctx->chn_off.p + chn_n + 1;
-                launch_chain_index_bytes((const u32*)ctx->csz.p, chn_n, b1, b2 > chn_n ? chn_n : b2, b3, (u32*)ctx->chn_len.p, (u64*)ctx->chn_off.p, (u64*)ctx->scan_tmp.p,
+                launch_chain_index_bytes(d_sizes, chn_n, b1, b2 > chn_n ? chn_n : b2, b3, (u32*)ctx->chn_len.p, (u64*)ctx->chn_off.p, (u64*)ctx->scan_tmp.p,
                                          (u8*)ctx->chn_out.p, d_info, st);
-                chn_eager = std::min<size_t>((size_t)chn_n * 5, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4 + 64 - 16);
+                chn_eager = std::min<size_t>((size_t)chn_n * 5, n_sizes * 4 + 64 - 16);
                 HIPC(hipMemcpyAsync(h_csz, d_info, 16, hipMemcpyDeviceToHost, st));
                 if (chn_eager) HIPC(hipMemcpyAsync((u8*)h_csz + 16, ctx->chn_out.p, chn_eager, hipMemcpyDeviceToHost, st));
                 chn_on_device = true;
@@ -1574,7 +1614,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // (written into a scratch vector that keeps its size from call to call -- growing the blob itself zero-fills 2.5 MB every call --
         //  and copied out at its final size)
         std::vector<u8>& o = ctx->chain_tmp;
-        const size_t o_need = ((size_t)nchains * 2 + (size_t)nsub * 2 + (seg_len ? nblocks : 0)) * 5 + 64;
+        const size_t o_need = ((size_t)nchains + ngc + (size_t)nsub * 2 + (seg_len ? nblocks : 0)) * 5 + 64;
         if (o.size() < o_need) o.resize(o_need);
         u8* w = o.data();
         auto put = [&w](u32 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
@@ -1594,7 +1634,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
         put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u) | ((gm && gen_on) ? 32u : 0u) /* bases: the match model */);
-        if (gm && gen_on) put(gmplan.tb);
+        if (gm && gen_on) { put(gmplan.tb); put(ggeo.chain_reads); put(ngc); }      // (the index's bits; the base chains' records, their number)
         put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
         if (chn_on_device) {           // the lists as the device wrote them
@@ -1613,10 +1653,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             memcpy(w, lb, (size_t)la); w += la;
             if (rec_chains) { put(ca.rgeo.chain_reads); put(nsub); memcpy(w, lb + la, (size_t)(lall - la)); w += lall - la; }
         } else {
-        put_list(h_csz, nchains); put_list(h_csz + nchains, nchains);
+        put_list(h_csz, nchains); put_list(h_csz + nchains, ngc);
         if (rec_chains) {              // header chains: records per chain, their number, stream sizes, header bytes
             put(ca.rgeo.chain_reads); put(nsub);
-            put_list(h_csz + (size_t)2 * nchains, nsub); put_list(h_csz + (size_t)2 * nchains + nsub, nsub);
+            put_list(h_csz + (size_t)nchains + ngc, nsub); put_list(h_csz + (size_t)nchains + ngc + nsub, nsub);
         }
         }
         ctx->chain_blob.assign(o.data(), w);
@@ -1859,6 +1899,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0, gm_on = 0, gm_tb = 0;
+    u32 gchain_reads = 0, gcpb = 0, ngc = 0; u64 gm_ngc = 0;      // the base chains (the quality chains' geometry unless the match model has its own)
     bool exc_rice = false;
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
     std::vector<u32> h_rsz, h_rhb, rec_prior_f;
@@ -1883,6 +1924,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             u64 t = 0;
             if (!gen_on || !exc_rice || !get_v(cb, cn, cp, t) || t < 8 || t > 26) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: match model)");
             gm_tb = (u32)t;
+            // the base chains' own geometry: records per chain (at most the quality chains'), their number
+            u64 gc = 0, gn = 0;
+            if (!get_v(cb, cn, cp, gc) || !get_v(cb, cn, cp, gn) || gc == 0 || gc > chain_reads) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: base chains)");
+            gchain_reads = (u32)gc; gm_ngc = gn;
         }
         if (!get_v(cb, cn, cp, v)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
         if (chain_reads > block_reads) return fail(ctx, SFQ_E_CORRUPT, "chain index: %u records per chain, %u per block", chain_reads, block_reads);
@@ -1907,10 +1952,20 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         }
         if (v != want || want > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu chains, the blocks have %llu", (unsigned long long)v, (unsigned long long)want);
         nchains = (u32)want;
+        gcpb = cpb; ngc = nchains;
+        if (gm_on) {
+            if (segs ? (gchain_reads != 1 || gm_ngc != want) : false) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: base chains of a call in segments)");
+            if (!segs) {
+                gcpb = (block_reads + gchain_reads - 1) / gchain_reads;
+                const u64 wantg = (u64)(nblocks - 1) * gcpb + (last_nrec + gchain_reads - 1) / gchain_reads;
+                if (gm_ngc != wantg || wantg > 0x7FFFFFFFull) return fail(ctx, SFQ_E_CORRUPT, "chain index: %llu base chains, the blocks have %llu", (unsigned long long)gm_ngc, (unsigned long long)wantg);
+                ngc = (u32)wantg;
+            }
+        } else gchain_reads = chain_reads;
         h_csz = bump.take<u32>(cn + 16);
         h_coff = bump.take<u64>(cn + 16);
-        if (!h_csz || !h_coff || (size_t)nchains * 2 > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
-        ncs = (size_t)nchains * 2;
+        if (!h_csz || !h_coff || (size_t)nchains + ngc > cn) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        ncs = (size_t)nchains + ngc;
         // what the call needs besides the streams is checked here, on host state alone, before any device work is queued
         if (ctx->prior_blob.empty()) return fail(ctx, SFQ_E_ARG, "frozen tables need the quality prior (qlt.pri)");
         if (rec_chains) {
@@ -1944,12 +1999,13 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         };
         for (int k = 0; k < 2; k++) {
             const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
+            const u32 kn = k ? ngc : nchains, kcpb = k ? gcpb : cpb;
             u32* const sz = h_csz + (size_t)k * nchains; u64* const off = h_coff + (size_t)k * nchains;
-            if (!read_sizes(cb, cn, cp, deltas, sz, nchains)) { lists_err = "bad chain index (chn.idx)"; return SFQ_E_CORRUPT; }
+            if (!read_sizes(cb, cn, cp, deltas, sz, kn)) { lists_err = "bad chain index (chn.idx)"; return SFQ_E_CORRUPT; }
             u64 at = stream_offset[sid];
             for (u32 b = 0; b < nblocks; b++) {
                 u64 sum = 0;
-                const u64 bc0 = seg_len ? seg_c0[b] : (u64)b * cpb, bc1 = seg_len ? seg_c0[b + 1] : std::min<u64>(bc0 + cpb, nchains);
+                const u64 bc0 = seg_len ? seg_c0[b] : (u64)b * kcpb, bc1 = seg_len ? seg_c0[b + 1] : std::min<u64>(bc0 + kcpb, kn);
                 for (u64 cc = bc0; cc < bc1; cc++) { off[cc] = at + sum; sum += sz[cc]; }
                 at += sum;
                 if (sum != h_blocks[b].size[sid]) { char m[160]; snprintf(m, sizeof m, "chain index: block %u's chains do not add up to its %s stream", b, sfq_stream_name(sid)); lists_err = m; return SFQ_E_CORRUPT; }
@@ -2178,8 +2234,10 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if (ngen < 3) return fail(ctx, SFQ_E_CORRUPT, "chain index: the match model on a call of %u generations", ngen);
             if ((rc = reserve(ctx, ctx->gm_T, (size_t)8 << gm_tb))) return rc;
             HIPC(hipMemsetAsync(ctx->gm_T.p, 0xFF, (size_t)8 << gm_tb, st_gen));
+            ca.geo.chain_reads = gchain_reads; ca.geo.cpb = gcpb; ca.geo.nchains = ngc;        // (the base chains' own geometry; nothing behind this reads the quality chains')
+            auto gchain0_of = [&](u32 b) -> u32 { return seg_len ? seg_c0[b] : (u32)std::min<u64>((u64)b * gcpb, ngc); };
             for (u32 g = 0; g < ngen; g++) {
-                launch_gm_decode_c(ca, da, chain0_of(bound[g]), chain0_of(bound[g + 1]), (u64)bound[g] * block_reads, (const u64*)ctx->gm_T.p, gm_tb, tot_s, st_gen);
+                launch_gm_decode_c(ca, da, gchain0_of(bound[g]), gchain0_of(bound[g + 1]), (u64)bound[g] * block_reads, (const u64*)ctx->gm_T.p, gm_tb, tot_s, st_gen);
                 if (g + 1 < ngen) launch_gm_insert(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * block_reads, dec_max_line, (u64*)ctx->gm_T.p, gm_tb, st_gen);
             }
         } else
@@ -2275,7 +2333,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             ChainArgs cr; memset(&cr, 0, sizeof cr);
             cr.m = da.m; cr.rrows = (const u32*)ctx->rrows.p; cr.rdec = (const u16*)ctx->rdec.p;
             cr.rgeo.chain_reads = rchain_reads; cr.rgeo.cpb = rcpb; cr.rgeo.nchains = nsub;
-            cr.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; cr.coff = (const u64*)ctx->coff.p + 2 * (size_t)nchains;
+            cr.csz = (u32*)ctx->csz.p + (size_t)nchains + ngc; cr.coff = (const u64*)ctx->coff.p + (size_t)nchains + ngc;
             cr.rmap = (const u16*)ctx->rmap.p; cr.rhot = cr.rmap + PR_REC_ROWS; cr.r_hot = ctx->r_hot_dec;
             u32* rflags = nullptr; u32* dtok = nullptr; u32* dtoff = nullptr; u32* dflags = nullptr; bool all_pre = false;
             if (version >= 5) {                                        // (load_pre5 archives: the general path)

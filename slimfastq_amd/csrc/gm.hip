@@ -167,17 +167,85 @@ __global__ __launch_bounds__(256) void k_gm_insert(ChainArgs a, u32 b0, u32 b1, 
     }
 }
 
-// ---- the walk (encoder's plan, the verdict's price) ---------------------------------------------------------------------------
+// ---- the walk ----------------------------------------------------------------------------------------------------------------
+// One routine for the encoder's plan, the verdict's price and the decoder: the state of a lane, what it predicts for base i
+// (gm_predict), and what base i does to it (gm_update).  WITHOUT BRANCHES but for the loads: a lane that walks its chain alone -- the
+// early generations of a decode are a few thousand lanes on a chip that holds half a million -- pays 20-40 cycles for every exec-mask
+// branch, and the first version of this walk, written with ifs, had 37 of them per base: 0.9 us a base, 6.5 ms for a generation of
+// 3 328 chains that decode nothing but flat bases.  The entry of a lookup is read behind base i and looked at behind base i + 1 --
+// before anything could depend on it but the lookup of base i + 1, which the rule forbids while a pointer is pending -- so the order
+// of events is the oracle's, and a lone wave has a base's worth of instructions between the load and its use.
 struct GmCosts { u16 hit[4], miss[4]; };          // 1/1024 bit: a predicted base that comes / does not come, by Fo level
-// One line (or segment) of n bases at stage position q0; lim = the first position of the lane's generation.
+struct GmWalk {
+    u32 kmer, m, pend_at, ask_check;
+    u32 have, asked;                              // masks: all ones / zero
+    u64 ptr, swb, pend_p, ent;
+    uint4 sw, swn;                                // the sixteen bytes at swb, the sixteen behind them (asked for halfway through sw)
+    __device__ __forceinline__ void reset() {
+        kmer = 0; m = 0; pend_at = ~0u; ask_check = 0; have = 0; asked = 0; ptr = 0; swb = 0; pend_p = 0; ent = GM_EMPTY;
+        sw = make_uint4(0, 0, 0, 0); swn = make_uint4(0, 0, 0, 0);
+    }
+};
+__device__ __forceinline__ u64 sel64(u32 mask, u64 a, u64 b) { return (a & (u64)(i64)(i32)mask) | (b & ~(u64)(i64)(i32)mask); }
+// what the walk says of base i: have (mask), the predicted base e, its Fo level lv; fo / fm are the frequencies of a base that is not /
+// that is the predicted one (both 1024 without a pointer)
+__device__ __forceinline__ void gm_predict(GmWalk& W, u32 i, const u8* __restrict__ stage, u64 cap, u32 solid, u32& e, u32& lv, u32& fo, u32& fm) {
+    // a pointer whose time has come (its sixteen bytes are in sw since the entry was looked at): not across a line's end
+    const u32 act = W.pend_at == i ? ~0u : 0u;
+    const u32 ok = act & (gm_newline_ahead(W.sw) ? 0u : ~0u);
+    W.have |= ok;
+    W.m = ok ? GM_K : W.m;
+    W.ptr = sel64(ok, W.pend_p + GM_D, W.ptr);
+    W.pend_at |= act;
+    // the window: taken over where the pointer has left it, the one behind it asked for halfway through
+    u32 o = (u32)W.ptr - (u32)W.swb;
+    const u32 sh = W.have & (o >= 16u ? ~0u : 0u);
+    W.sw.x = sh ? W.swn.x : W.sw.x; W.sw.y = sh ? W.swn.y : W.sw.y; W.sw.z = sh ? W.swn.z : W.sw.z; W.sw.w = sh ? W.swn.w : W.sw.w;
+    W.swb += sh & 16u;
+    o -= sh & 16u;
+    const bool want = W.have && o == 8u;
+    if (__any(want)) { if (want) W.swn = gm_ld16(stage, W.swb + 16u, cap); }
+    const u32 sb = gm_byte_at(W.sw, o & 15u);
+    W.have &= sb == '\n' ? 0u : ~0u;
+    e = gm_code(sb, solid);
+    lv = gm_level(W.m);
+    fo = W.have ? gm_fo_of_level(lv) : 1024u;
+    fm = W.have ? 4096u - 3u * fo : 1024u;
+}
+// base i was b (n = the line's bases, lim = the first stage position of the lane's generation)
+__device__ __forceinline__ void gm_update(GmWalk& W, u32 i, u32 n, u32 b, u32 e, u64 lim, const u64* __restrict__ T, u32 tb, const u8* __restrict__ stage, u64 cap) {
+    const u32 hit = b == e ? ~0u : 0u;
+    const u32 drop = W.have & ~hit & (W.m < GM_DROP ? ~0u : 0u);
+    W.m = hit ? (W.m < GM_MCAP ? W.m + 1u : W.m) : 0u;                  // (without a pointer m does not matter)
+    W.have &= ~drop;
+    W.ptr += W.have & 1u;
+    W.kmer = (W.kmer << 2) | b;
+    // the entry read behind the base before this one
+    const u32 found = W.asked & ~W.have & (W.ent != GM_EMPTY ? ~0u : 0u) & ((u32)(W.ent & 0xFFFFFFull) == W.ask_check ? ~0u : 0u) & ((W.ent >> 24) < lim ? ~0u : 0u);
+    W.asked = 0;
+    if (__any(found != 0u)) {
+        if (found) {                                                     // read behind base i - 1: the pointer predicts from base i + GM_D on
+            W.pend_at = i + GM_D; W.pend_p = W.ent >> 24; W.swb = W.pend_p;
+            W.sw = gm_ld16(stage, W.pend_p, cap);
+        }
+    }
+    const u32 elig = (lim != 0 && !W.have && W.pend_at == ~0u && i + 1u >= GM_K && i + 1u + GM_D < n) ? ~0u : 0u;
+    if (__any(elig != 0u)) {
+        const u64 h = gm_hash(W.kmer);
+        const u32 samp = elig & (gm_sampled(h) ? ~0u : 0u);
+        if (samp) W.ent = T[gm_slot(h, tb)];
+        W.ask_check = gm_check(h, tb); W.asked = samp;
+    }
+}
+// One line (or segment) of n bases at stage position q0, the bases read from the stage (encoder).
 // PRICE: the cost in 1/1024 bit is returned, nothing written; else a token per base at tok[q0 + i]:
 //   0 = coded flat;  0x80 | level << 2 | e = predicted base e at Fo level `level`
 template <bool PRICE>
 __device__ __forceinline__ u64 gm_plan_line(const u8* __restrict__ stage, u64 stage_bytes, u64 q0, u32 n, u64 lim, u32 solid, const u64* __restrict__ T, u32 tb,
                                             u8* __restrict__ tok, const GmCosts& gc) {
-    u32 kmer = 0, seen = 0, m = 0; bool have = false;
-    u64 ptr = 0, swb = 0, pend_p = 0; u32 pend_at = ~0u;
-    uint4 sw = make_uint4(0, 0, 0, 0);
+    GmWalk W; W.reset();
+    const u64 hitc = (u64)gc.hit[0] | ((u64)gc.hit[1] << 16) | ((u64)gc.hit[2] << 32) | ((u64)gc.hit[3] << 48);
+    const u64 misc = (u64)gc.miss[0] | ((u64)gc.miss[1] << 16) | ((u64)gc.miss[2] << 32) | ((u64)gc.miss[3] << 48);
     u64 cost = 0;
     for (u32 i0 = 0; i0 < n; i0 += 16u) {
         const uint4 w = gm_ld16(stage, q0 + i0, stage_bytes);
@@ -188,33 +256,11 @@ __device__ __forceinline__ u64 gm_plan_line(const u8* __restrict__ stage, u64 st
             if (j < cnt) {
                 const u32 i = i0 + j;
                 const u32 b = gm_code(piece_byte(w, j), solid);
-                if (pend_at == i) {
-                    pend_at = ~0u;
-                    sw = gm_ld16(stage, pend_p, stage_bytes); swb = pend_p;
-                    if (!gm_newline_ahead(sw)) { have = true; m = GM_K; ptr = pend_p + GM_D; }
-                }
-                u32 sb = 0;
-                if (have) {
-                    if (ptr - swb >= 16u) { swb = ptr; sw = gm_ld16(stage, ptr, stage_bytes); }
-                    sb = gm_byte_at(sw, (u32)(ptr - swb));
-                    if (sb == '\n') have = false;
-                }
-                if (have) {
-                    const u32 e = gm_code(sb, solid), lv = gm_level(m);
-                    if (PRICE) cost += b == e ? gc.hit[lv] : gc.miss[lv];
-                    else tk[j >> 2] |= (0x80u | (lv << 2) | e) << ((j & 3u) * 8u);
-                    if (b == e) { m = m < GM_MCAP ? m + 1u : m; ptr++; }
-                    else if (m < GM_DROP) have = false;
-                    else { m = 0; ptr++; }
-                } else if (PRICE) cost += 2048u;
-                kmer = (kmer << 2) | b; seen++;
-                if (lim && !have && pend_at == ~0u && seen >= GM_K && i + 1u + GM_D < n) {
-                    const u64 h = gm_hash(kmer);
-                    if (gm_sampled(h)) {
-                        const u64 e = T[gm_slot(h, tb)];
-                        if (e != GM_EMPTY && (u32)(e & 0xFFFFFFull) == gm_check(h, tb) && (e >> 24) < lim) { pend_at = i + 1u + GM_D; pend_p = e >> 24; }
-                    }
-                }
+                u32 e, lv, fo, fm;
+                gm_predict(W, i, stage, stage_bytes, solid, e, lv, fo, fm);
+                if (PRICE) cost += W.have ? (u32)((b == e ? hitc : misc) >> (16u * lv)) & 0xffffu : 2048u;
+                else tk[j >> 2] |= (W.have & (0x80u | (lv << 2) | e)) << ((j & 3u) * 8u);
+                gm_update(W, i, n, b, e, lim, T, tb, stage, stage_bytes);
             }
         }
         if (!PRICE) {
@@ -331,29 +377,10 @@ __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs
         const u32 n = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
         LaneOut out; out.begin(da.seq_stage + off);
-        u32 kmer = 0, m = 0; bool have = false;
-        u64 ptr = 0, swb = 0, pend_p = 0; u32 pend_at = ~0u;
-        uint4 sw = make_uint4(0, 0, 0, 0), swn = make_uint4(0, 0, 0, 0);
-        bool asked = false; u64 ent = GM_EMPTY; u32 ask_check = 0;             // a lookup in flight: issued behind base i - 1, looked at behind base i
+        GmWalk W; W.reset();
         for (u32 i = 0; i < n; i++) {
-            if (pend_at == i) {
-                pend_at = ~0u;                                                   // (sw holds the sixteen bytes at pend_p since four bases ago)
-                if (!gm_newline_ahead(sw)) { have = true; m = GM_K; ptr = pend_p + GM_D; }        // (ptr - swb = 4: the next window is asked for at 8)
-            }
-            u32 sb = 0;
-            if (have) {
-                // the window after this one is asked for when the pointer is HALFWAY through this one, and taken over when it gets
-                // there: asked for at the moment of the switch, the load lands in spare registers (the old window still lives in its
-                // own) and the compiler waits for it on the spot, to copy it -- the round trip the prefetch is there to hide
-                u32 o = (u32)(ptr - swb);
-                if (o >= 16u) { sw = swn; swb += 16u; o -= 16u; }
-                if (o == 8u) swn = gm_ld16(stage, swb + 16u, stage_bytes);
-                sb = gm_byte_at(sw, (u32)(ptr - swb));
-                if (sb == '\n') have = false;
-            }
-            const u32 e = gm_code(sb, solid);
-            const u32 fo = have ? gm_fo_of_level(gm_level(m)) : 1024u;
-            const u32 fm = have ? 4096u - 3u * fo : 1024u;
+            u32 e, lv, fo, fm;
+            gm_predict(W, i, stage, stage_bytes, solid, e, lv, fo, fm);
             rc.top_up();
             u32 r;
             const u32 q = rc.get_freq_bits(GM_BITS, r);
@@ -363,28 +390,7 @@ __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs
             const u32 cum = b == 0u ? 0u : b == 1u ? k1 : b == 2u ? k2 : k3;
             rc.decode(r, cum, b == e ? fm : fo);
             out.put((alphabet >> (8u * b)) & 0xffu);
-            if (have) {
-                if (b == e) { m = m < GM_MCAP ? m + 1u : m; ptr++; }
-                else if (m < GM_DROP) have = false;
-                else { m = 0; ptr++; }
-            }
-            kmer = (kmer << 2) | b;
-            // the lookup issued behind the base before this one
-            if (asked) {
-                asked = false;
-                if (!have && ent != GM_EMPTY && (u32)(ent & 0xFFFFFFull) == ask_check && (ent >> 24) < lim) {
-                    // (issued behind base i - 1: the pointer predicts from base i + GM_D on)
-                    pend_at = i + GM_D; pend_p = ent >> 24; swb = pend_p;
-                    sw = gm_ld16(stage, pend_p, stage_bytes);
-                }
-            }
-            // NOTE: the oracle looks the entry up behind base i and takes it at once; here the entry is read behind base i and examined
-            // behind base i + 1 -- before anything at base i + 1 could depend on it but the lookup of base i + 1 itself, which the rule
-            // forbids while a pointer is pending: the examination above comes first, so the order of events is the oracle's
-            if (lim && !have && pend_at == ~0u && i + 1u >= GM_K && i + 1u + GM_D < n) {        // (lim = 0: the first generation has nothing before it)
-                const u64 h = gm_hash(kmer);
-                if (gm_sampled(h)) { ent = T[gm_slot(h, tb)]; ask_check = gm_check(h, tb); asked = true; }
-            }
+            gm_update(W, i, n, b, e, lim, T, tb, stage, stage_bytes);
         }
         out.end();
     }

@@ -34,10 +34,23 @@ def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None):
     tb = gm_table_bits(len(fq))
     if seg:
         want, sizes, on = O.gm_encode_segs(fq, goff, glen, other, tb, br, seg)
+        gcr = 1
     else:
-        want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, cr)
+        # the base chains of a call that takes the model are cut shorter than the quality chains (api.cpp): 4 KiB of text each, of equal
+        # length inside a block; a call that does not take it keeps the quality chains' records
+        nrec = len(goff)
+        per = max(1, len(fq) // max(1, nrec))
+        gcpb = -(-br // min(-(-4096 // per), cr))
+        gcr = max(1, -(-min(br, nrec) // gcpb))
+        if gcr >= cr:
+            gcr = cr
+        want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, gcr)
+        if not on:
+            want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, cr)
+            gcr = cr
     assert (ci["flags"] & 1) == on and bool(ci["flags"] & 32) == bool(on)
     assert not on or ci["gm_table_bits"] == tb
+    assert ci["gen_chain_reads"] == gcr
     return want, sizes, on
 
 

@@ -115,9 +115,13 @@ def unpack_chains(blob: bytes, nblocks=None):
     cr, flags = v[0], v[1]
     p = 2
     out = {"chain_reads": cr, "flags": flags}
-    if flags & 32:                                   # bit 5: the bases are coded under the match model (gm.hip): the index's bits
-        out["gm_table_bits"] = v[p]; p += 1
+    ng = None
+    if flags & 32:                                   # bit 5: the bases are coded under the match model (gm.hip): the index's bits,
+        out["gm_table_bits"] = v[p]                  # then the base chains' own geometry -- records per chain, their number
+        out["gen_chain_reads"] = v[p + 1]; ng = v[p + 2]; p += 3
     n = v[p]; p += 1
+    if ng is None:
+        ng = n; out["gen_chain_reads"] = cr
     if flags & 8:
         assert nblocks is not None
         out["seg_len"] = v[p]; out["seg_blocks"] = v[p + 1:p + 1 + nblocks]; p += 1 + nblocks
@@ -128,8 +132,8 @@ def unpack_chains(blob: bytes, nblocks=None):
             return np.array(raw, np.uint32)
         d = np.array([(x >> 1) ^ -(x & 1) for x in raw], np.int64)
         return np.cumsum(d).astype(np.uint32)
-    out.update(qlt=sizes(v[p:p + n]), gen=sizes(v[p + n:p + 2 * n]))
-    p += 2 * n
+    out.update(qlt=sizes(v[p:p + n]), gen=sizes(v[p + n:p + n + ng]))
+    p += n + ng
     if flags & 2:
         rcr, m = v[p], v[p + 1]; p += 2
         out.update(rec_chain_reads=rcr, rec=sizes(v[p:p + m]), rec_hdr_bytes=sizes(v[p + m:p + 2 * m]))
