@@ -1208,15 +1208,18 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         }
         if ((rc = reserve(ctx, ctx->csz, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4))) return rc;
         HIPC(hipMemsetAsync(ctx->csz.p, 0, ((size_t)nchains * 2 + (size_t)nsub * 2) * 4, st));
-        // The base chains of a call that takes the match model (gm.hip) are SHORTER than the quality chains: 4 KiB of text each (the
-        // floor of default_chain_reads).  A decoder walks the generations one after the other and each takes as long as ONE lane needs for
+        // The base chains of a call that takes the match model (gm.hip) are SHORTER than the quality chains.  A decoder walks the generations one after the other and each takes as long as ONE lane needs for
         // its chain -- 6.6 ms at 49 records whatever the generation's size, seven times over; at 12 records the same call decodes in
         // 30 ms instead of 60 and is 0.13 % larger (bench.py --kind 3 --chain-reads 12 / 49, profiles/r05g).  Known only with the
         // verdict: their sizes go to a list of their own.
         ggeo = ca.geo;
         if (gm && !seg_len) {
+            // (about 819 200 of them a call -- four times the quality chains: the last generation, half the call, then has six waves a
+            //  SIMD and runs at the chip's rate, not at one lane's -- down to 2 KiB of text a chain: a 2 M-read call decodes in 10 ms
+            //  instead of 17 for 0.4 % more bytes)
             const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
-            const u32 gfloor = (u32)std::min<u64>((4096 + per_rec - 1) / per_rec, ca.geo.chain_reads);
+            const u64 gwant = std::max<u64>((2048 + per_rec - 1) / per_rec, (nrec + 819199) / 819200);
+            const u32 gfloor = (u32)std::min<u64>(gwant, ca.geo.chain_reads);
             ggeo.cpb = (block_reads + gfloor - 1) / gfloor;
             ggeo.chain_reads = std::max<u32>(1u, (u32)((std::min<u64>(block_reads, nrec) + ggeo.cpb - 1) / ggeo.cpb));
             ggeo.cpb = (block_reads + ggeo.chain_reads - 1) / ggeo.chain_reads;

@@ -40,8 +40,8 @@ __device__ __forceinline__ u32 gm_level(u32 m) { return m < 4u ? 0u : m < 8u ? 1
 __device__ __forceinline__ u32 gm_fo_of_level(u32 lv) { return (0x10182840u >> (8u * lv)) & 0xffu; }       // 64, 40, 24, 16
 // a staged letter -> its code ("ACGT": bits 1..2 of the letter are 0, 1, 3, 2; "0123": the low two bits)
 __device__ __forceinline__ u32 gm_code(u32 byte, u32 solid) {
-    const u32 x = (byte >> 1) & 3u;
-    return solid ? (byte & 3u) : (x ^ (x >> 1));
+    const u32 x = (byte >> 1) & 3u, sm = 0u - (solid & 1u);             // (masks, not a select: `solid` differs from lane to lane, and the
+    return (byte & 3u & sm) | ((x ^ (x >> 1)) & ~sm);                    //  compiler makes an exec-mask branch of a select between two computed values)
 }
 __device__ __forceinline__ u32 gm_byte_at(const uint4& w, u32 idx) {          // idx 0..15, lane-variable: two selects and a 64-bit shift
     const u64 lo = (u64)w.x | ((u64)w.y << 32), hi = (u64)w.z | ((u64)w.w << 32);      // (written with selects of dwords the compiler keeps the window in LDS)
@@ -176,26 +176,31 @@ __global__ __launch_bounds__(256) void k_gm_insert(ChainArgs a, u32 b0, u32 b1, 
 // before anything could depend on it but the lookup of base i + 1, which the rule forbids while a pointer is pending -- so the order
 // of events is the oracle's, and a lone wave has a base's worth of instructions between the load and its use.
 struct GmCosts { u16 hit[4], miss[4]; };          // 1/1024 bit: a predicted base that comes / does not come, by Fo level
+// P: the type of a stage position -- u32 where the stage is below 4 GiB (every call of up to 4 G bases: half the 64-bit arithmetic of a
+// step gone), u64 else
+template <typename P>
 struct GmWalk {
     u32 kmer, m, pend_at, ask_check;
     u32 have, asked;                              // masks: all ones / zero
-    u64 ptr, swb, pend_p, ent;
+    P ptr, swb, pend_p; u64 ent;
     uint4 sw, swn;                                // the sixteen bytes at swb, the sixteen behind them (asked for halfway through sw)
     __device__ __forceinline__ void reset() {
         kmer = 0; m = 0; pend_at = ~0u; ask_check = 0; have = 0; asked = 0; ptr = 0; swb = 0; pend_p = 0; ent = GM_EMPTY;
         sw = make_uint4(0, 0, 0, 0); swn = make_uint4(0, 0, 0, 0);
     }
 };
-__device__ __forceinline__ u64 sel64(u32 mask, u64 a, u64 b) { return (a & (u64)(i64)(i32)mask) | (b & ~(u64)(i64)(i32)mask); }
+__device__ __forceinline__ u64 selp(u32 mask, u64 a, u64 b) { return (a & (u64)(i64)(i32)mask) | (b & ~(u64)(i64)(i32)mask); }
+__device__ __forceinline__ u32 selp(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
 // what the walk says of base i: have (mask), the predicted base e, its Fo level lv; fo / fm are the frequencies of a base that is not /
 // that is the predicted one (both 1024 without a pointer)
-__device__ __forceinline__ void gm_predict(GmWalk& W, u32 i, const u8* __restrict__ stage, u64 cap, u32 solid, u32& e, u32& lv, u32& fo, u32& fm) {
+template <typename P>
+__device__ __forceinline__ void gm_predict(GmWalk<P>& W, u32 i, const u8* __restrict__ stage, u64 cap, u32 solid, u32& e, u32& lv, u32& fo, u32& fm) {
     // a pointer whose time has come (its sixteen bytes are in sw since the entry was looked at): not across a line's end
     const u32 act = W.pend_at == i ? ~0u : 0u;
     const u32 ok = act & (gm_newline_ahead(W.sw) ? 0u : ~0u);
     W.have |= ok;
     W.m = ok ? GM_K : W.m;
-    W.ptr = sel64(ok, W.pend_p + GM_D, W.ptr);
+    W.ptr = selp(ok, (P)(W.pend_p + GM_D), W.ptr);
     W.pend_at |= act;
     // the window: taken over where the pointer has left it, the one behind it asked for halfway through
     u32 o = (u32)W.ptr - (u32)W.swb;
@@ -213,7 +218,8 @@ __device__ __forceinline__ void gm_predict(GmWalk& W, u32 i, const u8* __restric
     fm = W.have ? 4096u - 3u * fo : 1024u;
 }
 // base i was b (n = the line's bases, lim = the first stage position of the lane's generation)
-__device__ __forceinline__ void gm_update(GmWalk& W, u32 i, u32 n, u32 b, u32 e, u64 lim, const u64* __restrict__ T, u32 tb, const u8* __restrict__ stage, u64 cap) {
+template <typename P>
+__device__ __forceinline__ void gm_update(GmWalk<P>& W, u32 i, u32 n, u32 b, u32 e, P lim, const u64* __restrict__ T, u32 tb, const u8* __restrict__ stage, u64 cap) {
     const u32 hit = b == e ? ~0u : 0u;
     const u32 drop = W.have & ~hit & (W.m < GM_DROP ? ~0u : 0u);
     W.m = hit ? (W.m < GM_MCAP ? W.m + 1u : W.m) : 0u;                  // (without a pointer m does not matter)
@@ -221,11 +227,11 @@ __device__ __forceinline__ void gm_update(GmWalk& W, u32 i, u32 n, u32 b, u32 e,
     W.ptr += W.have & 1u;
     W.kmer = (W.kmer << 2) | b;
     // the entry read behind the base before this one
-    const u32 found = W.asked & ~W.have & (W.ent != GM_EMPTY ? ~0u : 0u) & ((u32)(W.ent & 0xFFFFFFull) == W.ask_check ? ~0u : 0u) & ((W.ent >> 24) < lim ? ~0u : 0u);
+    const u32 found = W.asked & ~W.have & (W.ent != GM_EMPTY ? ~0u : 0u) & ((u32)(W.ent & 0xFFFFFFull) == W.ask_check ? ~0u : 0u) & ((W.ent >> 24) < (u64)lim ? ~0u : 0u);
     W.asked = 0;
     if (__any(found != 0u)) {
         if (found) {                                                     // read behind base i - 1: the pointer predicts from base i + GM_D on
-            W.pend_at = i + GM_D; W.pend_p = W.ent >> 24; W.swb = W.pend_p;
+            W.pend_at = i + GM_D; W.pend_p = (P)(W.ent >> 24); W.swb = W.pend_p;
             W.sw = gm_ld16(stage, W.pend_p, cap);
         }
     }
@@ -240,10 +246,10 @@ __device__ __forceinline__ void gm_update(GmWalk& W, u32 i, u32 n, u32 b, u32 e,
 // One line (or segment) of n bases at stage position q0, the bases read from the stage (encoder).
 // PRICE: the cost in 1/1024 bit is returned, nothing written; else a token per base at tok[q0 + i]:
 //   0 = coded flat;  0x80 | level << 2 | e = predicted base e at Fo level `level`
-template <bool PRICE>
-__device__ __forceinline__ u64 gm_plan_line(const u8* __restrict__ stage, u64 stage_bytes, u64 q0, u32 n, u64 lim, u32 solid, const u64* __restrict__ T, u32 tb,
+template <bool PRICE, typename P>
+__device__ __forceinline__ u64 gm_plan_line(const u8* __restrict__ stage, u64 stage_bytes, u64 q0, u32 n, P lim, u32 solid, const u64* __restrict__ T, u32 tb,
                                             u8* __restrict__ tok, const GmCosts& gc) {
-    GmWalk W; W.reset();
+    GmWalk<P> W; W.reset();
     const u64 hitc = (u64)gc.hit[0] | ((u64)gc.hit[1] << 16) | ((u64)gc.hit[2] << 32) | ((u64)gc.hit[3] << 48);
     const u64 misc = (u64)gc.miss[0] | ((u64)gc.miss[1] << 16) | ((u64)gc.miss[2] << 32) | ((u64)gc.miss[3] << 48);
     u64 cost = 0;
@@ -294,7 +300,9 @@ __global__ __launch_bounds__(256) void k_gm_plan(ChainArgs a, u64 nlanes, const 
         n = (u32)(len - lo < cp.sub_len ? len - lo : cp.sub_len); q0 = soff[r] + lo;
     } else { n = slen[r]; q0 = soff[r]; }
     const u32 b = (u32)(r / a.block_reads);
-    gm_plan_line<false>(stage, stage_bytes, q0, n, gm_limit(a, soff, b), a.m.blocks[b].solid, T, tb, tok, gc);
+    const u64 lim = gm_limit(a, soff, b);
+    if (stage_bytes >> 32) gm_plan_line<false, u64>(stage, stage_bytes, q0, n, lim, a.m.blocks[b].solid, T, tb, tok, gc);
+    else gm_plan_line<false, u32>(stage, stage_bytes, q0, n, (u32)lim, a.m.blocks[b].solid, T, tb, tok, gc);
 }
 // the verdict's price: every step-th record from r0 below r1 (whole lines), all under the limit soff[lim_rec]; cost[0] += 1/1024 bits, cost[1] += bases
 __global__ __launch_bounds__(256) void k_gm_price(ChainArgs a, u64 r0, u64 r1, u64 step, u64 lim_rec, const u8* __restrict__ stage, u64 stage_bytes, const u64* __restrict__ soff,
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void k_gm_price(ChainArgs a, u64 r0, u64 r1, u
     const u64 r = r0 + ((u64)blockIdx.x * 256 + threadIdx.x) * step;
     u64 c = 0; u32 n = 0;
     const u64 lim = soff[lim_rec];
-    if (r < r1) { n = slen[r]; c = gm_plan_line<true>(stage, stage_bytes, soff[r], n, lim, a.m.blocks[(u32)(r / a.block_reads)].solid, T, tb, nullptr, gc); }
+    if (r < r1) { n = slen[r]; c = gm_plan_line<true, u64>(stage, stage_bytes, soff[r], n, lim, a.m.blocks[(u32)(r / a.block_reads)].solid, T, tb, nullptr, gc); }
     u64 nb = n;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d, 64); nb += __shfl_xor(nb, d, 64); }
@@ -355,11 +363,11 @@ __global__ __launch_bounds__(THREADS) void k_gm_code(ChainArgs a, const u8* __re
 // ---- decoder ----------------------------------------------------------------------------------------------------------------
 // the chains [c0, c1) of one generation; soff[lim_rec] = the generation's first stage position.  What a lookup needs from memory is in flight
 // while the bases between it and its use are decoded: the entry for one base, the sixteen bytes at the pointer for four.
-template <int THREADS>
+template <int THREADS, typename P>
 __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs da, u32 c0, u32 c1, u64 lim_rec, const u64* __restrict__ T, u32 tb, u64 stage_bytes) {
     const u32 c = c0 + blockIdx.x * THREADS + threadIdx.x;
     if (c >= c1) return;
-    const u64 lim = da.soff[lim_rec];
+    const P lim = (P)da.soff[lim_rec];
     ChainPos cp = chain_pos(a, c);
     const BlockDesc* d = &a.m.blocks[cp.b];
     LaneDecQ rc; rc.init(da.streams + a.coff[c], a.csz[c], reinterpret_cast<const u8*>(a.qesc));
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs
         const u32 n = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
         LaneOut out; out.begin(da.seq_stage + off);
-        GmWalk W; W.reset();
+        GmWalk<P> W; W.reset();
         for (u32 i = 0; i < n; i++) {
             u32 e, lv, fo, fm;
             gm_predict(W, i, stage, stage_bytes, solid, e, lv, fo, fm);
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs
             const u32 f0 = e == 0u ? fm : fo, f1 = e == 1u ? fm : fo, f2 = e == 2u ? fm : fo;
             const u32 k1 = f0, k2 = f0 + f1, k3 = k2 + f2;
             const u32 b = (q >= k1 ? 1u : 0u) + (q >= k2 ? 1u : 0u) + (q >= k3 ? 1u : 0u);
-            const u32 cum = b == 0u ? 0u : b == 1u ? k1 : b == 2u ? k2 : k3;
+            const u32 cum = (b > 0u ? f0 : 0u) + (b > 1u ? f1 : 0u) + (b > 2u ? f2 : 0u);
             rc.decode(r, cum, b == e ? fm : fo);
             out.put((alphabet >> (8u * b)) & 0xffu);
             gm_update(W, i, n, b, e, lim, T, tb, stage, stage_bytes);
@@ -444,5 +452,6 @@ void launch_gm_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 c0, u32 c1
     constexpr int TH = 256;
     if (c1 > a.geo.nchains) c1 = a.geo.nchains;
     if (c1 <= c0) return;
-    hipLaunchKernelGGL(k_gm_decode_c<TH>, dim3((c1 - c0 + TH - 1) / TH), dim3(TH), 0, st, a, da, c0, c1, lim_rec, T, tb, stage_bytes);
+    if (stage_bytes >> 32) hipLaunchKernelGGL((k_gm_decode_c<TH, u64>), dim3((c1 - c0 + TH - 1) / TH), dim3(TH), 0, st, a, da, c0, c1, lim_rec, T, tb, stage_bytes);
+    else hipLaunchKernelGGL((k_gm_decode_c<TH, u32>), dim3((c1 - c0 + TH - 1) / TH), dim3(TH), 0, st, a, da, c0, c1, lim_rec, T, tb, stage_bytes);
 }

@@ -36,11 +36,11 @@ def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None):
         want, sizes, on = O.gm_encode_segs(fq, goff, glen, other, tb, br, seg)
         gcr = 1
     else:
-        # the base chains of a call that takes the model are cut shorter than the quality chains (api.cpp): 4 KiB of text each, of equal
+        # the base chains of a call that takes the model are cut shorter than the quality chains (api.cpp): 2 KiB of text each or more (about 819 200 a call), of equal
         # length inside a block; a call that does not take it keeps the quality chains' records
         nrec = len(goff)
         per = max(1, len(fq) // max(1, nrec))
-        gcpb = -(-br // min(-(-4096 // per), cr))
+        gcpb = -(-br // min(max(-(-2048 // per), -(-nrec // 819200)), cr))
         gcr = max(1, -(-min(br, nrec) // gcpb))
         if gcr >= cr:
             gcr = cr
