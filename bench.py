@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 path (process group, shared prior, gather) with one rank")
     ap.add_argument("--no-format6-leg", action="store_true", help="skip the format-6 (one block, the reference's own streams) encode / decode timing")
     ap.add_argument("--format6-reads", type=int, default=60_000, help="records of the format-6 leg (a single serial chain per stream: MB/s, not GB/s)")
+    ap.add_argument("--no-c4-leg", action="store_true", help="--gpus 8 only: skip BASELINE configuration C4 (100 M reads at -l 4 over the 8 GPUs) behind the timed steps")
+    ap.add_argument("--c4-reads-per-gpu", type=int, default=12_500_000)
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the genome-sampled secondary workload (the honest stress of the base model, SURVEY 8d)")
     ap.add_argument("--genome-reads", type=int, default=10_000_000)
     ap.add_argument("--genome-ratio-reads", type=int, default=2_000_000, help="records the reference itself codes for the genome leg's ratio (30x coverage of the 10 Mbp genome)")
@@ -326,17 +328,23 @@ def main():
             sdist.gather_bytes_finish(flight["gather"])
             flight["gather"] = None
 
-    def step(tables=args.tables):
+    def step(tables=args.tables, src=None, level=None):
+        # (src: another text resident in HBM -- (tensor, bytes, output capacity, two output tensors) -- and level: the C4 leg below)
+        nonlocal_in, nonlocal_n, nonlocal_cap, nonlocal_outs = (d_in, nbytes, cap, d_outs) if src is None else src
+        lvl = args.level if level is None else level
+        return _step(tables, nonlocal_in, nonlocal_n, nonlocal_cap, nonlocal_outs, lvl)
+
+    def _step(tables, d_in, nbytes, cap, d_outs, level):
         ps = prior_step
         if multi and prior_step == capi.PRIOR_AUTO:
             # one prior for the whole job and no rank the others wait for: every rank counts a 1 / world share of the
             # sample over its own shard, the count tables are summed over the ranks (all_reduce: 17 MiB), every rank builds the
             # same priors from the sums -- so a record block's bytes do not depend on how many GPUs shared the file
-            sdist.allreduce_prior_counts(ctx, d_in.data_ptr(), nbytes, d_in.device, level=args.level, block_reads=args.block_reads, tables=tables)
+            sdist.allreduce_prior_counts(ctx, d_in.data_ptr(), nbytes, d_in.device, level=level, block_reads=args.block_reads, tables=tables)
             ps = capi.PRIOR_COUNTS
         buf = d_outs[flight["n"] % len(d_outs)]
         flight["n"] += 1
-        res = ctx.encode_device(d_in.data_ptr(), nbytes, buf.data_ptr(), cap, level=args.level,
+        res = ctx.encode_device(d_in.data_ptr(), nbytes, buf.data_ptr(), cap, level=level,
                                 block_reads=args.block_reads, models=models, kernel=args.kernel, prior_step=ps,
                                 tables=tables, chain_reads=args.chain_reads, lds_rows=args.lds_rows)
         if multi:
@@ -376,6 +384,38 @@ def main():
     else:
         all_in, all_out = float(nbytes), float(res.total_bytes)
 
+    # ---- N = 8: BASELINE.json's configuration C4 beside the headline -- 100 M x 150 bp reads at -l 4, 12.5 M a rank, the same step
+    #      (shared prior by all-reduce, the streams to the writer rank over RCCL), timed the same way; never part of `value`
+    c4 = None
+    if dist and (world == 8 or os.environ.get("SFQ_BENCH_C4") == "1") and not args.no_c4_leg and args.kind == 0 and args.workload == "full" and not args.models:
+        try:
+            del d_in
+            d_outs.clear(); d_out = None
+            torch.cuda.empty_cache()
+            n4 = args.c4_reads_per_gpu
+            f4 = capi.synth_fastq(n4, args.read_len, seed=seed, first_read=rank * n4, kind=0)
+            nb4 = len(f4)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t4 = torch.from_numpy(np.frombuffer(f4, np.uint8)).cuda()
+            del f4
+            cap4 = capi.lib().sfq_encode_bound(nb4)
+            outs4 = [torch.empty(cap4, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            src4 = (t4, nb4, cap4, outs4)
+            step(src=src4, level=4); land()
+            dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                r4 = step(src=src4, level=4)
+            land(); dist.barrier(); torch.cuda.synchronize()
+            d4 = time.perf_counter() - t0
+            t = torch.tensor([d4], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tot = torch.tensor([nb4, r4.total_bytes], dtype=torch.float64, device="cuda"); dist.all_reduce(tot)
+            c4 = {"workload": "BASELINE C4: synthetic %d x %d bp reads (%d a GPU), -l 4, record blocks sharded over 8 GPUs, RCCL gather" % (n4 * world, args.read_len, n4),
+                  "value": round(float(tot[0].item()) * 3 / float(t.item()) / 1e6, 2), "unit": "MB/s", "ms_per_step": round(float(t.item()) / 3 * 1e3, 3),
+                  "ratio": round(float(tot[0].item()) / float(tot[1].item()), 4), "steps": 3}
+            del t4, outs4
+        except Exception as e:                                # (a leg, not the measurement: the headline line must come out whatever happens here)
+            c4 = {"error": str(e)[:200]}
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -447,6 +487,8 @@ def main():
                         "rec": round(phase[capi.T_REC], 3), "usr": round(phase[capi.T_USR], 3), "pack": round(phase[capi.T_PACK], 3),
                         "device_total": round(phase[capi.T_TOTAL], 3)},
            "roofline": roofline, "synth_s": round(t_gen, 2)}
+    if c4 is not None:
+        out["c4"] = c4
     if len(coder) > 3 and coder[3] > 0:
         # the one part of the path that IS a stream: the framing kernel reads the text once and writes the line index
         fr_bytes = nbytes + 8 * 4 * int(res.n_records)

@@ -815,6 +815,22 @@ def test_compressed_size_within_one_percent_of_the_reference_at_every_level(ctx,
     assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
 
 
+@pytest.mark.parametrize("level", (1, 2, 3, 4))
+def test_bases_that_can_be_learned_come_out_no_larger_than_the_references(ctx, level):
+    """reads whose bases can be learned -- every real FASTQ -- at every level: 500 k reads sampled from a 10 Mbp
+    genome (7.5-fold coverage; the reference's base table has 2^18 ... 2^26 contexts by level).  Everything a decoder of the block
+    format needs against the reference's streams: at most 1.01 x (round 5: the match model reads its predictions from the earlier
+    reads themselves, gm.hip -- well under 1.00 x at every level), and the way back."""
+    fq = capi.synth_fastq(500_000, 150, seed=23, kind=3)
+    ref = O.compress(fq, level)
+    ref_bytes = ref.payload_bytes() - len(ref.streams["<info>"])
+    enc = ctx.encode_host(fq, level=level, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
+    assert util.unpack_chains(enc.chains)["flags"] & 32                  # the match model is on
+    assert enc.archive_bytes <= 1.01 * ref_bytes, (level, enc.archive_bytes, ref_bytes)
+    assert len(enc.stream("gen")) < len(ref.streams["gen"])
+    assert ctx.decode_host(enc, level=level, out_cap=len(fq) + 4096) == fq
+
+
 def test_two_ranks_compress_one_file_into_one_archive(tmp_path):
     """slimfastq_amd.dist_compress: each rank codes its record-aligned share of the file, rank 0 gathers and writes one
     archive with a segment per rank; the CLI restores the file.  Two ranks share this box's one GPU, so the exchange
