@@ -920,9 +920,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         const u32 tiles = frame_tiles(nbytes);
         if ((rc = reserve(ctx, ctx->chunk_base, (size_t)tiles * 8))) return rc;          // the tiles' look-back words
         if ((rc = reserve(ctx, ctx->scan_tmp, ((size_t)(nbytes / 16384) / 1024 + 4) * 8 + 65536))) return rc;      // (the scans of the packing: one entry per 1024 blocks)
-        // One pass (frame.hip k_frame): the index is sized before the lines are counted -- room for a line every 32 bytes (150 bp
-        // reads: one per 87), or what an earlier call left; a text of shorter lines is framed again with the count the pass returns
-        u64 cap = std::max<u64>(ctx->line_off.cap / 8 > 2 ? ctx->line_off.cap / 8 - 2 : 0, nbytes / 32 + 1024);
+        // One pass (frame.hip k_frame): the index is sized before the lines are counted -- room for a line every 64 bytes (150 bp
+        // reads: one per 87; 0.125 + 0.03 bytes of index and marks per byte of text -- round 4 guessed a line per 32 bytes, 0.9 GB for
+        // the default call: ADVICE), or what an earlier call left; a text of shorter lines is framed again with the count the pass returns
+        u64 cap = std::max<u64>(ctx->line_off.cap / 8 > 2 ? ctx->line_off.cap / 8 - 2 : 0, nbytes / 64 + 1024);
         u64 nlines = 0;
         for (int attempt = 0; ; attempt++) {
             if ((rc = reserve(ctx, ctx->line_off, (size_t)(cap + 2) * 8))) return rc;
@@ -1382,6 +1383,9 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
         if (models & SFQ_M_QLT) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p;
+            // (round 5, measured and dropped: with the match model on, the quality chains held back until the bases' plan is through -- beside
+            //  them the stage, the index and the plan take 3.7 + 6.0 + 5.8 ms against 1 + 3 + 4 alone.  The bases' phase 20.8 -> 17.0 ms, the
+            //  quality chains end at 21.9 instead of 11.8, the call 24.3 -> 25.9 ms: the chip's work is conserved, whoever goes first)
             HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
         }
         HIPC(hipEventRecord(ctx->ev[3], st));

@@ -44,7 +44,7 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* lds /* >= 8 u32 *
 // The line index must be sized before the number of lines is known: the caller guesses (cap entries), the kernel never writes
 // past it and reports the count; a text of shorter lines than guessed is framed again with the exact size.
 // =========================================================================================================
-struct FrameOut { u64 nlines; u32 guard_tripped; u32 pad; };
+struct FrameOut { u64 nlines; u32 guard_tripped; u32 ticket; };      // (zeroed by the caller: ticket = the tile number a starting workgroup takes)
 __device__ __forceinline__ u32 flags4(u32 m) { return (m * 0x00204081u) >> 28; }      // the 0x80 flags of four bytes as four bits
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #pragma unroll
@@ -54,33 +54,42 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #define TS_AGG  (1ull << 62)
 #define TS_PFX  (2ull << 62)
 #define TS_VAL  ((1ull << 62) - 1)
-// A workgroup takes a TILE of FRAME_TILE bytes in FRAME_WIN sub-tiles of 16 KiB, twice: first it only COUNTS the tile's
-// newlines (what the tiles behind it wait for), then -- its place in the file known from the look-back -- it goes over the
-// sub-tiles again, out of L2 this time, and writes offsets and marks.  The text is always LOADED coalesced -- 16 bytes a lane, a
-// wave's 64 lanes one KiB --; in the second round a sub-tile is handed through LDS to the threads that own 64 CONTIGUOUS bytes
-// of it each (windows 80 bytes apart in LDS: a thread's four 16-byte reads fall in banks no neighbour of its quarter wave uses).
-// (Measured on the way, per 3.7 GB: a thread loading its own 64 contiguous bytes straight from memory -- four loads of 16 bytes at a
-//  stride of 64 bytes or more across the lanes, every lane another sector -- 1.9-2.0 ms whatever the tile size: the vector memory
-//  path takes such a load a lane at a time.  One round with every window's masks kept in registers: 158-288 VGPRs.)
+// A workgroup takes a TILE of FRAME_TILE bytes in FRAME_WIN sub-tiles of 16 KiB.  Round one LOADS the text -- coalesced, 16 bytes a
+// lane, a wave's 64 lanes one KiB -- and keeps of every 64-byte window five 64-bit masks in LDS: newlines, '@', '+', '!' candidates,
+// odd-base candidates (40 bytes per 64 of text: 40 KiB a tile); its newline count is what the tiles behind it wait for.  Round two --
+// the tile's place in the file known from the look-back -- runs FROM THE MASKS: a thread takes a window, writes offsets and marks per
+// line end, and checks the '@' / '+' behind a line end in the masks too.  The text is read ONCE (round 5).
+// (Round 4 read it twice -- the second time "out of L2", which the counters did not bear out: TCC_MISS 6.1e7 of 7.1e7 requests, 7.4 GB
+//  fetched per 3.7 GB of text after the guide's gfx950 correction: 256 workgroups x 128 KiB in flight are four times the L2s.  Measured
+//  on the way, per 3.7 GB: a thread loading its own 64 contiguous bytes straight from memory 1.9-2.0 ms; one round with every window's
+//  masks kept in registers: 158-288 VGPRs.)
+// Tiles are numbered by a TICKET taken when a workgroup starts, not by blockIdx: a tile's predecessors in the look-back are then
+// always running or through, whatever order the hardware starts workgroups in (ADVICE, round 4).
 #ifndef FRAME_WIN
-#define FRAME_WIN 8
+#define FRAME_WIN 4
 #endif
 #define FRAME_SUB 16384u
 #define FRAME_TILE (FRAME_SUB * FRAME_WIN)
-#define FRAME_PAD 80u                    /* bytes of LDS per 64-byte window */
-__device__ __forceinline__ u32 nl_flags(u32 x) {            // 0x80 where the byte is '\n'
-    const u32 y = x ^ 0x0a0a0a0au;
+#define FRAME_NW (FRAME_TILE / 64u)      /* windows of a tile */
+__device__ __forceinline__ u32 eq_flags(u32 x, u32 c4) {    // 0x80 where the byte equals the one c4 repeats four times
+    const u32 y = x ^ c4;
     return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
 }
+__device__ __forceinline__ u32 nl_flags(u32 x) { return eq_flags(x, 0x0a0a0a0au); }
+__device__ __forceinline__ u32 mask16(u32 fx, u32 fy, u32 fz, u32 fw) { return flags4(fx) | (flags4(fy) << 4) | (flags4(fz) << 8) | (flags4(fw) << 12); }
 template <bool MARKS>
 __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n, u64* __restrict__ tstat, u64* __restrict__ line_off, u64 cap,
                                                u32* __restrict__ status, u8* __restrict__ exc_flag, u64 ecap, FrameOut* __restrict__ fo) {
-    __shared__ __attribute__((aligned(16))) u8 stage[256 * FRAME_PAD];
+    constexpr u32 NM = MARKS ? 5u : 3u;
+    __shared__ u64 mk[NM][FRAME_NW];                         // [newline, '@', '+', '!' candidate, odd-base candidate][window]
     __shared__ u32 wtot[4];
     __shared__ u32 s_last[4];
     __shared__ u64 s_base;
+    __shared__ u32 s_tile;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 tile = blockIdx.x;
+    if (tid == 0) s_tile = atomicAdd(&fo->ticket, 1u);
+    __syncthreads();
+    const u64 tile = s_tile;
     const u64 tb = tile * FRAME_TILE;
     // a sub-tile's text, coalesced: piece j of a thread = bytes [sb + 4096 j + 16 tid, + 16); bytes at or past n read as 0
     auto fetch = [&](u64 sb, uint4 (&v)[4]) {
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
             }
         }
     };
-    // ---- round 1: the tile's newlines ---------------------------------------------------------------------------------------------
+    // ---- round 1: the text, once -- the windows' masks into LDS, the tile's newlines counted -------------------------------------------
     u32 cnt = 0;
     {
         uint4 nx[4];
@@ -108,8 +117,26 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
             for (int j = 0; j < 4; j++) v[j] = nx[j];
             if (wi + 1 < FRAME_WIN) fetch(tb + (u64)FRAME_SUB * (wi + 1), nx);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                cnt += (u32)__popc(nl_flags(v[j].x)) + (u32)__popc(nl_flags(v[j].y)) + (u32)__popc(nl_flags(v[j].z)) + (u32)__popc(nl_flags(v[j].w));
+            for (int j = 0; j < 4; j++) {
+                // piece j of thread tid lies in window 64 j + tid / 4 of the sub-tile, at bytes 16 (tid % 4)
+                const u32 W = wi * 256u + 64u * j + (tid >> 2), q = tid & 3u;
+                const uint4 x = v[j];
+                const u32 nl = mask16(nl_flags(x.x), nl_flags(x.y), nl_flags(x.z), nl_flags(x.w));
+                cnt += (u32)__popc(nl);
+                reinterpret_cast<u16*>(&mk[0][W])[q] = (u16)nl;
+                reinterpret_cast<u16*>(&mk[1][W])[q] = (u16)mask16(eq_flags(x.x, 0x40404040u), eq_flags(x.y, 0x40404040u), eq_flags(x.z, 0x40404040u), eq_flags(x.w, 0x40404040u));
+                reinterpret_cast<u16*>(&mk[2][W])[q] = (u16)mask16(eq_flags(x.x, 0x2b2b2b2bu), eq_flags(x.y, 0x2b2b2b2bu), eq_flags(x.z, 0x2b2b2b2bu), eq_flags(x.w, 0x2b2b2b2bu));
+                if constexpr (MARKS) {
+                    // '!' candidates: a byte b with (b & 0x5e) == 0 -- in a quality line (0x21 .. 0x7e) that is '!' alone   (no carry between bytes: 0x5e + 0x7f < 0x100)
+                    // odd-base candidates: bit 3 (N, '.') or bits 5 and 6 (lowercase) -- every N-like or lowercase base, and no A C G T 0 1 2 3
+#define FR_BANG(w) (~(((w) & 0x5e5e5e5eu) + 0x7f7f7f7fu) & 0x80808080u)
+#define FR_ODD(w) ((((w) << 4) | (((w) << 1) & ((w) << 2))) & 0x80808080u)
+                    reinterpret_cast<u16*>(&mk[3][W])[q] = (u16)mask16(FR_BANG(x.x), FR_BANG(x.y), FR_BANG(x.z), FR_BANG(x.w));
+                    reinterpret_cast<u16*>(&mk[4][W])[q] = (u16)mask16(FR_ODD(x.x), FR_ODD(x.y), FR_ODD(x.z), FR_ODD(x.w));
+#undef FR_BANG
+#undef FR_ODD
+                }
+            }
         }
     }
 #pragma unroll
@@ -156,48 +183,18 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
     // does a line start with the sub-tile at hand (thread 0's business)?  With the file it does; elsewhere the byte before says
     u32 carry_nl = 0;
     if (tid == 0) carry_nl = tb == 0 ? 1u : (tb <= n && fq[tb - 1] == '\n') ? 1u : 0u;
-    // ---- round 2: offsets, the '@' / '+' checks, the marks ------------------------------------------------------------------------------
-    uint4 nx[4];
-    fetch(tb, nx);
+    // ---- round 2: offsets, the '@' / '+' checks, the marks -- from the masks -----------------------------------------------------------
 #pragma nounroll
     for (u32 wi = 0; wi < FRAME_WIN; wi++) {
         const u64 sb = tb + (u64)FRAME_SUB * wi;
         if (sb >= n) break;                                  // (the same for every thread)
-        // piece j of thread tid lies in window 64 j + tid / 4, at 16 (tid % 4)
-#pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<uint4*>(stage + (64u * j + (tid >> 2)) * FRAME_PAD + 16u * (tid & 3u)) = nx[j];
-        __syncthreads();
-        if (wi + 1 < FRAME_WIN) fetch(sb + FRAME_SUB, nx);                       // (in flight while this sub-tile is worked on)
-        u32 w[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint4 v = *reinterpret_cast<const uint4*>(stage + tid * FRAME_PAD + 16u * j);
-            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-        }
+        const u32 W = wi * 256u + tid;
         const u64 w0 = sb + 64u * tid;
-        u32 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const u32 x = w[q];
-            u32* d = q < 8 ? lo : hi;
-            const u32 sh = 4u * (q & 7);
-            d[0] |= flags4(nl_flags(x)) << sh;
-
-            if constexpr (MARKS) {
-                // '!' candidates: a byte b with (b & 0x5e) == 0 -- in a quality line (0x21 .. 0x7e) that is '!' alone
-                const u32 mb = ~((x & 0x5e5e5e5eu) + 0x7f7f7f7fu) & 0x80808080u;                  // (no carry between bytes: 0x5e + 0x7f < 0x100)
-                // odd-base candidates: bit 3 (N, '.') or bits 5 and 6 (lowercase) -- every N-like or lowercase base, and no A C G T 0 1 2 3
-                const u32 mo = ((x << 4) | ((x << 1) & (x << 2))) & 0x80808080u;
-                d[1] |= flags4(mb) << sh;
-                d[2] |= flags4(mo) << sh;
-            }
-        }
-        const u64 nlm = (u64)lo[0] | ((u64)hi[0] << 32);
-        const u32 first_byte = w[0] & 0xffu;
+        const u64 nlm = mk[0][W], atm = mk[1][W], plm = mk[2][W];
         u64 bang = 0, odd = 0;
         if constexpr (MARKS) {
             const u64 live = w0 >= n ? 0ull : (n - w0) >= 64 ? ~0ull : ((1ull << (n - w0)) - 1);      // (bytes past the end read as 0: a '!' candidate)
-            bang = ((u64)lo[1] | ((u64)hi[1] << 32)) & live; odd = ((u64)lo[2] | ((u64)hi[2] << 32)) & live;
+            bang = mk[3][W] & live; odd = mk[4][W] & live;
         }
         // this window's newlines among its sub-tile's
         const u32 c = (u32)__popcll(nlm);
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
         if (lane == 63) { wtot[wave] = incl; s_last[wave] = (u32)(nlm >> 63); }
-        __syncthreads();                                     // (also: every thread has read its window, the stage may be written again)
+        __syncthreads();
         u32 bw = 0, tw = 0;
 #pragma unroll
         for (u32 k = 0; k < 4; k++) { const u32 t = wtot[k]; if (k < wave) bw += t; tw += t; }
@@ -216,7 +213,7 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
         u32 prev_nl = (u32)__shfl_up((int)(u32)(nlm >> 63), 1, 64);
         if (lane == 0) prev_nl = wave ? s_last[wave - 1] : carry_nl;
         if (tid == 0) carry_nl = s_last[3];
-        if (prev_nl && w0 < n && ((u32)k & 1u) == 0u && first_byte != (((u32)k & 2u) ? '+' : '@')) atomicMax(status, (u32)(-SFQ_E_FORMAT));
+        if (prev_nl && w0 < n && ((u32)k & 1u) == 0u && !((((u32)k & 2u) ? plm : atm) & 1ull)) atomicMax(status, (u32)(-SFQ_E_FORMAT));
         if (w0 < n) {
             u64 m = nlm;
             u64 below = 0;                                   // the window's bytes up to the line end looked at last
@@ -233,11 +230,10 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
                 k++;                                         // the line that starts behind this newline
                 const u64 start = w0 + i + 1;
                 if (k <= cap) line_off[k] = start;
-                // ... and a line that starts inside it: the byte behind the line end, still in the stage (written again only behind
-                // this round's last barrier)
+                // ... and a line that starts inside it: the byte behind the line end, in the '@' / '+' masks
                 if (i < 63u && start < n) {
                     const u32 type = (u32)k & 3u;
-                    if ((type & 1u) == 0u && stage[tid * FRAME_PAD + i + 1] != (type ? '+' : '@')) atomicMax(status, (u32)(-SFQ_E_FORMAT));
+                    if ((type & 1u) == 0u && !(((type ? plm : atm) >> (i + 1u)) & 1ull)) atomicMax(status, (u32)(-SFQ_E_FORMAT));
                 }
             }
             if constexpr (MARKS) {                           // what lies behind the window's last line end (or the whole window)
