@@ -1771,7 +1771,18 @@ static void gfz_cb(void* arg, u32 ctx, int code) {
     ch_encode(g->c, cum, f[code], f[0] + f[1] + f[2] + f[3]);                   /* base2_ranger.hpp:74-84 without the update */
 }
 /* gen_on: 1 = the generation tables were used (decided from generation 1's cost under generation 0's rows) */
-static int g_gen_force_off = 0;           /* sfqo_gm_*: the match model's verdict said no -- every chain codes with the initial row */
+static int g_gen_force_off = 0;           /* sfqo_gm_*: the match model's verdict said no -- no table, and (round 5) every line's bases FOUR AT A
+                                             TIME: the codes of bases 4 q .. 4 q + k - 1 of a line (k = 4, fewer at its end) as one symbol
+                                             S = sum code[j] << 2 j of 4^k equally likely ones ("chn.idx" flag bit 6).  The same two bits a base as
+                                             the initial row's 3 of 12, a quarter of the coder steps -- and each of them a shift */
+static void gen_flat_quads(chenc* c, const u8* line, size_t n) {
+    for (size_t i = 0; i < n; i += 4) {
+        const size_t k = n - i < 4 ? n - i : 4;
+        u32 S = 0;
+        for (size_t j = 0; j < k; j++) { int cd = gencode_of(line[i + j]); if (cd > 4) cd = 0; S |= (u32)(cd & 3) << (2 * j); }
+        ch_encode(c, S, 1, 1u << (2 * k));
+    }
+}
 static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32* glen, size_t nrec, int gen_bits, size_t block_reads,
                                  size_t chain_reads, u32 step, u8** out, size_t* out_len, u32* sizes, int* gen_on,
                                  u32 seg_len /* != 0: segments of one record */, const u32* other_len) {
@@ -1829,6 +1840,8 @@ static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32*
                     const u64 o1 = goff[r] + lo; const u32 l1 = (u32)(glen[r] - lo < L ? glen[r] - lo : L);
                     chenc c; ch_init(&c);
                     gfz gz = { &c, on ? rows[g] : NULL };
+                    if (g_gen_force_off) gen_flat_quads(&c, base + o1, l1);
+                    else
                     gen_walk(base, &o1, &l1, 0, 1, mask, gfz_cb, &gz);        /* (a segment starts from the seed, as a line) */
                     const size_t nb = ch_finish(&c);
                     ob_write(&o, c.out, nb);
@@ -1842,6 +1855,8 @@ static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32*
             const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
             chenc c; ch_init(&c);
             gfz gz = { &c, on ? rows[g] : NULL };
+            if (g_gen_force_off) for (size_t r = r0; r < r1; r++) gen_flat_quads(&c, base + goff[r], glen[r]);
+            else
             gen_walk(base, goff, glen, r0, r1, mask, gfz_cb, &gz);
             const size_t n = ch_finish(&c);
             ob_write(&o, c.out, n);
@@ -1887,7 +1902,8 @@ long long sfqo_gen_encode_segs(const u8* base, const u64* goff, const u32* glen,
        sentinel lies in [p, p + GM_D].  (GM_D = 4 bases pass between lookup and use: a decoder has the entry and the bases at p
        in flight meanwhile and never waits for memory.)
    Whether a call uses the model at all is decided once: generation 0's counted records indexed, every eighth counted record of
-   generation 1 priced (integer log2 costs); on if that beats two bits a base by 1 %.                                        */
+   generation 1 priced (integer log2 costs; in stretches of 256 bases, each walked as a line of its own); on if that beats two bits
+   a base by 1 %.                                        */
 #define GM_K 16
 #define GM_D 4
 #define GM_DROP 8
@@ -1968,7 +1984,8 @@ static long long gm_encode_x(const u8* base, const u64* goff, const u32* glen, s
         T = xmalloc(sizeof(u64) << tb); memset(T, 0xFF, sizeof(u64) << tb);
         gm_insert(st, soff, glen, REC_OF(bound[0]), REC_OF(bound[1]), GSTRIDE(0), T, tb);
         gmw w = { st, T, tb, soff[REC_OF(bound[1])], NULL, 0, 0 };
-        for (size_t r = REC_OF(bound[1]); r < REC_OF(bound[2]); r += GSTRIDE(1) * 8) gm_walk(&w, soff[r], glen[r]);
+        for (size_t r = REC_OF(bound[1]); r < REC_OF(bound[2]); r += GSTRIDE(1) * 8)                       /* (in stretches of 256 bases, each walked as a line) */
+            for (u32 lo = 0; lo < glen[r]; lo += 256) gm_walk(&w, soff[r] + lo, glen[r] - lo < 256 ? glen[r] - lo : 256);
         on = w.nbases && w.cost * 100 < w.nbases * 2048 * 99;
         if (on) for (size_t g = 1; g + 1 < ngen; g++) gm_insert(st, soff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), GSTRIDE(g), T, tb);
     }

@@ -704,7 +704,7 @@ int gm_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u64 nrec, u32 max_l
         costs[lv] = (u16)(12 * 1024 - log2fp_u32(4096u - 3u * fo)); costs[4 + lv] = (u16)(12 * 1024 - log2fp_u32(fo));
     }
     const u64 r1 = (u64)bound[1] * br;
-    launch_gm_price(gp.cg, r1, gp.r2, (u64)gen_count_stride(recs(bound[1], bound[2])) * GEN_PRE, r1, (const u8*)ctx->gm_stage.p, gp.cap, (const u64*)ctx->gm_soff.p,
+    launch_gm_price(gp.cg, r1, gp.r2, (u64)gen_count_stride(recs(bound[1], bound[2])) * GEN_PRE, max_line, r1, (const u8*)ctx->gm_stage.p, gp.cap, (const u64*)ctx->gm_soff.p,
                     (const u32*)ctx->gm_slen.p, (const u64*)ctx->gm_T.p, gp.tb, costs, (u64*)ctx->gcost.p, st);
     HIPC(hipMemcpyAsync((u8*)ctx->pin + PIN_GEN_OFF, ctx->gcost.p, 16, hipMemcpyDeviceToHost, st));
     return SFQ_OK;
@@ -1377,7 +1377,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             //  row gathers wait for the same thing, random 64-byte sectors of tables larger than the caches, and their times add up.)
             HIPC(hipEventRecord(ctx->ev[16], mst[3]));
             if (gm && gen_on) launch_gm_code(gmplan.cg, (const u8*)ctx->gm_tok.p, mst[3]);
-            else launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on);
+            else { ca.flat_quads = (gm && !gen_on) ? 1u : 0u; launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on); }
             HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
@@ -1640,7 +1640,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             for (; i < n; i++) { const i32 d = (i32)(v[i] - prev); put(((u32)d << 1) ^ (u32)(d >> 31)); prev = v[i]; }
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
-        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u) | ((gm && gen_on) ? 32u : 0u) /* bases: the match model */);
+        put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u) | ((gm && gen_on) ? 32u : 0u) /* bases: the match model */
+            | ((gm && !gen_on) ? 64u : 0u) /* bases without a model: four a symbol */);
         if (gm && gen_on) { put(gmplan.tb); put(ggeo.chain_reads); put(ngc); }      // (the index's bits; the base chains' records, their number)
         put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
@@ -1906,6 +1907,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0, gm_on = 0, gm_tb = 0;
+    u32 flat_quads = 0;
     u32 gchain_reads = 0, gcpb = 0, ngc = 0; u64 gm_ngc = 0;      // the base chains (the quality chains' geometry unless the match model has its own)
     bool exc_rice = false;
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
@@ -1926,7 +1928,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         const bool segs = ((u32)v >> 3) & 1u;                // chains are segments of one record (long reads): their length and the blocks' shares follow
         exc_rice = ((u32)v >> 4) & 1u;                       // the base exceptions are Rice-coded gap lists (exc.hip; round 4)
         gm_on = ((u32)v >> 5) & 1u;                          // the bases are coded under the match model (gm.hip; round 5): the index's bits follow
-        if (v >> 6) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        flat_quads = ((u32)v >> 6) & 1u;                     // bases without a model are coded four a symbol (round 5)
+        if (v >> 7 || (flat_quads && gen_on)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
         if (gm_on) {
             u64 t = 0;
             if (!gen_on || !exc_rice || !get_v(cb, cn, cp, t) || t < 8 || t > 26) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: match model)");
@@ -2248,7 +2251,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 if (g + 1 < ngen) launch_gm_insert(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * block_reads, dec_max_line, (u64*)ctx->gm_T.p, gm_tb, st_gen);
             }
         } else
-        if (!gen_on || ngen < 3) launch_gen_decode_c(ca, da, 0, nchains, st_gen);
+        if (!gen_on || ngen < 3) { ca.flat_quads = flat_quads; launch_gen_decode_c(ca, da, 0, nchains, st_gen); }
         else {
             const u64 nctx = 1ull << g_bits;
             if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;

@@ -663,6 +663,37 @@ __device__ __forceinline__ u32 walk_bases_b(const ChainArgs& a, u64 r0, u32 nrec
     return illegal;
 }
 
+// The walk of a chain without a model (round 5): quad(sym, k) for every four bases of a line -- sym = their codes, the first in the
+// low bits; k = 4, fewer (or none: the quad lies behind the line's end) in a line's last piece.
+template <typename QUAD>
+__device__ __forceinline__ u32 walk_bases_q(const ChainArgs& a, u64 r0, u32 nrec, u32 solid, const u8* lut, QUAD&& quad, u8* exc_flag, u64 sub_lo = 0, u64 sub_len = 0) {
+    LineWalk lw; lw.init(a, r0, nrec, 1, solid, sub_lo, sub_len);
+    u32 illegal = 0;
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    while (__any(pc.valid)) {
+        const Piece pn = lw.next();
+        const uint4 wn = lw.fetch(pn);
+        const u32 len = pc.j1;
+        u32 codes = 0, odd = 0;
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            const u32 cd = lut[piece_byte(w, j)];
+            codes |= (cd & 3u) << (2 * j);
+            odd |= cd & (j < len ? ~0u : 0u);
+        }
+        if (exc_flag && (odd & 0x34u) && pc.valid) exc_flag[r0 + pc.rk] = 1;
+        illegal |= odd & 0x10u;
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            const u32 k = len > 4u * q ? (len - 4u * q < 4u ? len - 4u * q : 4u) : 0u;
+            quad((codes >> (8u * q)) & 0xffu, k);
+        }
+        pc = pn; w = wn;
+    }
+    return illegal;
+}
+
 // counts of (context, base) over the records of blocks [b0, b1): one record per lane.  With `rows` given, also the
 // cost (in 1/1024 bit) those bases would have under these rows: cost[0] += sum log2(tot) - log2(f[code])
 // Long lines (seg_len != 0): a lane takes one stretch of seg_len bases of a record, lane id = record x segs + stretch --
@@ -944,7 +975,13 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
     rc.init(ring, threadIdx.x, outp, cap);
     const u32* rows = (!FLAT && live) ? gen_rows_of(a, cp.b) : nullptr;
     u32 illegal = 0;
-    if (FLAT || !__any(rows != nullptr)) {
+    if (a.flat_quads && (FLAT || !__any(rows != nullptr))) {
+        // no model, four bases a symbol (round 5): a shift, a multiply and ONE renormalisation step per four bases -- a byte leaves per full
+        // quad, exactly -- where the initial row's 3 of 12 took a divide and a step per base (0.94e9 of the default call's 6.6e9 wave instructions)
+        illegal = walk_bases_q(a, cp.r0, cp.nrec, live ? d->solid : 0u, lut,
+            [&](u32 sym, u32 k) { const u32 bits = 2u * k; rc.encode_bits_if(k ? ~0u : 0u, sym & ((1u << bits) - 1u), 1u, bits); rc.drain(); },
+            a.exc_flag, cp.sub_lo, cp.sub_len);
+    } else if (FLAT || !__any(rows != nullptr)) {
         // every lane of the wave codes with the initial row (3, 3, 3, 3): cum = 3 * code, freq 3 of 12, no lookups
         const u32 r12 = fz_recip(12u);
         illegal = walk_bases_b(a, cp.r0, cp.nrec, live ? d->solid : 0u, 0u, lut, [&](u32, u32) {},
@@ -1041,6 +1078,15 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
                 out.put((alphabet >> (8 * b)) & 0xff);
                 last = (last << 2) | b;
                 v = b == 0 ? cand.x : b == 1 ? cand.y : b == 2 ? cand.z : cand.w;
+            }
+        } else if (a.flat_quads) {                                                          // no model, four bases a symbol ("chn.idx" flag bit 6)
+            for (u32 i = 0; i < llen; i += 4u) {
+                const u32 k = llen - i < 4u ? llen - i : 4u;
+                rc.top_up();
+                u32 r;
+                const u32 S = rc.get_freq_bits(2u * k, r);
+                rc.decode1(r, S, 1u);
+                for (u32 j = 0; j < k; j++) out.put((alphabet >> (8u * ((S >> (2u * j)) & 3u))) & 0xffu);
             }
         } else {
             for (u32 i = 0; i < llen; i++) {                                                // the initial row (3, 3, 3, 3)

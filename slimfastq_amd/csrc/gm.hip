@@ -304,13 +304,21 @@ __global__ __launch_bounds__(256) void k_gm_plan(ChainArgs a, u64 nlanes, const 
     if (stage_bytes >> 32) gm_plan_line<false, u64>(stage, stage_bytes, q0, n, lim, a.m.blocks[b].solid, T, tb, tok, gc);
     else gm_plan_line<false, u32>(stage, stage_bytes, q0, n, (u32)lim, a.m.blocks[b].solid, T, tb, tok, gc);
 }
-// the verdict's price: every step-th record from r0 below r1 (whole lines), all under the limit soff[lim_rec]; cost[0] += 1/1024 bits, cost[1] += bases
-__global__ __launch_bounds__(256) void k_gm_price(ChainArgs a, u64 r0, u64 r1, u64 step, u64 lim_rec, const u8* __restrict__ stage, u64 stage_bytes, const u64* __restrict__ soff,
+// the verdict's price: every step-th record from r0 below r1, a lane per STRETCH of GM_PRICE_STRETCH bases of it -- each walked as a
+// line of its own (no pointer, no k-mer at its start: the rule's, sfq_oracle.c; a lane per 30 kb read kept every chain of a long-read
+// call waiting 35 ms for the verdict) --, all under the limit soff[lim_rec]; cost[0] += 1/1024 bits, cost[1] += bases
+#define GM_PRICE_STRETCH 256u
+__global__ __launch_bounds__(256) void k_gm_price(ChainArgs a, u64 r0, u64 r1, u64 step, u32 segs, u64 lim_rec, const u8* __restrict__ stage, u64 stage_bytes, const u64* __restrict__ soff,
                                                   const u32* __restrict__ slen, const u64* __restrict__ T, u32 tb, GmCosts gc, u64* cost) {
-    const u64 r = r0 + ((u64)blockIdx.x * 256 + threadIdx.x) * step;
+    const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 r = r0 + (id / segs) * step;
+    const u32 lo = (u32)(id % segs) * GM_PRICE_STRETCH;
     u64 c = 0; u32 n = 0;
     const u64 lim = soff[lim_rec];
-    if (r < r1) { n = slen[r]; c = gm_plan_line<true, u64>(stage, stage_bytes, soff[r], n, lim, a.m.blocks[(u32)(r / a.block_reads)].solid, T, tb, nullptr, gc); }
+    if (r < r1 && lo < slen[r]) {
+        n = slen[r] - lo < GM_PRICE_STRETCH ? slen[r] - lo : GM_PRICE_STRETCH;
+        c = gm_plan_line<true, u64>(stage, stage_bytes, soff[r] + lo, n, lim, a.m.blocks[(u32)(r / a.block_reads)].solid, T, tb, nullptr, gc);
+    }
     u64 nb = n;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d, 64); nb += __shfl_xor(nb, d, 64); }
@@ -437,12 +445,13 @@ void launch_gm_insert(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 ma
 void launch_gm_plan(const ChainArgs& a, u64 nlanes, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb, u8* tok, hipStream_t st) {
     if (nlanes) hipLaunchKernelGGL(k_gm_plan, dim3((u32)((nlanes + 255) / 256)), dim3(256), 0, st, a, nlanes, stage, stage_bytes, soff, slen, T, tb, tok);
 }
-void launch_gm_price(const ChainArgs& a, u64 r0, u64 r1, u64 step, u64 lim_rec, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb,
+void launch_gm_price(const ChainArgs& a, u64 r0, u64 r1, u64 step, u32 max_line, u64 lim_rec, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb,
                      const u16* costs /* hit[4], miss[4] */, u64* cost, hipStream_t st) {
     if (r1 <= r0 || !step) return;
     GmCosts gc; for (int i = 0; i < 4; i++) { gc.hit[i] = costs[i]; gc.miss[i] = costs[4 + i]; }
-    const u64 lanes = (r1 - r0 + step - 1) / step;
-    hipLaunchKernelGGL(k_gm_price, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, r0, r1, step, lim_rec, stage, stage_bytes, soff, slen, T, tb, gc, cost);
+    const u32 segs = max_line ? (max_line + GM_PRICE_STRETCH - 1) / GM_PRICE_STRETCH : 1u;
+    const u64 lanes = ((r1 - r0 + step - 1) / step) * segs;
+    hipLaunchKernelGGL(k_gm_price, dim3((u32)((lanes + 255) / 256)), dim3(256), 0, st, a, r0, r1, step, segs, lim_rec, stage, stage_bytes, soff, slen, T, tb, gc, cost);
 }
 void launch_gm_code(const ChainArgs& a, const u8* tok, hipStream_t st) {
     constexpr int TH = 256;

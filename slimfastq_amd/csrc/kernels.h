@@ -86,6 +86,8 @@ struct ChainArgs {
     u32 g_bound[GEN_MAX_GENERATIONS + 1];      // generation g = blocks [g_bound[g], g_bound[g + 1])
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
     const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
+    u32 flat_quads;             // bases without a model (round 5, "chn.idx" flag bit 6): a line's bases four at a time, one symbol of 4^k equally likely ones
+                                // (k = 4, fewer at a line's end) instead of 3 of 12 a base
 };
 void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,
                      u8* img /* q_rows / 4 bytes of map + want x 100 bytes of rows */, u32* info, hipStream_t st);
@@ -107,7 +109,7 @@ void launch_gm_stage(const ModelArgs& m, u32 block_reads, u64 r0, u64 r1, u64 nb
 void launch_gm_insert(const ChainArgs& a, u32 b0, u32 b1, u64 nrec_range, u32 max_line, u64* T, u32 tb, hipStream_t st);
 void launch_gm_plan(const ChainArgs& a, u64 nlanes /* records, or chains where they are segments */, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen,
                     const u64* T, u32 tb, u8* tok, hipStream_t st);
-void launch_gm_price(const ChainArgs& a, u64 r0, u64 r1, u64 step, u64 lim_rec, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb,
+void launch_gm_price(const ChainArgs& a, u64 r0, u64 r1, u64 step, u32 max_line /* the call's longest base line: a lane per 256 bases of a record */, u64 lim_rec, const u8* stage, u64 stage_bytes, const u64* soff, const u32* slen, const u64* T, u32 tb,
                      const u16* costs /* hit[4], miss[4] in 1/1024 bit */, u64* cost /* [0] += cost, [1] += bases */, hipStream_t st);
 void launch_gm_code(const ChainArgs& a, const u8* tok, hipStream_t st);
 void launch_gm_decode_c(const ChainArgs& a, const struct DecodeArgs& da, u32 c0, u32 c1, u64 lim_rec, const u64* T, u32 tb, u64 stage_bytes, hipStream_t st);

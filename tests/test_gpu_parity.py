@@ -784,7 +784,8 @@ def _check_sampled_chains_against_oracle(fq, packed, soff, ci, prior, rec_prior,
         got = bytes(packed[soff[2] + int(qoffs[c]): soff[2] + int(qoffs[c + 1])].cpu().numpy())
         assert got == want, ("qlt chain", c)
         assert not ci["flags"] & 1                                    # iid bases: every base chain codes with the initial row
-        want, sizes, on = O.gen_encode_chains(sub, so[1::4], sl[1::4], blocks[0].gen_bits, r1 - r0, r1 - r0, 4)
+        assert ci["flags"] & 64                                        # ... four bases a symbol (round 5)
+        want, sizes, on = O.gm_encode_chains(sub, so[1::4], sl[1::4], 16, r1 - r0, r1 - r0)
         got = bytes(packed[soff[1] + int(goffs[c]): soff[1] + int(goffs[c + 1])].cpu().numpy())
         assert on == 0 and got == want, ("gen chain", c)
     rrows = O.rec_frozen_rows(util.unpack_rec_prior(rec_prior))
