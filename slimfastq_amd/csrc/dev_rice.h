@@ -80,7 +80,12 @@ struct RiceR {                 // a lane's bit source: zeros behind the stream's
             fill(); v = take(20);
             fill(); v |= (u64)take(20) << 20;
         }
-        if (!v) { valid = 0; return 0; }
+        if (!v) {
+            // (the list's end must lie INSIDE the stream: zeros are read behind it, and a stream cut short would end its list there
+            //  silently -- its last N's missing -- ADVICE, round 4)
+            if ((u64)pos * 8u - nbits > (u64)n * 8u) err = 1;
+            valid = 0; return 0;
+        }
         A += v; N++;
         if (N >= 32) { A >>= 1; N >>= 1; }
         return v;

@@ -333,6 +333,24 @@ def test_corrupt_archives_fail_cleanly_or_decode_to_something(ctx):
         assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_a_base_exception_list_cut_short_is_refused(ctx):
+    """a Rice-coded gap list ("gen.Ns" with frozen tables, exc.hip) reads zeros behind its stream, and a list's
+    end is a zero gap -- a stream cut short used to end its list silently, the last N's coming back as A.  The end of a list must
+    lie inside its stream."""
+    fq = capi.synth_fastq(3000, 150, seed=41)                 # (one N in a thousand bases: 450 of them)
+    enc = ctx.encode_host(fq, level=3, block_reads=4096, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=64)
+    assert len(enc.blocks) == 1 and util.unpack_chains(enc.chains)["flags"] & 16
+    s = capi.STREAM_NAMES.index("gen.Ns")
+    assert enc.blocks[0].size[s] > 8
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    for cut in (1, 2, 5):
+        bad = enc.clone()
+        bad.blocks[0].size[s] -= cut
+        with pytest.raises(capi.SfqError):
+            ctx.decode_host(bad, level=3, out_cap=len(fq) + 4096)
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 def test_ragged_and_error_inputs(ctx):
     one = b"@only 1\nACGT\n+\nIIII\n"
     enc = ctx.encode_host(one, level=3)
