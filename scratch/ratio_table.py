@@ -1,9 +1,9 @@
-"""profiles/r03_ratio_table.json: compressed size of the block format (frozen tables, the default) over the reference's own,
+"""profiles/r05_ratio_table.json (rounds 3 and 5): compressed size of the block format (frozen tables, the default) over the reference's own,
 per level and workload -- "ratio within 1 % of the reference at each -l level" (BASELINE.json north_star).
 The reference side is the oracle (stream-identical to the compiled reference: tests/test_oracle.py) on the same text;
 ours counts everything a decoder needs (streams, first headers, priors, chain and block index).
 
-    python scratch/ratio_table.py > profiles/r03_ratio_table.json        (on the GPU box)
+    python scratch/ratio_table.py > profiles/r05_ratio_table.json        (on the GPU box)
 """
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

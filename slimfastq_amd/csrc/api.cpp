@@ -1158,8 +1158,10 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (p.chain_reads & SFQ_CHAIN_SEGMENT_FLAG) { seg_len = p.chain_reads & ~SFQ_CHAIN_SEGMENT_FLAG; cr = 1; if (!seg_len) return fail(ctx, SFQ_E_ARG, "SFQ_CHAIN_SEGMENT(0)"); }
         else if (!p.chain_reads && cr == 1 && nrec < 204800) {
             // long records, few of them: a lane that walks a 50 kb read alone takes as long as the rest of the call -- the call's
-            // symbols in about 204 800 segments (default_chain_reads), of 2048 symbols or more
-            const u64 want = std::min<u64>(std::max<u64>(2048, nbytes / 2 / 204800), 1u << 20);
+            // symbols in about 204 800 segments (default_chain_reads), of 4096 symbols or more (round 5; 2048 before: a segment costs
+            // seven to eight bytes -- its context's warm-up, its flush, its index entries -- and 6000 reads in segments of 2048 came out
+            // 1.014 x the reference's at -l 4, profiles/r05_ratio_table.json)
+            const u64 want = std::min<u64>(std::max<u64>(4096, nbytes / 2 / 204800), 1u << 20);
             if (max_line > want) seg_len = (u32)want;
         }
         ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)

@@ -254,6 +254,43 @@ def test_frozen_counting_passes_take_long_lines_a_stretch_per_lane(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_match_model_with_chains_that_are_segments(ctx):
+    """The match model (gm.hip) where chains are SEGMENTS of one record: 3 kb reads sampled from the 10 Mbp genome, cut into segments of
+    700 symbols -- a segment starts as a line does (no pointer, no k-mer), the plan's lanes are the segments, the decoder's chains too.
+    Every segment's bytes against the oracle's, and the way back."""
+    fq = capi.synth_fastq(30000, 3000, seed=13, kind=3)
+    br, seg = 64, 700
+    enc = ctx.encode_host(fq, level=3, block_reads=br, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN, chain_reads=SEG | seg)
+    starts, lens = util.line_table(fq)
+    nblocks = -(-(len(starts) // 4) // br)
+    ci = util.unpack_chains(enc.chains, nblocks)
+    assert ci["flags"] & 8 and ci["flags"] & 32 and ci["seg_len"] == seg
+    want, sizes, on = base_chains_oracle(fq, starts[1::4], lens[1::4], ci, br, 1, seg, lens[3::4])
+    assert on == 1 and list(ci["gen"]) == list(sizes) and enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
+def test_match_model_in_colour_space(ctx):
+    """SOLiD reads ("0123" behind a primer base, usrs.cpp:186-267) whose colours repeat: the staged letters are digits, their codes the
+    low two bits (gm.hip gm_code), a '.' is the N.  Against the oracle, and back."""
+    fq = _folded_genome_reads(40000)
+    tr = bytes.maketrans(b"ACGTN", b"0123.")
+    lines = fq.split(b"\n")[:-1]
+    out = []
+    for i in range(0, len(lines), 4):
+        out += [lines[i], b"T" + lines[i + 1].translate(tr), lines[i + 2], b"!" + lines[i + 3]]
+    cs = b"\n".join(out) + b"\n"
+    br, cr = 128, 32
+    enc = ctx.encode_host(cs, level=3, block_reads=br, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=cr)
+    assert enc.blocks[0].solid == 1
+    ci = util.unpack_chains(enc.chains)
+    assert ci["flags"] & 32
+    starts, lens = util.line_table(cs)
+    want, sizes, on = base_chains_oracle(cs, starts[1::4] + 1, lens[1::4] - 1, ci, br, cr)
+    assert on == 1 and list(ci["gen"]) == list(sizes) and enc.stream("gen") == want
+    assert ctx.decode_host(enc, level=3, out_cap=len(cs) + 4096) == cs
+
+
 @pytest.mark.parametrize("name", util.golden_names())
 def test_frozen_golden_samples(ctx, name):
     fq = util.golden_fastq(name)
@@ -599,11 +636,11 @@ def test_long_records_are_cut_into_segments(ctx, seg, br, qdiff):
 
 def test_long_reads_take_segments_by_themselves(ctx):
     """The automatic choice: records of a chain's worth or more, fewer than 204 800 of them and a line longer than a segment --
-    the call's symbols in about 204 800 segments of 2048 symbols or more; short reads stay with whole records."""
+    the call's symbols in about 204 800 segments of 4096 symbols or more; short reads stay with whole records."""
     fq = capi.synth_fastq(300, 150, seed=5, kind=1)                       # 10-50 kb reads
     enc = ctx.encode_host(fq, level=3, block_reads=capi.BLOCK_AUTO, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
     ci = util.unpack_chains(enc.chains, len(enc.blocks))
-    assert ci["flags"] & 8 and ci["seg_len"] == 2048 and enc.res.n_chains > 5 * 300
+    assert ci["flags"] & 8 and ci["seg_len"] == 4096 and enc.res.n_chains > 3 * 300
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
     short = capi.synth_fastq(3000, 150, seed=5)
     enc = ctx.encode_host(short, level=3, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
