@@ -1355,11 +1355,11 @@ __global__ __launch_bounds__(64) void k_rec_encode_c(ChainArgs a, const u32* fla
 template <u32 ML>
 struct RecFastLds {
     static constexpr u32 maxlen = ML;
-    u64 cnumb[RF_NF][64];
+    u64 fvalue[RF_NF][64];
     u32 rows[REC_LDS_ROWS * 256];
     u8  text[2][ML + 1][64];
     u8  off[2][RF_NF][64], wln[2][RF_NF][64], sep[2][RF_NF][64];
-    u8  ctype[RF_NF][64];
+    u8  fkind[RF_NF][64];
     u8  map[PR_REC_ROWS];                // row -> LDS slot, 0xFF = not staged
 };
 // a field's type and value (dev_rec.h field_type) over text[buf][off ..][lane]
@@ -1421,7 +1421,7 @@ __device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lan
         if (n > LT::maxlen) return false;
         nf_prev = rf_stage(L, cur, lane, m.fq + h0, n);
         if (nf_prev > RF_NF) return false;
-        for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+        for (u32 f = 0; f < RF_NF; f++) L.fkind[f][lane] = 0;
         cur ^= 1u;
     }
     u64 nh0 = 0, nh1 = 0;                                                     // the next record's header line, fetched a record ahead
@@ -1444,7 +1444,7 @@ __device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lan
         if (shape) {                                                          // recs.cpp:292-305, in the chain itself
             cd.put_u(REC_FLAG_ROW + 2, n);
             for (u32 j = 0; j < n; j++) cd.put(REC_FLAG_ROW + 1, L.text[cur][j][lane]);
-            for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+            for (u32 f = 0; f < RF_NF; f++) L.fkind[f][lane] = 0;
             nf_prev = nf; cur = prv;
             continue;
         }
@@ -1461,24 +1461,24 @@ __device__ __forceinline__ bool rec_fast_lane(const ModelArgs& m, LT& L, u32 lan
         cd.put_u(0 * 16 + 2, map);                                            // put_num(0, map) recs.cpp:313
         for (u32 f = 0; f < nf; f++) {
             if (!((map >> f) & 1)) continue;
-            const u32 o = L.off[cur][f][lane], wl = L.wln[cur][f][lane], pct = L.ctype[f][lane];
-            u64 bnum;
-            u32 type = nw_lds(L, cur, lane, o, (int)wl, bnum, pct);
+            const u32 o = L.off[cur][f][lane], wl = L.wln[cur][f][lane], pct = L.fkind[f][lane];
+            u64 fnum;
+            u32 type = nw_lds(L, cur, lane, o, (int)wl, fnum, pct);
             if (type != ST_STR && !rec_number_prints_back(type, wl, L.text[cur][o][lane])) type = ST_STR;      // (chains are block format only: lossless)
             const u32 rr = (f + 1) * 16;
             if (type == ST_STR) {                                             // recs.cpp:324-331
                 cd.put(rr + 0, type);
                 cd.put_u(rr + 2, wl);
                 for (u32 j = 0; j < wl; j++) cd.put(rr + 1, L.text[cur][o + j][lane]);
-                L.ctype[f][lane] = 0;
+                L.fkind[f][lane] = 0;
                 continue;
             }
-            const u64 pnum = pct ? L.cnumb[f][lane] : 0;                       // recs.cpp:333-348
+            const u64 was = pct ? L.fvalue[f][lane] : 0;                       // recs.cpp:333-348
             u64 gap;
-            L.ctype[f][lane] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
-            L.cnumb[f][lane] = bnum;
-            if (bnum < pnum) { gap = pnum - bnum; type++; }
-            else gap = bnum - pnum;
+            L.fkind[f][lane] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+            L.fvalue[f][lane] = fnum;
+            if (fnum < was) { gap = was - fnum; type++; }
+            else gap = fnum - was;
             cd.put(rr + 0, type);
             cd.put_u(rr + 2, gap);
         }
@@ -1587,8 +1587,8 @@ __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, 
     for (u32 f = 0; f < nf; f++) {
         if (!((map >> f) & 1)) continue;
         const u32 o = L.off[0][f][col], wl = L.wln[0][f][col];
-        u64 bnum;
-        u32 type = nw_lds(L, 0, col, o, (int)wl, bnum, 0);
+        u64 fnum;
+        u32 type = nw_lds(L, 0, col, o, (int)wl, fnum, 0);
         if (type != ST_STR && !rec_number_prints_back(type, wl, L.text[0][o][col])) type = ST_STR;
         if (type >= ST_HGT && type <= ST_HLTC_Z) return false;
         const u32 rr = (f + 1) * 16;
@@ -1598,17 +1598,17 @@ __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, 
             for (u32 j = 0; j < wl; j++) em.put(rr + 1, L.text[0][o + j][col]);
             continue;
         }
-        u64 pnum = 0;                                                         // recs.cpp:333: the previous VALUE, if the field has one
+        u64 was = 0;                                                         // recs.cpp:333: the previous VALUE, if the field has one
         if ((since >> f) & 1) {
             const u32 po = L.off[0][f][col - 1], pwl = L.wln[0][f][col - 1];
             u64 pn;
             u32 pt = nw_lds(L, 0, col - 1, po, (int)pwl, pn, 0);
             if (pt != ST_STR && !rec_number_prints_back(pt, pwl, L.text[0][po][col - 1])) pt = ST_STR;
-            if (pt == ST_DGT || pt == ST_DGT_Z) pnum = pn;
+            if (pt == ST_DGT || pt == ST_DGT_Z) was = pn;
         }
         u64 gap;
-        if (bnum < pnum) { gap = pnum - bnum; type++; }
-        else gap = bnum - pnum;
+        if (fnum < was) { gap = was - fnum; type++; }
+        else gap = fnum - was;
         em.put(rr + 0, type);
         em.put_u(rr + 2, gap);
     }
@@ -1880,11 +1880,11 @@ __global__ __launch_bounds__(64) void k_rec_decode_c(ChainArgs a, DecodeArgs da,
 // stream -- hands the chain over (flags[c] = 1): the general kernel starts it again and reports what it finds.
 #define RF_DML 127u
 struct RecFastDecLds {
-    u64 cnumb[RF_NF][64];
+    u64 fvalue[RF_NF][64];
     u16 drows[RDEC_LDS_ROWS][RDEC_ROW];
     u8  text[2][RF_DML + 1][64];
     u8  off[RF_NF][64], wln[RF_NF][64], sep[RF_NF][64];        // of the previous header
-    u8  ctype[RF_NF][64];
+    u8  fkind[RF_NF][64];
     u8  map[PR_REC_ROWS];                                      // row -> LDS slot, 0xFF = not staged
 };
 struct RecFastDecSrc {
@@ -1927,7 +1927,7 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
     u32 prv = 0, cur = 1;
     u32 nf_prev = rfd_emit(L, prv, lane, n_prev, nullptr);
     if (nf_prev > RF_NF) return false;
-    for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+    for (u32 f = 0; f < RF_NF; f++) L.fkind[f][lane] = 0;
     LaneOut out; out.begin(a.hdr_stage + stage_off);
     u64 pos = 0;
     for (u32 k = 0; k < nrec; k++) {
@@ -1944,7 +1944,7 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
                 if (len > RF_DML) return false;
                 for (u32 j = 0; j < (u32)len; j++) L.text[cur][j][lane] = (u8)cd.get(REC_FLAG_ROW + 1);
                 n = (u32)len;
-                for (u32 f = 0; f < RF_NF; f++) L.ctype[f][lane] = 0;
+                for (u32 f = 0; f < RF_NF; f++) L.fkind[f][lane] = 0;
             } else {
                 const u64 map = cd.get_u(0 * 16 + 2);
                 u32 b = 0;
@@ -1962,10 +1962,10 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
                             if (len > RF_DML || b + len + 2 > RF_DML) return false;
                             for (u32 j = 0; j < (u32)len; j++) L.text[cur][b + j][lane] = (u8)cd.get(rr + 1);
                             b += (u32)len;
-                            L.ctype[i][lane] = 0;
+                            L.fkind[i][lane] = 0;
                         } else {                                               // recs.cpp:430-456
                             if (type > ST_DLT_Z) return false;
-                            const u64 pval = L.ctype[i][lane] ? L.cnumb[i][lane] : 0;
+                            const u64 pval = L.fkind[i][lane] ? L.fvalue[i][lane] : 0;
                             const u64 gap = cd.get_u(rr + 2);
                             const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC ||
                                               type == ST_HLTC_Z || type == ST_DLT_Z;
@@ -1974,8 +1974,8 @@ __device__ __forceinline__ bool rec_fast_decode_lane(const DecodeArgs& a, const 
                             const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z ||
                                               type == ST_DGT_Z || type == ST_DLT_Z;
                             const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
-                            L.ctype[i][lane] = deci ? 1 : 2;
-                            L.cnumb[i][lane] = val;
+                            L.fkind[i][lane] = deci ? 1 : 2;
+                            L.fvalue[i][lane] = val;
                             if (val == 0) L.text[cur][b++][lane] = '0';        // recs.cpp:453-454
                             else {
                                 if (lead) L.text[cur][b++][lane] = '0';

@@ -19,9 +19,9 @@ template <typename C>
 __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec, u64 rec0, u32 nrec, C& cd, XfEnc& x_rec, const PwTab& xpw,
                                                 u32& hdr_bytes_out, int& bad_out) {
     SpaceMap sm[2];
-    u8  ctype[2][66];
-    u64 cnumb[2][66];
-    u32 imap = 0; int bad = 0;
+    u8  fkind[2][66];
+    u64 fvalue[2][66];
+    u32 cur = 0; int bad = 0;
     u64 last_index = 0;                       // m_last.index recs.hpp:54
     u32 hdr_bytes = 0, step = 0, coded = 0;
     const u8* prev = nullptr;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
         const u8* buf = cd.stage(a.fq + h0, n, step++);
         if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
-        for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+        for (int i = 0; i < 66; i++) { fkind[0][i] = 0; fkind[1][i] = 0; }
         prev = buf;
     }
     for (u32 k = 0; k < nrec && !bad; k++) {
@@ -42,10 +42,10 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
         if (r == base_rec) continue;                                          // the base itself
         cd.record(coded++);
         const u8* buf = cd.stage(a.fq + h0, n, step++);  // the text itself, or the coder's faster copy of it
-        const u32 pmap = imap;
-        imap ^= 1;
-        if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
-        SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
+        const u32 prv = cur;
+        cur ^= 1;
+        if (!map_space(buf, n, sm[cur])) { bad = SFQ_E_FORMAT; break; }
+        SpaceMap& mi = sm[cur]; SpaceMap& mp = sm[prv];
         bool shape = mi.len != mp.len;
         if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
         if (a.lossless && mi.str[mi.len - 1] == 0) shape = true;              // a NUL inside: the fields behind it would be lost (dev_common.h)
@@ -59,7 +59,7 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
                 last_index = record_count;
                 x_rec.put_str(xpw, buf, n);
             }
-            for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            for (int i = 0; i < 66; i++) fkind[cur][i] = 0;
             prev = buf;
             continue;
         }
@@ -70,28 +70,28 @@ __device__ __forceinline__ void rec_encode_lane(const ModelArgs& a, u64 base_rec
         for (u32 i = 0; i < mi.len; i++) {
             if (map & (1ULL << i)) {
                 const u8* bp = buf + mi.off[i];
-                u64 bnum;
-                u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                u64 fnum;
+                u32 type = numberwang(bp, mi.wln[i], fnum, fkind[prv][i]);
                 if (a.lossless && type != ST_STR && !rec_number_prints_back(type, mi.wln[i], bp[0])) type = ST_STR;
                 const u32 rr = (i + 1) * 16;
                 if (type == ST_STR) {                                         // recs.cpp:324-331
                     cd.put(rr + 0, type);
                     cd.put_u(rr + 2, mi.wln[i]);
                     for (u32 j = 0; j < mi.wln[i]; j++) cd.put(rr + 1, bp[j]);
-                    ctype[imap][i] = 0;
+                    fkind[cur][i] = 0;
                     continue;
                 }
-                u64 pnum = ctype[pmap][i] ? cnumb[pmap][i] : 0;                // recs.cpp:333-348
+                u64 was = fkind[prv][i] ? fvalue[prv][i] : 0;                // recs.cpp:333-348
                 u64 gap;
-                ctype[imap][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
-                cnumb[imap][i] = bnum;
-                if (bnum < pnum) { gap = pnum - bnum; type++; }
-                else gap = bnum - pnum;
+                fkind[cur][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+                fvalue[cur][i] = fnum;
+                if (fnum < was) { gap = was - fnum; type++; }
+                else gap = fnum - was;
                 cd.put(rr + 0, type);
                 cd.put_u(rr + 2, gap);
             } else {
-                ctype[imap][i] = ctype[pmap][i];
-                cnumb[imap][i] = cnumb[pmap][i];
+                fkind[cur][i] = fkind[prv][i];
+                fvalue[cur][i] = fvalue[prv][i];
             }
         }
         prev = buf;
@@ -197,13 +197,13 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
     const u64 cap = a.hdr_stage_cap[blk];
     u64 pos = 0;            // write cursor in stage
     DSpaceMap sm;
-    u8  ctype[2][66];
-    u64 cnumb[2][66];
-    u32 imap = 0;
+    u8  fkind[2][66];
+    u64 fvalue[2][66];
+    u32 cur = 0;
     int bad = 0;
     // the base: the block's first header (load_first_line recs.cpp:113-119); records [rec0, rec0 + nrec) of the block follow it
     const u8* prev = a.first_hdrs + d->first_hdr_off; u32 prev_n = d->first_hdr_len;
-    for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+    for (int i = 0; i < 66; i++) { fkind[0][i] = 0; fkind[1][i] = 0; }
     if (prev_n > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; nrec = 0; }                        // (also refused by sfq_decode_blocks)
     for (u32 k = 0; k < nrec; k++) {
         const u64 r = rec0 + k, rcnt = rec_count_of(a.m, r, d->rec0);
@@ -215,8 +215,8 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
             n = prev_n;
             for (u32 i = 0; i < n; i++) buf[i] = prev[i];
         } else {
-            const u32 pmap = imap;
-            imap ^= 1;
+            const u32 prv = cur;
+            cur ^= 1;
             bool whole = false;
             if constexpr (C::inband) whole = cd.get(REC_FLAG_ROW) != 0; else whole = index == rcnt;
             if (whole && C::inband) {
@@ -224,14 +224,14 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
                 if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
                 for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)cd.get(REC_FLAG_ROW + 1);
                 n = (u32)len;
-                for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+                for (int i = 0; i < 66; i++) fkind[cur][i] = 0;
             } else if (whole) {                                                             // recs.cpp:386-393
                 u64 len = x_rec.get(xpw);
                 if (len > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
                 for (u32 j = 0; j < (u32)len; j++) buf[j] = (u8)x_rec.get_chr(xpw);
                 n = (u32)len;
                 index += x_rec.get(xpw);
-                for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+                for (int i = 0; i < 66; i++) fkind[cur][i] = 0;
             } else {
                 if (!d_map_space(prev, prev_n, sm)) { bad = SFQ_E_CORRUPT; break; }
                 const u64 map = cd.get_u(0 * 16 + 2);
@@ -247,8 +247,8 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
                             for (u32 j = 0; j < sm.wln[i]; j++) b[j] = pp[j];
                             b += sm.wln[i];
                             *b++ = sm.str[i];
-                            ctype[imap][i] = ctype[pmap][i];
-                            cnumb[imap][i] = cnumb[pmap][i];
+                            fkind[cur][i] = fkind[prv][i];
+                            fvalue[cur][i] = fvalue[prv][i];
                             continue;
                         }
                         const u32 type = cd.get(rr + 0);
@@ -257,11 +257,11 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
                             if (len > SFQ_MAX_ID_LLEN || (u64)(b - buf) + len + 64 > SFQ_MAX_ID_LLEN) { bad = SFQ_E_CORRUPT; break; }
                             for (u32 j = 0; j < (u32)len; j++) b[j] = (u8)cd.get(rr + 1);
                             b += len;
-                            ctype[imap][i] = 0;
+                            fkind[cur][i] = 0;
                             *b++ = sm.str[i];
                             continue;
                         }
-                        const u64 pval = ctype[pmap][i] == 0 ? 0 : cnumb[pmap][i];
+                        const u64 pval = fkind[prv][i] == 0 ? 0 : fvalue[prv][i];
                         const u64 gap = cd.get_u(rr + 2);
                         if (type > ST_DLT_Z) { bad = SFQ_E_CORRUPT; break; }
                         const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC ||
@@ -271,8 +271,8 @@ __device__ __forceinline__ void rec_decode_lane(const DecodeArgs& a, BlockDesc* 
                         const bool lead = type == ST_HGT_Z || type == ST_HLT_Z || type == ST_HGTC_Z || type == ST_HLTC_Z ||
                                           type == ST_DGT_Z || type == ST_DLT_Z;
                         const bool upper = type >= ST_HGTC && type <= ST_HLTC_Z;
-                        ctype[imap][i] = deci ? 1 : 2;
-                        cnumb[imap][i] = val;
+                        fkind[cur][i] = deci ? 1 : 2;
+                        fvalue[cur][i] = val;
                         if (val == 0) *b++ = '0';                                            // recs.cpp:453-454
                         else {
                             if (lead) *b++ = '0';

@@ -358,9 +358,9 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
     RcEncU rc; rc.init();
     XfEncW x_rec; x_rec.init(a.arena + d->out_off[SFQ_S_REC_X], d->out_cap[SFQ_S_REC_X], XF_REC_X);
     SpaceMap sm[2];
-    u8  ctype[2][66];
-    u64 cnumb[2][66];
-    u32 imap = 0; int bad = 0;
+    u8  fkind[2][66];
+    u64 fvalue[2][66];
+    u32 cur = 0; int bad = 0;
     u64 last_index = 0;
     u32 hdr_bytes = 0;
     const u8* prev = nullptr;
@@ -373,16 +373,16 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
         const u32 n = h1 > h0 ? (u32)(h1 - h0) : 0;
         hdr_bytes += n;
         if (k == 0) {                                                         // recs.cpp:279-287
-            imap = 0;
+            cur = 0;
             if (!map_space(buf, n, sm[0])) bad = SFQ_E_FORMAT;
-            for (int i = 0; i < 66; i++) { ctype[0][i] = 0; ctype[1][i] = 0; }
+            for (int i = 0; i < 66; i++) { fkind[0][i] = 0; fkind[1][i] = 0; }
             prev = buf;
             continue;
         }
-        const u32 pmap = imap;
-        imap ^= 1;
-        if (!map_space(buf, n, sm[imap])) { bad = SFQ_E_FORMAT; break; }
-        SpaceMap& mi = sm[imap]; SpaceMap& mp = sm[pmap];
+        const u32 prv = cur;
+        cur ^= 1;
+        if (!map_space(buf, n, sm[cur])) { bad = SFQ_E_FORMAT; break; }
+        SpaceMap& mi = sm[cur]; SpaceMap& mp = sm[prv];
         bool shape = mi.len != mp.len;
         if (!shape) for (u32 i = 0; i < mi.len; i++) if (mi.str[i] != mp.str[i]) { shape = true; break; }
         if (a.lossless && mi.str[mi.len - 1] == 0) shape = true;              // a NUL inside (dev_common.h)
@@ -390,7 +390,7 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
             x_rec.put(pw, record_count - last_index, lane);
             last_index = record_count;
             x_rec.put_str(pw, buf, n, lane);
-            for (int i = 0; i < 66; i++) ctype[imap][i] = 0;
+            for (int i = 0; i < 66; i++) fkind[cur][i] = 0;
             prev = buf;
             continue;
         }
@@ -401,28 +401,28 @@ __device__ __forceinline__ void rec_encode_block_slow(const ModelArgs& a, const 
         for (u32 i = 0; i < mi.len; i++) {
             if (map & (1ULL << i)) {
                 const u8* bp = buf + mi.off[i];
-                u64 bnum;
-                u32 type = numberwang(bp, mi.wln[i], bnum, ctype[pmap][i]);
+                u64 fnum;
+                u32 type = numberwang(bp, mi.wln[i], fnum, fkind[prv][i]);
                 if (a.lossless && type != ST_STR && !rec_number_prints_back(type, mi.wln[i], bp[0])) type = ST_STR;
                 const u32 rr = (i + 1) * 16;
                 if (type == ST_STR) {                                         // recs.cpp:324-331
                     pw.put(rr + 0, rc, snk, type, lane);
                     pw.put_u(rr + 2, rc, snk, mi.wln[i], lane);
                     for (u32 j = 0; j < mi.wln[i]; j++) pw.put(rr + 1, rc, snk, bp[j], lane);
-                    ctype[imap][i] = 0;
+                    fkind[cur][i] = 0;
                     continue;
                 }
-                u64 pnum = ctype[pmap][i] ? cnumb[pmap][i] : 0;                // recs.cpp:333-348
+                u64 was = fkind[prv][i] ? fvalue[prv][i] : 0;                // recs.cpp:333-348
                 u64 gap;
-                ctype[imap][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
-                cnumb[imap][i] = bnum;
-                if (bnum < pnum) { gap = pnum - bnum; type++; }
-                else gap = bnum - pnum;
+                fkind[cur][i] = (type < ST_STR || type >= ST_DGT_Z) ? 1 : 2;
+                fvalue[cur][i] = fnum;
+                if (fnum < was) { gap = was - fnum; type++; }
+                else gap = fnum - was;
                 pw.put(rr + 0, rc, snk, type, lane);
                 pw.put_u(rr + 2, rc, snk, gap, lane);
             } else {
-                ctype[imap][i] = ctype[pmap][i];
-                cnumb[imap][i] = cnumb[pmap][i];
+                fkind[cur][i] = fkind[prv][i];
+                fvalue[cur][i] = fvalue[prv][i];
             }
         }
         prev = buf;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
     const u64 lt = (1ull << lane) - 1;                    // lanes below this one
     HdrRegs pb = {0, 0};                                  // previous header
     u32 psep = 0, pspos = 0, pnf = 0;                     // its k-th separator char / position (lane k), field count
-    u32 ct = 0, cn_lo = 0, cn_hi = 0;                     // per field (lane k): ctype, cnumb (recs.hpp:75-76)
+    u32 ct = 0, cn_lo = 0, cn_hi = 0;                     // per field (lane k): fkind, fvalue (recs.hpp:75-76)
     u64 last_index = 0;
     u32 hdr_bytes = 0;
     int bad = 0;
@@ -547,8 +547,8 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
             const u32 i = (u32)__ffsll((long long)todo) - 1u;
             todo &= todo - 1;
             const u32 off = rl(offv, i), wln = rl(wlnv, i), pct = rl(ct, i);
-            u64 bnum;
-            u32 type = nw_lanes(cb, off, (int)wln, bnum, pct);
+            u64 fnum;
+            u32 type = nw_lanes(cb, off, (int)wln, fnum, pct);
             if (a.lossless && type != ST_STR && !rec_number_prints_back(type, wln, cb.at(off))) type = ST_STR;
             const u32 rr = (i + 1) * 16;
             if (type == ST_STR) {                         // recs.cpp:324-331
@@ -558,12 +558,12 @@ __device__ __forceinline__ void rec_encode_block_fast(const ModelArgs& a, const 
                 if (lane == i) ct = 0;
                 continue;
             }
-            const u64 pnum = pct ? ((u64)rl(cn_hi, i) << 32 | rl(cn_lo, i)) : 0;       // recs.cpp:333-348
+            const u64 was = pct ? ((u64)rl(cn_hi, i) << 32 | rl(cn_lo, i)) : 0;       // recs.cpp:333-348
             u64 gap;
             const u32 nct = (type < ST_STR || type >= ST_DGT_Z) ? 1u : 2u;
-            if (lane == i) { ct = nct; cn_lo = (u32)bnum; cn_hi = (u32)(bnum >> 32); }
-            if (bnum < pnum) { gap = pnum - bnum; type++; }
-            else gap = bnum - pnum;
+            if (lane == i) { ct = nct; cn_lo = (u32)fnum; cn_hi = (u32)(fnum >> 32); }
+            if (fnum < was) { gap = was - fnum; type++; }
+            else gap = fnum - was;
             pw.put(rr + 0, rc, snk, type, lane);
             pw.put_u(rr + 2, rc, snk, gap, lane);
         }
