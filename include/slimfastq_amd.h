@@ -77,13 +77,17 @@ typedef struct sfq_params {
                               long reads).  The block format is LOSSLESS: where the reference would alter the text,
                               its blocks depart from the reference's bytes (a header field that would not print back
                               is coded as a string, lowercase bases are listed in "gen.lc") or refuse the input    */
-    int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size */
+    int32_t  gen_bits;     /* base-model context bits; 0 = the level's (gens.hpp:43-53) capped by block size.  (The table they size is
+                              the adaptive modes' and kernel = 2's; the default frozen mode's match model has no table of rows) */
     uint32_t models;       /* SFQ_M_* mask; 0 = SFQ_M_ALL                                             */
     uint32_t kernel;       /* 0 = default kernels; 1 = lane-per-block reference kernels (the reference loop on one lane:
                               slow, the cross-check of the default kernels; adaptive tables); 2 = the default kernels, but
                               with frozen tables the base exceptions (gen.Ns / gen.Nn / gen.lc) keep the reference's own
                               coding -- XFile streams through adaptive PowerRanger rows, what archives written before
-                              round 4 hold -- instead of Rice-coded gap lists ("chn.idx" flag bit 4)  */
+                              round 4 hold -- instead of Rice-coded gap lists ("chn.idx" flag bit 4), and the
+                              BASES keep round 4's coding: generation tables of Base2 rows where they pay, the initial row's 3 of 12
+                              a base where they do not -- instead of the generation match model ("chn.idx" flag bit 5: a chain
+                              follows a pointer into the earlier generations' bases, gm.hip) and four bases a symbol (bit 6)   */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);
@@ -94,7 +98,8 @@ typedef struct sfq_params {
                               (Log64Ranger / Base2Ranger updated per symbol), a wavefront per block;
                               SFQ_TABLES_FROZEN (1) = the rows are built by counting passes and frozen while a chain
                               is coded -- qualities from the transmitted prior, bases from the counts of the earlier
-                              generations of the same call -- one chain per LANE               */
+                              generations of the same call (round 5: read as such -- the match model, DESIGN.md 4.3 --, not
+                              counted into a table) -- one chain per LANE                              */
     uint32_t chain_reads;  /* frozen tables: records per chain; 0 = automatic (about 205 000 chains a call, of 4 KiB of text or more; long
                               reads -- fewer than 204 800 records, each a chain's worth or more -- are cut into SEGMENTS of one record);
                               SFQ_CHAIN_SEGMENT(n): chains of (at most) n quality symbols / bases of ONE record                     */

@@ -254,6 +254,39 @@ def test_frozen_counting_passes_take_long_lines_a_stretch_per_lane(ctx):
     assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
 
 
+def test_match_model_archives_that_are_damaged_fail_cleanly(ctx):
+    """Untrusted input on the way back through the match model's decoder (its index is built from what it decodes, its pointers
+    come out of that index): flipped bytes in the base stream, a chain index that lies about the base chains or the index's bits.
+    Every decode ends in an SfqError or in some bytes -- never in a device fault -- and the context decodes the intact archive afterwards."""
+    import random
+    rnd = random.Random(5)
+    fq = _folded_genome_reads(20000)
+    enc = ctx.encode_host(fq, level=3, block_reads=128, prior_step=1, tables=capi.TABLES_FROZEN, chain_reads=32)
+    ci = util.unpack_chains(enc.chains)
+    assert ci["flags"] & 32
+    s = capi.STREAM_NAMES.index("gen")
+    g0, g1 = int(enc.res.stream_offset[s]), int(enc.res.stream_offset[s]) + int(enc.res.stream_bytes[s])
+    outcomes = {"error": 0, "bytes": 0}
+    for trial in range(40):
+        bad = enc.clone()
+        if trial % 2 == 0:                                     # flipped bytes in the base stream: wrong bases, wrong k-mers, wrong pointers
+            data = bytearray(bad.data)
+            for _ in range(rnd.randint(1, 20)):
+                data[rnd.randrange(g0, g1)] ^= 1 << rnd.randrange(8)
+            bad.data = bytes(data)
+        else:                                                  # the chain index's head: index bits, base chains' geometry, chain counts
+            ch = bytearray(bad.chains)
+            ch[rnd.randrange(0, 8)] ^= 1 << rnd.randrange(7)
+            bad.chains = bytes(ch)
+        try:
+            ctx.decode_host(bad, level=3, out_cap=2 * len(fq) + 4096)
+            outcomes["bytes"] += 1
+        except capi.SfqError:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 0
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+
+
 def test_match_model_with_chains_that_are_segments(ctx):
     """The match model (gm.hip) where chains are SEGMENTS of one record: 3 kb reads sampled from the 10 Mbp genome, cut into segments of
     700 symbols -- a segment starts as a line does (no pointer, no k-mer), the plan's lanes are the segments, the decoder's chains too.
