@@ -664,6 +664,10 @@ u32 gm_table_bits(u64 nbytes) {          // an entry per eight bases of the call
     while (tb < 24 && (1ull << tb) < nbytes / 16) tb++;
     return tb;
 }
+#ifndef GM_CHAIN_WANT
+#define GM_CHAIN_WANT 819200ull       /* base chains a call under the match model aims at ... */
+#define GM_CHAIN_FLOOR 2048ull        /* ... of this much text or more each */
+#endif
 struct GmPlan { u32 ngen = 0; u32 bound[GEN_MAX_GENERATIONS + 1]; u32 tb = 0; u64 cap = 0; u64 r2 = 0; ChainArgs cg; ChainGeoArgs ggeo; u32* gcsz = nullptr; };
 // the stage of records [0, n): line lengths, their scan, the places, the letters
 int gm_stage_upto(sfq_ctx* ctx, const ChainArgs& ca, u64 n, u64 from, hipStream_t st) {
@@ -1221,7 +1225,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             //  SIMD and runs at the chip's rate, not at one lane's -- down to 2 KiB of text a chain: a 2 M-read call decodes in 10 ms
             //  instead of 17 for 0.4 % more bytes)
             const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
-            const u64 gwant = std::max<u64>((2048 + per_rec - 1) / per_rec, (nrec + 819199) / 819200);
+            const u64 gwant = std::max<u64>((GM_CHAIN_FLOOR + per_rec - 1) / per_rec, (nrec + GM_CHAIN_WANT - 1) / GM_CHAIN_WANT);
             const u32 gfloor = (u32)std::min<u64>(gwant, ca.geo.chain_reads);
             ggeo.cpb = (block_reads + gfloor - 1) / gfloor;
             ggeo.chain_reads = std::max<u32>(1u, (u32)((std::min<u64>(block_reads, nrec) + ggeo.cpb - 1) / ggeo.cpb));
@@ -2163,7 +2167,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 64))) return rc;          // (gm.hip's windows read sixteen bytes at any place up to tot_s)
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;
     da.seq_stage = (u8*)ctx->seq_stage.p; da.qual_stage = (u8*)ctx->qual_stage.p;
-    if (gm_on) launch_gm_sentinels(da.seq_stage, da.soff, da.slen, nrec, st);
+    if (gm_on && seg_len) launch_gm_sentinels(da.seq_stage, da.soff, da.slen, nrec, st);        // (whole-record chains write their lines' sentinels themselves)
 
     ht.mark("head queued");
     if (lists_pending) {                                  // frozen tables: the chain lists, then their copies to the device

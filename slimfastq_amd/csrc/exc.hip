@@ -39,12 +39,24 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_r(DecodeArgs a, u32 nbloc
     const u64 b0 = bo ? bo[0] : 0;
     const u64 nb = bo ? bo[d->nrec] - b0 : a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
     u32 bad = 0;
-    u64 at = 0; u32 k = 0;
-    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] = (u8)n_byte; }
-    at = 0; k = 0;
-    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] |= 0x80u; }
-    at = 0; k = 0;
-    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } if (bo) while (b0 + at - 1 >= bo[k + 1]) k++; g[at - 1 + k] |= 0x20u; }
+    // the record of base position `at` (1-based over the block's bases): guessed from the block's mean line length -- reads of one
+    // length: exact --, then stepped to (a walk from the list's previous entry, record by record, was 3000 dependent loads a lane: 1.27 ms
+    // per 10 M reads against 0.43 without the sentinels)
+    const u32 nr = d->nrec;
+    auto rec_of = [&](u64 at) -> u32 {
+        const u64 P = b0 + at - 1;
+        u32 k = nb ? (u32)(((at - 1) * nr) / nb) : 0u;
+        if (k >= nr) k = nr - 1;
+        while (k > 0 && bo[k] > P) k--;
+        while (k + 1 < nr && bo[k + 1] <= P) k++;
+        return k;
+    };
+    u64 at = 0;
+    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] = (u8)n_byte; }
+    at = 0;
+    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] |= 0x80u; }
+    at = 0;
+    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] |= 0x20u; }
     if (bad | r_ns.err | r_nn.err | r_lc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_gen_exc_decode_r(const DecodeArgs& a, u32 nblocks, hipStream_t st) {

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(THREADS) void k_gm_decode_c(ChainArgs a, DecodeArgs
             out.put((alphabet >> (8u * b)) & 0xffu);
             gm_update(W, i, n, b, e, lim, T, tb, stage, stage_bytes);
         }
+        if (!a.seg_len) out.put('\n');                        // the line's sentinel (chains that are segments: k_gm_sentinels has written them)
         out.end();
     }
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
