@@ -1899,13 +1899,13 @@ long long sfqo_gen_encode_segs(const u8* base, const u64* goff, const u32* glen,
        Without one the base is coded flat (1024 of 4096).  Without a pointer and none pending, after base i, with sixteen bases of
        the line seen and i + 1 + GM_D < n: if the k-mer is one of the quarter, its entry holds its check bits and a position p
        below the generation's first stage position, the pointer p + GM_D starts to predict at base i + 1 + GM_D -- unless a
-       sentinel lies in [p, p + GM_D].  (GM_D = 4 bases pass between lookup and use: a decoder has the entry and the bases at p
-       in flight meanwhile and never waits for memory.)
+       sentinel lies in [p, p + GM_D].  (GM_D = 1 base passes between lookup and use: a decoder reads the entry behind base i and
+       looks at it behind base i + 1, with that base's arithmetic to hide the round trip.)
    Whether a call uses the model at all is decided once: generation 0's counted records indexed, every eighth counted record of
    generation 1 priced (integer log2 costs; in stretches of 256 bases, each walked as a line of its own); on if that beats two bits
    a base by 1 %.                                        */
 #define GM_K 16
-#define GM_D 4
+#define GM_D 1
 #define GM_DROP 8
 #define GM_MCAP 31
 #define GM_EMPTY (~0ull)

@@ -17,8 +17,9 @@
 //   walk     sfq_oracle.c "the generation MATCH model" has the rule: with a pointer the base under it is coded at 4096 - 3 Fo[m] of
 //            4096 (m = bases matched in a row), a miss resets m, a second miss within eight bases or a '\n' drops the pointer;
 //            without one the base is coded flat and the k-mers of the sampled quarter are looked up; a pointer found behind base i
-//            predicts from base i + 1 + GM_D on (GM_D = 4: the decoder has the entry and the sixteen bytes at the pointer in
-//            flight meanwhile and never waits for memory).
+//            predicts from base i + 1 + GM_D on (GM_D = 1: a decoder reads the entry behind base i, looks at it behind base i + 1 and
+//            has the base between them to hide the round trip; 4 was measured no faster -- a lone wave's base takes 1 us, as long as
+//            a round trip -- and costs 0.08 bit a base more).
 // Encode in two passes -- k_gm_plan: a RECORD per lane (ten million lanes: the lookups' round trips hide behind each other) writes
 // a token per base (pointer or not, Fo level, predicted base); k_gm_code: a CHAIN per lane codes bases + tokens, no random access.
 // Decode: k_gm_decode_c, a chain per lane, generation by generation, k_gm_insert behind each.
@@ -29,7 +30,7 @@
 #include "dev_walk.h"
 
 #define GM_K 16u
-#define GM_D 4u
+#define GM_D 1u                          // bases between a lookup and its pointer's first prediction
 #define GM_DROP 8u
 #define GM_MCAP 31u
 #define GM_HASH 0x9E3779B97F4A7C15ull
@@ -48,10 +49,11 @@ __device__ __forceinline__ u32 gm_byte_at(const uint4& w, u32 idx) {          //
     const u64 h = (idx & 8u) ? hi : lo;
     return (u32)(h >> ((idx & 7u) * 8u)) & 0xffu;
 }
-// a '\n' among bytes 0 .. GM_D of the window
+// a '\n' among bytes 0 .. GM_D of the window (GM_D <= 7)
 __device__ __forceinline__ bool gm_newline_ahead(const uint4& w) {
-    const u32 a = w.x ^ 0x0A0A0A0Au, b = (w.y & 0xffu) ^ 0x0Au;
-    return (((a - 0x01010101u) & ~a & 0x80808080u) != 0u) || b == 0u;
+    constexpr u64 keep = GM_D >= 7u ? ~0ull : ((1ull << (8u * (GM_D + 1u))) - 1ull);
+    const u64 a = (((u64)w.x | ((u64)w.y << 32)) ^ 0x0A0A0A0A0A0A0A0Aull) | ~keep;              // a zero byte = a '\n' among the bytes kept
+    return ((a - 0x0101010101010101ull) & ~a & 0x8080808080808080ull) != 0ull;
 }
 // sixteen bytes at `at` of a buffer that is readable up to cap + 16: ONE load whatever the place (the address is held at cap; what a
 // window holds beyond the buffer's last line is never looked at -- a pointer stops at its line's '\n').  A load with a second path for the
