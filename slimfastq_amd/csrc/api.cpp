@@ -685,18 +685,21 @@ int gm_begin(sfq_ctx* ctx, const ChainArgs& ca, u32 nblocks, u64 nrec, u32 max_l
     const u32* bound = gp.bound;
     int rc;
     gp.tb = gm_table_bits(ca.nbytes);
-    gp.cap = ca.nbytes;                                            // (a staged byte is a byte of the text: a base, or its line's '\n')
+    const u64 br = ca.block_reads;
+    gp.r2 = std::min<u64>(nrec, (u64)bound[2] * br);
+    // The verdict needs the first two generations staged, no more: a call that turns the model down -- the default workload -- keeps
+    // 50 MB of stage and offsets, not the 4 GB a stage of its whole text and every record's offsets would be.  (A staged byte is a
+    // byte of the text -- a base, or its line's '\n' --, and a record has at most max_line of them and one.)
+    gp.cap = std::min<u64>(ca.nbytes, gp.r2 * ((u64)max_line + 1));
     if ((rc = reserve(ctx, ctx->gm_T, (size_t)8 << gp.tb))) return rc;
-    if ((rc = reserve(ctx, ctx->gm_slen, (size_t)nrec * 4 + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->gm_soff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_slen, (size_t)gp.r2 * 4 + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)gp.r2 + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_soff, ((size_t)gp.r2 + 1) * 8))) return rc;
     if ((rc = reserve(ctx, ctx->gm_scan, ((size_t)nrec / 1024 + 4) * 8 + 65536))) return rc;
     if ((rc = reserve(ctx, ctx->gm_stage, (size_t)gp.cap + 64))) return rc;
     if ((rc = reserve(ctx, ctx->gcost, 64))) return rc;
     HIPC(hipMemsetAsync(ctx->gm_T.p, 0xFF, (size_t)8 << gp.tb, st));
     HIPC(hipMemsetAsync(ctx->gcost.p, 0, 64, st));
-    const u64 br = ca.block_reads;
-    gp.r2 = std::min<u64>(nrec, (u64)bound[2] * br);
     if ((rc = gm_stage_upto(ctx, ca, gp.r2, 0, st))) return rc;
     gp.cg = ca;
     gp.cg.st_buf = (const u8*)ctx->gm_stage.p; gp.cg.st_bytes = gp.cap; gp.cg.st_off = (const u64*)ctx->gm_soff.p; gp.cg.st_len = (const u32*)ctx->gm_slen.p;
@@ -725,8 +728,16 @@ int gm_finish(sfq_ctx* ctx, ChainArgs& ca, u64 nrec, u32 max_line, hipStream_t s
     if (!nbases || cost * 100 >= nbases * 2048 * 99) return SFQ_OK;           // nothing to gain: every chain codes with the initial row
     *gen_on = 1;
     int rc;
+    // the whole call's stage now (buffers that grow are new ones: everything is staged again, the first two generations included --
+    // their places, and so the index's entries, do not change)
+    gp.cap = ca.nbytes;
+    if ((rc = reserve(ctx, ctx->gm_slen, (size_t)nrec * 4 + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_soff, ((size_t)nrec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->gm_stage, (size_t)gp.cap + 64))) return rc;
     if ((rc = reserve(ctx, ctx->gm_tok, (size_t)gp.cap + 64))) return rc;
-    if ((rc = gm_stage_upto(ctx, ca, nrec, gp.r2, st))) return rc;             // (the scan again over all the records: the first ones' places do not change)
+    if ((rc = gm_stage_upto(ctx, ca, nrec, 0, st))) return rc;
+    gp.cg.st_buf = (const u8*)ctx->gm_stage.p; gp.cg.st_bytes = gp.cap; gp.cg.st_off = (const u64*)ctx->gm_soff.p; gp.cg.st_len = (const u32*)ctx->gm_slen.p;
     const u64 br = ca.block_reads;
     auto recs = [&](u32 b0, u32 b1) { return (u64)(b1 - b0) * br; };
     for (u32 g = 1; g + 1 < ngen; g++) launch_gm_insert(gp.cg, bound[g], bound[g + 1], recs(bound[g], bound[g + 1]), max_line, (u64*)ctx->gm_T.p, gp.tb, st);
