@@ -446,6 +446,18 @@ def gm_encode_chains(buf: bytes, goff, glen, table_bits, block_reads, chain_read
     return _take(out, n), sizes, on.value
 
 
+def gm_decode_chains(streams: bytes, sizes, glen, table_bits, block_reads, chain_reads):
+    """The base chains of a call under the match model decoded on the CPU -> the bases' codes (uint8, 0..3), records back to back."""
+    L = lib()
+    sizes, ps = _arr(sizes, np.uint32); glen, pl = _arr(glen, np.uint32)
+    out = np.zeros(int(glen.sum()), np.uint8)
+    L.sfqo_gm_decode_chains.restype = C.c_int
+    L.sfqo_gm_decode_chains.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+    if L.sfqo_gm_decode_chains(streams, ps, pl, len(glen), table_bits, block_reads, chain_reads, out.ctypes.data_as(C.c_void_p)) != 0:
+        raise _err()
+    return out
+
+
 def gm_encode_segs(buf: bytes, goff, glen, other_len, table_bits, block_reads, seg_len):
     """The same for chains that are SEGMENTS of one record."""
     L = lib()

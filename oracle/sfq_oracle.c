@@ -2037,6 +2037,95 @@ static long long gm_encode_x(const u8* base, const u64* goff, const u32* glen, s
     *out = o.p ? o.p : xmalloc(1); *out_len = o.n;
     return g_failed ? -1 : (long long)nc;
 }
+/* ---- the way back (CPU; what tests/test_oracle.py checks the rule's decodability with -- the product's decoder is gm.hip) ----
+   A chain's stream read as RCoder reads (coder.hpp:40-48, 83-102): the four elided zero bytes, then the stored ones, zeros behind the end. */
+typedef struct { const u8* p; size_t n, pos; u64 low, code; u32 range; } chdec;
+static u8 chd_get(chdec* d) { const u8 b = d->pos < d->n ? d->p[d->pos] : 0; d->pos++; return b; }
+static void chd_init(chdec* d, const u8* p, size_t n) {
+    d->p = p; d->n = n; d->pos = 0; d->low = 0; d->range = (u32)-1; d->code = 0;
+    for (int i = 0; i < 4; i++) d->code = (d->code << 8) | chd_get(d);        /* (code's first four bytes are the elided zeros) */
+}
+static u32 chd_freq(chdec* d, u32 tot) { d->range /= tot; return (u32)(d->code / d->range); }
+static void chd_decode(chdec* d, u32 cum, u32 freq) {
+    const u32 temp = cum * d->range;
+    d->low += temp; d->code -= temp; d->range *= freq;
+    int guard = 0;
+    while (d->range < TOP) {
+        if ((d->low ^ (d->low + d->range)) & (0xffULL << 56)) d->range = (((u32)d->low | (u32)(TOP - 1)) - (u32)d->low);
+        d->code = (d->code << 8) | chd_get(d);
+        d->range <<= 8; d->low <<= 8;
+        if (++guard > 64) { fail("decoder stuck"); return; }
+    }
+}
+/* one line (or segment) of n bases decoded to stage positions q0 .. (the mirror of gm_walk) */
+static void gm_unwalk(chdec* d, u8* st, const u64* T, int tb, u64 lim, u64 q0, size_t n) {
+    u32 kmer = 0, seen = 0, m = 0; int have = 0; u64 ptr = 0; long long pend_at = -1; u64 pend_p = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (pend_at == (long long)i) {
+            pend_at = -1;
+            int ok = 1; for (int k = 0; k <= GM_D; k++) if (st[pend_p + k] == 0xFF) { ok = 0; break; }
+            if (ok) { have = 1; m = GM_K; ptr = pend_p + GM_D; }
+        }
+        if (have && st[ptr] == 0xFF) have = 0;
+        u32 b;
+        const u32 q = chd_freq(d, 4096);
+        if (have) {
+            const u32 e = st[ptr], fo = gm_fo(m), fm = 4096u - 3u * fo;
+            u32 cum = 0; b = 0;
+            for (;; b++) { const u32 f = b == e ? fm : fo; if (b == 3 || q < cum + f) break; cum += f; }
+            chd_decode(d, cum, b == e ? fm : fo);
+            if (b == e) { if (m < GM_MCAP) m++; ptr++; }
+            else if (m < GM_DROP) have = 0;
+            else { m = 0; ptr++; }
+        } else { b = q >> 10; if (b > 3) b = 3; chd_decode(d, b * 1024u, 1024u); }
+        st[q0 + i] = (u8)b;
+        kmer = (kmer << 2) | b; seen++;
+        if (!have && pend_at < 0 && seen >= GM_K && i + 1 + GM_D < n) {
+            const u64 h = (u64)kmer * 0x9E3779B97F4A7C15ull;
+            if ((h >> 62) == 0) {
+                const u64 e = T[(h >> (62 - tb)) & ((1ull << tb) - 1)];
+                if (e != GM_EMPTY && (e & 0xFFFFFF) == ((h >> (38 - tb)) & 0xFFFFFF) && (e >> 24) < lim) { pend_at = (long long)(i + 1 + GM_D); pend_p = e >> 24; }
+            }
+        }
+    }
+}
+/* The chains of a call under the match model (gen_on = 1; whole-record chains) back to the bases' codes: codes[sum glen] in record order.
+   The decoder knows the line lengths (the "usr" streams give them) and the chains' sizes ("chn.idx"); it indexes a generation
+   when it has decoded it -- and must arrive at the bases the encoder started from.  Returns 0, or -1. */
+int sfqo_gm_decode_chains(const u8* streams, const u32* sizes, const u32* glen, size_t nrec, int tb, size_t block_reads, size_t chain_reads, u8* codes) {
+    g_failed = 0; g_err[0] = 0;
+    const size_t nblocks = (nrec + block_reads - 1) / block_reads;
+    size_t bound[48];
+    const size_t ngen = gen_bounds(nblocks, bound);
+    if (ngen < 3 || tb < 8 || tb > 26) { fail("gm decode: %zu generations, %d index bits", ngen, tb); return -1; }
+#define REC_OF(b) ((b) * block_reads < nrec ? (b) * block_reads : nrec)
+    u64* soff = xmalloc((nrec + 1) * sizeof(u64));
+    u64 sp = 0; for (size_t r = 0; r < nrec; r++) { soff[r] = sp; sp += (u64)glen[r] + 1; } soff[nrec] = sp;
+    u8* st = xmalloc(sp + 64); memset(st, 0, sp + 64);
+    for (size_t r = 0; r < nrec; r++) st[soff[r] + glen[r]] = 0xFF;                    /* the sentinels, before anything is decoded */
+    memset(st + sp, 0xFF, 64);
+    u64* T = xmalloc(sizeof(u64) << tb); memset(T, 0xFF, sizeof(u64) << tb);
+    size_t at = 0, nc = 0;
+    for (size_t g = 0; g < ngen && !g_failed; g++) {
+        const u64 lim = soff[REC_OF(bound[g])];
+        for (size_t b = bound[g]; b < bound[g + 1]; b++) {
+            const size_t b0 = REC_OF(b), b1 = REC_OF(b + 1);
+            for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
+                const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+                chdec d; chd_init(&d, streams + at, sizes[nc]);
+                for (size_t r = r0; r < r1; r++) gm_unwalk(&d, st, T, tb, lim, soff[r], glen[r]);
+                at += sizes[nc];
+            }
+        }
+        if (g + 1 < ngen) gm_insert(st, soff, glen, REC_OF(bound[g]), REC_OF(bound[g + 1]), gen_count_stride((bound[g + 1] - bound[g]) * block_reads), T, tb);
+    }
+#undef REC_OF
+    size_t o = 0;
+    for (size_t r = 0; r < nrec; r++) { memcpy(codes + o, st + soff[r], glen[r]); o += glen[r]; }
+    free(st); free(soff); free(T);
+    return g_failed ? -1 : 0;
+}
+
 long long sfqo_gm_encode_chains(const u8* base, const u64* goff, const u32* glen, size_t nrec, int table_bits, size_t block_reads,
                                 size_t chain_reads, u8** out, size_t* out_len, u32* sizes, int* gen_on) {
     return gm_encode_x(base, goff, glen, nrec, table_bits, block_reads, chain_reads, out, out_len, sizes, gen_on, 0, NULL);

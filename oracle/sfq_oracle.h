@@ -121,6 +121,8 @@ long long sfqo_gm_encode_chains(const uint8_t* base, const uint64_t* goff, const
                                 size_t chain_reads, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
 long long sfqo_gm_encode_segs(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint32_t* other_len, size_t nrec, int table_bits, size_t block_reads,
                               uint32_t seg_len, uint8_t** out, size_t* out_len, uint32_t* sizes, int* gen_on);
+/* the way back on the CPU (whole-record chains of a call that took the model): the bases' codes 0..3, codes[sum glen]; 0 or -1 */
+int sfqo_gm_decode_chains(const uint8_t* streams, const uint32_t* sizes, const uint32_t* glen, size_t nrec, int table_bits, size_t block_reads, size_t chain_reads, uint8_t* codes);
 /* frozen tables, round 4: a block's three base-exception lists ("gen.Ns", "gen.Nn", "gen.lc") as adaptive Rice codes
    (chains.hip k_gen_exc_r; NOT the reference's XFile coding: DESIGN.md 4.10) and the way back */
 int sfqo_exc_rice_block(const uint8_t* base, const uint64_t* goff, const uint32_t* glen, const uint64_t* qoff, const uint32_t* qlen, size_t nrec,

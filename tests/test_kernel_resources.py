@@ -12,7 +12,9 @@ CSRC = os.path.join(ROOT, "slimfastq_amd", "csrc")
 HOT = {"frame.hip": ("k_frame",), "models_w.hip": ("k_qlt_encode_k2", "k_rec_encode_w_fast"), "models_k.hip": ("k_gen_encode_kILi2E",),
        # the default path: one chain per lane over frozen tables (encoders and decoders)
        "chains.hip": ("k_qlt_encode_c", "k_gen_encode_c", "k_rec_encode_fILj62E", "k_rec_encode_fILj94E", "k_rec_encode_fILj127E",
-                      "k_qlt_decode_c", "k_gen_decode_c", "k_rec_decode_f", "k_rec_tokens", "k_rec_code", "k_rec_dsym", "k_rec_dtext")}
+                      "k_qlt_decode_c", "k_gen_decode_c", "k_rec_decode_f", "k_rec_tokens", "k_rec_code", "k_rec_dsym", "k_rec_dtext"),
+       # the bases' match model (round 5)
+       "gm.hip": ("k_gm_stage", "k_gm_insert", "k_gm_plan", "k_gm_price", "k_gm_code", "k_gm_decode_c")}
 
 
 def kernel_metadata(src, tmp_path):

@@ -3,10 +3,12 @@ compiled reference is present (build container) -- against the reference itself.
 import glob
 import os
 
+import numpy as np
 import pytest
 
 import util
 from oracle import oracle as O
+from slimfastq_amd import capi
 
 LEVELS = (1, 2, 3, 4)
 
@@ -162,3 +164,41 @@ def test_pre5_header_stream_is_what_the_reference_decodes():
     assert O.parse(img).info["version"] == "4"
     assert O.ref_decompress(img) == fq                       # the reference itself, through load_pre5
     assert O.decompress(img) == fq                           # and the oracle's restatement of it
+
+
+def test_match_model_chains_decode_back_on_the_cpu():
+    """The block format's base model of round 5 (oracle/sfq_oracle.c "the generation MATCH model"; the product's kernels are gm.hip) is this
+    project's own rule, so the oracle pins it to ITSELF here, without a GPU: the chains it writes for reads that overlap -- 12 000 reads of
+    a 60 kb genome, either strand, half a per cent of substitutions, a few N -- decode, generation by generation, with an index the decoder
+    builds from what it has decoded, to the bases they were made from; the model pays (well under two bits a base); and bases that
+    do not repeat leave it off, coded four to a symbol."""
+    rng = np.random.default_rng(7)
+    G = rng.integers(0, 4, 60_000, dtype=np.uint8)
+    n, L = 12_000, 100
+    comp = np.array([3, 2, 1, 0], np.uint8)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    recs, codes = [], []
+    for i in range(n):
+        p = int(rng.integers(0, len(G) - L))
+        c = G[p:p + L].copy()
+        if rng.integers(2):
+            c = comp[c[::-1]]
+        flip = rng.random(L) < 0.005
+        c[flip] = (c[flip] + rng.integers(1, 4, int(flip.sum()), dtype=np.uint8)) & 3
+        line = letters[c].copy()
+        if i % 97 == 0:
+            line[int(rng.integers(L))] = ord("N"); c = c.copy(); c[line == ord("N")] = 0       # (an N is coded as A, gens.cpp:116-136)
+        codes.append(c); recs.append(b"@r%d\n" % i + line.tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    fq = b"".join(recs)
+    starts, lens = util.line_table(fq)
+    goff, glen = starts[1::4], lens[1::4]
+    br, cr, tb = 64, 8, 18
+    want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, cr)
+    assert on == 1 and len(want) * 8 < 1.2 * n * L
+    back = O.gm_decode_chains(want, sizes, glen, tb, br, cr)
+    assert np.array_equal(back, np.concatenate(codes))
+    # bases that do not repeat: the verdict says no, four bases a symbol -- two bits a base and a few bytes a chain
+    iid = capi.synth_fastq(6000, 100, seed=3)
+    s2, l2 = util.line_table(iid)
+    flat, sizes2, on2 = O.gm_encode_chains(iid, s2[1::4], l2[1::4], 16, br, cr)
+    assert on2 == 0 and 6000 * 100 // 4 <= len(flat) <= 6000 * 100 // 4 + 6 * len(sizes2)
