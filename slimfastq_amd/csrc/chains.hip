@@ -17,6 +17,9 @@
 #include "kernels.h"
 #include "dev_chain.h"
 #include "dev_walk.h"
+// a dword of text at any address: vector global loads need no alignment on gfx9, SCALAR loads drop the address's low bits -- and a plain u32 pointer lets the
+// compiler take one where the address is wave-uniform (the record that lane 0 of a wave stages alone)
+typedef u32 __attribute__((aligned(1))) u32_any;
 
 #define LAST_QLT 63u
 #define QROW_BYTES 256u                 // 64 entries x 4 bytes
@@ -1159,7 +1162,7 @@ struct RecFrozenEnc {
         u8* dst = lbuf + (k & 1u) * REC_HBUF;
         const u32 nw = (n + 4) / 4;                                     // covers bytes 0..n; the text goes on behind the header line
 #pragma unroll 8
-        for (u32 i = 0; i < nw; i++) reinterpret_cast<u32*>(dst)[i] = reinterpret_cast<const u32*>(g)[i];     // (global loads need no alignment on gfx9)
+        for (u32 i = 0; i < nw; i++) reinterpret_cast<u32*>(dst)[i] = reinterpret_cast<const u32_any*>(g)[i];     // (vector global loads need no alignment on gfx9)
         return dst;
     }
     __device__ __forceinline__ void put(u32 row, u32 sym) {
@@ -1384,7 +1387,7 @@ struct RecFastEnc {
 // 0xFFFF: a NUL inside).
 template <typename LT>
 __device__ __forceinline__ u32 rf_stage(LT& L, u32 buf, u32 lane, const u8* text, u32 n) {
-    const u32* g = reinterpret_cast<const u32*>(text);             // (global loads need no alignment on gfx9; the text goes on behind the line)
+    const u32_any* g = reinterpret_cast<const u32_any*>(text);     // (vector global loads need no alignment on gfx9; the text goes on behind the line)
     const u32 nw = (n + 4) / 4;
     u32 nf = 0, start = 0; bool stop = false;
     for (u32 i0 = 0; i0 < nw; i0 += 8) {
@@ -1567,20 +1570,86 @@ void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nru
 template <u32 ML>
 struct RecTokLds {                       // column l + 1 = lane l's record, column 0 = the record before lane 0's
     static constexpr u32 maxlen = ML;
-    u8 text[1][ML + 1][66];
+    static constexpr u32 NW = (ML + 4) / 4;               // dwords that hold bytes 0 .. ML of a header (the '\n' behind the text is one of them)
+    static constexpr u32 NWP = NW | 1u;                   // a column's stride in dwords: odd, so the 64 columns' dword k lie in 64 banks
+    u32 tw[66][NWP];                                      // the text, a header per column, staged a dword at a time
     u8 off[1][RF_NF][66], wln[1][RF_NF][66], sep[1][RF_NF][66];
     u8 nf[66];
+    __device__ __forceinline__ u32 byte(u32 col, u32 pos) const { return reinterpret_cast<const u8*>(tw[col])[pos]; }
 };
+// Where a header's fields end: bit p = byte p is neither a letter nor a digit (map_space, recs.cpp:141-157), p = 0 .. n (bit n: the line's '\n')
+struct HdrMask {
+    u64 lo, hi;
+    __device__ __forceinline__ u32 count() const { return (u32)__popcll(lo) + (u32)__popcll(hi); }
+    __device__ __forceinline__ u32 take() {               // the lowest set bit, cleared
+        if (lo) { const u32 p = (u32)__ffsll((long long)lo) - 1u; lo &= lo - 1; return p; }
+        const u32 p = 63u + (u32)__ffsll((long long)hi); hi &= hi - 1; return p;
+    }
+};
+// A header into its column, and its field ends as a mask.  Four bytes a step: a byte is a field character if it lies in '0'-'9' or, with bit 5 set, in
+// 'a'-'z' -- two range tests on all four bytes at once (x + (0x80 - lo) carries into bit 7 where x >= lo; x + (0x7f - hi) does not where x <= hi; the
+// bytes are below 0x80 there, so nothing carries across) --, and a multiplication gathers the four flags into a nibble of the mask.  Round 4 walked
+// the bytes one at a time, each with its own test, its own LDS store and -- the lanes' fields ending at different bytes -- its own divergent
+// "a field ends here" branch.  Returns false where a NUL lies inside (map_space stops there: not for this kernel).
+template <typename LT>
+__device__ __forceinline__ bool rt_stage(LT& L, u32 col, const u8* text, u32 n, HdrMask& M) {
+    const u32_any* g = reinterpret_cast<const u32_any*>(text);     // (the text goes on behind the line)
+    const u32 kn = n >> 2, nw = kn + 1;
+    const u32 fill = (n & 3u) == 3u ? 0u : ~0u << (8u * ((n & 3u) + 1u));      // the last dword's bytes behind the '\n': made 0xFF (no NUL, no field character)
+    u32 zero = 0, mw[4] = {};
+#pragma unroll
+    for (u32 k0 = 0; k0 < LT::NW; k0 += 4) {
+        if (!__any(k0 < nw)) break;
+        u32 wv[4];
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) wv[q] = k0 + q < nw && k0 + q < LT::NW ? g[k0 + q] : ~0u;
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            const u32 k = k0 + q;
+            if (k >= LT::NW) break;
+            L.tw[col][k] = wv[q];
+            const u32 w = wv[q] | (k == kn ? fill : 0u);
+            const u32 x = w & 0x7f7f7f7fu, y = x | 0x20202020u;
+            const u32 dig = (x + 0x50505050u) & ~(x + 0x46464646u);
+            const u32 let = (y + 0x1f1f1f1fu) & ~(y + 0x05050505u);
+            const u32 t = ~((dig | let) & ~w) & 0x80808080u;                     // bit 7 of each byte: not a field character
+            mw[k / 8] |= (((t >> 7) * 0x01020408u) >> 24) << (4u * (k % 8));
+            zero |= ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;      // bit 7 of each byte: the byte is 0
+        }
+    }
+    M.lo = mw[0] | ((u64)mw[1] << 32);
+    M.hi = mw[2] | ((u64)mw[3] << 32);
+    // only bytes 0 .. n count
+    if (n < 63) { M.lo &= (2ull << n) - 1; M.hi = 0; }
+    else if (n == 63) M.hi = 0;
+    else M.hi &= (2ull << (n - 64)) - 1;
+    return zero == 0;
+}
+// the field tables of the header in column col from its mask: field f = bytes off .. off + wln, closed by the byte sep
+template <typename LT>
+__device__ __forceinline__ void rt_fields(LT& L, u32 col, HdrMask m, u32 nf) {
+    u32 start = 0;
+    for (u32 f = 0; f < nf; f++) {
+        const u32 p = m.take();
+        L.off[0][f][col] = (u8)start; L.wln[0][f][col] = (u8)(p - start); L.sep[0][f][col] = (u8)L.byte(col, p);
+        start = p + 1;
+    }
+}
 struct TokCount { u32 n; __device__ __forceinline__ void put(u32, u32) { n++; } __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); } };
 struct TokStore { u32* p; __device__ __forceinline__ void put(u32 row, u32 sym) { *p++ = (row << 8) | sym; } __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); } };
 // the symbols of the record in column col (n bytes, nf fields), against the record in column col - 1; since: the fields that have
 // changed since the chain began / the shape last changed.  false: a field types as hexadecimal.
+// a field's type and value (dev_rec.h field_type) over the header in column col
+template <typename LT>
+__device__ __forceinline__ u32 nw_tok(const LT& L, u32 col, u32 off, u32 len, u64& num) {
+    return field_type([&](u32 j) -> u32 { return L.byte(col, off + j); }, len, num, 0);
+}
 template <typename LT, typename EM>
 __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, bool shape, u64 map, u64 since, EM& em) {
     em.put(REC_FLAG_ROW, shape ? 1u : 0u);
     if (shape) {                                                              // recs.cpp:292-305, in the chain itself
         em.put_u(REC_FLAG_ROW + 2, n);
-        for (u32 j = 0; j < n; j++) em.put(REC_FLAG_ROW + 1, L.text[0][j][col]);
+        for (u32 j = 0; j < n; j++) em.put(REC_FLAG_ROW + 1, L.byte(col, j));
         return true;
     }
     em.put_u(0 * 16 + 2, map);                                                // put_num(0, map) recs.cpp:313
@@ -1588,22 +1657,22 @@ __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, 
         if (!((map >> f) & 1)) continue;
         const u32 o = L.off[0][f][col], wl = L.wln[0][f][col];
         u64 fnum;
-        u32 type = nw_lds(L, 0, col, o, (int)wl, fnum, 0);
-        if (type != ST_STR && !rec_number_prints_back(type, wl, L.text[0][o][col])) type = ST_STR;
+        u32 type = nw_tok(L, col, o, wl, fnum);
+        if (type != ST_STR && !rec_number_prints_back(type, wl, L.byte(col, o))) type = ST_STR;
         if (type >= ST_HGT && type <= ST_HLTC_Z) return false;
         const u32 rr = (f + 1) * 16;
         if (type == ST_STR) {                                                 // recs.cpp:324-331
             em.put(rr + 0, type);
             em.put_u(rr + 2, wl);
-            for (u32 j = 0; j < wl; j++) em.put(rr + 1, L.text[0][o + j][col]);
+            for (u32 j = 0; j < wl; j++) em.put(rr + 1, L.byte(col, o + j));
             continue;
         }
         u64 was = 0;                                                         // recs.cpp:333: the previous VALUE, if the field has one
         if ((since >> f) & 1) {
             const u32 po = L.off[0][f][col - 1], pwl = L.wln[0][f][col - 1];
             u64 pn;
-            u32 pt = nw_lds(L, 0, col - 1, po, (int)pwl, pn, 0);
-            if (pt != ST_STR && !rec_number_prints_back(pt, pwl, L.text[0][po][col - 1])) pt = ST_STR;
+            u32 pt = nw_tok(L, col - 1, po, pwl, pn);
+            if (pt != ST_STR && !rec_number_prints_back(pt, pwl, L.byte(col - 1, po))) pt = ST_STR;
             if (pt == ST_DGT || pt == ST_DGT_Z) was = pn;
         }
         u64 gap;
@@ -1630,7 +1699,12 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
         const u64 h0 = a.m.line_off[4 * base] + 1, h1 = a.m.line_off[4 * base + 1] - 1;
         base_n = h1 > h0 ? (u32)(h1 - h0) : 0;
         if (base_n > ML) bad = 1;
-        else { const u32 nf = rf_stage(L, 0, 0, a.m.fq + h0, base_n); if (nf > RF_NF) bad = 1; L.nf[0] = (u8)(nf & 0xffu); }
+        else {
+            HdrMask m0;
+            const bool ok = rt_stage(L, 0, a.m.fq + h0, base_n, m0);
+            const u32 nf = m0.count();
+            if (!ok || nf > RF_NF) bad = 1; else { rt_fields(L, 0, m0, nf); L.nf[0] = (u8)nf; }
+        }
     }
     if (__any(bad != 0)) { if (lane == 0) flags[c] = 1; return; }
     const u64 end = cp.r0 + cp.nrec;
@@ -1648,7 +1722,12 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
             const u64 h0 = a.m.line_off[4 * r] + 1, h1 = a.m.line_off[4 * r + 1] - 1;
             n = h1 > h0 ? (u32)(h1 - h0) : 0;
             if (n > ML) bad = 1;
-            else { nf = rf_stage(L, 0, col, a.m.fq + h0, n); if (nf > RF_NF) bad = 1; L.nf[col] = (u8)(nf & 0xffu); }
+            else {
+                HdrMask m;
+                const bool ok = rt_stage(L, col, a.m.fq + h0, n, m);
+                nf = m.count();
+                if (!ok || nf > RF_NF) bad = 1; else { rt_fields(L, col, m, nf); L.nf[col] = (u8)nf; }
+            }
         }
         if (__any(bad != 0)) { if (lane == 0) flags[c] = 1; return; }
         __syncthreads();
@@ -1663,7 +1742,7 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
                     bool ch = wl != L.wln[0][f][col - 1];
                     if (!ch) {
                         const u32 o = L.off[0][f][col], po = L.off[0][f][col - 1];
-                        for (u32 j = 0; j < wl; j++) if (L.text[0][o + j][col] != L.text[0][po + j][col - 1]) { ch = true; break; }
+                        for (u32 j = 0; j < wl; j++) if (L.byte(col, o + j) != L.byte(col - 1, po + j)) { ch = true; break; }
                     }
                     if (ch) map |= 1ull << f;
                 }
@@ -1696,7 +1775,7 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
         hdr_bytes += rl(wave_incl_scan(n), 63);
         __syncthreads();
         if (rb + 64 < end) {                                                  // lane 63's record is the next round's left neighbour
-            for (u32 p = lane; p <= ML; p += 64) L.text[0][p][0] = L.text[0][p][64];
+            for (u32 p = lane; p < RecTokLds<ML>::NWP; p += 64) L.tw[0][p] = L.tw[64][p];
             if (lane < RF_NF) { L.off[0][lane][0] = L.off[0][lane][64]; L.wln[0][lane][0] = L.wln[0][lane][64]; L.sep[0][lane][0] = L.sep[0][lane][64]; }
             if (lane == 0) L.nf[0] = L.nf[64];
             __syncthreads();
