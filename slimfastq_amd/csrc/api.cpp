@@ -466,17 +466,21 @@ u32 gen_bounds(u32 nblocks, u32* bound) {
     bound[++n] = nblocks;
     return n;                                              // number of generations
 }
+#define SFQ_CHAINS_WANT 262144ull
 int default_chain_reads(u64 nrec, u64 nbytes) {
     // Chains are the unit of parallelism (64 per wavefront) and a lane's walk through its chain is the floor of a call's time, so
-    // the COUNT of chains is held, not their length: about 205 k of them -- 200 workgroups of the quality chains' image kernel
-    // (1024 lanes, one per CU, which its registers fill: the other models' kernels get their work done on the 56 CUs it leaves;
-    // 229 workgroups made the header steps take 10.1 ms instead of 7.3 and the 3.7 GB call 17.1 ms instead of 15.8) --
-    // down to chains of 4 KiB of text (12 records of 150 bp), below which a chain's flush and index entry start to show
-    // (round 4 size sweep, 0.25 / 0.5 / 1 / 2 / 3.7 GB of 150 bp reads: 12 / 12 / 12 / 24 / 49 records per chain; the streams of the
-    //  1 GB prefix are 0.14 % larger at 12 records than at 49).  Round 3 floored a chain at 16 KiB: a 740 MB call then had 45 k
-    //  chains -- a sixth of the chip -- each as long as a 3.7 GB call's, and took longer than that call.
+    // the COUNT of chains is held, not their length: as many as 256 workgroups of the quality chains' image kernel hold (1024 lanes,
+    // one per CU, which its 120 registers fill: SFQ_CHAINS_WANT, and encode_blocks lengthens the chains until the blocks' chains of
+    // equal length stay within it) -- down to chains of 4 KiB of text (12 records of 150 bp), below which a chain's flush and index
+    // entry start to show (round 4 size sweep, 0.25 / 0.5 / 1 / 2 / 3.7 GB of 150 bp reads: 12 / 12 / 12 / 24 / 49 records per
+    // chain; the streams of the 1 GB prefix are 0.14 % larger at 12 records than at 49).  Round 3 floored a chain at 16 KiB: a 740 MB
+    // call then had 45 k chains -- a sixth of the chip -- each as long as a 3.7 GB call's, and took longer than that call.
+    // (Rounds 4 and 5 held 205 k chains, 200 workgroups: "the other models' kernels get their work done on the 56 CUs it leaves".  They
+    //  do -- and then the quality chains run on alone for 5 of the call's 13 ms on 200 CUs.  Round 5, the default call at 49 / 40 / 32 /
+    //  24 / 16 records a chain = 200 / 248 / 305 / 407 / 610 workgroups: 13.06 / 12.65 / 14.50 / 13.37 / 13.78 ms, decode 18.5 / 17.2 /
+    //  21.7 / 20.4 / 20.1 -- a 257th workgroup waits for a CU and then walks its chains alone.)
     const u64 per_rec = std::max<u64>(1, nbytes / std::max<u64>(1, nrec));
-    u64 cr = std::max<u64>(1, (nrec + 204799) / 204800);
+    u64 cr = std::max<u64>(1, (nrec + SFQ_CHAINS_WANT - 1) / SFQ_CHAINS_WANT);
     cr = std::max<u64>(cr, (4096 + per_rec - 1) / per_rec);
     return (int)std::min<u64>(cr, 4096);
 }
@@ -1179,6 +1183,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             const u64 want = std::min<u64>(std::max<u64>(4096, nbytes / 2 / 204800), 1u << 20);
             if (max_line > want) seg_len = (u32)want;
         }
+        if (!p.chain_reads && !seg_len)             // (the blocks' chains are of equal length: the count is blocks x chains per block, and rounds up)
+            while (cr < block_reads && (u64)nblocks * ((block_reads + cr - 1) / cr) > SFQ_CHAINS_WANT) cr++;
         ca.geo.chain_reads = (u32)std::min<u64>(std::min(cr, block_reads), nrec);     // (a decoder sees min(block_reads, nrec) as the block size)
         ca.geo.cpb = (block_reads + ca.geo.chain_reads - 1) / ca.geo.chain_reads;
         // the automatic choice: the block's chains of equal length (1024 records in chains of 50 would leave a last chain of
@@ -1365,6 +1371,11 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // base chains started 8 ms into the call.
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
         HIPC(hipEventRecord(ctx->ev[2], st));
+        static const int qfirst = getenv("SFQ_QLT_FIRST") ? atoi(getenv("SFQ_QLT_FIRST")) : 0;
+        if (qfirst && (models & SFQ_M_QLT)) {
+            ca.m = a; ca.csz = (u32*)ctx->csz.p;
+            HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
+        }
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
             ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rdec = (const u16*)ctx->rdec.p;
@@ -1374,7 +1385,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
-            if (nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
+            if (!qfirst && nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
             launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1], min_hdr);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
@@ -1398,7 +1409,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
-        if (models & SFQ_M_QLT) {
+        if (!qfirst && (models & SFQ_M_QLT)) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p;
             // (round 5, measured and dropped: with the match model on, the quality chains held back until the bases' plan is through -- beside
             //  them the stage, the index and the plan take 3.7 + 6.0 + 5.8 ms against 1 + 3 + 4 alone.  The bases' phase 20.8 -> 17.0 ms, the

@@ -1639,9 +1639,24 @@ struct TokCount { u32 n; __device__ __forceinline__ void put(u32, u32) { n++; } 
 struct TokStore { u32* p; __device__ __forceinline__ void put(u32 row, u32 sym) { *p++ = (row << 8) | sym; } __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); } };
 // the symbols of the record in column col (n bytes, nf fields), against the record in column col - 1; since: the fields that have
 // changed since the chain began / the shape last changed.  false: a field types as hexadecimal.
-// a field's type and value (dev_rec.h field_type) over the header in column col
+// a field's type and value (dev_rec.h field_type) over the header in column col.  The usual field is a few decimal digits: one multiply-add a
+// digit, in 32 bits; field_type's general pass -- both readings carried in 64 bits, the classes, the wrap test: 35 instructions a byte, and with
+// two fields parsed per changed field and two passes four fifths of this kernel's instructions -- is for the lanes whose field is anything else
 template <typename LT>
 __device__ __forceinline__ u32 nw_tok(const LT& L, u32 col, u32 off, u32 len, u64& num) {
+    u32 v = 0, lead = 0;
+    bool plain = len <= 9u;
+    if (plain)
+        for (u32 j = 0; j < len; j++) {
+            const u32 d = L.byte(col, off + j) - '0';
+            plain = plain && d <= 9u;
+            lead |= (j < 2u && d == 0u) ? 1u << j : 0u;
+            v = v * 10u + d;
+        }
+    if (plain) {
+        num = (lead & 3u) == 3u ? 0u : v;                                       // "00...": field_type's first test
+        return (lead & 3u) == 3u ? ST_STR : (lead & 1u) ? ST_DGT_Z : ST_DGT;
+    }
     return field_type([&](u32 j) -> u32 { return L.byte(col, off + j); }, len, num, 0);
 }
 template <typename LT, typename EM>
@@ -1653,8 +1668,8 @@ __device__ __forceinline__ bool rec_tokens(const LT& L, u32 col, u32 n, u32 nf, 
         return true;
     }
     em.put_u(0 * 16 + 2, map);                                                // put_num(0, map) recs.cpp:313
-    for (u32 f = 0; f < nf; f++) {
-        if (!((map >> f) & 1)) continue;
+    for (u64 todo = map; todo; todo &= todo - 1) {                            // the changed fields, in order
+        const u32 f = (u32)__ffsll((long long)todo) - 1u;
         const u32 o = L.off[0][f][col], wl = L.wln[0][f][col];
         u64 fnum;
         u32 type = nw_tok(L, col, o, wl, fnum);
