@@ -1371,11 +1371,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // base chains started 8 ms into the call.
         a.batch0 = 0; a.nbatch = std::min(slots, nblocks_r);
         HIPC(hipEventRecord(ctx->ev[2], st));
-        static const int qfirst = getenv("SFQ_QLT_FIRST") ? atoi(getenv("SFQ_QLT_FIRST")) : 0;
-        if (qfirst && (models & SFQ_M_QLT)) {
-            ca.m = a; ca.csz = (u32*)ctx->csz.p;
-            HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
-        }
         if (models & SFQ_M_REC) {
             if ((rc = rec_prior_finish(ctx, given, mst[1]))) return rc;
             ca.m = a; ca.rrows = (const u32*)ctx->rrows.p; ca.rdec = (const u16*)ctx->rdec.p;
@@ -1385,7 +1380,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipMemsetAsync(ctx->rflags.p, 0, (size_t)nsub * 4 * 2, mst[1]));
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
-            if (!qfirst && nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
+            if (nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
             launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1], min_hdr);
             HIPC(hipEventRecord(ctx->ev[19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
@@ -1409,11 +1404,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
-        if (!qfirst && (models & SFQ_M_QLT)) {
+        if (models & SFQ_M_QLT) {
             ca.m = a; ca.csz = (u32*)ctx->csz.p;
             // (round 5, measured and dropped: with the match model on, the quality chains held back until the bases' plan is through -- beside
             //  them the stage, the index and the plan take 3.7 + 6.0 + 5.8 ms against 1 + 3 + 4 alone.  The bases' phase 20.8 -> 17.0 ms, the
-            //  quality chains end at 21.9 instead of 11.8, the call 24.3 -> 25.9 ms: the chip's work is conserved, whoever goes first)
+            //  quality chains end at 21.9 instead of 11.8, the call 24.3 -> 25.9 ms: the chip's work is conserved, whoever goes first.
+            //  The other way round -- the quality chains queued FIRST, ahead of the two host decisions, in the default call: they take 6.4-8 ms
+            //  instead of 9.1, the base and header chains 8 instead of 4.8, the call 12.4-13.8 ms against 12.6-12.8.)
             HIPC(hipEventRecord(ctx->ev[14], st)); launch_qlt_encode_c(ca, st); HIPC(hipEventRecord(ctx->ev[15], st));
         }
         HIPC(hipEventRecord(ctx->ev[3], st));
