@@ -1567,6 +1567,7 @@ void launch_rec_count(const ModelArgs& a, u64 nrec, u64 stride, u32 run, u32 nru
 // left neighbour's column, "has changed since" carried as an OR-scan over the lanes, the symbols (row, byte) written to a token
 // buffer; step 2 is a coder per lane over the tokens, as cheap as the quality chains' coder.  The bytes are those of k_rec_encode_f.
 #define RT_TOK_PER_REC 40u               /* token room per record, pooled over a chain; a chain that needs more goes to k_rec_encode_f */
+#define RT_STAGED 24u                    /* symbols of a record that wait in LDS for their place (a record with more is walked a second time) */
 template <u32 ML>
 struct RecTokLds {                       // column l + 1 = lane l's record, column 0 = the record before lane 0's
     static constexpr u32 maxlen = ML;
@@ -1575,6 +1576,7 @@ struct RecTokLds {                       // column l + 1 = lane l's record, colu
     u32 tw[66][NWP];                                      // the text, a header per column, staged a dword at a time
     u8 off[1][RF_NF][66], wln[1][RF_NF][66], sep[1][RF_NF][66];
     u8 nf[66];
+    u32 tokst[RT_STAGED][64];                             // a record's symbols until the wave knows where they go
     __device__ __forceinline__ u32 byte(u32 col, u32 pos) const { return reinterpret_cast<const u8*>(tw[col])[pos]; }
 };
 // Where a header's fields end: bit p = byte p is neither a letter nor a digit (map_space, recs.cpp:141-157), p = 0 .. n (bit n: the line's '\n')
@@ -1636,6 +1638,11 @@ __device__ __forceinline__ void rt_fields(LT& L, u32 col, HdrMask m, u32 nf) {
     }
 }
 struct TokCount { u32 n; __device__ __forceinline__ void put(u32, u32) { n++; } __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); } };
+struct TokStage {                        // into the lane's column of RecTokLds::tokst, counting on beyond it
+    u32* p; u32 n;
+    __device__ __forceinline__ void put(u32 row, u32 sym) { if (n < RT_STAGED) p[n * 64u] = (row << 8) | sym; n++; }
+    __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); }
+};
 struct TokStore { u32* p; __device__ __forceinline__ void put(u32 row, u32 sym) { *p++ = (row << 8) | sym; } __device__ __forceinline__ void put_u(u32 row0, u64 num) { put_u_rows(*this, row0, num); } };
 // the symbols of the record in column col (n bytes, nf fields), against the record in column col - 1; since: the fields that have
 // changed since the chain began / the shape last changed.  false: a field types as hexadecimal.
@@ -1777,15 +1784,21 @@ __global__ __launch_bounds__(64) void k_rec_tokens(ChainArgs a, u32* __restrict_
             const u32 lrs = (u32)__shfl((int)rs, 63, 64); const u64 lmm = (u64)__shfl((unsigned long long)mm, 63, 64);
             since0 = lrs ? lmm : (since0 | lmm);
         }
-        // count, place, write
-        TokCount tc; tc.n = 0;
+        // the symbols: made once, into LDS; placed by a wave scan of their numbers; copied out.  (Round 4 walked every record twice -- count, then write --,
+        // each walk typing the changed fields and their left neighbours' again: 47 + 27 of this kernel's 100 M instructions per 2 M records.)
+        TokStage tl; tl.p = &L.tokst[0][lane]; tl.n = 0;
         bool ok = true;
-        if (valid) ok = rec_tokens(L, col, n, nf, shape, map, since, tc);
+        if (valid) ok = rec_tokens(L, col, n, nf, shape, map, since, tl);
         if (__any(!ok)) { if (lane == 0) flags[c] = 1; return; }
-        const u32 incl = wave_incl_scan(tc.n);
+        const u32 cnt = tl.n;
+        const u32 incl = wave_incl_scan(cnt);
         const u32 round = rl(incl, 63);
         if (total + round > cap) { if (lane == 0) flags[c] = 1; return; }
-        if (valid) { TokStore ts; ts.p = out + total + (incl - tc.n); rec_tokens(L, col, n, nf, shape, map, since, ts); }
+        u32* const dst = out + total + (incl - cnt);
+        if (__any(cnt > RT_STAGED)) {                                         // (a record that spells its header out: the walk again, to memory)
+            if (valid) { TokStore ts; ts.p = dst; rec_tokens(L, col, n, nf, shape, map, since, ts); }
+        } else
+            for (u32 j = 0; __any(j < cnt); j++) if (j < cnt) dst[j] = L.tokst[j][lane];
         total += round;
         hdr_bytes += rl(wave_incl_scan(n), 63);
         __syncthreads();
