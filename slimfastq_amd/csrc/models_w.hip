@@ -175,6 +175,195 @@ __global__ __launch_bounds__(64) void k_gen_exc_w(ModelArgs a, const u8* __restr
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// The same lists (RICE only), the SCAN a marked record per lane (round 5).  k_gen_exc_w hands every marked record to the whole wave -- 64 lanes
+// looking at 150 bases, ballots, a loop per event: 400 wave instructions a record, 0.6 G a default call for the N's of a seventh of its records.
+// Here the marked records of a block queue up in LDS and are taken 64 at a time, a lane each, sixteen bytes a step: what is no plain base
+// (either case of ACGT -- one v_perm lookup --, or a colour-space digit), what sits under a '!', what is lower case is found four bytes at
+// a time and leaves a bit; only those bytes are looked at singly and become EVENTS (position, kind, character) in the lane's list.  The lists
+// are then emitted in the records' order by the wave -- the gaps and their Rice codes are sequential by nature -- with no text read again.
+// A record of more than EXQ_MAXLEN bases, or with more events than its list holds, is walked by the whole wave as before.
+// ---------------------------------------------------------------------------------------------------------------------
+#define EXQ_QCAP 128u
+#define EXQ_EVCAP 8u
+#define EXQ_MAXLEN 1024u
+struct ExqLds {
+    u64 g[EXQ_QCAP], q[EXQ_QCAP], ofs[EXQ_QCAP];
+    u32 llen[EXQ_QCAP], qlen[EXQ_QCAP];
+    u32 ev[64][EXQ_EVCAP + 1];
+};
+typedef u32 __attribute__((aligned(1))) u32_anyw;
+// four bytes of text at p of which `avail` exist (0xFF where none does): nothing is read behind them
+__device__ __forceinline__ u32 exq_ld4(const u8* p, u32 avail) {
+    if (avail >= 4u) return *reinterpret_cast<const u32_anyw*>(p);
+    u32 v = ~0u;
+    for (u32 j = 0; j < avail; j++) v = (v & ~(0xffu << (8u * j))) | ((u32)p[j] << (8u * j));
+    return v;
+}
+__device__ __forceinline__ u32 exq_zero(u32 x) { return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }   // bit 7 of every byte of x that is 0
+__device__ __forceinline__ u32 exq_nib(u32 t) { return ((t >> 7) * 0x01020408u) >> 24; }                               // those four bits as a nibble
+// one marked record by the whole wave (k_gen_exc_w's walk, 64 bases a step)
+struct ExqState { u64 ns_index, nn_index, lc_index; u32 n_byte; int bad; };
+__device__ __forceinline__ void exq_wave_record(const ModelArgs& a, XfRiceW& x_ns, XfRiceW& x_nn, XfRiceW& x_lc, WavePw& pw, ExqState& st,
+                                                const u8* gp, const u8* qp, u32 llen, u32 qlen, u64 genofs, u32 lane) {
+    for (u32 base = 0; base < llen; base += 64) {
+        const u32 idx = base + lane;
+        const u32 gch = idx < llen ? gp[idx] : 'A';
+        const u32 qch = (idx < llen && idx < qlen) ? qp[idx] : 40u;                      // gens.cpp:153
+        const bool in = idx < llen;
+        const u32 n = gencode_w(gch);
+        if (__ballot(in && n > 4)) st.bad = SFQ_E_GENCHAR;
+        const u64 mN = __ballot(in && n == 4), mQ = __ballot(in && qch == '!');
+        u64 mx = mN | mQ;
+        while (mx) {
+            const u32 bit = (u32)__ffsll((long long)mx) - 1u;
+            mx &= mx - 1;
+            const u64 pos = genofs + base + bit + 1;
+            const bool is_n = (mN >> bit) & 1, is_q = (mQ >> bit) & 1;
+            if (!is_n) { x_nn.put(pw, pos - st.nn_index, lane); st.nn_index = pos; }
+            else {
+                u32 ch = rl(gch, bit);
+                if (a.lossless && ch == 'n') ch = 'N';                                    // its case travels in "gen.lc"
+                if (!st.n_byte) st.n_byte = ch;
+                if (ch != st.n_byte) st.bad = SFQ_E_GENCHAR;
+                if (!is_q) { x_ns.put(pw, pos - st.ns_index, lane); st.ns_index = pos; }
+            }
+        }
+        if (a.lossless) {
+            u64 ml = __ballot(in && is_lower_base(gch));
+            while (ml) {
+                const u32 bit = (u32)__ffsll((long long)ml) - 1u;
+                ml &= ml - 1;
+                const u64 pos = genofs + base + bit + 1;
+                x_lc.put(pw, pos - st.lc_index, lane); st.lc_index = pos;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_gen_exc_q(ModelArgs a, const u8* __restrict__ flags, u32* ticket) {
+    __shared__ ExqLds L;
+    const u32 lane = threadIdx.x;
+    WavePw pw; pw.slots = nullptr; pw.hdr = nullptr; pw.epoch = 0; pw.hslots = nullptr; pw.hhdr = nullptr; pw.hrow0 = 0; pw.hn = 0;      // (XfRiceW's interface; the Rice lists have no rows)
+    for (u32 b = next_block(ticket); b < a.nblocks; b = next_block(ticket)) {
+        BlockDesc* d = &a.blocks[b];
+        XfRiceW x_ns, x_nn, x_lc;
+        x_ns.init(a.arena + d->out_off[SFQ_S_GEN_NS], d->out_cap[SFQ_S_GEN_NS], XF_GEN_NS);
+        x_nn.init(a.arena + d->out_off[SFQ_S_GEN_NN], d->out_cap[SFQ_S_GEN_NN], XF_GEN_NN);
+        x_lc.init(a.arena + d->out_off[SFQ_S_GEN_LC], d->out_cap[SFQ_S_GEN_LC], XF_GEN_LC);
+        const u32 solid = d->solid;
+        const u64 rec0 = d->rec0; const u32 nrec = d->nrec;
+        ExqState st; st.ns_index = st.nn_index = st.lc_index = 0; st.n_byte = 0; st.bad = 0;
+        u64 genofs = 0;
+        u32 qn = 0;                                                            // records waiting in the queue
+        // the first m records of the queue: a lane each finds its events, the wave emits them in order
+        auto take = [&](u32 m) {
+            const bool mine = lane < m;
+            const u8* gp = a.fq + (mine ? L.g[lane] : 0);
+            const u8* qp = a.fq + (mine ? L.q[lane] : 0);
+            const u32 llen = mine ? L.llen[lane] : 0u, qlen = mine ? L.qlen[lane] : 0u;
+            u32 cnt = 0;
+            bool whole = mine && llen > EXQ_MAXLEN;                            // -> the whole wave's walk
+            u32 illegal = 0;
+            for (u32 off = 0; __any(!whole && off < llen); off += 16) {
+                u32 fl = 0;
+                if (!whole && off < llen) {
+                    const u32 nb = llen - off < 16u ? llen - off : 16u;
+                    const u32 nq = qlen > off ? (qlen - off < 16u ? qlen - off : 16u) : 0u;
+                    u32 fb = 0, fq = 0;
+#pragma unroll
+                    for (u32 dw = 0; dw < 4; dw++) {
+                        const u32 w = exq_ld4(gp + off + 4 * dw, nb > 4 * dw ? nb - 4 * dw : 0u);
+                        const u32 qw = exq_ld4(qp + off + 4 * dw, nq > 4 * dw ? nq - 4 * dw : 0u);
+                        const u32 want = __builtin_amdgcn_perm(0u, 0x47544341u, (w >> 1) & 0x03030303u);       // "ACTG"[(c >> 1) & 3]: the letter c should be, if it is one
+                        const u32 letter = exq_zero(want ^ (w & 0xDFDFDFDFu));
+                        const u32 digit = exq_zero((w & 0xFCFCFCFCu) ^ 0x30303030u);
+                        u32 t = ~(letter | digit) & 0x80808080u;                                                 // no plain base
+                        if (a.lossless) t |= letter & ((w << 2) & 0x80808080u);                                  // a lower-case one
+                        fb |= exq_nib(t) << (4 * dw);
+                        fq |= exq_nib(exq_zero(qw ^ 0x21212121u)) << (4 * dw);
+                    }
+                    fl = (fb & ((1u << nb) - 1u)) | (fq & ((1u << nq) - 1u) & ((1u << nb) - 1u));
+                }
+                while (__any(fl != 0)) {
+                    if (fl) {
+                        const u32 j = (u32)__ffs((int)fl) - 1u;
+                        fl &= fl - 1;
+                        const u32 idx = off + j;
+                        const u32 c = gp[idx];
+                        const u32 qc = idx < qlen ? qp[idx] : 40u;                      // gens.cpp:153
+                        const u32 n = gencode_w(c);
+                        if (n > 4) illegal = 1;
+                        const u32 kind = (n == 4 ? 1u : 0u) | (qc == '!' ? 2u : 0u) | ((a.lossless && is_lower_base(c)) ? 4u : 0u);
+                        if (kind) {
+                            if (cnt < EXQ_EVCAP) L.ev[lane][cnt] = idx | (kind << 16) | (c << 24);
+                            else whole = true;
+                            cnt++;
+                        }
+                    }
+                }
+            }
+            if (__any(illegal != 0)) st.bad = SFQ_E_GENCHAR;
+            for (u32 i = 0; i < m; i++) {
+                const u64 ofs = L.ofs[i];
+                if (rl(whole ? 1u : 0u, i)) {
+                    exq_wave_record(a, x_ns, x_nn, x_lc, pw, st, a.fq + L.g[i], a.fq + L.q[i], L.llen[i], L.qlen[i], ofs, lane);
+                    continue;
+                }
+                const u32 ne = rl(cnt, i);
+                for (u32 e = 0; e < ne; e++) {
+                    const u32 ev = rl(L.ev[i][e], 0);
+                    const u64 pos = ofs + (ev & 0xffffu) + 1;
+                    const bool is_n = (ev >> 16) & 1, is_q = (ev >> 17) & 1;
+                    if (is_n | is_q) {
+                        if (!is_n) { x_nn.put(pw, pos - st.nn_index, lane); st.nn_index = pos; }
+                        else {
+                            u32 ch = ev >> 24;
+                            if (a.lossless && ch == 'n') ch = 'N';                          // its case travels in "gen.lc"
+                            if (!st.n_byte) st.n_byte = ch;
+                            if (ch != st.n_byte) st.bad = SFQ_E_GENCHAR;
+                            if (!is_q) { x_ns.put(pw, pos - st.ns_index, lane); st.ns_index = pos; }
+                        }
+                    }
+                    if ((ev >> 18) & 1) { x_lc.put(pw, pos - st.lc_index, lane); st.lc_index = pos; }
+                }
+            }
+        };
+        for (u32 k0 = 0; k0 < nrec; k0 += 64) {
+            const u32 kk = k0 + lane;
+            const bool have = kk < nrec;
+            const u64 rr = rec0 + (have ? kk : 0);
+            const u64 lg0 = a.line_off[4 * rr + 1] + solid, lg1 = a.line_off[4 * rr + 2] - 1;
+            const u64 lq0 = a.line_off[4 * rr + 3] + solid, lq1 = a.line_off[4 * rr + 4] - 1;
+            const u32 my_llen = have && lg1 > lg0 ? (u32)(lg1 - lg0) : 0u;
+            const u32 my_qlen = have && lq1 > lq0 ? (u32)(lq1 - lq0) : 0u;
+            const u32 incl = wave_incl_scan(my_llen);
+            const bool marked = have && (flags ? flags[rr] != 0 : true);
+            const u64 todo = __ballot(marked);
+            if (marked) {
+                const u32 at = qn + (u32)__popcll(todo & ((1ull << lane) - 1ull));
+                L.g[at] = lg0; L.q[at] = lq0; L.ofs[at] = genofs + (incl - my_llen); L.llen[at] = my_llen; L.qlen[at] = my_qlen;
+            }
+            qn += (u32)__popcll(todo);
+            genofs += rl(incl, 63);
+            if (qn >= 64) {
+                take(64);
+                qn -= 64;
+                const u64 tg = L.g[64 + lane], tq = L.q[64 + lane], to = L.ofs[64 + lane]; const u32 tl = L.llen[64 + lane], tql = L.qlen[64 + lane];
+                if (lane < qn) { L.g[lane] = tg; L.q[lane] = tq; L.ofs[lane] = to; L.llen[lane] = tl; L.qlen[lane] = tql; }
+            }
+        }
+        if (qn) take(qn);
+        const u32 sz_ns = x_ns.finish(pw, lane), sz_nn = x_nn.finish(pw, lane), sz_lc = x_lc.finish(pw, lane);
+        if (lane == 0) {
+            d->n_byte = st.n_byte;
+            d->size[SFQ_S_GEN_NS] = sz_ns;
+            d->size[SFQ_S_GEN_NN] = sz_nn;
+            d->size[SFQ_S_GEN_LC] = sz_lc;
+            if (x_ns.sink.pos > x_ns.sink.cap || x_nn.sink.pos > x_nn.sink.cap || x_lc.sink.pos > x_lc.sink.cap) atomicMax(&d->status, (u32)(-SFQ_E_OVERFLOW));
+            if (st.bad) atomicMax(&d->status, (u32)(-st.bad));
+        }
+    }
+}
 // The way back (decode_l.hip k_gen_exc_decode_l on one lane: every gap a walk of dependent reads through its row): a wave
 // per block, the row search across the lanes (WavePw::get).  gen.Ns lists the N positions whose quality is not '!' (-> the
 // N byte), gen.Nn the real bases under quality '!' (-> bit 7, which k_assemble reads as "keep this base"); gens.cpp:187-188.
@@ -347,7 +536,7 @@ void launch_gen_exc_w(const ModelArgs& a, const u8* flags, u32* ticket, hipStrea
 }
 void launch_gen_exc_r(const ModelArgs& a, const u8* flags, u32* ticket, hipStream_t st) {
     const u32 grid = a.nbatch < 6144u ? a.nbatch : 6144u;
-    hipLaunchKernelGGL(k_gen_exc_w<true>, dim3(grid), dim3(64), 0, st, a, flags, ticket);
+    hipLaunchKernelGGL(k_gen_exc_q, dim3(grid), dim3(64), 0, st, a, flags, ticket);
 }
 
 
