@@ -1835,28 +1835,36 @@ __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __rest
     RecFastEnc<RecCodeLds> cd; cd.rows = a.rrows; cd.L = &L; cd.rc.init(outp, cap);
     const uint4* t = reinterpret_cast<const uint4*>(tok + cp.r0 * RT_TOK_PER_REC);       // (160 bytes per record: 16-byte aligned)
     const u32 n = ntok[c];
-    // Tokens four at a time, two groups ahead; their row entries one group ahead of the coder -- the rows are frozen, so an
+    // Tokens sixteen at a time, two groups ahead; their row entries one group ahead of the coder -- the rows are frozen, so an
     // entry depends on nothing the coder does.  (Round 4: written as fetch-then-code per token the coder's own stores kept the
     // compiler from moving a fetch up, and a lane paid a memory round trip per symbol: 0.93 ms for the 128-record chains of
-    // a 600 k-read call, 600 ns a symbol.)
+    // a 600 k-read call, 600 ns a symbol.  Round 5: groups of four made it a round trip per four symbols -- 640 of them down a chain of 171
+    // records, 2 ms with the chip to itself and 4.9 at the tail of a call whose CUs the quality chains hold; sixteen entries in flight now.)
     const u32* const grows = a.rrows;
 #define RC_ENTRY(tk, on) rec_code_entry(L, grows, (on) ? (tk) >> 8 : 0u, (tk) & 0xffu)
 #define RC_ENTRIES(v, i) make_uint4(RC_ENTRY((v).x, (i) < n), RC_ENTRY((v).y, (i) + 1 < n), RC_ENTRY((v).z, (i) + 2 < n), RC_ENTRY((v).w, (i) + 3 < n))
     // (a token group is loaded under an `if`, not chosen by `? :` against a zero constant: that becomes a load through a chosen
     //  POINTER, with the constant in scratch)
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-    if (n) v0 = t[0];
-    if (n > 4) v1 = t[1];
-    uint4 e = RC_ENTRIES(v0, 0u);
-    for (u32 i = 0; i < n; i += 4) {
-        uint4 v2 = make_uint4(0, 0, 0, 0);
-        if (i + 8 < n) v2 = t[(i >> 2) + 2];
-        const uint4 e2 = RC_ENTRIES(v1, i + 4u);
-        cd.rc.encode16(FZ_CUM(e.x), FZ_FREQ(e.x));
-        if (i + 1 < n) cd.rc.encode16(FZ_CUM(e.y), FZ_FREQ(e.y));
-        if (i + 2 < n) cd.rc.encode16(FZ_CUM(e.z), FZ_FREQ(e.z));
-        if (i + 3 < n) cd.rc.encode16(FZ_CUM(e.w), FZ_FREQ(e.w));
-        v1 = v2; e = e2;
+    constexpr u32 Q = 4;                                                      // uint4s a group
+    uint4 t1[Q], e[Q];
+#pragma unroll
+    for (u32 k = 0; k < Q; k++) { uint4 t0 = make_uint4(0, 0, 0, 0); t1[k] = t0; if (4 * k < n) t0 = t[k]; if (4 * (Q + k) < n) t1[k] = t[Q + k]; e[k] = RC_ENTRIES(t0, 4u * k); }
+    for (u32 i = 0; i < n; i += 4 * Q) {
+        uint4 t2[Q], e2[Q];
+#pragma unroll
+        for (u32 k = 0; k < Q; k++) { t2[k] = make_uint4(0, 0, 0, 0); if (i + 4 * (2 * Q + k) < n) t2[k] = t[(i >> 2) + 2 * Q + k]; }
+#pragma unroll
+        for (u32 k = 0; k < Q; k++) e2[k] = RC_ENTRIES(t1[k], i + 4u * (Q + k));
+#pragma unroll
+        for (u32 k = 0; k < Q; k++) {
+            const u32 j = i + 4 * k;
+            if (j < n) cd.rc.encode16(FZ_CUM(e[k].x), FZ_FREQ(e[k].x));
+            if (j + 1 < n) cd.rc.encode16(FZ_CUM(e[k].y), FZ_FREQ(e[k].y));
+            if (j + 2 < n) cd.rc.encode16(FZ_CUM(e[k].z), FZ_FREQ(e[k].z));
+            if (j + 3 < n) cd.rc.encode16(FZ_CUM(e[k].w), FZ_FREQ(e[k].w));
+        }
+#pragma unroll
+        for (u32 k = 0; k < Q; k++) { t1[k] = t2[k]; e[k] = e2[k]; }
     }
 #undef RC_ENTRIES
 #undef RC_ENTRY
