@@ -441,10 +441,12 @@ def main():
     match_on = bool(args.tables and args.block_reads and (_varints(ctx.chains(), 2)[1] & 32))
     if match_on:
         kname[capi.T_GEN] = "k_gm_code"
-    dom = max(names, key=lambda k: phase[k])
+    # (the longest single piece decides: a model's coding kernel, or what its phase holds besides -- a phase that is long because its
+    #  kernels WAIT, the header coder confined to the CUs the quality chains leave, is not where the call's time goes)
+    dom = max(names, key=lambda k: max(float(coder[cslot[k]]), float(phase[k]) - float(coder[cslot[k]])))
     dom_ms = float(coder[cslot[dom]])
     over = "kernel"
-    if dom_ms < 0.8 * float(phase[dom]):
+    if dom_ms < 0.5 * float(phase[dom]):
         over = "phase"
         dom_ms = float(phase[dom])
         if dom == capi.T_GEN and match_on:

@@ -157,7 +157,9 @@ typedef struct sfq_result {
                                               everything on its stream -- counting passes, row building, the coding kernel */
     double   coder_ms[4];                  /* encode: the coding kernel alone (HIP events around its launch on its stream):
                                               [0] quality, [1] bases, [2] headers, [3] the framing kernel (k_frame).  What a kernel trace shows as
-                                              k_qlt_encode_c / k_gen_encode_c / k_rec_encode_f (k_*_encode_k / _w with adaptive tables) */
+                                              k_qlt_encode_c / k_gen_encode_c (k_gm_code under the match model) / k_rec_tokens -- the longest of the
+                                              header chains' kernels; the coder behind it, k_rec_code, is in the phase -- (k_*_encode_k / _w with
+                                              adaptive tables) */
 } sfq_result;
 
 #define SFQ_T_FRAME   0   /* line index + block descriptors                     */

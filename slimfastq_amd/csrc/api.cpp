@@ -1381,8 +1381,8 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             ca.csz = (u32*)ctx->csz.p + 2 * (size_t)nchains; ca.rhb = ca.csz + nsub;
             HIPC(hipEventRecord(ctx->ev[18], mst[1]));
             if (nbytes / nrec <= 4000) HIPC(hipStreamWaitEvent(st, ctx->ev[18], 0));   // (the quality chains behind the header prior's passes, as when the host waited for those; not where records are long: few headers, long ones, and the chains have better things to do than wait for their sample)
-            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1], min_hdr);
-            HIPC(hipEventRecord(ctx->ev[19], mst[1]));
+            launch_rec_encode_c(ca, (u32*)ctx->rflags.p, (u32*)ctx->rflags.p + nsub, (u32*)ctx->rtok.p, (u32*)ctx->rflags.p + 2 * (size_t)nsub, ctx->r_hot_dec, max_hdr, mst[1], min_hdr, min_hdr > 127 ? nullptr : ctx->ev[25]);
+            HIPC(hipEventRecord(ctx->ev[min_hdr > 127 ? 25 : 19], mst[1]));
             HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));          // (the header chains are through here; the copy below is not part of the model's phase)
             if ((rc = rec_prior_copy_back(ctx, mst[1]))) return rc;
         } else HIPC(hipEventRecord(ctx->ev[3 + 2 * 1], mst[1]));
@@ -1717,7 +1717,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     if (frozen) {
         if (models & SFQ_M_QLT) res->coder_ms[0] = ev_ms(ctx->ev[14], ctx->ev[15]);
         if (models & SFQ_M_GEN) res->coder_ms[1] = ev_ms(ctx->ev[16], ctx->ev[17]);
-        if (models & SFQ_M_REC) res->coder_ms[2] = ev_ms(ctx->ev[18], ctx->ev[19]);
+        if (models & SFQ_M_REC) res->coder_ms[2] = ev_ms(ctx->ev[18], ctx->ev[25]);      // (the token step; where every header is long, the general kernel)
     } else {                                       // one persistent kernel per model: the phase is the kernel
         res->coder_ms[0] = res->kernel_ms[SFQ_T_QLT]; res->coder_ms[1] = res->kernel_ms[SFQ_T_GEN]; res->coder_ms[2] = res->kernel_ms[SFQ_T_REC];
     }

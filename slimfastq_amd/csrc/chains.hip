@@ -1873,7 +1873,7 @@ __global__ __launch_bounds__(256) void k_rec_code(ChainArgs a, const u32* __rest
     if (cd.rc.err & 1) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 // flags, flags2: one dword per header chain each, zeroed by the caller; tok: RT_TOK_PER_REC dwords per record of the call; ntok: [chains]
-void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, u32* ntok, u32 n_hot, u32 max_hdr, hipStream_t st, u32 min_hdr) {
+void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, u32* ntok, u32 n_hot, u32 max_hdr, hipStream_t st, u32 min_hdr, hipEvent_t after_tokens) {
     const u32 nc = a.rgeo.nchains;
     if (!nc) return;
     if (min_hdr > 127) {           // every header is past the token step's and the fast lane kernel's 127 bytes (long reads' UUID headers): the general kernel alone
@@ -1883,6 +1883,7 @@ void launch_rec_encode_c(const ChainArgs& a, u32* flags, u32* flags2, u32* tok, 
     if (max_hdr <= 62) hipLaunchKernelGGL(k_rec_tokens<62>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);
     else if (max_hdr <= 94) hipLaunchKernelGGL(k_rec_tokens<94>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);
     else hipLaunchKernelGGL(k_rec_tokens<127>, dim3(nc), dim3(64), 0, st, a, tok, ntok, flags);
+    if (after_tokens) (void)hipEventRecord(after_tokens, st);
     hipLaunchKernelGGL(k_rec_code, dim3((nc + 255) / 256), dim3(256), 0, st, a, (const u32*)tok, (const u32*)ntok, (const u32*)flags, n_hot < RC_LDS_ROWS ? n_hot : RC_LDS_ROWS);
     // what the token step left: a chain per lane with everything in LDS, then the general kernel for what that leaves
     const dim3 grid((nc + 63) / 64);

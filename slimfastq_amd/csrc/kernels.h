@@ -138,7 +138,8 @@ void launch_rec_prior_freqs(const u32* cnt, u32 nrows, u32* f, u32* rtot, u32 nh
 // one header chain per lane; a.csz / a.rhb per chain; max_hdr = the call's longest header (picks the LDS image of the fast kernel)
 void launch_rec_encode_c(const ChainArgs& a, u32* flags /* [rgeo.nchains], zeroed */, u32* flags2 /* the same */, u32* tok /* rec_token_bytes(records) */, u32* ntok /* [rgeo.nchains] */,
                          u32 n_hot, u32 max_hdr, hipStream_t st,
-                         u32 min_hdr = 0 /* the call's shortest header: over 127 = every chain to the general kernel, nothing else launched */);
+                         u32 min_hdr = 0 /* the call's shortest header: over 127 = every chain to the general kernel, nothing else launched */,
+                         hipEvent_t after_tokens = nullptr /* recorded behind the token step (the longest kernel of the five), for sfq_result.coder_ms */);
 u64 rec_token_bytes(u64 nrec);
 // segments: chains per record (from the text's line index, or from the decoder's line lengths), then the chains' records
 void launch_seg_count(const u64* line_off, const BlockDesc* blocks, u32 block_reads, u64 nrec, u32 seg_len, u32* nseg, hipStream_t st);
