@@ -2167,7 +2167,9 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         da.boff = (const u64*)ctx->gm_boff.p;
     } else
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
-    launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+    // the quality lines' places in their stage: on 32-byte sectors where the lines are long enough for that to cost little (dev_chain.h LaneOut32)
+    const u32 qpad = (frozen && nrec && out_cap / nrec >= 128) ? 31u : 0u;
+    launch_scan_u32(da.qlen, (u64*)ctx->qoff.p, nrec, (u64*)ctx->scan_tmp.p, st, qpad);
     u64 tot_s = 0, tot_q = 0;
     u32 dec_max_line = 0;                              // the longest base line (how the base tables' counting passes split their work)
     if (frozen && gen_on) {                            // (only the generation tables' counting passes ask: 0.12 ms of the head otherwise)
@@ -2181,7 +2183,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
     // (a damaged usr stream can claim any lengths: what cannot fit the caller's buffer is refused before anything is decoded)
-    if (tot_s > out_cap || tot_q > out_cap) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
+    if (tot_s > out_cap || tot_q > out_cap + (u64)qpad * nrec) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
                                                            (unsigned long long)tot_s, (unsigned long long)tot_q, (unsigned long long)out_cap);
     if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 64))) return rc;          // (gm.hip's windows read sixteen bytes at any place up to tot_s)
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;

@@ -424,9 +424,9 @@ __global__ __launch_bounds__(THREADS) void k_qlt_decode_c(ChainArgs a, DecodeArg
         const u32 n = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.qlen[cp.r0 + k + 1]; off_next = da.qoff[cp.r0 + k + 1]; }
 #ifdef SFQ_EXP_OUT_LOCAL               /* scratch experiment: every lane's output into a small region that stays in L2 (the text comes out wrong) */
-        LaneOut out; out.begin(da.qual_stage + (size_t)(c & 8191u) * 64u + 0 * off);
+        LaneOut32 out; out.begin(da.qual_stage + (size_t)(c & 8191u) * 64u + 0 * off);
 #else
-        LaneOut out; out.begin(da.qual_stage + off);
+        LaneOut32 out; out.begin(da.qual_stage + off);
 #endif
         u32 last = 0, p1 = 0, p2 = 0, delta = 5;
         for (u32 i = 0; i < n; i++) {

@@ -227,6 +227,40 @@ struct LaneOut {
     }
 };
 
+// The same, thirty-two bytes -- a whole sector of HBM -- a time, for lines that START on a sector (the quality decoder's: api.cpp pads their places).
+// LaneOut's sixteen-byte stores at any alignment dirty a sector twice or three times, a symbol-step apart -- 60 us --, and a quarter of a million half
+// written sectors do not wait in L2 that long: the quality decoder wrote 4.6 GB for 1.5 GB of text (profiles/r05z_pmc_summary.txt).  Two stores back to back
+// fill a sector at once.
+struct LaneOut32 {
+    u8* p; u32 n, acc; u32 w0, w1, w2, w3, w4, w5, w6;
+    __device__ __forceinline__ void begin(u8* dst) { p = dst; n = 0; acc = 0; w0 = w1 = w2 = w3 = w4 = w5 = w6 = 0; }
+    __device__ __forceinline__ void put(u32 byte) {
+        acc = __builtin_amdgcn_alignbit(byte, acc, 8);             // (acc >> 8) | (byte << 24)
+        n++;
+        if ((n & 3u) == 0) {                                       // a dword is full: the first seven of a row of thirty-two bytes wait
+            const u32 q = (n >> 2) & 7u;
+            if (q == 0) {
+                *reinterpret_cast<uint4*>(p + n - 32) = make_uint4(w0, w1, w2, w3);
+                *reinterpret_cast<uint4*>(p + n - 16) = make_uint4(w4, w5, w6, acc);
+            }
+            w0 = q == 1 ? acc : w0; w1 = q == 2 ? acc : w1; w2 = q == 3 ? acc : w2; w3 = q == 4 ? acc : w3;
+            w4 = q == 5 ? acc : w4; w5 = q == 6 ? acc : w5; w6 = q == 7 ? acc : w6;
+        }
+    }
+    __device__ __forceinline__ void end() {                       // what is left: up to seven dwords, up to three bytes
+        const u32 full = (n >> 2) & 7u, base = n & ~31u;
+        if (full > 0) *reinterpret_cast<u32*>(p + base) = w0;
+        if (full > 1) *reinterpret_cast<u32*>(p + base + 4) = w1;
+        if (full > 2) *reinterpret_cast<u32*>(p + base + 8) = w2;
+        if (full > 3) *reinterpret_cast<u32*>(p + base + 12) = w3;
+        if (full > 4) *reinterpret_cast<u32*>(p + base + 16) = w4;
+        if (full > 5) *reinterpret_cast<u32*>(p + base + 20) = w5;
+        if (full > 6) *reinterpret_cast<u32*>(p + base + 24) = w6;
+        const u32 pend = n & 3u;
+        for (u32 i = 0; i < pend; i++) p[n - pend + i] = (u8)(acc >> (8 * (4 - pend + i)));
+    }
+};
+
 struct LaneDec {
     u64 low, code; u32 range;
     const u8* p; u32 pos, n;

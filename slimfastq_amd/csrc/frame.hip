@@ -340,11 +340,11 @@ void launch_text_fingerprint(const u8* fq, u64 n, u64* out, hipStream_t st) {
 
 // ---- generic exclusive scan u32 -> u64 -------------------------------------------------------------
 #define SCAN_TILE 1024u
-__global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* in, u64 n, u64* sums) {
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* in, u64 n, u64* sums, u32 pad) {
     __shared__ u32 lds[8];
     u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * 4;
     u32 s = 0;
-    for (int j = 0; j < 4; j++) if (base + j < n) s += in[base + j];
+    for (int j = 0; j < 4; j++) if (base + j < n) s += (in[base + j] + pad) & ~pad;
     u32 total;
     block_excl_scan_256(s, lds, &total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
@@ -374,23 +374,24 @@ __global__ __launch_bounds__(256) void k_scan_sums(u64* sums, u64 ntiles) {   //
     }
     if (threadIdx.x == 0) sums[ntiles] = carry_s;
 }
-__global__ __launch_bounds__(256) void k_scan_tiles(const u32* in, u64 n, const u64* sums, u64* out, u64 ntiles) {
+__global__ __launch_bounds__(256) void k_scan_tiles(const u32* in, u64 n, const u64* sums, u64* out, u64 ntiles, u32 pad) {
     __shared__ u32 lds[8];
     u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * 4;
     u32 v[4]; u32 s = 0;
-    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    for (int j = 0; j < 4; j++) { v[j] = base + j < n ? (in[base + j] + pad) & ~pad : 0; s += v[j]; }
     u32 total;
     u32 ex = block_excl_scan_256(s, lds, &total);
     u64 run = sums[blockIdx.x] + ex;
     for (int j = 0; j < 4; j++) { if (base + j < n) out[base + j] = run; run += v[j]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[ntiles];
 }
-void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st) {
+// pad: 0, or 2^k - 1 -- every value rounded up to a multiple of 2^k first (places of lines that start on 32-byte sectors)
+void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp, hipStream_t st, u32 pad) {
     u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (ntiles == 0) ntiles = 1;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3((u32)ntiles), dim3(256), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((u32)ntiles), dim3(256), 0, st, in, n, tmp, pad);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, tmp, ntiles);
-    hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(256), 0, st, in, n, (const u64*)tmp, out, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(256), 0, st, in, n, (const u64*)tmp, out, ntiles, pad);
 }
 
 // ---- format 6: the reference's OVERSIZE records (usrs.cpp:269-301) -----------------------------------------------------

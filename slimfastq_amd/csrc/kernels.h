@@ -185,7 +185,7 @@ void launch_text_fingerprint(const u8* fq, u64 n, u64* out /* zeroed */, hipStre
 #define FRAME_CHUNK 16384u
 
 // generic exclusive scan u32 -> u64 (out has n+1 entries)
-void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp /* >= n/1024+2 */, hipStream_t st);
+void launch_scan_u32(const u32* in, u64* out, u64 n, u64* tmp /* >= n/1024+2 */, hipStream_t st, u32 pad = 0 /* 2^k - 1: the values rounded up to multiples of 2^k */);
 
 // models, lane-per-block reference kernels
 void launch_qlt_encode_l(const ModelArgs& a, hipStream_t st);
