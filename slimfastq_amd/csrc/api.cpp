@@ -1177,10 +1177,13 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         if (p.chain_reads & SFQ_CHAIN_SEGMENT_FLAG) { seg_len = p.chain_reads & ~SFQ_CHAIN_SEGMENT_FLAG; cr = 1; if (!seg_len) return fail(ctx, SFQ_E_ARG, "SFQ_CHAIN_SEGMENT(0)"); }
         else if (!p.chain_reads && cr == 1 && nrec < 204800) {
             // long records, few of them: a lane that walks a 50 kb read alone takes as long as the rest of the call -- the call's
-            // symbols in about 204 800 segments (default_chain_reads), of 4096 symbols or more (round 5; 2048 before: a segment costs
+            // symbols in about 250 000 segments (default_chain_reads), of 4096 symbols or more (round 5; 2048 before: a segment costs
             // seven to eight bytes -- its context's warm-up, its flush, its index entries -- and 6000 reads in segments of 2048 came out
             // 1.014 x the reference's at -l 4, profiles/r05_ratio_table.json)
-            const u64 want = std::min<u64>(std::max<u64>(4096, nbytes / 2 / 204800), 1u << 20);
+            // (every record's last segment is a short one: about half a segment per record over the symbols' share -- the count stays within
+            //  the 256 workgroups of default_chain_reads; 60 000 reads of 10-50 kb: 232.9 k segments of 7297 -> 251 k of 6673, 258 -> 263 GB/s, decode 15.4 -> 14.9 ms)
+            const u64 segs_want = SFQ_CHAINS_WANT - 8192 - std::min<u64>(nrec / 2, 100000);
+            const u64 want = std::min<u64>(std::max<u64>(4096, nbytes / 2 / segs_want), 1u << 20);
             if (max_line > want) seg_len = (u32)want;
         }
         if (!p.chain_reads && !seg_len)             // (the blocks' chains are of equal length: the count is blocks x chains per block, and rounds up)
