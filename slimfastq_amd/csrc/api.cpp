@@ -2162,11 +2162,19 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         da.m.batch0 = b0; da.m.nbatch = std::min(slots, nblocks - b0);
         if (p.kernel == 0 && !has_over) launch_usr_decode_w(da, st, usr_prefilled); else launch_usr_decode_l(da, st, usr_prefilled);
     }
+    const u32 spad = (frozen && !gm_on && !gen_on && exc_rice && !seg_len && nrec && out_cap / nrec >= 128) ? 31u : 0u;
     if (gm_on) {
         // the match model's stage: a '\n' behind every base line (gm.hip) -- soff[r] = (bases before r) + r
         if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
         launch_scan_u32(da.slen, (u64*)ctx->gm_boff.p, nrec, (u64*)ctx->scan_tmp.p, st);
         launch_gm_soff((const u64*)ctx->gm_boff.p, nrec, (u64*)ctx->soff.p, st);
+        da.boff = (const u64*)ctx->gm_boff.p;
+    } else if (spad) {
+        // flat bases (no model of either kind), Rice-coded exception lists: the lines start on 32-byte sectors, as the quality lines do; the
+        // exception lists' positions count bases, so the bases before every record go along (exc.hip)
+        if ((rc = reserve(ctx, ctx->gm_boff, ((size_t)nrec + 1) * 8))) return rc;
+        launch_scan_u32(da.slen, (u64*)ctx->gm_boff.p, nrec, (u64*)ctx->scan_tmp.p, st);
+        launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st, spad);
         da.boff = (const u64*)ctx->gm_boff.p;
     } else
     launch_scan_u32(da.slen, (u64*)ctx->soff.p, nrec, (u64*)ctx->scan_tmp.p, st);
@@ -2186,7 +2194,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     HIPC(hipEventRecord(ctx->ev[1], st));
     HIPC(hipStreamSynchronize(st));
     // (a damaged usr stream can claim any lengths: what cannot fit the caller's buffer is refused before anything is decoded)
-    if (tot_s > out_cap || tot_q > out_cap + (u64)qpad * nrec) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
+    if (tot_s > out_cap + (u64)spad * nrec || tot_q > out_cap + (u64)qpad * nrec) return fail(ctx, SFQ_E_CORRUPT, "line lengths add up to %llu bases / %llu qualities, the output buffer holds %llu bytes",
                                                            (unsigned long long)tot_s, (unsigned long long)tot_q, (unsigned long long)out_cap);
     if ((rc = reserve(ctx, ctx->seq_stage, (size_t)tot_s + 64))) return rc;          // (gm.hip's windows read sixteen bytes at any place up to tot_s)
     if ((rc = reserve(ctx, ctx->qual_stage, (size_t)tot_q + 16))) return rc;

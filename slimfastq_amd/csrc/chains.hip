@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
     for (u32 k = 0; k < cp.nrec; k++) {
         const u32 llen = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
-        LaneOut out; out.begin(da.seq_stage + off);
+        LaneOut32 out; out.begin(da.seq_stage + off);
         u32 last = INIT;
         if (rows) {                                                                         // (gen_bits >= 2: the four candidates are in bounds)
             u32 v = rows[last & mask];

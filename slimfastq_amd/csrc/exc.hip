@@ -33,9 +33,11 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_r(DecodeArgs a, u32 nbloc
     r_lc.init(a.streams + a.blk_stream_off[(u64)b * SFQ_NSTREAMS + SFQ_S_GEN_LC], (u32)d->size[SFQ_S_GEN_LC]);
     const u32 n_byte = d->n_byte ? d->n_byte : 'N';                                         // gens.cpp:169
     u8* const g = a.seq_stage + a.soff[d->rec0];
-    // (the match model's stage -- gm.hip -- keeps a '\n' behind every line: a list's positions count BASES, so the record a position
-    //  lies in is followed along, the lists being ascending, and one byte per record before it added)
+    // (the match model's stage -- gm.hip -- keeps a '\n' behind every line, and a call without it starts its lines on 32-byte sectors
+    //  (api.cpp, dev_chain.h LaneOut32): a list's positions count BASES, so where the lines are not back to back (a.boff: the bases before
+    //  every record) the record a position lies in is looked up and the position placed in that record's line)
     const u64* const bo = a.boff ? a.boff + d->rec0 : nullptr;
+    const u64* const so = a.soff + d->rec0;
     const u64 b0 = bo ? bo[0] : 0;
     const u64 nb = bo ? bo[d->nrec] - b0 : a.soff[d->rec0 + d->nrec] - a.soff[d->rec0];
     u32 bad = 0;
@@ -52,11 +54,16 @@ __global__ __launch_bounds__(64) void k_gen_exc_decode_r(DecodeArgs a, u32 nbloc
         return k;
     };
     u64 at = 0;
-    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] = (u8)n_byte; }
+    auto place = [&](u64 at) -> u8* {                    // where base `at` of the block lies in the stage
+        if (!bo) return g + at - 1;
+        const u32 k = rec_of(at);
+        return a.seq_stage + so[k] + (b0 + at - 1 - bo[k]);
+    };
+    for (u64 gap = r_ns.get(); gap; gap = r_ns.get()) { at += gap; if (at > nb) { bad = 1; break; } *place(at) = (u8)n_byte; }
     at = 0;
-    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] |= 0x80u; }
+    for (u64 gap = r_nn.get(); gap; gap = r_nn.get()) { at += gap; if (at > nb) { bad = 1; break; } *place(at) |= 0x80u; }
     at = 0;
-    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } g[at - 1 + (bo ? rec_of(at) : 0u)] |= 0x20u; }
+    for (u64 gap = r_lc.get(); gap; gap = r_lc.get()) { at += gap; if (at > nb) { bad = 1; break; } *place(at) |= 0x20u; }
     if (bad | r_ns.err | r_nn.err | r_lc.err) atomicMax(&d->status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_gen_exc_decode_r(const DecodeArgs& a, u32 nblocks, hipStream_t st) {
