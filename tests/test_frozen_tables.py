@@ -678,3 +678,83 @@ def test_long_reads_take_segments_by_themselves(ctx):
     short = capi.synth_fastq(3000, 150, seed=5)
     enc = ctx.encode_host(short, level=3, block_reads=500, prior_step=capi.PRIOR_AUTO, tables=capi.TABLES_FROZEN)
     assert not util.unpack_chains(enc.chains)["flags"] & 8
+
+
+def _headers_of_every_length(n, top, seed):
+    """Headers whose lengths run through 1 .. top and whose fields end at every byte of a dword: the token step stages a header four bytes
+    a time and keeps its field ends as a mask (chains.hip rt_stage) -- bit 63 / 64, the last dword's spare bytes, a header that ends on a
+    separator, bytes over 0x7f, fields of ten digits and more, "00", a tab, an underscore, fields that change width."""
+    rng = np.random.default_rng(seed)
+    seps = [":", " ", ".", "_", "\t", "/", "-", "#", "=", "\xe9"]
+    out = []
+    for i in range(n):
+        want = 1 + (i * 7 + i // 130) % top
+        parts = ["r%d" % (i // 3)]
+        k = 0
+        while len("".join(parts)) < want:
+            kind = (i + k) % 9
+            if kind == 0: f = str(10 ** int(rng.integers(0, 12)) + i)              # one to twelve digits: the short way and the general one
+            elif kind == 1: f = "00" + str(i % 7)
+            elif kind == 2: f = "0" + str(1 + i % 9)
+            elif kind == 3: f = "ab" if i % 2 else "AB"
+            elif kind == 4: f = str(int(rng.integers(0, 100000)))
+            elif kind == 5: f = ""                                                   # two separators in a row
+            elif kind == 6: f = "x\xfcy"                                              # a byte over 0x7f inside a field: it ends one
+            elif kind == 7: f = str(99999 - i) if i < 99999 else "7"
+            else: f = "Z" * int(rng.integers(1, 9))
+            parts.append(seps[(i // 11 + k) % len(seps)] + f)
+            k += 1
+            if k > 14: break                                                         # (sixteen fields at most stay on the token step's path)
+        hdr = "".join(parts)[:want]
+        ln = 30 + i % 5
+        seq = "".join("ACGT"[int(v)] for v in rng.integers(0, 4, ln))
+        q = "".join(chr(33 + int(v)) for v in rng.integers(2, 41, ln))
+        out.append("@%s\n%s\n+\n%s\n" % (hdr, seq, q))
+    return "".join(out).encode("latin-1")
+
+
+@pytest.mark.parametrize("top", (61, 94, 127))
+def test_frozen_header_tokens_at_every_header_length(ctx, top):
+    fq = _headers_of_every_length(3000, top, 21 + top)
+    enc = check_against_oracle(ctx, fq, 3, br=700, cr=90, step=1, what="headers of 1 .. %d bytes" % top)
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq
+
+
+def _exception_heavy_fastq(n, seed):
+    """Records for the exception pass (models_w.hip k_gen_exc_q: a marked record per lane, sixteen bytes a step, eight events a list): none, one, nine
+    and ninety events a record; N, n and '.' under every kind of quality; '!' over real bases; lower-case runs; quality lines shorter than their bases
+    (what lies behind them counts as 'I'); records over 1024 bases (the whole wave's walk) between short ones; lengths that end a sixteen-byte step early
+    and late."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(1, 60)) if i % 13 == 0 else (int(rng.integers(1025, 2500)) if i % 41 == 7 else int(rng.integers(90, 200)))
+        b = np.array(list("ACGT"), dtype="U1")[rng.integers(0, 4, ln)]
+        q = rng.integers(2, 41, ln) + 33
+        kind = i % 8
+        ev = 0 if kind == 0 else 1 if kind < 4 else 9 if kind < 7 else min(ln, 90)
+        at = rng.choice(ln, size=min(ev, ln), replace=False)
+        for j, p in enumerate(at):
+            w = (i + j) % 6
+            if w == 0: b[p] = "N"
+            elif w == 1: b[p] = "N"; q[p] = 33
+            elif w == 2: q[p] = 33
+            elif w == 3: b[p] = str(b[p]).lower()
+            elif w == 4: b[p] = "N"; q[p] = 34
+            else: b[p] = str(b[p]).lower(); q[p] = 33
+        if i % 17 == 3: b[: ln // 2] = np.char.lower(b[: ln // 2])
+        ql = ln if i % 5 else max(1, ln - int(rng.integers(1, 20)))                 # a short quality line now and then
+        out.append("@e%d x:%d\n%s\n+\n%s\n" % (i, i % 1000, "".join(b), "".join(chr(int(v)) for v in q[:ql])))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("br,cr", ((1024, 64), (150, 7)))
+def test_exception_scan_takes_records_of_every_kind(ctx, br, cr):
+    fq = _exception_heavy_fastq(4000, 33)
+    enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="exception-heavy records, blocks of %d" % br)
+    assert ctx.decode_host(enc, level=3, out_cap=2 * len(fq) + 4096) == fq
+    # one N byte per block is the format's rule (gens.cpp:169): a block that holds both 'N' and '.' is refused, not mangled
+    bad = fq.replace(b"N", b".", 1)
+    if bad != fq and b"N" in bad:
+        with pytest.raises(capi.SfqError):
+            ctx.encode_host(bad, level=3, block_reads=len(fq), tables=capi.TABLES_FROZEN, chain_reads=cr)
