@@ -934,9 +934,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     u64 nrec = 0;
     hipStream_t vst = legacy ? st : ctx->st_aux[0];             // where k_validate_records runs
     // the line index of the current text (d_fastq, nbytes) and the per-record checks
-    // (the '@' / '+' prefixes of a plain encode are looked at beside the counting passes -- frame.hip k_check_prefixes -- and fail a block; a call that ends
-    //  before the blocks' statuses are read, or frames twice -- format 6 with oversize records --, has k_validate_lines look at them)
-    const bool defer_prefixes = !legacy && !priors_only && !ctx->counts_only;
     auto frame = [&]() -> int {
         int rc;
         const u32 tiles = frame_tiles(nbytes);
@@ -981,7 +978,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         // (the block format: the per-record checks run on a stream of their own, beside the block descriptors and the quality sample's
         //  histogram)
         if (vst != st) { HIPC(hipEventRecord(ctx->ev[22], st)); HIPC(hipStreamWaitEvent(vst, ctx->ev[22], 0)); }
-        launch_validate_lines(defer_prefixes ? nullptr : d_fastq, (const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, vst);
+        launch_validate_lines((const u64*)ctx->line_off.p, nrec, legacy ? 0x3ffffffeu : 0x1ffeu, 0x3ffffffeu, (u32*)ctx->status.p, vst);
         return SFQ_OK;
     };
     // (an encode from summed counts right behind sfq_count_priors on the same buffer: that call's line index, marks and checks stand)
@@ -1428,8 +1425,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         }
         if (models & SFQ_M_USR)
             for (u32 b0 = 0; b0 < nblocks; b0 += slots) { ModelArgs ua = a; ua.batch0 = b0; ua.nbatch = std::min(slots, nblocks - b0); launch_usr_encode_w(ua, mst[2]); }
-        // (the '@' / '+' prefixes, here: beside the chains, where two scattered bytes a record cost nothing -- beside the quality sample's histogram they made it 0.63 ms of 0.40)
-        if (defer_prefixes && reframe) launch_check_prefixes(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, mst[2]);
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 2], mst[2]));
         side_late = false;
         HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * 1], 0));        // header chains
@@ -1486,7 +1481,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             const u32 ocap[3] = { (u32)over_cap, (u32)over_cap, (u32)over_cap };
             launch_over_encode_w(a, d_file, (const u64*)ctx->line_off_o.p, (const u32*)ctx->olist.p, n_over, ooff, ocap, mst[m]);
         }
-        if (m == 2 && defer_prefixes && reframe) launch_check_prefixes(d_fastq, (const u64*)ctx->line_off.p, nrec, block_reads, (BlockDesc*)ctx->blocks.p, mst[m]);
         HIPC(hipEventRecord(ctx->ev[3 + 2 * m], mst[m]));
         if (m) HIPC(hipStreamWaitEvent(st, ctx->ev[3 + 2 * m], 0));
     }
@@ -1626,7 +1620,6 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     for (u32 b = 0; b < nblocks; b++) if (hb[b].status) worst = std::max<int>(worst, (int)hb[b].status);
     if (worst) return fail(ctx, -worst, "block kernel reported error %d (%s)", -worst,
                            -worst == SFQ_E_OVERFLOW ? "stream arena too small" : -worst == SFQ_E_GENCHAR ? "unexpected genome char / switched N byte" :
-                           -worst == SFQ_E_FORMAT ? "fastq file: expecting '@' / '+' line prefixes (usrs.cpp:162-167)" :
                            -worst == SFQ_E_UNSUPPORTED ? "a '+' line that is neither empty nor its record's header: the block format refuses what it could not give back (usrs.cpp:236-239)" : "see status codes");
     ht.mark("  statuses looked at");
     if (run > out_cap) return fail(ctx, SFQ_E_OVERFLOW, "output needs %llu bytes, caller gave %llu", (unsigned long long)run, (unsigned long long)out_cap);

@@ -2,8 +2,8 @@
 //
 // The reference frames records on one host core with a 1 MiB sliding buffer (UsrSave::get_record,
 // usrs.cpp:303-390).  Here the whole text is resident in HBM and framing is a newline index, built in ONE pass over
-// the text (k_frame: line start offsets, the marks of the exception pass), then per record the line limits (usrs.hpp:34-36) and the
-// '@' / '+' prefixes (usrs.cpp:311, 346) from the index and two bytes of text (k_validate_lines), and one descriptor per record block (the
+// the text (k_frame: line start offsets, the '@' / '+' prefix checks of usrs.cpp:311,346, the marks of the exception pass),
+// then the per-record line limits (usrs.hpp:34-36) from the index alone and one descriptor per record block (the
 // first-record analysis of UsrSave::determine_record, usrs.cpp:186-267).  All of it is streaming, HBM-bound work.
 #include "kernels.h"
 
@@ -40,8 +40,7 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* lds /* >= 8 u32 *
 //     word, so no fence is needed) instead of a counting pass and a scan kernel;
 //   * newlines, '!' candidates and odd-base candidates are 64-bit masks per thread (a SWAR test per dword, four flag bits gathered
 //     with one multiply), so offsets and marks are a few bit operations per LINE END in the window, not per byte;
-//   * the '@' / '+' checks of UsrSave::get_record (usrs.cpp:311, 346) are k_validate_lines': two bytes a record (until round 5b they were two
-//     more masks of every window here -- a quarter of this kernel's instructions for two bytes a record).
+//   * the '@' / '+' checks of UsrSave::get_record (usrs.cpp:311, 346) ride on the line ends: the byte behind a newline is in cache.
 // The line index must be sized before the number of lines is known: the caller guesses (cap entries), the kernel never writes
 // past it and reports the count; a text of shorter lines than guessed is framed again with the exact size.
 // =========================================================================================================
@@ -56,10 +55,10 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #define TS_PFX  (2ull << 62)
 #define TS_VAL  ((1ull << 62) - 1)
 // A workgroup takes a TILE of FRAME_TILE bytes in FRAME_WIN sub-tiles of 16 KiB.  Round one LOADS the text -- coalesced, 16 bytes a
-// lane, a wave's 64 lanes one KiB -- and keeps of every 64-byte window three 64-bit masks in LDS: newlines, '!' candidates,
-// odd-base candidates (24 bytes per 64 of text: 24 KiB a tile); its newline count is what the tiles behind it wait for.  Round two --
-// the tile's place in the file known from the look-back -- runs FROM THE MASKS: a thread takes a window and writes offsets and marks per
-// line end.  The text is read ONCE (round 5).
+// lane, a wave's 64 lanes one KiB -- and keeps of every 64-byte window five 64-bit masks in LDS: newlines, '@', '+', '!' candidates,
+// odd-base candidates (40 bytes per 64 of text: 40 KiB a tile); its newline count is what the tiles behind it wait for.  Round two --
+// the tile's place in the file known from the look-back -- runs FROM THE MASKS: a thread takes a window, writes offsets and marks per
+// line end, and checks the '@' / '+' behind a line end in the masks too.  The text is read ONCE (round 5).
 // (Round 4 read it twice -- the second time "out of L2", which the counters did not bear out: TCC_MISS 6.1e7 of 7.1e7 requests, 7.4 GB
 //  fetched per 3.7 GB of text after the guide's gfx950 correction: 256 workgroups x 128 KiB in flight are four times the L2s.  Measured
 //  on the way, per 3.7 GB: a thread loading its own 64 contiguous bytes straight from memory 1.9-2.0 ms; one round with every window's
@@ -81,9 +80,10 @@ __device__ __forceinline__ u32 mask16(u32 fx, u32 fy, u32 fz, u32 fw) { return f
 template <bool MARKS>
 __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n, u64* __restrict__ tstat, u64* __restrict__ line_off, u64 cap,
                                                u32* __restrict__ status, u8* __restrict__ exc_flag, u64 ecap, FrameOut* __restrict__ fo) {
-    constexpr u32 NM = MARKS ? 3u : 1u;
-    __shared__ u64 mk[NM][FRAME_NW];                         // [newline, '!' candidate, odd-base candidate][window]
+    constexpr u32 NM = MARKS ? 5u : 3u;
+    __shared__ u64 mk[NM][FRAME_NW];                         // [newline, '@', '+', '!' candidate, odd-base candidate][window]
     __shared__ u32 wtot[4];
+    __shared__ u32 s_last[4];
     __shared__ u64 s_base;
     __shared__ u32 s_tile;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,15 +124,15 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
                 const u32 nl = mask16(nl_flags(x.x), nl_flags(x.y), nl_flags(x.z), nl_flags(x.w));
                 cnt += (u32)__popc(nl);
                 reinterpret_cast<u16*>(&mk[0][W])[q] = (u16)nl;
-                // (the '@' and '+' a record's first and third line start with -- usrs.cpp:311, 346 -- were two more masks here, a test of every byte for what
-                //  two bytes a record are asked: a quarter of this kernel's instructions.  k_validate_lines reads those two bytes.)
+                reinterpret_cast<u16*>(&mk[1][W])[q] = (u16)mask16(eq_flags(x.x, 0x40404040u), eq_flags(x.y, 0x40404040u), eq_flags(x.z, 0x40404040u), eq_flags(x.w, 0x40404040u));
+                reinterpret_cast<u16*>(&mk[2][W])[q] = (u16)mask16(eq_flags(x.x, 0x2b2b2b2bu), eq_flags(x.y, 0x2b2b2b2bu), eq_flags(x.z, 0x2b2b2b2bu), eq_flags(x.w, 0x2b2b2b2bu));
                 if constexpr (MARKS) {
                     // '!' candidates: a byte b with (b & 0x5e) == 0 -- in a quality line (0x21 .. 0x7e) that is '!' alone   (no carry between bytes: 0x5e + 0x7f < 0x100)
                     // odd-base candidates: bit 3 (N, '.') or bits 5 and 6 (lowercase) -- every N-like or lowercase base, and no A C G T 0 1 2 3
 #define FR_BANG(w) (~(((w) & 0x5e5e5e5eu) + 0x7f7f7f7fu) & 0x80808080u)
 #define FR_ODD(w) ((((w) << 4) | (((w) << 1) & ((w) << 2))) & 0x80808080u)
-                    reinterpret_cast<u16*>(&mk[1][W])[q] = (u16)mask16(FR_BANG(x.x), FR_BANG(x.y), FR_BANG(x.z), FR_BANG(x.w));
-                    reinterpret_cast<u16*>(&mk[2][W])[q] = (u16)mask16(FR_ODD(x.x), FR_ODD(x.y), FR_ODD(x.z), FR_ODD(x.w));
+                    reinterpret_cast<u16*>(&mk[3][W])[q] = (u16)mask16(FR_BANG(x.x), FR_BANG(x.y), FR_BANG(x.z), FR_BANG(x.w));
+                    reinterpret_cast<u16*>(&mk[4][W])[q] = (u16)mask16(FR_ODD(x.x), FR_ODD(x.y), FR_ODD(x.z), FR_ODD(x.w));
 #undef FR_BANG
 #undef FR_ODD
                 }
@@ -180,31 +180,40 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
     __syncthreads();
     u64 run = s_base;                                        // newlines before the sub-tile at hand
     if (tile == 0 && tid == 0) line_off[0] = 0;
-    // ---- round 2: offsets and the marks -- from the masks -----------------------------------------------------------
+    // does a line start with the sub-tile at hand (thread 0's business)?  With the file it does; elsewhere the byte before says
+    u32 carry_nl = 0;
+    if (tid == 0) carry_nl = tb == 0 ? 1u : (tb <= n && fq[tb - 1] == '\n') ? 1u : 0u;
+    // ---- round 2: offsets, the '@' / '+' checks, the marks -- from the masks -----------------------------------------------------------
 #pragma nounroll
     for (u32 wi = 0; wi < FRAME_WIN; wi++) {
         const u64 sb = tb + (u64)FRAME_SUB * wi;
         if (sb >= n) break;                                  // (the same for every thread)
         const u32 W = wi * 256u + tid;
         const u64 w0 = sb + 64u * tid;
-        const u64 nlm = mk[0][W];
+        const u64 nlm = mk[0][W], atm = mk[1][W], plm = mk[2][W];
         u64 bang = 0, odd = 0;
         if constexpr (MARKS) {
             const u64 live = w0 >= n ? 0ull : (n - w0) >= 64 ? ~0ull : ((1ull << (n - w0)) - 1);      // (bytes past the end read as 0: a '!' candidate)
-            bang = mk[1][W] & live; odd = mk[2][W] & live;
+            bang = mk[3][W] & live; odd = mk[4][W] & live;
         }
         // this window's newlines among its sub-tile's
         const u32 c = (u32)__popcll(nlm);
         u32 incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if (lane >= (u32)d) incl += o; }
-        if (lane == 63) wtot[wave] = incl;
+        if (lane == 63) { wtot[wave] = incl; s_last[wave] = (u32)(nlm >> 63); }
         __syncthreads();
         u32 bw = 0, tw = 0;
 #pragma unroll
         for (u32 k = 0; k < 4; k++) { const u32 t = wtot[k]; if (k < wave) bw += t; tw += t; }
         u64 k = run + bw + incl - c;                         // newlines before the window = the number of the line its first byte lies in
         run += tw;
+        // usrs.cpp:311, 346: a record's first line starts with '@', its third with '+'.  A line that starts WITH the window (the
+        // byte before it, the window before's last, is a newline -- handed over from lane to lane, wave to wave, sub-tile to sub-tile):
+        u32 prev_nl = (u32)__shfl_up((int)(u32)(nlm >> 63), 1, 64);
+        if (lane == 0) prev_nl = wave ? s_last[wave - 1] : carry_nl;
+        if (tid == 0) carry_nl = s_last[3];
+        if (prev_nl && w0 < n && ((u32)k & 1u) == 0u && !((((u32)k & 2u) ? plm : atm) & 1ull)) atomicMax(status, (u32)(-SFQ_E_FORMAT));
         if (w0 < n) {
             u64 m = nlm;
             u64 below = 0;                                   // the window's bytes up to the line end looked at last
@@ -221,6 +230,11 @@ __global__ __launch_bounds__(256) void k_frame(const u8* __restrict__ fq, u64 n,
                 k++;                                         // the line that starts behind this newline
                 const u64 start = w0 + i + 1;
                 if (k <= cap) line_off[k] = start;
+                // ... and a line that starts inside it: the byte behind the line end, in the '@' / '+' masks
+                if (i < 63u && start < n) {
+                    const u32 type = (u32)k & 3u;
+                    if ((type & 1u) == 0u && !(((type ? plm : atm) >> (i + 1u)) & 1ull)) atomicMax(status, (u32)(-SFQ_E_FORMAT));
+                }
             }
             if constexpr (MARKS) {                           // what lies behind the window's last line end (or the whole window)
                 const u64 seg = ~below;
@@ -237,9 +251,9 @@ void launch_frame(const u8* fq, u64 n, u64* tstat /* [frame_tiles(n)], zeroed */
     if (exc_flag) hipLaunchKernelGGL(k_frame<true>, dim3(tiles), dim3(256), 0, st, fq, n, tstat, line_off, cap, status, exc_flag, ecap, reinterpret_cast<FrameOut*>(frame_out));
     else hipLaunchKernelGGL(k_frame<false>, dim3(tiles), dim3(256), 0, st, fq, n, tstat, line_off, cap, status, exc_flag, ecap, reinterpret_cast<FrameOut*>(frame_out));
 }
-// the per-record checks: line limits (usrs.hpp:34-36) from the line index, the '@' / '+' prefixes (usrs.cpp:311, 346) from the two bytes it
-// points at, and the call's longest header and base line
-__global__ __launch_bounds__(256) void k_validate_lines(const u8* __restrict__ fq /* null: the prefixes are k_check_prefixes' */, const u64* __restrict__ line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
+// the per-record checks that need the line index alone (the '@' / '+' prefixes are k_frame's): line limits (usrs.hpp:34-36) and the
+// call's longest header and base line
+__global__ __launch_bounds__(256) void k_validate_lines(const u64* __restrict__ line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status) {
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
     u32 hl = 0, gl = 0, bad = 0, over = 0, hmin = 0;
@@ -262,8 +276,7 @@ __global__ __launch_bounds__(256) void k_validate_lines(const u8* __restrict__ f
         // status[3] != 0: some record may be over format 6's line limits (usrs.hpp:34-36; a SOLiD line may be one longer -- the
         // oversize pass decides exactly)
         over = ((l1 - l0 - 2) > 0x1ffe || (l2 - l1 - 1) > 0xfffe || (l4 - l3 - 1) > 0xfffe) ? 1u : 0u;
-        // usrs.cpp:311, 346: a record's first line starts with '@', its third with '+' (usrs.cpp:162-167 is the message)
-        if ((l1 - l0) < 2 || (l3 - l2) < 2 || (fq && (fq[l0] != '@' || fq[l2] != '+'))) bad = bad > (u32)(-SFQ_E_FORMAT) ? bad : (u32)(-SFQ_E_FORMAT);
+        if ((l1 - l0) < 2 || (l3 - l2) < 2) bad = (u32)(-SFQ_E_FORMAT);        // (a header or '+' line without its prefix: k_frame has flagged it too)
     }
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) {
@@ -278,21 +291,8 @@ __global__ __launch_bounds__(256) void k_validate_lines(const u8* __restrict__ f
         if (hmin > status[4]) atomicMax(status + 4, hmin);   // ~(the shortest header's length)
     }
 }
-void launch_validate_lines(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
-    hipLaunchKernelGGL(k_validate_lines, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, max_hdr, max_line, status);
-}
-
-// The '@' / '+' prefixes alone, for a call whose host does not wait for them: two scattered bytes a record -- a third of the text's sectors -- are 0.7 ms
-// of a 10 M-read call where the host waits (k_validate_lines gives it the longest header), nothing beside the counting passes.  A record without its prefix
-// fails its BLOCK (-SFQ_E_FORMAT in BlockDesc::status, which the call's end looks at).
-__global__ __launch_bounds__(256) void k_check_prefixes(const u8* __restrict__ fq, const u64* __restrict__ line_off, u64 nrec, u32 block_reads, BlockDesc* blocks) {
-    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrec) return;
-    const u64 l0 = line_off[4 * r], l2 = line_off[4 * r + 2];
-    if (fq[l0] != '@' || fq[l2] != '+') atomicMax(&blocks[block_reads ? r / block_reads : 0].status, (u32)(-SFQ_E_FORMAT));
-}
-void launch_check_prefixes(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, hipStream_t st) {
-    if (nrec) hipLaunchKernelGGL(k_check_prefixes, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, fq, line_off, nrec, block_reads, blocks);
+void launch_validate_lines(const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_validate_lines, dim3((u32)((nrec + 255) / 256)), dim3(256), 0, st, line_off, nrec, max_hdr, max_line, status);
 }
 
 // out[0] = max(out[0], max of v[0..n)); a thread takes sixteen values, a wave one atomic

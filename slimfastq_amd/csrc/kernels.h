@@ -180,9 +180,7 @@ void launch_block_prepare(const u8* fq, const u64* line_off, u64 nrec, u32 block
 u32 frame_tiles(u64 n);
 void launch_frame(const u8* fq, u64 n, u64* tstat /* [frame_tiles(n)], zeroed */, u64* line_off, u64 cap, u32* status, u8* exc_flag /* or null */, u64 ecap /* its entries */,
                   void* frame_out /* 16 bytes, zeroed */, hipStream_t st);
-void launch_validate_lines(const u8* fq, const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st);
-// the '@' / '+' prefixes of every record (usrs.cpp:311, 346), off the host's path: a record without one fails its block
-void launch_check_prefixes(const u8* fq, const u64* line_off, u64 nrec, u32 block_reads, BlockDesc* blocks, hipStream_t st);
+void launch_validate_lines(const u64* line_off, u64 nrec, u32 max_hdr, u32 max_line, u32* status, hipStream_t st);
 void launch_text_fingerprint(const u8* fq, u64 n, u64* out /* zeroed */, hipStream_t st);
 #define FRAME_CHUNK 16384u
 
