@@ -2306,6 +2306,9 @@ __global__ __launch_bounds__(64) void k_rec_dtext(ChainArgs a, DecodeArgs da, co
             }
             const bool isstr = ch && type == ST_STR, isnum = ch && !isstr;
             const bool less = type == ST_DLT || type == ST_HLT || type == ST_HLT_Z || type == ST_HLTC || type == ST_HLTC_Z || type == ST_DLT_Z;
+            // (a field that no record of the round changes -- most fields of most rounds -- has nothing to add up and no writer: the six-step scan of a
+            //  64-bit sum, a flag and a lane number was a fifth of this kernel's instructions)
+            if (!__any(ch)) { L.wsrc[f][lane] = 0xFFu; continue; }
             // the field's running value: a sum of the signed gaps over the lanes, starting over behind a string
             u32 rs = isstr ? 1u : 0u;
             u64 sv = isnum ? (less ? (u64)0 - gap : gap) : 0ull;
@@ -2340,9 +2343,15 @@ __global__ __launch_bounds__(64) void k_rec_dtext(ChainArgs a, DecodeArgs da, co
                         if (deci) {                                      // "%lld"
                             if ((i64)val < 0) bad = true;                // (a sign changes the fields: the general path's business)
                             u32 nd = 0;
-                            for (u64 t = val; t; t /= 10) nd++;
-                            u64 t = val;
-                            for (u32 j = nd; j-- > 0;) { L.scratch[spos + len + j][lane] = (u8)('0' + t % 10); t /= 10; }
+                            if (!__any(!bad && (val >> 32) != 0)) {      // (the usual number fits 32 bits: a multiply-high a digit, not a 64-bit division)
+                                for (u32 t = (u32)val; t; t /= 10u) nd++;
+                                u32 t = (u32)val;
+                                for (u32 j = nd; j-- > 0;) { const u32 q = t / 10u; L.scratch[spos + len + j][lane] = (u8)('0' + (t - q * 10u)); t = q; }
+                            } else {
+                                for (u64 t = val; t; t /= 10) nd++;
+                                u64 t = val;
+                                for (u32 j = nd; j-- > 0;) { L.scratch[spos + len + j][lane] = (u8)('0' + t % 10); t /= 10; }
+                            }
                             len += nd;
                         } else {                                         // "%llx" / "%llX"
                             int sh = 60;
