@@ -16,6 +16,6 @@ i0 = idx[-2] + 1 if len(idx) > 1 else 0
 t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:iend + 1]:
     s = (int(r['Start_Timestamp']) - t0) / 1e6; e = (int(r['End_Timestamp']) - t0) / 1e6
-    if e - s > 0.1: print('%-44s %7.2f %7.2f  %5.2f' % (r['Kernel_Name'].replace('void ', '')[:44], s, e, e - s))
+    if e - s > 0.02: print('%-44s %7.2f %7.2f  %5.2f' % (r['Kernel_Name'].replace('void ', '')[:44], s, e, e - s))
 PY
 rm -rf $OUT/prof

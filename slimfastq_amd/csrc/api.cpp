@@ -14,6 +14,7 @@
 #include <functional>
 #include <future>
 #include <thread>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 
@@ -1944,6 +1945,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // the chain lists of "chn.idx" are read beside the head of the call (ctx->worker); whatever way this function is left, the job is
     // through before the locals it writes to are gone
     std::string lists_err; bool lists_pending = false;
+    std::atomic<int> lists_stage{0};                    // 1: the quality chains' list stands in h_csz / h_coff (the decoder that needs it is the call's longest); -1: the job has failed
     struct ListsGuard { sfq_ctx* c; bool* pending; ~ListsGuard() { if (*pending) (void)c->worker.wait(); } } lists_guard{ ctx, &lists_pending };
     if (frozen) {
         const u8* cb = ctx->chain_blob.data(); const size_t cn = ctx->chain_blob.size();
@@ -2035,10 +2037,12 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             }
             return true;
         };
+        struct Fail { std::atomic<int>& st; bool ok = false; ~Fail() { if (!ok) st.store(-1, std::memory_order_release); } } on_exit{ lists_stage };
         for (int k = 0; k < 2; k++) {
             const int sid = k ? SFQ_S_GEN : SFQ_S_QLT;
             const u32 kn = k ? ngc : nchains, kcpb = k ? gcpb : cpb;
             u32* const sz = h_csz + (size_t)k * nchains; u64* const off = h_coff + (size_t)k * nchains;
+            if (k == 1) lists_stage.store(1, std::memory_order_release);
             if (!read_sizes(cb, cn, cp, deltas, sz, kn)) { lists_err = "bad chain index (chn.idx)"; return SFQ_E_CORRUPT; }
             u64 at = stream_offset[sid];
             for (u32 b = 0; b < nblocks; b++) {
@@ -2055,6 +2059,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
             if (ncs + nsub > cn + 16) { lists_err = "bad chain index (chn.idx: header chains)"; return SFQ_E_CORRUPT; }
             for (u32 c = 0; c < nsub; c++) { h_csz[ncs] = h_rsz[c]; h_coff[ncs] = at; ncs++; at += h_rsz[c]; }
         }
+        on_exit.ok = true;
         return SFQ_OK;
         });
     }
@@ -2202,15 +2207,39 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     if (gm_on && seg_len) launch_gm_sentinels(da.seq_stage, da.soff, da.slen, nrec, st);        // (whole-record chains write their lines' sentinels themselves)
 
     ht.mark("head queued");
-    if (lists_pending) {                                  // frozen tables: the chain lists, then their copies to the device
-        rc = ctx->worker.wait(); lists_pending = false;
-        if (rc) return fail(ctx, rc, "%s", lists_err.empty() ? "chain index (chn.idx): out of memory or damaged" : lists_err.c_str());
-        if ((rc = reserve(ctx, ctx->csz, ncs * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->coff, ncs * 8))) return rc;
-        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, ncs * 4, hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, ncs * 8, hipMemcpyHostToDevice, st));
+    const size_t lists_cap = lists_pending ? ctx->chain_blob.size() + 16 : 0;       // (every listed size is a byte of the index or more: what h_csz / h_coff were sized by)
+    if (lists_pending) {
+        // frozen tables: the chain lists.  The QUALITY chains' comes first in the index and its decoder is the call's longest kernel: as soon as that
+        // list stands it goes to the device and the decoder is queued; the base and header chains' lists follow behind it (below) -- the reading thread
+        // takes 1.2-1.4 ms for the half million sizes, the quality decoder used to wait for all of them.
+        if ((rc = reserve(ctx, ctx->csz, lists_cap * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->coff, lists_cap * 8))) return rc;
+        while (lists_stage.load(std::memory_order_acquire) == 0 && ctx->worker.busy()) std::this_thread::yield();
+        if (lists_stage.load(std::memory_order_acquire) != 1) {
+            rc = ctx->worker.wait(); lists_pending = false;
+            if (rc) return fail(ctx, rc, "%s", lists_err.empty() ? "chain index (chn.idx): out of memory or damaged" : lists_err.c_str());
+        }
+        HIPC(hipMemcpyAsync(ctx->csz.p, h_csz, (size_t)nchains * 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(ctx->coff.p, h_coff, (size_t)nchains * 8, hipMemcpyHostToDevice, st));
     }
-    ht.mark("chain lists read, copied");
+    ht.mark("quality chain list read, copied");
+    // the other lists: behind the quality decoder's launch (frozen tables), on the base decoder's stream; the header decoder's waits for them
+    auto rest_of_lists = [&](hipStream_t sg, hipStream_t sr) -> int {
+        if (!lists_cap) return SFQ_OK;
+        if (lists_pending) {
+            rc = ctx->worker.wait(); lists_pending = false;
+            if (rc) return fail(ctx, rc, "%s", lists_err.empty() ? "chain index (chn.idx): out of memory or damaged" : lists_err.c_str());
+        }
+        if (ncs > lists_cap) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx)");
+        if (ncs > nchains) {
+            HIPC(hipMemcpyAsync((u32*)ctx->csz.p + nchains, h_csz + nchains, (ncs - nchains) * 4, hipMemcpyHostToDevice, sg));
+            HIPC(hipMemcpyAsync((u64*)ctx->coff.p + nchains, h_coff + nchains, (ncs - nchains) * 8, hipMemcpyHostToDevice, sg));
+        }
+        HIPC(hipEventRecord(ctx->ev[27], sg));
+        HIPC(hipStreamWaitEvent(sr, ctx->ev[27], 0));
+        ht.mark("chain lists read, copied");
+        return SFQ_OK;
+    };
     // 2. quality, bases and (3.) headers are independent chains: three streams.  (The one rule that ties bases to
     //    qualities -- quality '!' means N -- is applied when the records are assembled.)
     //    The fork comes BEHIND the quality rows and the hot image's helper kernels (round 5): forked in front of them, the base and
@@ -2271,6 +2300,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         fprintf(stderr, "EXP qdec alone: %.3f ms\n", ev_ms(ctx->ev[2], ctx->ev[3]));
         return fail(ctx, SFQ_E_ARG, "experiment build");
 #endif
+        if ((rc = rest_of_lists(st_gen, st_rec))) return rc;
         HIPC(hipEventRecord(ctx->ev[7], st_gen));
         // bases: generation by generation -- a generation's rows come from the counts of everything decoded before it
         ca.csz = (u32*)ctx->csz.p + nchains; ca.coff = (const u64*)ctx->coff.p + nchains;
