@@ -261,7 +261,11 @@ bool read_sizes(const u8* b, size_t nb, size_t& p, bool deltas, u32* out, size_t
             }
         }
         u64 raw;
-        if (!get_v(b, nb, p, raw)) return false;
+        // (one or two bytes, nearly always: decoded in line -- get_v's loop and call were most of what an entry cost where the eight-at-a-time path does not apply,
+        //  a group of eight with a two-byte entry among them: more than half of the groups)
+        if (p < nb && b[p] < 0x80u) raw = b[p++];
+        else if (p + 1 < nb && b[p + 1] < 0x80u) { raw = (u64)(b[p] & 0x7fu) | ((u64)b[p + 1] << 7); p += 2; }
+        else if (!get_v(b, nb, p, raw)) return false;
         if (deltas) {
             if (raw > 0x1FFFFFFFFull) return false;
             const i64 v = (i64)prev + ((i64)(raw >> 1) ^ -(i64)(raw & 1));
