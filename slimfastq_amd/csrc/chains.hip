@@ -252,6 +252,9 @@ void launch_seg_fill(const u64* seg_off, u64 nrec, u32* seg_rec, hipStream_t st)
 // =========================================================================================================
 // LDS staging of the hottest rows: the workgroup copies the call's hot image (above) into LDS once; a symbol whose context
 // is staged reads its entry there (map word, two cums), the others gather it from the L2-resident table.
+#ifndef QLT_STEP
+#define QLT_STEP 8u      /* symbols whose row entries are looked up at a time, a step ahead of the coder (16 / QLT_STEP steps a piece) */
+#endif
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 // MARK: the chains mark the records with a '!' for the exception pass (a.exc_flag; the framing does that where it can)
 template <int THREADS, bool LDS, bool MARK>
@@ -283,12 +286,16 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     // piece AHEAD of the one being coded, so the gathers' latency hides behind sixteen coder steps.  No branches and no
     // masks on the model's state: whatever follows the lane's bytes in a line's last piece runs through the same
     // instructions and is dropped by the coder's mask.
-    auto look = [&](const Piece& p, const uint4& f, u32 (&e)[16], u32& lowest, u32& top) {
-        if (p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
+    // The row entries of EIGHT symbols at a time (round 5b; sixteen before): a piece's two halves are looked up in turn, each while the half before it is
+    // coded, so sixteen + eight entries are live where sixteen + sixteen were -- the kernel's registers, 120 a lane, are what keeps every other kernel off
+    // the SIMDs it runs on.
+    auto look8 = [&](const Piece& p, const uint4& f, const u32 j0, u32 (&e)[QLT_STEP], u32& lowest, u32& top) {
+        if (j0 == 0 && p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
         const u32 len = p.j1;
         lowest = 255; top = 0;
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) {
+        for (u32 jj = 0; jj < QLT_STEP; jj++) {
+            const u32 j = j0 + jj;
             const u32 vm = j < len ? ~0u : 0u;
             const u32 b = (piece_byte(f, j) - '!') & 0xffu;
             const u32 sym = b < LAST_QLT ? b : LAST_QLT;
@@ -300,9 +307,9 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 if ((mr.x & bit) && sym < QH_SYMS) {
                     const u16* r = lrows + (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QH_ROW_U16 + sym;
                     const u32 c0 = r[0], c1 = r[1];
-                    e[j] = c0 | ((c1 - c0) << 16);
-                } else e[j] = a.qrows[(size_t)last * 64 + sym];
-            } else e[j] = a.qrows[(size_t)last * 64 + sym];
+                    e[jj] = c0 | ((c1 - c0) << 16);
+                } else e[jj] = a.qrows[(size_t)last * 64 + sym];
+            } else e[jj] = a.qrows[(size_t)last * 64 + sym];
             if (level <= 2) last = (b | (last << 6)) & mask12;                           // qlts.hpp:52-57
             else {                                                                       // qlts.hpp:62-74
                 delta += max(p1, b) - b;                                                 // if (p1 > b) delta += p1 - b
@@ -312,34 +319,24 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
             }
         }
     };
-    Piece pc = lw.next();
-    uint4 w = lw.fetch(pc);
-    Piece pn = lw.next();
-    uint4 wn = lw.fetch(pn);
-    u32 e[16], lowest, top;
-    look(pc, w, e, lowest, top);
-    while (__any(pc.valid)) {
-        const Piece pnn = lw.next();                  // the text two pieces ahead, the rows one piece ahead
-        const uint4 wnn = lw.fetch(pnn);
-        u32 e2[16], lowest2, top2;
-        look(pn, wn, e2, lowest2, top2);
-        const uint4& f = w;
-        const u32 len = pc.j1;
+    // (b) the serial part: the range coder, eight symbols
+    auto code8 = [&](const Piece& p, const uint4& f, const u32 j0, const u32 (&e)[QLT_STEP], u32 lowest, u32 top) {
+        const u32 len = p.j1;
         // a '!' marks the record for the pass over the N / quality-0 exceptions (k_gen_exc_w)
-        if constexpr (MARK) if (lowest == 0 && pc.valid) a.exc_flag[cp.r0 + pc.rk] = 1;
-        // (b) the serial part: the range coder
+        if constexpr (MARK) if (lowest == 0 && p.valid) a.exc_flag[cp.r0 + p.rk] = 1;
         if (!__any(top >= LAST_QLT)) {
 #pragma unroll
-            for (u32 j = 0; j < 16; j++) {
-                rc.encode16_if(j < len ? ~0u : 0u, FZ_CUM(e[j]), FZ_FREQ(e[j]));
-                if ((j & 3u) == 3u) rc.drain();
+            for (u32 jj = 0; jj < QLT_STEP; jj++) {
+                rc.encode16_if(j0 + jj < len ? ~0u : 0u, FZ_CUM(e[jj]), FZ_FREQ(e[jj]));
+                if (((j0 + jj) & 3u) == 3u) rc.drain();
             }
         } else {
             // a quality over 62 somewhere in the wave: the escape symbol, then the raw value through the frozen escape row (qlts.cpp:80-86)
 #pragma unroll
-            for (u32 j = 0; j < 16; j++) {
+            for (u32 jj = 0; jj < QLT_STEP; jj++) {
+                const u32 j = j0 + jj;
                 const u32 vm = j < len ? ~0u : 0u;
-                rc.encode16_if(vm, FZ_CUM(e[j]), FZ_FREQ(e[j]));
+                rc.encode16_if(vm, FZ_CUM(e[jj]), FZ_FREQ(e[jj]));
                 const u32 b = (piece_byte(f, j) - '!') & 0xffu;
                 const u32 em = (b >= LAST_QLT ? ~0u : 0u) & vm;
                 if (__any(em != 0)) {
@@ -350,10 +347,28 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 if ((j & 3u) == 3u) rc.drain();
             }
         }
-        pc = pn; w = wn; pn = pnn; wn = wnn;
+    };
+    Piece pc = lw.next();
+    uint4 w = lw.fetch(pc);
+    Piece pn = lw.next();
+    uint4 wn = lw.fetch(pn);
+    constexpr u32 NS = 16u / QLT_STEP;
+    u32 E[NS][QLT_STEP], lows[NS], tops[NS];
 #pragma unroll
-        for (u32 j = 0; j < 16; j++) e[j] = e2[j];
-        lowest = lowest2; top = top2;
+    for (u32 k = 0; k < NS; k++) look8(pc, w, k * QLT_STEP, E[k], lows[k], tops[k]);
+    while (__any(pc.valid)) {
+        const Piece pnn = lw.next();                  // the text two pieces ahead, the rows a step ahead
+        const uint4 wnn = lw.fetch(pnn);
+#pragma unroll
+        for (u32 k = 0; k < NS; k++) {
+            u32 T[QLT_STEP], lowt, topt;
+            look8(pn, wn, k * QLT_STEP, T, lowt, topt);          // the next piece's step k, while this piece's is coded
+            code8(pc, w, k * QLT_STEP, E[k], lows[k], tops[k]);
+#pragma unroll
+            for (u32 j = 0; j < QLT_STEP; j++) E[k][j] = T[j];
+            lows[k] = lowt; tops[k] = topt;
+        }
+        pc = pn; w = wn; pn = pnn; wn = wnn;
     }
     if (live) {
         const u32 size = rc.finish();
