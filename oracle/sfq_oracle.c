@@ -1775,6 +1775,28 @@ static int g_gen_force_off = 0;           /* sfqo_gm_*: the match model's verdic
                                              TIME: the codes of bases 4 q .. 4 q + k - 1 of a line (k = 4, fewer at its end) as one symbol
                                              S = sum code[j] << 2 j of 4^k equally likely ones ("chn.idx" flag bit 6).  The same two bits a base as
                                              the initial row's 3 of 12, a quarter of the coder steps -- and each of them a shift */
+/* Round 5b (block format 10, "chn.idx" flag bit 7; g_gen_force_off == 2): no coder at all -- a chain is its bases' codes, two bits each, four a byte, the
+   first in the low bits, across its records' ends; the last byte padded with zero bits.  The codes are gen_flat_quads' (N-like: 0). */
+typedef struct { u8* p; size_t n, cap; u32 acc, nb; } rawpk;
+static void raw_line(rawpk* r, const u8* line, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        int cd = gencode_of(line[i]); if (cd > 4) cd = 0;
+        r->acc |= (u32)(cd & 3) << r->nb; r->nb += 2;
+        if (r->nb == 8) {
+            if (r->n == r->cap) { r->cap = r->cap ? r->cap * 2 : 256; r->p = xrealloc(r->p, r->cap); }
+            r->p[r->n++] = (u8)r->acc; r->acc = 0; r->nb = 0;
+        }
+    }
+}
+static size_t raw_finish(rawpk* r) {
+    if (r->nb) {
+        if (r->n == r->cap) { r->cap = r->cap ? r->cap * 2 : 256; r->p = xrealloc(r->p, r->cap); }
+        r->p[r->n++] = (u8)r->acc; r->acc = 0; r->nb = 0;
+    }
+    return r->n;
+}
+static int g_flat_raw = 1;                 /* what a call without a base model writes: 1 = format 10's two bits a base, 0 = format 9's quads through the coder */
+void sfqo_set_flat_raw(int on) { g_flat_raw = on; }
 static void gen_flat_quads(chenc* c, const u8* line, size_t n) {
     for (size_t i = 0; i < n; i += 4) {
         const size_t k = n - i < 4 ? n - i : 4;
@@ -1838,6 +1860,15 @@ static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32*
                 for (size_t sg = 0; sg < n; sg++, nc++) {
                     const size_t lo = sg * L < glen[r] ? sg * L : glen[r];
                     const u64 o1 = goff[r] + lo; const u32 l1 = (u32)(glen[r] - lo < L ? glen[r] - lo : L);
+                    if (g_gen_force_off == 2) {
+                        rawpk rp = { 0, 0, 0, 0, 0 };
+                        raw_line(&rp, base + o1, l1);
+                        const size_t nb = raw_finish(&rp);
+                        ob_write(&o, rp.p, nb);
+                        if (sizes) sizes[nc] = (u32)nb;
+                        free(rp.p);
+                        continue;
+                    }
                     chenc c; ch_init(&c);
                     gfz gz = { &c, on ? rows[g] : NULL };
                     if (g_gen_force_off) gen_flat_quads(&c, base + o1, l1);
@@ -1853,6 +1884,15 @@ static long long gen_encode_chains_x(const u8* base, const u64* goff, const u32*
         }
         for (size_t r0 = b0; r0 < b1; r0 += chain_reads, nc++) {
             const size_t r1 = r0 + chain_reads < b1 ? r0 + chain_reads : b1;
+            if (g_gen_force_off == 2) {
+                rawpk rp = { 0, 0, 0, 0, 0 };
+                for (size_t r = r0; r < r1; r++) raw_line(&rp, base + goff[r], glen[r]);
+                const size_t n = raw_finish(&rp);
+                ob_write(&o, rp.p, n);
+                if (sizes) sizes[nc] = (u32)n;
+                free(rp.p);
+                continue;
+            }
             chenc c; ch_init(&c);
             gfz gz = { &c, on ? rows[g] : NULL };
             if (g_gen_force_off) for (size_t r = r0; r < r1; r++) gen_flat_quads(&c, base + goff[r], glen[r]);
@@ -1992,7 +2032,7 @@ static long long gm_encode_x(const u8* base, const u64* goff, const u32* glen, s
     if (gen_on) *gen_on = on;
     if (!on) {
         free(st); free(soff); free(T);
-        g_gen_force_off = 1;
+        g_gen_force_off = g_flat_raw ? 2 : 1;
         const long long rc = gen_encode_chains_x(base, goff, glen, nrec, 12, block_reads, chain_reads, 4, out, out_len, sizes, NULL, seg_len, other_len);
         g_gen_force_off = 0;
         return rc;

@@ -1174,6 +1174,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
     GenPlan gplan; GmPlan gmplan;
     ChainGeoArgs ggeo; memset(&ggeo, 0, sizeof ggeo);   // the base chains' geometry: the quality chains', or shorter ones (below)
     const u32* gen_csz = nullptr;                      // ... and where their sizes are
+    const bool flat_quads_req = getenv("SFQ_FLAT_QUADS") != nullptr;     // (a test hook: bases without a model as block format 9 wrote them, four a symbol through the coder)
     const bool gm = frozen && !exc_classic;            // bases: the match model (gm.hip); sfq_params.kernel = 2 keeps round 4's generation tables
     u32 seg_len = 0;                                   // chains that are segments of one record (chains.hip "segments")
     std::vector<u32> seg_blk;                          // ... and how many each block has ("chn.idx")
@@ -1408,7 +1409,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
             //  row gathers wait for the same thing, random 64-byte sectors of tables larger than the caches, and their times add up.)
             HIPC(hipEventRecord(ctx->ev[16], mst[3]));
             if (gm && gen_on) launch_gm_code(gmplan.cg, (const u8*)ctx->gm_tok.p, mst[3]);
-            else { ca.flat_quads = (gm && !gen_on) ? 1u : 0u; launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on); }
+            else { ca.flat_quads = (gm && !gen_on && flat_quads_req) ? 1u : 0u; ca.flat_raw = (gm && !gen_on && !flat_quads_req) ? 1u : 0u; launch_gen_encode_c(ca, mst[3], 0, 0, !gen_on); }
             HIPC(hipEventRecord(ctx->ev[17], mst[3]));
         }
         HIPC(hipEventRecord(ctx->ev[3 + 2 * 3], mst[3]));
@@ -1674,7 +1675,7 @@ static int encode_body(sfq_ctx* ctx, const u8* d_fastq_in, u64 nbytes_in, const 
         };
         const bool rec_chains = (chain_streams >> SFQ_S_REC) & 1;
         put(ca.geo.chain_reads); put(gen_on | (rec_chains ? 2u : 0u) | 4u /* sizes as differences */ | (seg_len ? 8u : 0u) | (exc_rice ? 16u : 0u) | ((gm && gen_on) ? 32u : 0u) /* bases: the match model */
-            | ((gm && !gen_on) ? 64u : 0u) /* bases without a model: four a symbol */);
+            | ((gm && !gen_on) ? (flat_quads_req ? 64u : 128u) : 0u) /* bases without a model: two bits each, no coder (block format 10; 64 = four a symbol through the coder: format 9's, still read) */);
         if (gm && gen_on) { put(gmplan.tb); put(ggeo.chain_reads); put(ngc); }      // (the index's bits; the base chains' records, their number)
         put(nchains);
         if (seg_len) { put(seg_len); for (u32 b = 0; b < nblocks; b++) put(seg_blk[b]); }      // segments: their length, every block's share of the chains
@@ -1940,7 +1941,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
     // frozen tables: the chain index ("chn.idx")
     const bool frozen = !ctx->chain_blob.empty();
     u32 chain_reads = 0, cpb = 0, nchains = 0, gen_on = 0, rec_chains = 0, rchain_reads = 0, rcpb = 0, nsub = 0, gm_on = 0, gm_tb = 0;
-    u32 flat_quads = 0;
+    u32 flat_quads = 0, flat_raw = 0;
     u32 gchain_reads = 0, gcpb = 0, ngc = 0; u64 gm_ngc = 0;      // the base chains (the quality chains' geometry unless the match model has its own)
     bool exc_rice = false;
     u32 seg_len = 0; std::vector<u32> seg_c0;            // segments (chains.hip): their length, the first chain of every block
@@ -1963,7 +1964,8 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
         exc_rice = ((u32)v >> 4) & 1u;                       // the base exceptions are Rice-coded gap lists (exc.hip; round 4)
         gm_on = ((u32)v >> 5) & 1u;                          // the bases are coded under the match model (gm.hip; round 5): the index's bits follow
         flat_quads = ((u32)v >> 6) & 1u;                     // bases without a model are coded four a symbol (round 5)
-        if (v >> 7 || (flat_quads && gen_on)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
+        flat_raw = ((u32)v >> 7) & 1u;                       // ... or not coded at all: two bits each, four a byte (round 5b, block format 10)
+        if (v >> 8 || ((flat_quads | flat_raw) && gen_on) || (flat_quads && flat_raw)) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: unknown flags)");
         if (gm_on) {
             u64 t = 0;
             if (!gen_on || !exc_rice || !get_v(cb, cn, cp, t) || t < 8 || t > 26) return fail(ctx, SFQ_E_CORRUPT, "bad chain index (chn.idx: match model)");
@@ -2323,7 +2325,7 @@ static int decode_body(sfq_ctx* ctx, const sfq_params* pp, const sfq_block_info*
                 if (g + 1 < ngen) launch_gm_insert(ca, bound[g], bound[g + 1], (u64)(bound[g + 1] - bound[g]) * block_reads, dec_max_line, (u64*)ctx->gm_T.p, gm_tb, st_gen);
             }
         } else
-        if (!gen_on || ngen < 3) { ca.flat_quads = flat_quads; launch_gen_decode_c(ca, da, 0, nchains, st_gen); }
+        if (!gen_on || ngen < 3) { ca.flat_quads = flat_quads; ca.flat_raw = flat_raw; launch_gen_decode_c(ca, da, 0, nchains, st_gen); }
         else {
             const u64 nctx = 1ull << g_bits;
             if ((rc = reserve(ctx, ctx->gcnt, (size_t)nctx * 16))) return rc;

@@ -993,6 +993,30 @@ __global__ __launch_bounds__(THREADS) void k_gen_encode_c(ChainArgs a, u32 c0, u
     rc.init(ring, threadIdx.x, outp, cap);
     const u32* rows = (!FLAT && live) ? gen_rows_of(a, cp.b) : nullptr;
     u32 illegal = 0;
+    if (a.flat_raw && (FLAT || !__any(rows != nullptr))) {
+        // no model, no coder (round 5b, block format 10): a base is two bits whatever comes before it, and a range coder that is told so writes a byte per four
+        // bases -- after a shift, a multiply, a renormalisation step and its carry test.  The chain's bases, four a byte (the first in the low bits), across
+        // its records' ends; the last byte padded with zeros.  N-like bases code as 0, as with the coder (the exception lists restore them).
+        rc.init_raw(ring, threadIdx.x, outp, cap);
+        u32 acc = 0, nb = 0;
+        illegal = walk_bases_q(a, cp.r0, cp.nrec, live ? d->solid : 0u, lut,
+            [&](u32 sym, u32 k) {
+                acc |= (sym & ((1u << (2u * k)) - 1u)) << nb;                 // (nb <= 6, 2 k <= 8: within 14 bits)
+                nb += 2u * k;
+                const u32 full = nb >= 8u ? ~0u : 0u;
+                rc.put_if(full, acc & 0xffu);
+                acc >>= 8u & full; nb -= 8u & full;
+                rc.drain();
+            },
+            a.exc_flag, cp.sub_lo, cp.sub_len);
+        if (live) {
+            if (nb) rc.put_if(~0u, acc & 0xffu);
+            a.csz[c] = rc.finish_raw();
+            if (rc.err & 2) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_OVERFLOW));
+            if (illegal) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_GENCHAR));
+        }
+        return;
+    }
     if (a.flat_quads && (FLAT || !__any(rows != nullptr))) {
         // no model, four bases a symbol (round 5): a shift, a multiply and ONE renormalisation step per four bases -- a byte leaves per full
         // quad, exactly -- where the initial row's 3 of 12 took a divide and a step per base (0.94e9 of the default call's 6.6e9 wave instructions)
@@ -1082,11 +1106,25 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
         const u64 lo = cp.sub_lo < n_next ? cp.sub_lo : n_next;
         n_next = (u32)(n_next - lo < cp.sub_len ? n_next - lo : cp.sub_len); off_next += lo;
     }
+    // (block format 10, "chn.idx" flag bit 7: the chain is its bases, two bits each, four a byte -- no coder)
+    const u8* const raw = da.streams + a.coff[c]; const u32 raw_n = a.csz[c];
+    u32 racc = 0, rnb = 0, rat = 0, rbad = 0;
     for (u32 k = 0; k < cp.nrec; k++) {
         const u32 llen = n_next; const u64 off = off_next;
         if (k + 1 < cp.nrec) { n_next = da.slen[cp.r0 + k + 1]; off_next = da.soff[cp.r0 + k + 1]; }
         LaneOut32 out; out.begin(da.seq_stage + off);
         u32 last = INIT;
+        if (a.flat_raw) {
+            for (u32 i = 0; i < llen; i++) {
+                if (rnb == 0) {                                                             // sixteen bases a load where four bytes are left
+                    if (rat + 4u <= raw_n) { racc = *reinterpret_cast<const u32_any*>(raw + rat); rat += 4u; rnb = 32u; }
+                    else if (rat < raw_n) { racc = raw[rat++]; rnb = 8u; }
+                    else { rbad = 1; racc = 0; rnb = 32u; }
+                }
+                out.put((alphabet >> (8u * (racc & 3u))) & 0xffu);
+                racc >>= 2; rnb -= 2u;
+            }
+        } else
         if (rows) {                                                                         // (gen_bits >= 2: the four candidates are in bounds)
             u32 v = rows[last & mask];
             for (u32 i = 0; i < llen; i++) {
@@ -1118,6 +1156,8 @@ __global__ __launch_bounds__(THREADS) void k_gen_decode_c(ChainArgs a, DecodeArg
         }
         out.end();
     }
+    if (a.flat_raw) { if (rbad || rat != raw_n || (rnb >= 8u) || racc) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT)); }      // (every byte used, the padding zero)
+    else
     if (rc.err) atomicMax(&a.m.blocks[cp.b].status, (u32)(-SFQ_E_CORRUPT));
 }
 void launch_gen_decode_c(const ChainArgs& a, const DecodeArgs& da, u32 c0, u32 c1, hipStream_t st) {

@@ -22,9 +22,10 @@
 #include "container.h"
 
 static const int   kInternalVersion = 6;      // config.cpp:41
-static const int   kBlockVersion = 9;          // 7: block format, the reference's quirks kept; 8: lossless ("gen.lc", 14 stream sizes per index entry);
+static const int   kBlockVersion = 10;         // 7: block format, the reference's quirks kept; 8: lossless ("gen.lc", 14 stream sizes per index entry);
                                                 // 9: "chn.idx" may carry flag bits 2-5 (difference-coded lists, segments, Rice-coded base exceptions, the bases' match
                                                 //    model): a reader of version 8 did not look at flags it did not know, so what sets them says 9 and is refused there
+                                                // 10: flag bit 7 (bases without a model as two bits each, no coder): a reader of version 9 refuses the flag, so what sets it says 10
 static const int   kBlockVersionMin = 7;
 static const char* kUserVersion = "2.04-amd";
 

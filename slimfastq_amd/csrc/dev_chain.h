@@ -179,6 +179,13 @@ struct LaneEncB {
             dq += 16u;
         }
     }
+    // The ring and its drains as a plain byte sink (bases packed two bits each, chains.hip: no coder): no elided bytes -- the first byte put is the stream's first
+    __device__ __forceinline__ void init_raw(u32* lds_ring, u32 tid, u8* p, u32 c) { init(lds_ring, tid, p, c); q = 16; }
+    __device__ __forceinline__ u32 finish_raw() {
+        drain();
+        for (u32 pos = dq; pos < q; pos++) { const u32 at = pos - 16u; if (at < cap) out[at] = ring[pos & (RB - 1u)]; else err |= 2; }
+        return q - 16u;
+    }
     // flush; returns the stream's size (the flush's own trailing zero bytes are dropped)
     __device__ __forceinline__ u32 finish() {
         const u64 v = (low + 0xFFFFFFull) & ~0xFFFFFFull;

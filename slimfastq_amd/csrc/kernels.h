@@ -87,6 +87,7 @@ struct ChainArgs {
     const u32* g_rows[GEN_MAX_GENERATIONS];    // its rows (null = the initial row)
     const u32* g_init;          // encode: one dword holding the initial row (3, 3, 3, 3), read where a generation has no rows
     u32 flat_quads;             // bases without a model (round 5, "chn.idx" flag bit 6): a line's bases four at a time, one symbol of 4^k equally likely ones
+    u32 flat_raw;               // bases without a model (round 5b, "chn.idx" flag bit 7, block format 10): a chain's bases two bits each, four a byte, no coder
                                 // (k = 4, fewer at a line's end) instead of 3 of 12 a base
 };
 void launch_hot_rows(const u32* hist, const u32* rows66, const u32* qrows, u32 q_rows, u32 want, u32* ctot /* [q_rows] */,

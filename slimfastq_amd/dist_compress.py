@@ -92,7 +92,7 @@ def assemble(parts, level: int, block_reads: int, orig_name: str, frozen=True, s
     need = L.sfq_pack_block_index(allb, nblocks, None, 0)
     idx = (C.c_uint8 * need)()
     L.sfq_pack_block_index(allb, nblocks, idx, need)
-    info = [("whoami", "slimfastq"), ("version", "9"), ("config.level", str(level)), ("orig.filename", orig_name),
+    info = [("whoami", "slimfastq"), ("version", "10"), ("config.level", str(level)), ("orig.filename", orig_name),
             ("orig.size", str(sum(p["raw"] for p in parts))), ("blk.reads", str(block_reads)), ("blk.count", str(nblocks)),
             ("num_records", str(rec))]
     streams = []

@@ -28,7 +28,7 @@ def gm_table_bits(nbytes):
     return tb
 
 
-def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None):
+def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None, quads=False):
     """The base chains as the oracle's restatement of the generation MATCH model (gm.hip; sfq_oracle.c sfqo_gm_*) writes them, and
     its verdict; "chn.idx" must say the same (flag bit 0: the model is on; bit 5 + the index's bits: it is the match model)."""
     tb = gm_table_bits(len(fq))
@@ -49,12 +49,14 @@ def base_chains_oracle(fq, goff, glen, ci, br, cr, seg=0, other=None):
             want, sizes, on = O.gm_encode_chains(fq, goff, glen, tb, br, cr)
             gcr = cr
     assert (ci["flags"] & 1) == on and bool(ci["flags"] & 32) == bool(on)
+    # no model: the bases two bits each, no coder (block format 10) -- or format 9's four a symbol, on request
+    assert ci["flags"] & 192 == (0 if on else 64 if quads else 128)
     assert not on or ci["gm_table_bits"] == tb
     assert ci["gen_chain_reads"] == gcr
     return want, sizes, on
 
 
-def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
+def check_against_oracle(ctx, fq, level, br, cr, step, what="", quads=False):
     enc = ctx.encode_host(fq, level=level, block_reads=br, prior_step=step, tables=capi.TABLES_FROZEN, chain_reads=cr)
     starts, lens = util.line_table(fq)
     nrec = len(starts) // 4
@@ -72,7 +74,7 @@ def check_against_oracle(ctx, fq, level, br, cr, step, what=""):
     assert sum(b.extra_hi for b in enc.blocks) == extra
     # bases: generation tables
     goff, glen = starts[1::4] + solid, lens[1::4] - solid
-    want, sizes, on = base_chains_oracle(fq, goff, glen, ci, br, got_cr)
+    want, sizes, on = base_chains_oracle(fq, goff, glen, ci, br, got_cr, quads=quads)
     assert list(gsz) == list(sizes), what
     assert enc.stream("gen") == want, what
     # headers: counted sample -> "rec.pri" -> frozen rows -> one chain per block
@@ -121,8 +123,9 @@ def test_base_exceptions_in_the_references_own_coding_on_request(ctx):
             assert len(got) or not ref.get(name, b"")
     for name in ("rec", "qlt", "usr.x", "usr.x.q"):
         assert old.stream(name) == new.stream(name)
-    # (the bases of a call without a model: round 4's 3 of 12 a base under kernel = 2, four bases a symbol -- "chn.idx" flag bit 6 -- now)
-    assert not util.unpack_chains(old.chains)["flags"] & 64 and util.unpack_chains(new.chains)["flags"] & 64
+    # (the bases of a call without a model: round 4's 3 of 12 a base under kernel = 2; two bits each without a coder -- "chn.idx" flag bit 7, block format
+    #  10 -- now; round 5a's four bases a symbol, flag bit 6, is still read: test_flat_bases_of_format_9_are_still_read)
+    assert not util.unpack_chains(old.chains)["flags"] & 192 and util.unpack_chains(new.chains)["flags"] & 192 == 128
     assert len(new.stream("gen")) <= len(old.stream("gen"))
     assert sum(len(new.stream(n)) for n in ("gen.Ns", "gen.Nn")) < sum(len(old.stream(n)) for n in ("gen.Ns", "gen.Nn"))
     assert ctx.decode_host(old, level=3, out_cap=len(fq) + 4096) == fq
@@ -758,3 +761,64 @@ def test_exception_scan_takes_records_of_every_kind(ctx, br, cr):
     if bad != fq and b"N" in bad:
         with pytest.raises(capi.SfqError):
             ctx.encode_host(bad, level=3, block_reads=len(fq), tables=capi.TABLES_FROZEN, chain_reads=cr)
+
+
+def test_flat_bases_pack_two_bits_each(ctx):
+    """A call whose bases have no model (iid bases: the match model's verdict says no) writes them without a coder -- block format 10, "chn.idx" flag bit 7:
+    a chain is its bases' codes, four a byte, the first in the low bits, across its records' ends, the last byte padded with zeros; N-like bases code
+    as 0 and come back through the exception lists.  Stated here in numpy, beside the oracle's C (check_against_oracle compares every chain with that)."""
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(3000):
+        ln = int(rng.integers(1, 40)) if i % 11 == 0 else int(rng.integers(95, 160))
+        b = np.array(list("ACGT"), dtype="U1")[rng.integers(0, 4, ln)]
+        if i % 7 == 0: b[int(rng.integers(0, ln))] = "N"
+        if i % 13 == 0: b[: ln // 3] = np.char.lower(b[: ln // 3])
+        recs.append("@p%d\n%s\n+\n%s\n" % (i, "".join(b), "".join(chr(int(v)) for v in rng.integers(35, 74, ln))))
+    fq = "".join(recs).encode()
+    br, cr = 512, 37
+    enc = check_against_oracle(ctx, fq, 3, br=br, cr=cr, step=1, what="flat bases, two bits each")
+    ci = util.unpack_chains(enc.chains)
+    assert ci["flags"] & 128 and not ci["flags"] & (1 | 32 | 64)
+    starts, lens = util.line_table(fq)
+    goff, glen = starts[1::4], lens[1::4]
+    code = np.zeros(256, np.uint8)
+    for ch, v in zip("ACGTacgt0123", [0, 1, 2, 3] * 3): code[ord(ch)] = v
+    a = np.frombuffer(fq, np.uint8)
+    want = bytearray(); sizes = []
+    nrec = len(goff)
+    for b0 in range(0, nrec, br):
+        for r0 in range(b0, min(b0 + br, nrec), cr):
+            r1 = min(r0 + cr, b0 + br, nrec)
+            c = np.concatenate([code[a[int(goff[r]): int(goff[r]) + int(glen[r])]] for r in range(r0, r1)])
+            c = np.concatenate([c, np.zeros(-len(c) % 4, np.uint8)]).reshape(-1, 4)
+            by = (c[:, 0] | c[:, 1] << 2 | c[:, 2] << 4 | c[:, 3] << 6).astype(np.uint8)
+            want += by.tobytes(); sizes.append(len(by))
+    assert list(ci["gen"]) == sizes and enc.stream("gen") == bytes(want)
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq
+    # the padding of a chain's last byte is zero bits, or the archive is damaged
+    nb = [int(sum(int(glen[r]) for r in range(r0, min(r0 + cr, (r0 // br) * br + br, nrec)))) for b0 in range(0, nrec, br) for r0 in range(b0, min(b0 + br, nrec), cr)]
+    c = next(i for i, n in enumerate(nb) if n % 4)
+    bad = enc.clone()
+    at = bad.res.stream_offset[capi.STREAM_NAMES.index("gen")] + int(np.sum(ci["gen"][: c + 1])) - 1
+    data = bytearray(bad.data.tobytes() if isinstance(bad.data, np.ndarray) else bad.data)
+    data[at] |= 0x80
+    bad.data = np.frombuffer(bytes(data), np.uint8).copy() if isinstance(enc.data, np.ndarray) else bytes(data)
+    with pytest.raises(capi.SfqError):
+        ctx.decode_host(bad, level=3, out_cap=len(fq) + 4096)
+
+
+def test_flat_bases_of_format_9_are_still_read(ctx):
+    """Round 5a coded the bases of a call without a model four a symbol through the range coder ("chn.idx" flag bit 6); archives that say so decode.
+    (SFQ_FLAT_QUADS=1 makes the encoder write them: a test hook, api.cpp.)"""
+    import os
+    fq = capi.synth_fastq(3000, 100, 5, 0)
+    os.environ["SFQ_FLAT_QUADS"] = "1"
+    O.lib().sfqo_set_flat_raw(0)
+    try:
+        enc = check_against_oracle(ctx, fq, 3, br=500, cr=50, step=1, what="format 9's quads", quads=True)
+    finally:
+        del os.environ["SFQ_FLAT_QUADS"]
+        O.lib().sfqo_set_flat_raw(1)
+    assert util.unpack_chains(enc.chains)["flags"] & 192 == 64
+    assert ctx.decode_host(enc, level=3, out_cap=len(fq) + 4096) == fq

@@ -802,7 +802,7 @@ def _check_sampled_chains_against_oracle(fq, packed, soff, ci, prior, rec_prior,
         got = bytes(packed[soff[2] + int(qoffs[c]): soff[2] + int(qoffs[c + 1])].cpu().numpy())
         assert got == want, ("qlt chain", c)
         assert not ci["flags"] & 1                                    # iid bases: every base chain codes with the initial row
-        assert ci["flags"] & 64                                        # ... four bases a symbol (round 5)
+        assert ci["flags"] & 192 == 128                               # ... two bits each, no coder (round 5b, block format 10)
         want, sizes, on = O.gm_encode_chains(sub, so[1::4], sl[1::4], 16, r1 - r0, r1 - r0)
         got = bytes(packed[soff[1] + int(goffs[c]): soff[1] + int(goffs[c + 1])].cpu().numpy())
         assert on == 0 and got == want, ("gen chain", c)
