@@ -87,7 +87,8 @@ typedef struct sfq_params {
                               round 4 hold -- instead of Rice-coded gap lists ("chn.idx" flag bit 4), and the
                               BASES keep round 4's coding: generation tables of Base2 rows where they pay, the initial row's 3 of 12
                               a base where they do not -- instead of the generation match model ("chn.idx" flag bit 5: a chain
-                              follows a pointer into the earlier generations' bases, gm.hip) and four bases a symbol (bit 6)   */
+                              follows a pointer into the earlier generations' bases, gm.hip) and, where they have nothing to learn, two bits a
+                              base without a coder (bit 7, block format 10)   */
     uint32_t version;      /* decode only: archive "version" info key (config.cpp:373); 0 = current (6).
                               Versions < 5 take RecLoad::load_pre5 (recs.cpp:400-401)                      */
     uint32_t prior_step;   /* encode, block mode only: 0 = cold blocks (each block == the reference run on that block);
