@@ -253,7 +253,7 @@ void launch_seg_fill(const u64* seg_off, u64 nrec, u32* seg_rec, hipStream_t st)
 // LDS staging of the hottest rows: the workgroup copies the call's hot image (above) into LDS once; a symbol whose context
 // is staged reads its entry there (map word, two cums), the others gather it from the L2-resident table.
 #ifndef QLT_STEP
-#define QLT_STEP 8u      /* symbols whose row entries are looked up at a time, a step ahead of the coder (16 / QLT_STEP steps a piece) */
+#define QLT_STEP 2u      /* symbols whose row entries are looked up at a time, a step ahead of the coder (16 / QLT_STEP steps a piece) */
 #endif
 #define QLT_RING 8       // ring dwords per lane: 15 bytes may wait for their row of 16, four symbols add at most 4 x (2 + 2 escape)
 // MARK: the chains mark the records with a '!' for the exception pass (a.exc_flag; the framing does that where it can)
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     // The row entries of EIGHT symbols at a time (round 5b; sixteen before): a piece's two halves are looked up in turn, each while the half before it is
     // coded, so sixteen + eight entries are live where sixteen + sixteen were -- the kernel's registers, 120 a lane, are what keeps every other kernel off
     // the SIMDs it runs on.
+    const __amdgpu_buffer_rsrc_t qtab = __builtin_amdgcn_make_buffer_rsrc((void*)a.qrows, 0, (int)(a.q_rows * 256u), 0x00020000);      // (raw, bounds-checked: q_rows x 64 dwords)
     auto look8 = [&](const Piece& p, const uint4& f, const u32 j0, u32 (&e)[QLT_STEP], u32& lowest, u32& top) {
         if (j0 == 0 && p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
         const u32 len = p.j1;
@@ -304,11 +305,15 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
             if constexpr (LDS) {
                 const uint2 mr = lmap[last >> 5];
                 const u32 bit = 1u << (last & 31u);
-                if ((mr.x & bit) && sym < QH_SYMS) {
-                    const u16* r = lrows + (mr.y + (u32)__popc(mr.x & (bit - 1u))) * QH_ROW_U16 + sym;
-                    const u32 c0 = r[0], c1 = r[1];
-                    e[jj] = c0 | ((c1 - c0) << 16);
-                } else e[jj] = a.qrows[(size_t)last * 64 + sym];
+                // No branch between the image and the table (round 5b): of 64 lanes one nearly always misses the image, so the `else` ran for every symbol --
+                // exec masks, a 64-bit address, the branch: 13 instructions of the kernel's 90 a symbol, 0.7 ms of the call.  The table is read through a
+                // BUFFER descriptor instead: a lane that hit asks for offset 0xFFFFFFFF, which the bounds check answers with 0 without touching memory;
+                // the image's entry is masked the other way (a lane that missed reads entry 0) and the two are ORed.
+                const u32 hm = ((mr.x & bit) && sym < QH_SYMS) ? ~0u : 0u;
+                const u32 ridx = ((mr.y + (u32)__popc(mr.x & (bit - 1u))) * QH_ROW_U16 + sym) & hm;
+                const u32 c0 = lrows[ridx], c1 = lrows[ridx + 1];
+                const u32 g = (u32)__builtin_amdgcn_raw_buffer_load_b32(qtab, (int)(((last << 8) | (sym << 2)) | hm), 0, 0);
+                e[jj] = ((c0 | ((c1 - c0) << 16)) & hm) | g;
             } else e[jj] = a.qrows[(size_t)last * 64 + sym];
             if (level <= 2) last = (b | (last << 6)) & mask12;                           // qlts.hpp:52-57
             else {                                                                       // qlts.hpp:62-74
