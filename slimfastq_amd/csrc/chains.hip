@@ -290,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     // coded, so sixteen + eight entries are live where sixteen + sixteen were -- the kernel's registers, 120 a lane, are what keeps every other kernel off
     // the SIMDs it runs on.
     const __amdgpu_buffer_rsrc_t qtab = __builtin_amdgcn_make_buffer_rsrc((void*)a.qrows, 0, (int)(a.q_rows * 256u), 0x00020000);      // (raw, bounds-checked: q_rows x 64 dwords)
-    auto look8 = [&](const Piece& p, const uint4& f, const u32 j0, u32 (&e)[QLT_STEP], u32& lowest, u32& top) {
+    auto look8 = [&](const Piece& p, const uint4& f, const u32 j0, u32 (&e)[QLT_STEP], u32 (&eg)[QLT_STEP], u32& lowest, u32& top) {
         if (j0 == 0 && p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
         const u32 len = p.j1;
         lowest = 255; top = 0;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
                 const u32 ridx = ((mr.y + (u32)__popc(mr.x & (bit - 1u))) * QH_ROW_U16 + sym) & hm;
                 const u32 c0 = lrows[ridx], c1 = lrows[ridx + 1];
                 const u32 g = (u32)__builtin_amdgcn_raw_buffer_load_b32(qtab, (int)(((last << 8) | (sym << 2)) | hm), 0, 0);
-                e[jj] = ((c0 | ((c1 - c0) << 16)) & hm) | g;
-            } else e[jj] = a.qrows[(size_t)last * 64 + sym];
+                e[jj] = (c0 | ((c1 - c0) << 16)) & hm; eg[jj] = g;                 // (ORed where the entry is used: the table's answer need not be there before)
+            } else { e[jj] = a.qrows[(size_t)last * 64 + sym]; eg[jj] = 0; }
             if (level <= 2) last = (b | (last << 6)) & mask12;                           // qlts.hpp:52-57
             else {                                                                       // qlts.hpp:62-74
                 delta += max(p1, b) - b;                                                 // if (p1 > b) delta += p1 - b
@@ -360,17 +360,22 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     constexpr u32 NS = 16u / QLT_STEP;
     u32 E[NS][QLT_STEP], lows[NS], tops[NS];
 #pragma unroll
-    for (u32 k = 0; k < NS; k++) look8(pc, w, k * QLT_STEP, E[k], lows[k], tops[k]);
+    for (u32 k = 0; k < NS; k++) {
+        u32 G[QLT_STEP];
+        look8(pc, w, k * QLT_STEP, E[k], G, lows[k], tops[k]);
+#pragma unroll
+        for (u32 j = 0; j < QLT_STEP; j++) E[k][j] |= G[j];
+    }
     while (__any(pc.valid)) {
         const Piece pnn = lw.next();                  // the text two pieces ahead, the rows a step ahead
         const uint4 wnn = lw.fetch(pnn);
 #pragma unroll
         for (u32 k = 0; k < NS; k++) {
-            u32 T[QLT_STEP], lowt, topt;
-            look8(pn, wn, k * QLT_STEP, T, lowt, topt);          // the next piece's step k, while this piece's is coded
+            u32 T[QLT_STEP], G[QLT_STEP], lowt, topt;
+            look8(pn, wn, k * QLT_STEP, T, G, lowt, topt);       // the next piece's step k, while this piece's is coded
             code8(pc, w, k * QLT_STEP, E[k], lows[k], tops[k]);
 #pragma unroll
-            for (u32 j = 0; j < QLT_STEP; j++) E[k][j] = T[j];
+            for (u32 j = 0; j < QLT_STEP; j++) E[k][j] = T[j] | G[j];
             lows[k] = lowt; tops[k] = topt;
         }
         pc = pn; w = wn; pn = pnn; wn = wnn;
