@@ -286,9 +286,10 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     // piece AHEAD of the one being coded, so the gathers' latency hides behind sixteen coder steps.  No branches and no
     // masks on the model's state: whatever follows the lane's bytes in a line's last piece runs through the same
     // instructions and is dropped by the coder's mask.
-    // The row entries of EIGHT symbols at a time (round 5b; sixteen before): a piece's two halves are looked up in turn, each while the half before it is
-    // coded, so sixteen + eight entries are live where sixteen + sixteen were -- the kernel's registers, 120 a lane, are what keeps every other kernel off
-    // the SIMDs it runs on.
+    // The row entries of QLT_STEP symbols at a time (round 5b; a piece's sixteen before): a piece's steps are looked up in turn, each while the step before
+    // it is coded, so sixteen + QLT_STEP entries are live where sixteen + sixteen were.  (Tried on top: the lookup in two halves a coder step apart -- the
+    // model's walk and the map word, then the row's place and the entries --, so that neither of the two dependent LDS reads is waited for: 92 bytes of
+    // scratch a lane instead of 52, the call 13.4 ms instead of 11.4.  The kernel is at its registers' end.)
     const __amdgpu_buffer_rsrc_t qtab = __builtin_amdgcn_make_buffer_rsrc((void*)a.qrows, 0, (int)(a.q_rows * 256u), 0x00020000);      // (raw, bounds-checked: q_rows x 64 dwords)
     auto look8 = [&](const Piece& p, const uint4& f, const u32 j0, u32 (&e)[QLT_STEP], u32 (&eg)[QLT_STEP], u32& lowest, u32& top) {
         if (j0 == 0 && p.newline) { last = 0; p1 = p2 = 0; delta = 5; }          // qlts.cpp:109-112
