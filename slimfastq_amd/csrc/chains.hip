@@ -359,26 +359,33 @@ __global__ __launch_bounds__(THREADS) void k_qlt_encode_c(ChainArgs a) {
     Piece pn = lw.next();
     uint4 wn = lw.fetch(pn);
     constexpr u32 NS = 16u / QLT_STEP;
-    u32 E[NS][QLT_STEP], lows[NS], tops[NS];
+    // (whether a step of the piece holds a quality over 62 ANYWHERE in the wave -- the escape's path -- is one bit a step in a scalar register; the lanes'
+    //  own maxima, a word a step, were eight registers of a kernel that has none to spare)
+    u32 E[NS][QLT_STEP], lows[MARK ? NS : 1u], esc = 0;
 #pragma unroll
     for (u32 k = 0; k < NS; k++) {
-        u32 G[QLT_STEP];
-        look8(pc, w, k * QLT_STEP, E[k], G, lows[k], tops[k]);
+        u32 G[QLT_STEP], lowt, topt;
+        look8(pc, w, k * QLT_STEP, E[k], G, lowt, topt);
 #pragma unroll
         for (u32 j = 0; j < QLT_STEP; j++) E[k][j] |= G[j];
+        if (__any(topt >= LAST_QLT)) esc |= 1u << k;
+        if constexpr (MARK) lows[k] = lowt;
     }
     while (__any(pc.valid)) {
         const Piece pnn = lw.next();                  // the text two pieces ahead, the rows a step ahead
         const uint4 wnn = lw.fetch(pnn);
+        u32 escn = 0;
 #pragma unroll
         for (u32 k = 0; k < NS; k++) {
             u32 T[QLT_STEP], G[QLT_STEP], lowt, topt;
             look8(pn, wn, k * QLT_STEP, T, G, lowt, topt);       // the next piece's step k, while this piece's is coded
-            code8(pc, w, k * QLT_STEP, E[k], lows[k], tops[k]);
+            code8(pc, w, k * QLT_STEP, E[k], MARK ? lows[MARK ? k : 0u] : 255u, ((esc >> k) & 1u) ? LAST_QLT : 0u);
 #pragma unroll
             for (u32 j = 0; j < QLT_STEP; j++) E[k][j] = T[j] | G[j];
-            lows[k] = lowt; tops[k] = topt;
+            if (__any(topt >= LAST_QLT)) escn |= 1u << k;
+            if constexpr (MARK) lows[k] = lowt;
         }
+        esc = escn;
         pc = pn; w = wn; pn = pnn; wn = wnn;
     }
     if (live) {
